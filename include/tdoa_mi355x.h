@@ -1,0 +1,174 @@
+/*
+ * tdoa_mi355x.h -- C ABI of the MI355X-native TDOA correlation processor.
+ *
+ * Drop-in boundary for the correlation hot path of KX0U-Jim/tdoa-geolocation
+ * (processor.go / simple_corr.go / fast_analyzer.go).  The reference has no FFI
+ * today: every entry point below replaces a Go function that a cgo shim would
+ * forward to (INTEGRATION.md shows the shim).  Citations are file:line in the
+ * reference.  Plain pointers and sizes only; no C++/torch types.
+ *
+ * Data layouts (identical to the reference's):
+ *   complex64 signal  = n x {float re, float im} interleaved   (Go []complex64)
+ *   IQ capture bytes  = n x {uint8 I, uint8 Q} centred at 127.5 (.dat files,
+ *                       librtlsdr-2freq/src/rtl_sdr.c:103-146), three equal
+ *                       blocks [f1 | f2 | f1]
+ *   delay             = samples, relative to the shorter input as template
+ *
+ * Ownership: the caller owns every pointer it passes; the library copies what
+ * it needs during the call and keeps no host pointer afterwards (cgo rule).
+ * A context is single-caller; use one context per GPU.  Every function
+ * returns a status code (0 = TDOA_OK) and never aborts the host process.
+ */
+#ifndef TDOA_MI355X_H
+#define TDOA_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TDOA_ABI_VERSION 1
+
+typedef struct tdoa_ctx tdoa_ctx;
+
+enum {
+    TDOA_OK = 0,
+    TDOA_ERR_INVALID = 1,     /* bad argument                                  */
+    TDOA_ERR_NO_DEVICE = 2,   /* no usable HIP device (no CPU fallback exists) */
+    TDOA_ERR_HIP = 3,         /* a HIP runtime call failed (tdoa_last_error)   */
+    TDOA_ERR_NOMEM = 4,
+    TDOA_ERR_UNSUPPORTED = 5, /* size outside the supported range              */
+    TDOA_ERR_STATE = 6        /* call order (e.g. process before upload)       */
+};
+
+/* The constants the reference hard-codes, as parameters. */
+typedef struct {
+    double  sample_rate;     /* 2e6     processor.go:440,488,821,841            */
+    int32_t max_lag;         /* 20000   processor.go:633                        */
+    int32_t corr_block;      /* 1000    processor.go:682                        */
+    double  weak_threshold;  /* 0.001   processor.go:476                        */
+    int64_t window_len;      /* 2000000 processor.go:772 (testChunkSize)        */
+    int32_t device;          /* HIP device ordinal                              */
+    int32_t windows_per_batch; /* station-windows processed per launch group; 0 = auto */
+} tdoa_params;
+
+/* One correlation peak.  lag > 0: the second station of the pair lags the first. */
+typedef struct {
+    int32_t lag;        /* samples                                           */
+    float   abs_corr;   /* |corr| as float (sort/weight key)                 */
+    double  corr;       /* signed, reference scale sum/sqrt(n_template)      */
+} tdoa_peak;
+
+/* Exact statistics of one FM-discriminated window (mode B preprocessing). */
+typedef struct {
+    int64_t  s1;
+    uint64_t s2_lo, s2_hi;
+    float    mean, scale;
+} tdoa_fm_stats;
+
+/* ---- lifecycle ------------------------------------------------------------ */
+void        tdoa_default_params(tdoa_params *p);
+int         tdoa_create(const tdoa_params *p, tdoa_ctx **out);
+void        tdoa_destroy(tdoa_ctx *ctx);
+const char *tdoa_strerror(int status);
+const char *tdoa_last_error(const tdoa_ctx *ctx);   /* detail of the last failure */
+int         tdoa_abi_version(void);
+int         tdoa_device_count(void);
+
+/* ---- mode A: the reference's executed call surface -------------------------
+ * Bit-faithful GPU evaluation of the Go functions (same filters, same
+ * accumulation order where the Go order is observable).                      */
+
+/* processor.go:166-205 loadIQData conversion: (float32(b)-127.5)/127.5 */
+int tdoa_load_iq_u8(tdoa_ctx *ctx, const uint8_t *raw, size_t n_samples, float *out_c64);
+
+/* processor.go:469-499 preprocessSignal (power gate, filter chains, normalise);
+ * *weak_chain receives 1 if enhanceWeakSignal (:437) was taken. */
+int tdoa_preprocess_c64(tdoa_ctx *ctx, const float *sig, size_t n, float *out_c64, int *weak_chain);
+
+/* processor.go:646-736 timeDomainCorrelation(signal1, signal2, maxLag) -> (delay, corr) */
+int tdoa_time_domain_correlation_c64(tdoa_ctx *ctx, const float *s1, size_t n1,
+                                     const float *s2, size_t n2, int max_lag,
+                                     int32_t *delay, double *corr);
+
+/* processor.go:619-643 crossCorrelate(signal1, signal2) -> (delay, corr):
+ * the station-pair call surface (callers :818, :838, correlation_sanity.go:50,55).
+ * Empty input returns TDOA_OK with (0, 0.0) like the reference (:622-625). */
+int tdoa_cross_correlate_c64(tdoa_ctx *ctx, const float *s1, size_t n1,
+                             const float *s2, size_t n2,
+                             int32_t *delay, double *corr);
+
+/* simple_corr.go:83-160 simpleCorrelate -> (delay, float32 corr) */
+int tdoa_simple_correlate_c64(tdoa_ctx *ctx, const float *s1, size_t n1,
+                              const float *s2, size_t n2,
+                              int32_t *delay, float *corr);
+
+/* fast_analyzer.go:163-227 fastSNRCalculation(samples, totalSamples) -> dB */
+int tdoa_fast_snr_u8(tdoa_ctx *ctx, const uint8_t *samples, int total_samples, double *snr_db);
+
+/* ---- mode B: the north-star pipeline ---------------------------------------
+ * u8 IQ -> FM discriminator -> Stockham FFT -> conj-multiply -> inverse FFT
+ * -> argmax, batched over (station, window) and (pair, window).
+ *
+ * A capture is 3 blocks of n = floor(total/3) samples.  Windows of
+ * window_len samples tile each block: windows_per_block = max(1, n /
+ * window_len) (a block shorter than window_len is one window of n samples).
+ * Window id wid = block * windows_per_block + w; block 1 is the target
+ * frequency, blocks 0 and 2 the reference frequency (processor.go:211-233).
+ * Pairs are ordered i<j as in processor.go:816-850.                          */
+
+/* copy one station's capture into HBM (ctx-owned) */
+int tdoa_capture_upload(tdoa_ctx *ctx, int station, const uint8_t *iq, size_t n_samples);
+/* or attach a buffer that is already in this device's memory (not copied, not freed) */
+int tdoa_capture_attach_device(tdoa_ctx *ctx, int station, const void *dev_iq, size_t n_samples);
+int tdoa_capture_clear(tdoa_ctx *ctx);
+
+int tdoa_num_windows(const tdoa_ctx *ctx, int *windows_per_block, int *n_windows_total);
+int tdoa_num_pairs(const tdoa_ctx *ctx);
+
+/* Correlate every pair on every window wid with wid % world == rank.
+ * out_host (may be NULL): [n_windows_total][n_pairs] tdoa_peak, entries of
+ *   windows owned by other ranks are zero-filled;
+ * out_dev (may be NULL): same array in device memory (for an RCCL all-gather
+ *   of the per-pair peaks without a host round trip). */
+int tdoa_process(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host, void *out_dev);
+
+/* upload + process in one call (host pointers in, host peaks out) */
+int tdoa_process_u8(tdoa_ctx *ctx, const uint8_t *const *station_iq, const size_t *n_samples,
+                    int n_stations, tdoa_peak *out);
+
+/* single pair of raw IQ windows -> peak (lags -(max_lag-1) .. max_lag-1) */
+int tdoa_fm_xcorr_u8(tdoa_ctx *ctx, const uint8_t *iq1, size_t n1, const uint8_t *iq2, size_t n2,
+                     int max_lag, tdoa_peak *peak);
+
+/* inspection hooks used by the parity tests */
+int tdoa_fm_preprocess_u8(tdoa_ctx *ctx, const uint8_t *iq, size_t n, float *out_f32, tdoa_fm_stats *stats);
+int tdoa_fm_xcorr_lags_u8(tdoa_ctx *ctx, const uint8_t *iq1, size_t n1, const uint8_t *iq2, size_t n2,
+                          int max_lag, double *lags_out /* [2*max_lag-1] */);
+
+/* ---- downstream (processor.go:125-163, 932-1045), host side ---------------- */
+void tdoa_latlon_to_ecef(double lat, double lon, double elev, double xyz[3]);
+void tdoa_ecef_to_latlon(double x, double y, double z, double lle[3]);
+/* reference 3-station solver, bit-compatible call: range_diff[0]=(0,1), [1]=(0,2) */
+int  tdoa_solve_3station(const double stations_lle[9], const double *range_diff,
+                         double out_lle[3], int *iterations);
+
+/* ---- measurement ----------------------------------------------------------- */
+enum {
+    TDOA_K_STATS = 0, TDOA_K_FWD_COL, TDOA_K_FWD_ROW, TDOA_K_INV_ROW, TDOA_K_INV_COL,
+    TDOA_K_PEAK, TDOA_K_COUNT
+};
+int         tdoa_profile_enable(tdoa_ctx *ctx, int on);
+int         tdoa_profile_reset(tdoa_ctx *ctx);
+int         tdoa_profile_get(tdoa_ctx *ctx, int kernel, double *total_ms, int64_t *launches,
+                             double *algorithmic_bytes);
+const char *tdoa_kernel_name(int kernel);
+/* plan facts: FFT length N (real), factors N1 x N2 of N/2, passes */
+int         tdoa_plan_info(const tdoa_ctx *ctx, int64_t *fft_n, int32_t *n1, int32_t *n2);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,68 @@
+// device_common.hpp -- shared device helpers for the gfx950 TDOA kernels.
+// wave = 64 lanes, LDS 160 KiB/CU; everything here is written for CDNA4 only.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tdoa {
+
+constexpr int kWave = 64;
+
+struct SWDesc {            // one (station, window) unit: raw IQ bytes in HBM
+    const uint8_t *base;   // first I byte of the window (2-byte aligned)
+    int32_t len;           // samples in the window
+    int32_t pad;
+};
+
+struct PWDesc {            // one (pair, window) unit
+    int32_t sw_a;          // index of the template station-window inside the batch
+    int32_t sw_b;          // index of the signal station-window inside the batch
+    int32_t out_index;     // slot in the peak array
+    int32_t len_a;         // template length (normalisation 1/sqrt(len_a))
+};
+
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cmul(float2 a, float2 b)
+{
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ float2 cmulc(float2 a, float2 b)   // conj(a) * b
+{
+    return make_float2(a.x * b.x + a.y * b.y, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
+
+// exp(sign * 2*pi*i * num / den), den a power of two, 0 <= num < 2^24 (exact in f32)
+__device__ __forceinline__ float2 unit_root(float num, float inv_den_times2, bool positive)
+{
+    float s, c;
+    float x = num * inv_den_times2;          // 2*num/den, exact scaling
+    sincospif(positive ? x : -x, &s, &c);
+    return make_float2(c, s);
+}
+
+// 64-bit peak key: [ |v| bits : 32 ][ (0x7fffffff - rank) : 31 ][ sign : 1 ]
+// rank orders lags 0, +1, -1, +2, -2, ... so the larger key is the larger |v|,
+// then the smaller |lag|, then the positive lag (processor.go:596-611 order).
+__device__ __forceinline__ unsigned long long peak_key(float v, int lag)
+{
+    unsigned int mag = __float_as_uint(fabsf(v));
+    unsigned int a = lag < 0 ? (unsigned int)(-lag) : (unsigned int)lag;
+    unsigned int rank = 2u * a - (lag > 0 ? 1u : 0u);
+    unsigned int low = ((0x7fffffffu - rank) << 1) | (v < 0.0f ? 1u : 0u);
+    return ((unsigned long long)mag << 32) | low;
+}
+
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        unsigned long long o = __shfl_xor(k, off, kWave);
+        k = o > k ? o : k;
+    }
+    return k;
+}
+
+}  // namespace tdoa

@@ -1,0 +1,370 @@
+// fft_stockham.hpp -- K2/K4: LDS-staged Stockham FFT building blocks and the four
+// passes of the packed-real cross-correlation (forward column, forward row,
+// inverse row with the fused conj-multiply K3, inverse column with fused argmax K5).
+//
+// A real window y[0..N) is packed as z[m] = y[2m] + i*y[2m+1], m < Nc = N/2, and
+// transformed with a four-step complex FFT, Nc = N1 * N2, input index
+// m = n2*N1 + n1, spectrum index k = k1*N2 + k2:
+//   forward column pass : Y[k2][n1] = sum_n2 z[n2*N1+n1] W_N2^(n2 k2), times W_Nc^(n1 k2)
+//   forward row pass    : Zs[k2][k1] = sum_n1 T[k2][n1] W_N1^(n1 k1)       (= Z[k1*N2+k2])
+// The spectrum stays in this transposed [k2][k1] layout: the pointwise product
+// does not care, and the inverse consumes it directly (no transpose kernel):
+//   inverse row pass    : Q from (Za, Zb) at k and Nc-k, row IFFT over k1, times W_Nc^(-n1 k2)
+//   inverse column pass : IFFT over k2, q[m] = N*4*(r[2m] + i r[2m+1]), argmax over lags
+//
+// Reference evidence for the conventions: forward sign e^{-2 pi i kj/n}, unnormalised
+// (processor.go:528); padding N = nextPow2(L + maxLag) (processor.go:563); cross power
+// conj(template)*signal so that lag > 0 means the signal is delayed (processor.go:700-705).
+#pragma once
+
+#include "device_common.hpp"
+#include "k1_discriminator.hpp"
+
+namespace tdoa {
+
+template <bool INV>
+__device__ __forceinline__ void bfly4(float2 &a0, float2 &a1, float2 &a2, float2 &a3)
+{
+    float2 t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), d = csub(a1, a3);
+    float2 t3 = INV ? make_float2(-d.y, d.x) : make_float2(d.y, -d.x);   // d * (+i | -i)
+    a0 = cadd(t0, t2);
+    a1 = cadd(t1, t3);
+    a2 = csub(t0, t2);
+    a3 = csub(t1, t3);
+}
+
+// Generic in-LDS Stockham autosort FFT of NV interleaved vectors of length M
+// (element e of vector v at [e*NV + v]); radix-4 rounds plus one radix-2 round
+// when log2(M) is odd.  Ping-pongs between b0 and b1; returns the buffer that
+// holds the result.  All threads of the block must call it.
+template <bool INV>
+__device__ float2 *lds_fft(float2 *b0, float2 *b1, int M, int logM, int NV, int logNV)
+{
+    float2 *src = b0, *dst = b1;
+    int Ns = 1, rem = logM;
+    while (rem > 0) {
+        if (rem >= 2) {
+            const int q = M >> 2;
+            const int items = q << logNV;
+            const float inv2 = 2.0f / (float)(Ns * 4);
+            for (int it = threadIdx.x; it < items; it += blockDim.x) {
+                int v = it & (NV - 1), j = it >> logNV;
+                int jm = j & (Ns - 1);
+                float2 x0 = src[((j) << logNV) + v];
+                float2 x1 = src[((j + q) << logNV) + v];
+                float2 x2 = src[((j + 2 * q) << logNV) + v];
+                float2 x3 = src[((j + 3 * q) << logNV) + v];
+                if (Ns > 1) {
+                    float2 w1 = unit_root((float)jm, inv2, INV);
+                    float2 w2 = cmul(w1, w1);
+                    float2 w3 = cmul(w2, w1);
+                    x1 = cmul(x1, w1);
+                    x2 = cmul(x2, w2);
+                    x3 = cmul(x3, w3);
+                }
+                bfly4<INV>(x0, x1, x2, x3);
+                int d = ((j - jm) << 2) + jm;
+                dst[((d) << logNV) + v] = x0;
+                dst[((d + Ns) << logNV) + v] = x1;
+                dst[((d + 2 * Ns) << logNV) + v] = x2;
+                dst[((d + 3 * Ns) << logNV) + v] = x3;
+            }
+            Ns <<= 2;
+            rem -= 2;
+        } else {
+            const int q = M >> 1;
+            const int items = q << logNV;
+            const float inv2 = 2.0f / (float)(Ns * 2);
+            for (int it = threadIdx.x; it < items; it += blockDim.x) {
+                int v = it & (NV - 1), j = it >> logNV;
+                int jm = j & (Ns - 1);
+                float2 x0 = src[((j) << logNV) + v];
+                float2 x1 = src[((j + q) << logNV) + v];
+                if (Ns > 1) x1 = cmul(x1, unit_root((float)jm, inv2, INV));
+                int d = ((j - jm) << 1) + jm;
+                dst[((d) << logNV) + v] = cadd(x0, x1);
+                dst[((d + Ns) << logNV) + v] = csub(x0, x1);
+            }
+            Ns <<= 1;
+            rem -= 1;
+        }
+        __syncthreads();
+        float2 *t = src;
+        src = dst;
+        dst = t;
+    }
+    return src;
+}
+
+struct FftPlan {
+    int N1, N2, logN1, logN2;   // Nc = N1*N2
+    int C, logC;                // columns per tile in the column passes
+    long long Nc;
+};
+
+// ---------------------------------------------------------------------------
+// forward column pass, fused with K1: u8 IQ -> discriminator -> normalise ->
+// pack -> length-N2 FFT down C adjacent columns -> twiddle -> T[k2][n1]
+// grid: (N1 / C, n_station_windows), dynamic LDS: 2 * N2 * C * 8 bytes
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_fwd_col_u8(const SWDesc *sw, const FmStats *stats, float2 *T, FftPlan pl)
+{
+    extern __shared__ float2 lds[];
+    const int tile = pl.N2 << pl.logC;
+    const SWDesc d = sw[blockIdx.y];
+    const uint16_t *p = reinterpret_cast<const uint16_t *>(d.base);
+    const int len = d.len;
+    const float mean = stats[blockIdx.y].mean, scale = stats[blockIdx.y].scale;
+    const int c0 = blockIdx.x << pl.logC;
+    for (int e = threadIdx.x; e < tile; e += blockDim.x) {
+        int c = e & (pl.C - 1), n2 = e >> pl.logC;
+        long long m = (long long)n2 * pl.N1 + c0 + c;
+        long long i0 = 2 * m;
+        float v0 = 0.0f, v1 = 0.0f;
+        if (i0 < len) v0 = k1_normalise(k1_window_phase(p, (int)i0, len), mean, scale);
+        if (i0 + 1 < len) v1 = k1_normalise(k1_window_phase(p, (int)i0 + 1, len), mean, scale);
+        lds[e] = make_float2(v0, v1);
+    }
+    __syncthreads();
+    float2 *r = lds_fft<false>(lds, lds + tile, pl.N2, pl.logN2, pl.C, pl.logC);
+    float2 *out = T + (size_t)blockIdx.y * pl.Nc;
+    const float inv2 = 2.0f / (float)pl.Nc;
+    for (int e = threadIdx.x; e < tile; e += blockDim.x) {
+        int c = e & (pl.C - 1), k2 = e >> pl.logC;
+        int n1 = c0 + c;
+        long long ex = ((long long)n1 * k2) & (pl.Nc - 1);
+        float2 w = unit_root((float)ex, inv2, false);
+        out[(size_t)k2 * pl.N1 + n1] = cmul(r[e], w);
+    }
+}
+
+// forward column pass for a complex64 signal already in HBM (mode A correlation):
+// z[m] = sig[m], zero padded beyond len.  Same grid/LDS as above.
+__global__ __launch_bounds__(256) void k_fwd_col_c64(const float2 *sig, int len, float2 *T, FftPlan pl)
+{
+    extern __shared__ float2 lds[];
+    const int tile = pl.N2 << pl.logC;
+    const int c0 = blockIdx.x << pl.logC;
+    for (int e = threadIdx.x; e < tile; e += blockDim.x) {
+        int c = e & (pl.C - 1), n2 = e >> pl.logC;
+        long long m = (long long)n2 * pl.N1 + c0 + c;
+        lds[e] = m < len ? sig[m] : make_float2(0.0f, 0.0f);
+    }
+    __syncthreads();
+    float2 *r = lds_fft<false>(lds, lds + tile, pl.N2, pl.logN2, pl.C, pl.logC);
+    const float inv2 = 2.0f / (float)pl.Nc;
+    for (int e = threadIdx.x; e < tile; e += blockDim.x) {
+        int c = e & (pl.C - 1), k2 = e >> pl.logC;
+        int n1 = c0 + c;
+        long long ex = ((long long)n1 * k2) & (pl.Nc - 1);
+        T[(size_t)k2 * pl.N1 + n1] = cmul(r[e], unit_root((float)ex, inv2, false));
+    }
+}
+
+// ---------------------------------------------------------------------------
+// forward row pass: length-N1 FFT of each contiguous row, in place (T -> Zs)
+// grid: (N2, n_station_windows), dynamic LDS: 2 * N1 * 8 bytes
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_fwd_row(float2 *TZ, FftPlan pl)
+{
+    extern __shared__ float2 lds[];
+    float2 *row = TZ + (size_t)blockIdx.y * pl.Nc + (size_t)blockIdx.x * pl.N1;
+    for (int e = threadIdx.x; e < pl.N1; e += blockDim.x) lds[e] = row[e];
+    __syncthreads();
+    float2 *r = lds_fft<false>(lds, lds + pl.N1, pl.N1, pl.logN1, 1, 0);
+    for (int e = threadIdx.x; e < pl.N1; e += blockDim.x) row[e] = r[e];
+}
+
+// ---------------------------------------------------------------------------
+// K3 fused into the inverse row pass (packed-real mode).
+// With E2 = z + conj(zm), O2 = -i (z - conj(zm)) (twice the even/odd spectra),
+// A+- = E2a +- w O2a, B+- = E2b +- w O2b, w = W_N^k:
+//   G = conj(A+) B+ (= 4 G[k]),  H = conj(A-) B- (= 4 conj(G[Nc-k]))
+//   Q[k]    = (G + H) + i (G - H) conj(w)
+//   Q[Nc-k] = conj(G + H) + i conj((G - H) conj(w))
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void pair_q(float2 za, float2 zam, float2 zb, float2 zbm, float2 w,
+                                       float2 &q, float2 &qm)
+{
+    float2 e2a = make_float2(za.x + zam.x, za.y - zam.y);
+    float2 da = make_float2(za.x - zam.x, za.y + zam.y);     // z - conj(zm)
+    float2 o2a = make_float2(da.y, -da.x);                    // -i * da
+    float2 e2b = make_float2(zb.x + zbm.x, zb.y - zbm.y);
+    float2 db = make_float2(zb.x - zbm.x, zb.y + zbm.y);
+    float2 o2b = make_float2(db.y, -db.x);
+    float2 woa = cmul(w, o2a), wob = cmul(w, o2b);
+    float2 ap = cadd(e2a, woa), am = csub(e2a, woa);
+    float2 bp = cadd(e2b, wob), bm = csub(e2b, wob);
+    float2 g = cmulc(ap, bp), h = cmulc(am, bm);
+    float2 qe = cadd(g, h);
+    float2 qo = cmul(csub(g, h), cconj(w));
+    q = make_float2(qe.x - qo.y, qe.y + qo.x);               // qe + i qo
+    qm = make_float2(qe.x + qo.y, -qe.y + qo.x);             // conj(qe) + i conj(qo)
+}
+
+// grid: (N2 / 2, n_pair_windows), dynamic LDS: 2 * (2*N1) * 8 bytes
+// block a == 0 owns the two self-mirrored rows (0 and N2/2); block a > 0 owns the
+// mutually mirrored rows (a, N2 - a).
+__global__ __launch_bounds__(256) void k_inv_row_pair(const PWDesc *pw, const float2 *Z, float2 *V, FftPlan pl)
+{
+    extern __shared__ float2 lds[];
+    const PWDesc d = pw[blockIdx.y];
+    const float2 *Za = Z + (size_t)d.sw_a * pl.Nc;
+    const float2 *Zb = Z + (size_t)d.sw_b * pl.Nc;
+    const int N1 = pl.N1, N2 = pl.N2;
+    const int a = blockIdx.x;
+    const int rowA = a == 0 ? 0 : a;
+    const int rowB = a == 0 ? (N2 >> 1) : N2 - a;
+    const float inv2N = 1.0f / (float)pl.Nc;      // 2 / N with N = 2 Nc
+    if (a == 0) {
+        for (int e = threadIdx.x; e < 2 * N1; e += blockDim.x) {
+            int v = e & 1, k1 = e >> 1;
+            int row = v ? rowB : rowA;
+            int mk1 = v ? (N1 - 1 - k1) : ((N1 - k1) & (N1 - 1));
+            size_t i = (size_t)row * N1 + k1, im = (size_t)row * N1 + mk1;
+            long long k = (long long)k1 * N2 + row;
+            float2 w = unit_root((float)k, inv2N, false);
+            float2 q, qm;
+            pair_q(Za[i], Za[im], Zb[i], Zb[im], w, q, qm);
+            lds[e] = q;
+        }
+    } else {
+        for (int k1 = threadIdx.x; k1 < N1; k1 += blockDim.x) {
+            int mk1 = N1 - 1 - k1;
+            size_t i = (size_t)rowA * N1 + k1, im = (size_t)rowB * N1 + mk1;
+            long long k = (long long)k1 * N2 + rowA;
+            float2 w = unit_root((float)k, inv2N, false);
+            float2 q, qm;
+            pair_q(Za[i], Za[im], Zb[i], Zb[im], w, q, qm);
+            lds[2 * k1] = q;
+            lds[2 * mk1 + 1] = qm;
+        }
+    }
+    __syncthreads();
+    float2 *r = lds_fft<true>(lds, lds + 2 * N1, N1, pl.logN1, 2, 1);
+    float2 *out = V + (size_t)blockIdx.y * pl.Nc;
+    const float inv2 = 2.0f / (float)pl.Nc;
+    for (int e = threadIdx.x; e < 2 * N1; e += blockDim.x) {
+        int v = e & 1, n1 = e >> 1;
+        int k2 = v ? rowB : rowA;
+        long long ex = ((long long)n1 * k2) & (pl.Nc - 1);
+        out[(size_t)k2 * N1 + n1] = cmul(r[e], unit_root((float)ex, inv2, true));
+    }
+}
+
+// inverse row pass for complex (unpacked) spectra, mode A: Q = conj(Za) * Zb
+// grid: (N2, 1), dynamic LDS: 2 * N1 * 8 bytes
+__global__ __launch_bounds__(256) void k_inv_row_c64(const float2 *Za, const float2 *Zb, float2 *V, FftPlan pl)
+{
+    extern __shared__ float2 lds[];
+    const int N1 = pl.N1;
+    const int k2 = blockIdx.x;
+    for (int e = threadIdx.x; e < N1; e += blockDim.x) {
+        size_t i = (size_t)k2 * N1 + e;
+        lds[e] = cmulc(Za[i], Zb[i]);
+    }
+    __syncthreads();
+    float2 *r = lds_fft<true>(lds, lds + N1, N1, pl.logN1, 1, 0);
+    const float inv2 = 2.0f / (float)pl.Nc;
+    for (int n1 = threadIdx.x; n1 < N1; n1 += blockDim.x) {
+        long long ex = ((long long)n1 * k2) & (pl.Nc - 1);
+        V[(size_t)k2 * N1 + n1] = cmul(r[n1], unit_root((float)ex, inv2, true));
+    }
+}
+
+// ---------------------------------------------------------------------------
+// inverse column pass + K5 argmax.  After the length-N2 IFFT down a column,
+// element (n2, n1) is q[m], m = n2*N1 + n1.
+//   packed-real mode: lags 2m (real part) and 2m+1 (imag part), minus N when >= N/2
+//   complex mode    : lag m (real part only: Re(conj(t) s), processor.go:705)
+// Candidates with lag_lo <= lag <= lag_hi enter a 64-bit atomicMax key.
+// grid: (N1 / C, n_pair_windows), dynamic LDS: 2 * N2 * C * 8 bytes
+// ---------------------------------------------------------------------------
+template <bool PACKED>
+__global__ __launch_bounds__(256) void k_inv_col_peak(const float2 *V, unsigned long long *keys, const PWDesc *pw,
+                                                      FftPlan pl, int lag_lo, int lag_hi, float *lag_dump,
+                                                      float dump_scale)
+{
+    extern __shared__ float2 lds[];
+    const int tile = pl.N2 << pl.logC;
+    const float2 *in = V + (size_t)blockIdx.y * pl.Nc;
+    const int c0 = blockIdx.x << pl.logC;
+    for (int e = threadIdx.x; e < tile; e += blockDim.x) {
+        int c = e & (pl.C - 1), k2 = e >> pl.logC;
+        lds[e] = in[(size_t)k2 * pl.N1 + c0 + c];
+    }
+    __syncthreads();
+    float2 *r = lds_fft<true>(lds, lds + tile, pl.N2, pl.logN2, pl.C, pl.logC);
+    unsigned long long best = 0;
+    const long long Nc = pl.Nc;
+    for (int e = threadIdx.x; e < tile; e += blockDim.x) {
+        int c = e & (pl.C - 1), n2 = e >> pl.logC;
+        long long m = (long long)n2 * pl.N1 + c0 + c;
+        float2 v = r[e];
+        if (PACKED) {
+            long long d0 = 2 * m;
+            if (d0 >= Nc) d0 -= 2 * Nc;
+            long long d1 = d0 + 1;
+            if (d0 >= lag_lo && d0 <= lag_hi && v.x == v.x) {
+                unsigned long long k = peak_key(v.x, (int)d0);
+                best = k > best ? k : best;
+                if (lag_dump) lag_dump[d0 - lag_lo] = v.x * dump_scale;
+            }
+            if (d1 >= lag_lo && d1 <= lag_hi && v.y == v.y) {
+                unsigned long long k = peak_key(v.y, (int)d1);
+                best = k > best ? k : best;
+                if (lag_dump) lag_dump[d1 - lag_lo] = v.y * dump_scale;
+            }
+        } else {
+            long long d0 = m;
+            if (d0 >= Nc / 2) d0 -= Nc;
+            if (d0 >= lag_lo && d0 <= lag_hi && v.x == v.x) {
+                unsigned long long k = peak_key(v.x, (int)d0);
+                best = k > best ? k : best;
+                if (lag_dump) lag_dump[d0 - lag_lo] = v.x * dump_scale;
+            }
+        }
+    }
+    best = wave_max_u64(best);
+    __shared__ unsigned long long red[4];
+    int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
+    if (lane == 0) red[wid] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long b = red[0];
+        for (int w = 1; w < (int)(blockDim.x / kWave); w++) b = red[w] > b ? red[w] : b;
+        if (b) atomicMax(&keys[pw[blockIdx.y].out_index], b);
+    }
+}
+
+struct PeakOut {      // mirrors tdoa_peak
+    int32_t lag;
+    float abs_corr;
+    double corr;
+};
+
+// decode keys -> peaks; scale = 1 / (4 N sqrt(len_a)) (packed) or 1 / (Nc sqrt(M)) (complex)
+__global__ void k_decode_peaks(const unsigned long long *keys, const double *scales, PeakOut *out, int n)
+{
+    int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n) return;
+    unsigned long long k = keys[id];
+    unsigned int mag = (unsigned int)(k >> 32), low = (unsigned int)k;
+    PeakOut p;
+    if (k == 0 || mag == 0) {
+        p.lag = 0;
+        p.abs_corr = 0.0f;
+        p.corr = 0.0;
+    } else {
+        unsigned int rank = 0x7fffffffu - (low >> 1);
+        int lag = rank == 0 ? 0 : ((rank & 1u) ? (int)((rank + 1u) >> 1) : -(int)(rank >> 1));
+        double v = (double)__uint_as_float(mag) * scales[id];
+        if (low & 1u) v = -v;
+        p.lag = lag;
+        p.corr = v;
+        p.abs_corr = (float)fabs(v);
+    }
+    out[id] = p;
+}
+
+}  // namespace tdoa

@@ -1,0 +1,710 @@
+// tdoa_mi355x.hip -- C-ABI implementation (include/tdoa_mi355x.h) for gfx950.
+//
+// Host side: context, FFT plans, (station, window) x (pair, window) batching,
+// HIP stream + event plumbing.  Device side: the kernels in the headers below.
+// There is no CPU fallback: without a HIP device every compute entry point
+// fails with TDOA_ERR_NO_DEVICE.
+#include "../../include/tdoa_mi355x.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "device_common.hpp"
+#include "k1_discriminator.hpp"
+#include "fft_stockham.hpp"
+#include "exact_reference.hpp"
+#include "host_geodesy.hpp"
+
+using namespace tdoa;
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+struct ProfRec {
+    int kernel;
+    hipEvent_t start, stop;
+    double bytes;
+};
+
+}  // namespace
+
+struct tdoa_ctx {
+    tdoa_params prm;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string last_error;
+
+    struct Capture {
+        const uint8_t *dev = nullptr;
+        size_t n = 0;
+        bool owned = false;
+    };
+    std::vector<Capture> caps;
+
+    DevBuf sw_desc, pw_desc, partials, stats, tz, v, keys, scales, peaks, scratch_a, scratch_b, lagdump;
+    DevBuf ex_a, ex_b, ex_c, ex_d, ex_part;
+
+    bool profiling = false;
+    std::vector<ProfRec> recs;
+    double prof_ms[TDOA_K_COUNT] = {0};
+    int64_t prof_launches[TDOA_K_COUNT] = {0};
+    double prof_bytes[TDOA_K_COUNT] = {0};
+
+    FftPlan plan{};
+    int64_t plan_n = 0;
+};
+
+namespace {
+
+static_assert(sizeof(PeakOut) == sizeof(tdoa_peak), "tdoa_peak layout");
+static_assert(sizeof(FmStats) == sizeof(tdoa_fm_stats), "tdoa_fm_stats layout");
+
+int fail(tdoa_ctx *ctx, int status, const char *what, hipError_t e = hipSuccess)
+{
+    if (ctx) {
+        char buf[512];
+        if (e != hipSuccess)
+            snprintf(buf, sizeof(buf), "%s: %s", what, hipGetErrorString(e));
+        else
+            snprintf(buf, sizeof(buf), "%s", what);
+        ctx->last_error = buf;
+    }
+    return status;
+}
+
+#define HIPCHK(ctx, call)                                              \
+    do {                                                               \
+        hipError_t e_ = (call);                                        \
+        if (e_ != hipSuccess) return fail(ctx, TDOA_ERR_HIP, #call, e_); \
+    } while (0)
+
+int ensure(tdoa_ctx *ctx, DevBuf &b, size_t bytes)
+{
+    if (bytes <= b.cap) return TDOA_OK;
+    if (b.p) {
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        HIPCHK(ctx, hipFree(b.p));
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(ctx, TDOA_ERR_NOMEM, "hipMalloc", e);
+    }
+    b.cap = want;
+    return TDOA_OK;
+}
+
+void release(DevBuf &b)
+{
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+}
+
+int ilog2(long long v)
+{
+    int l = 0;
+    while ((1ll << l) < v) l++;
+    return l;
+}
+
+long long next_pow2(long long n)   // processor.go:502-512
+{
+    long long p = 1;
+    while (p < n) p <<= 1;
+    return p;
+}
+
+constexpr size_t kLdsCap = 128 * 1024;
+
+// factor Nc = N1 * N2 for the four-step FFT; rows (N1) live whole in LDS
+int make_plan(long long n_real, bool packed, FftPlan *pl)
+{
+    long long nc = packed ? n_real / 2 : n_real;
+    if (nc < 32 || nc > (1ll << 24) || (nc & (nc - 1))) return TDOA_ERR_UNSUPPORTED;
+    long long n1, n2;
+    if (nc >= 65536) {
+        n1 = 4096;
+        n2 = nc / n1;
+    } else if (nc >= 256) {
+        n2 = 16;
+        n1 = nc / n2;
+    } else {
+        n2 = 2;
+        n1 = nc / n2;
+    }
+    long long c = 32;
+    while (c > 1 && (c > n1 || (size_t)(2 * n2 * c * 8) > kLdsCap)) c >>= 1;
+    pl->N1 = (int)n1;
+    pl->N2 = (int)n2;
+    pl->logN1 = ilog2(n1);
+    pl->logN2 = ilog2(n2);
+    pl->C = (int)c;
+    pl->logC = ilog2(c);
+    pl->Nc = nc;
+    return TDOA_OK;
+}
+
+template <typename K>
+int set_lds(tdoa_ctx *ctx, K kernel, size_t bytes)
+{
+    if (bytes > 48 * 1024)
+        HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return TDOA_OK;
+}
+
+struct ProfScope {
+    tdoa_ctx *ctx;
+    ProfRec rec{};
+    bool on;
+    ProfScope(tdoa_ctx *c, int kernel, double bytes) : ctx(c), on(c->profiling)
+    {
+        if (!on) return;
+        rec.kernel = kernel;
+        rec.bytes = bytes;
+        if (hipEventCreate(&rec.start) != hipSuccess || hipEventCreate(&rec.stop) != hipSuccess) {
+            on = false;
+            return;
+        }
+        (void)hipEventRecord(rec.start, ctx->stream);
+    }
+    ~ProfScope()
+    {
+        if (!on) return;
+        (void)hipEventRecord(rec.stop, ctx->stream);
+        ctx->recs.push_back(rec);
+    }
+};
+
+void prof_collect(tdoa_ctx *ctx)
+{
+    for (auto &r : ctx->recs) {
+        float ms = 0;
+        if (hipEventSynchronize(r.stop) == hipSuccess && hipEventElapsedTime(&ms, r.start, r.stop) == hipSuccess) {
+            ctx->prof_ms[r.kernel] += ms;
+            ctx->prof_launches[r.kernel] += 1;
+            ctx->prof_bytes[r.kernel] += r.bytes;
+        }
+        (void)hipEventDestroy(r.start);
+        (void)hipEventDestroy(r.stop);
+    }
+    ctx->recs.clear();
+}
+
+// ---- mode B core: run stats + forward + inverse + peak over prepared descriptors
+// sw/pw descriptors are already in device memory; maxlen = longest window.
+int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const PWDesc *d_pw, int n_pw,
+                 unsigned long long *d_keys, const FftPlan &pl, int lag_lo, int lag_hi, float *lag_dump,
+                 float dump_scale, double sum_len)
+{
+    int rc;
+    const int chunks = std::max(1, (maxlen + kStatsChunk - 1) / kStatsChunk);
+    if ((rc = ensure(ctx, ctx->partials, sizeof(StatsPartial) * (size_t)chunks * n_sw))) return rc;
+    if ((rc = ensure(ctx, ctx->stats, sizeof(FmStats) * (size_t)n_sw))) return rc;
+    if ((rc = ensure(ctx, ctx->tz, sizeof(float2) * (size_t)pl.Nc * n_sw))) return rc;
+    if (n_pw && (rc = ensure(ctx, ctx->v, sizeof(float2) * (size_t)pl.Nc * n_pw))) return rc;
+    auto *partials = static_cast<StatsPartial *>(ctx->partials.p);
+    auto *stats = static_cast<FmStats *>(ctx->stats.p);
+    auto *tz = static_cast<float2 *>(ctx->tz.p);
+    auto *v = static_cast<float2 *>(ctx->v.p);
+    hipStream_t st = ctx->stream;
+    const double nc8 = 8.0 * (double)pl.Nc;
+
+    {
+        ProfScope ps(ctx, TDOA_K_STATS, 2.0 * sum_len);
+        hipLaunchKernelGGL(k_fm_stats, dim3(chunks, n_sw), dim3(kStatsThreads), 0, st, d_sw, partials, chunks);
+        hipLaunchKernelGGL(k_fm_stats_final, dim3((n_sw + 63) / 64), dim3(64), 0, st, d_sw, partials, chunks, stats,
+                           n_sw);
+    }
+    const size_t lds_col = sizeof(float2) * 2 * (size_t)pl.N2 * pl.C;
+    const size_t lds_row = sizeof(float2) * 2 * (size_t)pl.N1;
+    const size_t lds_row2 = sizeof(float2) * 4 * (size_t)pl.N1;
+    if ((rc = set_lds(ctx, k_fwd_col_u8, lds_col))) return rc;
+    if ((rc = set_lds(ctx, k_fwd_row, lds_row))) return rc;
+    if ((rc = set_lds(ctx, k_inv_row_pair, lds_row2))) return rc;
+    if ((rc = set_lds(ctx, k_inv_col_peak<true>, lds_col))) return rc;
+    {
+        ProfScope ps(ctx, TDOA_K_FWD_COL, 2.0 * sum_len + nc8 * n_sw);
+        hipLaunchKernelGGL(k_fwd_col_u8, dim3(pl.N1 / pl.C, n_sw), dim3(256), lds_col, st, d_sw, stats, tz, pl);
+    }
+    {
+        ProfScope ps(ctx, TDOA_K_FWD_ROW, 2.0 * nc8 * n_sw);
+        hipLaunchKernelGGL(k_fwd_row, dim3(pl.N2, n_sw), dim3(256), lds_row, st, tz, pl);
+    }
+    if (n_pw) {
+        {
+            ProfScope ps(ctx, TDOA_K_INV_ROW, 3.0 * nc8 * n_pw);
+            hipLaunchKernelGGL(k_inv_row_pair, dim3(pl.N2 / 2, n_pw), dim3(256), lds_row2, st, d_pw, tz, v, pl);
+        }
+        {
+            ProfScope ps(ctx, TDOA_K_INV_COL, nc8 * n_pw);
+            hipLaunchKernelGGL(k_inv_col_peak<true>, dim3(pl.N1 / pl.C, n_pw), dim3(256), lds_col, st, v, d_keys,
+                               d_pw, pl, lag_lo, lag_hi, lag_dump, dump_scale);
+        }
+    }
+    HIPCHK(ctx, hipGetLastError());
+    return TDOA_OK;
+}
+
+int check_ctx(tdoa_ctx *ctx)
+{
+    if (!ctx) return TDOA_ERR_INVALID;
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e != hipSuccess) return fail(ctx, TDOA_ERR_HIP, "hipSetDevice", e);
+    return TDOA_OK;
+}
+
+// copy two host IQ windows into scratch and build 2 sw + 1 pw descriptors
+int stage_pair_u8(tdoa_ctx *ctx, const uint8_t *iq1, size_t n1, const uint8_t *iq2, size_t n2,
+                  SWDesc **d_sw, PWDesc **d_pw)
+{
+    int rc;
+    size_t b1 = (2 * n1 + 15) & ~(size_t)15;
+    if ((rc = ensure(ctx, ctx->scratch_a, b1 + 2 * n2 + 16))) return rc;
+    auto *base = static_cast<uint8_t *>(ctx->scratch_a.p);
+    if (n1) HIPCHK(ctx, hipMemcpyAsync(base, iq1, 2 * n1, hipMemcpyHostToDevice, ctx->stream));
+    if (n2) HIPCHK(ctx, hipMemcpyAsync(base + b1, iq2, 2 * n2, hipMemcpyHostToDevice, ctx->stream));
+    SWDesc sw[2] = {{base, (int32_t)n1, 0}, {base + b1, (int32_t)n2, 0}};
+    PWDesc pw = {0, 1, 0, (int32_t)n1};
+    if ((rc = ensure(ctx, ctx->sw_desc, sizeof(sw)))) return rc;
+    if ((rc = ensure(ctx, ctx->pw_desc, sizeof(pw)))) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->sw_desc.p, sw, sizeof(sw), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->pw_desc.p, &pw, sizeof(pw), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // sw/pw are stack objects
+    *d_sw = static_cast<SWDesc *>(ctx->sw_desc.p);
+    *d_pw = static_cast<PWDesc *>(ctx->pw_desc.p);
+    return TDOA_OK;
+}
+
+int fm_pair(tdoa_ctx *ctx, const uint8_t *iq1, size_t n1, const uint8_t *iq2, size_t n2, int max_lag,
+            tdoa_peak *peak, double *lags_out)
+{
+    int rc;
+    if ((rc = check_ctx(ctx))) return rc;
+    if (max_lag < 1 || (!peak && !lags_out)) return fail(ctx, TDOA_ERR_INVALID, "bad argument");
+    if (n1 == 0 || n2 == 0) {   // processor.go:622-625 behaviour: (0, 0.0)
+        if (peak) *peak = tdoa_peak{0, 0.0f, 0.0};
+        if (lags_out) std::fill(lags_out, lags_out + (2 * max_lag - 1), 0.0);
+        return TDOA_OK;
+    }
+    if (n1 > 0x7fffffff / 2 || n2 > 0x7fffffff / 2) return fail(ctx, TDOA_ERR_UNSUPPORTED, "window too long");
+    long long n = std::max<long long>(next_pow2((long long)std::max(n1, n2) + max_lag), 64);
+    FftPlan pl;
+    if ((rc = make_plan(n, true, &pl))) return fail(ctx, rc, "FFT size unsupported");
+    SWDesc *d_sw;
+    PWDesc *d_pw;
+    if ((rc = stage_pair_u8(ctx, iq1, n1, iq2, n2, &d_sw, &d_pw))) return rc;
+    if ((rc = ensure(ctx, ctx->keys, sizeof(unsigned long long)))) return rc;
+    if ((rc = ensure(ctx, ctx->scales, sizeof(double)))) return rc;
+    if ((rc = ensure(ctx, ctx->peaks, sizeof(PeakOut)))) return rc;
+    const int nl = 2 * max_lag - 1;
+    float *dump = nullptr;
+    if (lags_out) {
+        if ((rc = ensure(ctx, ctx->lagdump, sizeof(float) * (size_t)nl))) return rc;
+        dump = static_cast<float *>(ctx->lagdump.p);
+        HIPCHK(ctx, hipMemsetAsync(dump, 0, sizeof(float) * (size_t)nl, ctx->stream));
+    }
+    double scale = 1.0 / (4.0 * (double)n * std::sqrt((double)n1));
+    HIPCHK(ctx, hipMemsetAsync(ctx->keys.p, 0, sizeof(unsigned long long), ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->scales.p, &scale, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    rc = run_fm_batch(ctx, d_sw, 2, (int)std::max(n1, n2), d_pw, 1, static_cast<unsigned long long *>(ctx->keys.p),
+                      pl, -(max_lag - 1), max_lag - 1, dump, 1.0f, (double)(n1 + n2));
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_decode_peaks, dim3(1), dim3(64), 0, ctx->stream,
+                       static_cast<unsigned long long *>(ctx->keys.p), static_cast<double *>(ctx->scales.p),
+                       static_cast<PeakOut *>(ctx->peaks.p), 1);
+    tdoa_peak pk;
+    HIPCHK(ctx, hipMemcpyAsync(&pk, ctx->peaks.p, sizeof(pk), hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<float> hl;
+    if (lags_out) {
+        hl.resize(nl);
+        HIPCHK(ctx, hipMemcpyAsync(hl.data(), dump, sizeof(float) * (size_t)nl, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    prof_collect(ctx);
+    if (peak) *peak = pk;
+    if (lags_out)
+        for (int i = 0; i < nl; i++) lags_out[i] = (double)hl[i] * scale;
+    return TDOA_OK;
+}
+
+}  // namespace
+
+// ===========================================================================
+// lifecycle
+// ===========================================================================
+extern "C" {
+
+void tdoa_default_params(tdoa_params *p)
+{
+    if (!p) return;
+    p->sample_rate = 2000000.0;   // processor.go:440
+    p->max_lag = 20000;           // processor.go:633
+    p->corr_block = 1000;         // processor.go:682
+    p->weak_threshold = 0.001;    // processor.go:476
+    p->window_len = 2000000;      // processor.go:772
+    p->device = 0;
+    p->windows_per_batch = 0;
+}
+
+int tdoa_abi_version(void) { return TDOA_ABI_VERSION; }
+
+int tdoa_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+const char *tdoa_strerror(int status)
+{
+    switch (status) {
+        case TDOA_OK: return "ok";
+        case TDOA_ERR_INVALID: return "invalid argument";
+        case TDOA_ERR_NO_DEVICE: return "no HIP device (this library has no CPU fallback)";
+        case TDOA_ERR_HIP: return "HIP runtime error";
+        case TDOA_ERR_NOMEM: return "out of device memory";
+        case TDOA_ERR_UNSUPPORTED: return "unsupported size";
+        case TDOA_ERR_STATE: return "invalid call order";
+        default: return "unknown status";
+    }
+}
+
+const char *tdoa_last_error(const tdoa_ctx *ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+const char *tdoa_kernel_name(int k)
+{
+    static const char *names[TDOA_K_COUNT] = {"k_fm_stats", "k_fwd_col_u8", "k_fwd_row", "k_inv_row_pair",
+                                              "k_inv_col_peak", "k_decode_peaks"};
+    return (k >= 0 && k < TDOA_K_COUNT) ? names[k] : "";
+}
+
+int tdoa_create(const tdoa_params *p, tdoa_ctx **out)
+{
+    if (!out) return TDOA_ERR_INVALID;
+    *out = nullptr;
+    tdoa_params prm;
+    if (p)
+        prm = *p;
+    else
+        tdoa_default_params(&prm);
+    if (prm.max_lag < 1 || prm.corr_block < 1 || prm.window_len < 2 || !(prm.sample_rate > 0))
+        return TDOA_ERR_INVALID;
+    int ndev = tdoa_device_count();
+    if (ndev <= 0 || prm.device < 0 || prm.device >= ndev) return TDOA_ERR_NO_DEVICE;
+    if (hipSetDevice(prm.device) != hipSuccess) return TDOA_ERR_NO_DEVICE;
+    tdoa_ctx *ctx = new (std::nothrow) tdoa_ctx();
+    if (!ctx) return TDOA_ERR_NOMEM;
+    ctx->prm = prm;
+    ctx->device = prm.device;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return TDOA_ERR_HIP;
+    }
+    *out = ctx;
+    return TDOA_OK;
+}
+
+void tdoa_destroy(tdoa_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    prof_collect(ctx);
+    tdoa_capture_clear(ctx);
+    DevBuf *bufs[] = {&ctx->sw_desc, &ctx->pw_desc, &ctx->partials, &ctx->stats, &ctx->tz, &ctx->v, &ctx->keys,
+                      &ctx->scales, &ctx->peaks, &ctx->scratch_a, &ctx->scratch_b, &ctx->lagdump,
+                      &ctx->ex_a, &ctx->ex_b, &ctx->ex_c, &ctx->ex_d, &ctx->ex_part};
+    for (DevBuf *b : bufs) release(*b);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+// ===========================================================================
+// mode B
+// ===========================================================================
+
+int tdoa_capture_upload(tdoa_ctx *ctx, int station, const uint8_t *iq, size_t n_samples)
+{
+    int rc;
+    if ((rc = check_ctx(ctx))) return rc;
+    if (station < 0 || station > 1023 || (!iq && n_samples)) return fail(ctx, TDOA_ERR_INVALID, "bad station/iq");
+    if ((size_t)station >= ctx->caps.size()) ctx->caps.resize(station + 1);
+    auto &c = ctx->caps[station];
+    if (c.owned && c.dev) (void)hipFree(const_cast<uint8_t *>(c.dev));
+    c = tdoa_ctx::Capture{};
+    void *d = nullptr;
+    hipError_t e = hipMalloc(&d, 2 * n_samples + 64);
+    if (e != hipSuccess) return fail(ctx, TDOA_ERR_NOMEM, "hipMalloc capture", e);
+    e = hipMemcpy(d, iq, 2 * n_samples, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(d);
+        return fail(ctx, TDOA_ERR_HIP, "hipMemcpy capture", e);
+    }
+    c.dev = static_cast<const uint8_t *>(d);
+    c.n = n_samples;
+    c.owned = true;
+    return TDOA_OK;
+}
+
+int tdoa_capture_attach_device(tdoa_ctx *ctx, int station, const void *dev_iq, size_t n_samples)
+{
+    int rc;
+    if ((rc = check_ctx(ctx))) return rc;
+    if (station < 0 || station > 1023 || !dev_iq || ((uintptr_t)dev_iq & 1)) return fail(ctx, TDOA_ERR_INVALID, "bad station/pointer");
+    if ((size_t)station >= ctx->caps.size()) ctx->caps.resize(station + 1);
+    auto &c = ctx->caps[station];
+    if (c.owned && c.dev) (void)hipFree(const_cast<uint8_t *>(c.dev));
+    c.dev = static_cast<const uint8_t *>(dev_iq);
+    c.n = n_samples;
+    c.owned = false;
+    return TDOA_OK;
+}
+
+int tdoa_capture_clear(tdoa_ctx *ctx)
+{
+    if (!ctx) return TDOA_ERR_INVALID;
+    for (auto &c : ctx->caps)
+        if (c.owned && c.dev) (void)hipFree(const_cast<uint8_t *>(c.dev));
+    ctx->caps.clear();
+    return TDOA_OK;
+}
+
+static int window_geometry(const tdoa_ctx *ctx, long long *block, long long *wlen, int *wpb)
+{
+    if (ctx->caps.size() < 2) return TDOA_ERR_STATE;
+    size_t nmin = (size_t)-1;
+    for (auto &c : ctx->caps) {
+        if (!c.dev) return TDOA_ERR_STATE;
+        nmin = std::min(nmin, c.n);
+    }
+    long long b = (long long)(nmin / 3);   // processor.go:214
+    if (b < 2) return TDOA_ERR_UNSUPPORTED;
+    long long l = std::min<long long>(ctx->prm.window_len, b);
+    *block = b;
+    *wlen = l;
+    *wpb = (int)std::max<long long>(1, b / l);
+    return TDOA_OK;
+}
+
+int tdoa_num_windows(const tdoa_ctx *ctx, int *windows_per_block, int *n_windows_total)
+{
+    if (!ctx) return TDOA_ERR_INVALID;
+    long long b, l;
+    int wpb;
+    int rc = window_geometry(ctx, &b, &l, &wpb);
+    if (rc) return rc;
+    if (windows_per_block) *windows_per_block = wpb;
+    if (n_windows_total) *n_windows_total = 3 * wpb;
+    return TDOA_OK;
+}
+
+int tdoa_num_pairs(const tdoa_ctx *ctx)
+{
+    if (!ctx) return 0;
+    int s = (int)ctx->caps.size();
+    return s * (s - 1) / 2;
+}
+
+int tdoa_plan_info(const tdoa_ctx *ctx, int64_t *fft_n, int32_t *n1, int32_t *n2)
+{
+    if (!ctx || !ctx->plan_n) return TDOA_ERR_STATE;
+    if (fft_n) *fft_n = ctx->plan_n;
+    if (n1) *n1 = ctx->plan.N1;
+    if (n2) *n2 = ctx->plan.N2;
+    return TDOA_OK;
+}
+
+int tdoa_process(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host, void *out_dev)
+{
+    int rc;
+    if ((rc = check_ctx(ctx))) return rc;
+    if (world < 1 || rank < 0 || rank >= world) return fail(ctx, TDOA_ERR_INVALID, "bad rank/world");
+    long long block, wlen;
+    int wpb;
+    if ((rc = window_geometry(ctx, &block, &wlen, &wpb))) return fail(ctx, rc, "captures missing or too small");
+    const int S = (int)ctx->caps.size();
+    const int P = S * (S - 1) / 2;
+    const int W = 3 * wpb;
+    const long long n = std::max<long long>(next_pow2(wlen + ctx->prm.max_lag), 64);
+    FftPlan pl;
+    if ((rc = make_plan(n, true, &pl))) return fail(ctx, rc, "FFT size unsupported");
+    ctx->plan = pl;
+    ctx->plan_n = n;
+
+    std::vector<int> mine;
+    for (int w = rank; w < W; w += world) mine.push_back(w);
+    int per_batch = ctx->prm.windows_per_batch > 0 ? ctx->prm.windows_per_batch : 8;
+    // keep the batch workspace under ~24 GiB
+    const double bytes_per_window = 8.0 * (double)pl.Nc * (S + P);
+    per_batch = (int)std::max(1.0, std::min<double>(per_batch, 24.0 * 1073741824.0 / bytes_per_window));
+
+    // all descriptors, uploaded once
+    std::vector<SWDesc> sw(mine.size() * (size_t)S);
+    std::vector<PWDesc> pw(mine.size() * (size_t)P);
+    for (size_t wi = 0; wi < mine.size(); wi++) {
+        int wid = mine[wi];
+        long long off = (long long)(wid / wpb) * block + (long long)(wid % wpb) * wlen;
+        int local = (int)(wi % per_batch);
+        for (int s = 0; s < S; s++) sw[wi * S + s] = SWDesc{ctx->caps[s].dev + 2 * off, (int32_t)wlen, 0};
+        int p = 0;
+        for (int i = 0; i < S; i++)
+            for (int j = i + 1; j < S; j++, p++)
+                pw[wi * P + p] = PWDesc{local * S + i, local * S + j, wid * P + p, (int32_t)wlen};
+    }
+    const size_t slots = (size_t)W * P;
+    if ((rc = ensure(ctx, ctx->keys, sizeof(unsigned long long) * slots))) return rc;
+    if ((rc = ensure(ctx, ctx->scales, sizeof(double) * slots))) return rc;
+    if ((rc = ensure(ctx, ctx->peaks, sizeof(PeakOut) * slots))) return rc;
+    if ((rc = ensure(ctx, ctx->sw_desc, sizeof(SWDesc) * std::max<size_t>(sw.size(), 1)))) return rc;
+    if ((rc = ensure(ctx, ctx->pw_desc, sizeof(PWDesc) * std::max<size_t>(pw.size(), 1)))) return rc;
+    std::vector<double> scales(slots, 1.0 / (4.0 * (double)n * std::sqrt((double)wlen)));
+    hipStream_t st = ctx->stream;
+    HIPCHK(ctx, hipMemsetAsync(ctx->keys.p, 0, sizeof(unsigned long long) * slots, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->scales.p, scales.data(), sizeof(double) * slots, hipMemcpyHostToDevice, st));
+    if (!sw.empty()) {
+        HIPCHK(ctx, hipMemcpyAsync(ctx->sw_desc.p, sw.data(), sizeof(SWDesc) * sw.size(), hipMemcpyHostToDevice, st));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->pw_desc.p, pw.data(), sizeof(PWDesc) * pw.size(), hipMemcpyHostToDevice, st));
+    }
+    HIPCHK(ctx, hipStreamSynchronize(st));   // host vectors go out of scope below
+
+    for (size_t w0 = 0; w0 < mine.size(); w0 += per_batch) {
+        int nw = (int)std::min<size_t>(per_batch, mine.size() - w0);
+        rc = run_fm_batch(ctx, static_cast<SWDesc *>(ctx->sw_desc.p) + w0 * S, nw * S, (int)wlen,
+                          static_cast<PWDesc *>(ctx->pw_desc.p) + w0 * P, nw * P,
+                          static_cast<unsigned long long *>(ctx->keys.p), pl, -(ctx->prm.max_lag - 1),
+                          ctx->prm.max_lag - 1, nullptr, 1.0f, (double)wlen * nw * S);
+        if (rc) return rc;
+    }
+    {
+        ProfScope ps(ctx, TDOA_K_PEAK, 32.0 * (double)slots);
+        hipLaunchKernelGGL(k_decode_peaks, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, st,
+                           static_cast<unsigned long long *>(ctx->keys.p), static_cast<double *>(ctx->scales.p),
+                           static_cast<PeakOut *>(ctx->peaks.p), (int)slots);
+    }
+    if (out_dev)
+        HIPCHK(ctx, hipMemcpyAsync(out_dev, ctx->peaks.p, sizeof(PeakOut) * slots, hipMemcpyDeviceToDevice, st));
+    if (out_host)
+        HIPCHK(ctx, hipMemcpyAsync(out_host, ctx->peaks.p, sizeof(PeakOut) * slots, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    prof_collect(ctx);
+    return TDOA_OK;
+}
+
+int tdoa_process_u8(tdoa_ctx *ctx, const uint8_t *const *station_iq, const size_t *n_samples, int n_stations,
+                    tdoa_peak *out)
+{
+    if (!ctx || !station_iq || !n_samples || n_stations < 2 || !out) return fail(ctx, TDOA_ERR_INVALID, "bad argument");
+    int rc = tdoa_capture_clear(ctx);
+    for (int s = 0; s < n_stations && !rc; s++) rc = tdoa_capture_upload(ctx, s, station_iq[s], n_samples[s]);
+    if (rc) return rc;
+    return tdoa_process(ctx, 0, 1, out, nullptr);
+}
+
+int tdoa_fm_xcorr_u8(tdoa_ctx *ctx, const uint8_t *iq1, size_t n1, const uint8_t *iq2, size_t n2, int max_lag,
+                     tdoa_peak *peak)
+{
+    if (!peak) return fail(ctx, TDOA_ERR_INVALID, "peak is NULL");
+    return fm_pair(ctx, iq1, n1, iq2, n2, max_lag, peak, nullptr);
+}
+
+int tdoa_fm_xcorr_lags_u8(tdoa_ctx *ctx, const uint8_t *iq1, size_t n1, const uint8_t *iq2, size_t n2, int max_lag,
+                          double *lags_out)
+{
+    if (!lags_out) return fail(ctx, TDOA_ERR_INVALID, "lags_out is NULL");
+    return fm_pair(ctx, iq1, n1, iq2, n2, max_lag, nullptr, lags_out);
+}
+
+int tdoa_fm_preprocess_u8(tdoa_ctx *ctx, const uint8_t *iq, size_t n, float *out_f32, tdoa_fm_stats *stats)
+{
+    int rc;
+    if ((rc = check_ctx(ctx))) return rc;
+    if (!iq || n == 0 || n > 0x3fffffff) return fail(ctx, TDOA_ERR_INVALID, "bad argument");
+    if ((rc = ensure(ctx, ctx->scratch_a, 2 * n + 16))) return rc;
+    if ((rc = ensure(ctx, ctx->scratch_b, sizeof(float) * n))) return rc;
+    if ((rc = ensure(ctx, ctx->sw_desc, sizeof(SWDesc)))) return rc;
+    const int chunks = (int)((n + kStatsChunk - 1) / kStatsChunk);
+    if ((rc = ensure(ctx, ctx->partials, sizeof(StatsPartial) * (size_t)chunks))) return rc;
+    if ((rc = ensure(ctx, ctx->stats, sizeof(FmStats)))) return rc;
+    hipStream_t st = ctx->stream;
+    SWDesc sw = {static_cast<uint8_t *>(ctx->scratch_a.p), (int32_t)n, 0};
+    HIPCHK(ctx, hipMemcpyAsync(ctx->scratch_a.p, iq, 2 * n, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->sw_desc.p, &sw, sizeof(sw), hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    auto *d_sw = static_cast<SWDesc *>(ctx->sw_desc.p);
+    hipLaunchKernelGGL(k_fm_stats, dim3(chunks, 1), dim3(kStatsThreads), 0, st, d_sw,
+                       static_cast<StatsPartial *>(ctx->partials.p), chunks);
+    hipLaunchKernelGGL(k_fm_stats_final, dim3(1), dim3(64), 0, st, d_sw, static_cast<StatsPartial *>(ctx->partials.p),
+                       chunks, static_cast<FmStats *>(ctx->stats.p), 1);
+    hipLaunchKernelGGL(k_fm_dump, dim3((unsigned)((n + 255) / 256), 1), dim3(256), 0, st, d_sw,
+                       static_cast<FmStats *>(ctx->stats.p), static_cast<float *>(ctx->scratch_b.p));
+    HIPCHK(ctx, hipGetLastError());
+    if (out_f32) HIPCHK(ctx, hipMemcpyAsync(out_f32, ctx->scratch_b.p, sizeof(float) * n, hipMemcpyDeviceToHost, st));
+    if (stats) HIPCHK(ctx, hipMemcpyAsync(stats, ctx->stats.p, sizeof(FmStats), hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    return TDOA_OK;
+}
+
+// ===========================================================================
+// measurement
+// ===========================================================================
+int tdoa_profile_enable(tdoa_ctx *ctx, int on)
+{
+    if (!ctx) return TDOA_ERR_INVALID;
+    ctx->profiling = on != 0;
+    return TDOA_OK;
+}
+
+int tdoa_profile_reset(tdoa_ctx *ctx)
+{
+    if (!ctx) return TDOA_ERR_INVALID;
+    prof_collect(ctx);
+    for (int k = 0; k < TDOA_K_COUNT; k++) {
+        ctx->prof_ms[k] = 0;
+        ctx->prof_launches[k] = 0;
+        ctx->prof_bytes[k] = 0;
+    }
+    return TDOA_OK;
+}
+
+int tdoa_profile_get(tdoa_ctx *ctx, int kernel, double *total_ms, int64_t *launches, double *algorithmic_bytes)
+{
+    if (!ctx || kernel < 0 || kernel >= TDOA_K_COUNT) return TDOA_ERR_INVALID;
+    if (total_ms) *total_ms = ctx->prof_ms[kernel];
+    if (launches) *launches = ctx->prof_launches[kernel];
+    if (algorithmic_bytes) *algorithmic_bytes = ctx->prof_bytes[kernel];
+    return TDOA_OK;
+}
+
+// ===========================================================================
+// downstream geodesy / solver (host)
+// ===========================================================================
+void tdoa_latlon_to_ecef(double lat, double lon, double elev, double xyz[3]) { geo::latlon_to_ecef(lat, lon, elev, xyz); }
+void tdoa_ecef_to_latlon(double x, double y, double z, double lle[3]) { geo::ecef_to_latlon(x, y, z, lle); }
+int tdoa_solve_3station(const double stations_lle[9], const double *range_diff, double out_lle[3], int *iterations)
+{
+    if (!stations_lle || !range_diff || !out_lle) return TDOA_ERR_INVALID;
+    return geo::solve_3station(stations_lle, range_diff, out_lle, iterations) ? TDOA_ERR_INVALID : TDOA_OK;
+}
+
+}  // extern "C"
+
+#include "exact_reference_api.inc"

@@ -1,0 +1,47 @@
+"""Builds libtdoa_mi355x.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+import os
+import shutil
+import subprocess
+
+PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(PKG_ROOT, "csrc")
+LIB = os.path.join(PKG_ROOT, "libtdoa_mi355x.so")
+HEADER = os.path.join(os.path.dirname(PKG_ROOT), "include", "tdoa_mi355x.h")
+
+
+def _sources():
+    out = [HEADER]
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith((".hip", ".hpp", ".inc", ".cpp", ".h")):
+            out.append(os.path.join(CSRC, f))
+    return out
+
+
+def hipcc():
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: the MI355X library cannot be built")
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(s) > t for s in _sources())
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return LIB
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-Wall", "-Wno-unused-function",
+           "-o", LIB, os.path.join(CSRC, "tdoa_mi355x.hip")]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

@@ -1,0 +1,317 @@
+"""ctypes binding of include/tdoa_mi355x.h.  No CPU fallback: loading fails loudly if the
+HIP library is missing, and every compute call raises TdoaError on a non-zero status."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+OK = 0
+KERNELS = ["STATS", "FWD_COL", "FWD_ROW", "INV_ROW", "INV_COL", "PEAK"]
+
+
+class TdoaError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__("tdoa_mi355x status %d: %s" % (status, msg))
+        self.status = status
+
+
+class Params(C.Structure):
+    _fields_ = [("sample_rate", C.c_double), ("max_lag", C.c_int32), ("corr_block", C.c_int32),
+                ("weak_threshold", C.c_double), ("window_len", C.c_int64),
+                ("device", C.c_int32), ("windows_per_batch", C.c_int32)]
+
+
+class Peak(C.Structure):
+    _fields_ = [("lag", C.c_int32), ("abs_corr", C.c_float), ("corr", C.c_double)]
+
+
+PEAK_DTYPE = np.dtype([("lag", np.int32), ("abs_corr", np.float32), ("corr", np.float64)])
+
+
+class FmStats(C.Structure):
+    _fields_ = [("s1", C.c_int64), ("s2_lo", C.c_uint64), ("s2_hi", C.c_uint64),
+                ("mean", C.c_float), ("scale", C.c_float)]
+
+
+# every symbol include/tdoa_mi355x.h declares
+SYMBOLS = [
+    "tdoa_default_params", "tdoa_create", "tdoa_destroy", "tdoa_strerror", "tdoa_last_error",
+    "tdoa_abi_version", "tdoa_device_count",
+    "tdoa_load_iq_u8", "tdoa_preprocess_c64", "tdoa_time_domain_correlation_c64",
+    "tdoa_cross_correlate_c64", "tdoa_simple_correlate_c64", "tdoa_fast_snr_u8",
+    "tdoa_capture_upload", "tdoa_capture_attach_device", "tdoa_capture_clear",
+    "tdoa_num_windows", "tdoa_num_pairs", "tdoa_process", "tdoa_process_u8",
+    "tdoa_fm_xcorr_u8", "tdoa_fm_preprocess_u8", "tdoa_fm_xcorr_lags_u8",
+    "tdoa_latlon_to_ecef", "tdoa_ecef_to_latlon", "tdoa_solve_3station",
+    "tdoa_profile_enable", "tdoa_profile_reset", "tdoa_profile_get", "tdoa_kernel_name",
+    "tdoa_plan_info",
+]
+
+_lib = None
+
+
+def library_path():
+    return _build.LIB
+
+
+def load(build_if_missing=True):
+    """Load the shared library (building it with hipcc if absent).  Raises if impossible."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if build_if_missing and _build.needs_build():
+        _build.build()
+    if not os.path.exists(_build.LIB):
+        raise RuntimeError("libtdoa_mi355x.so is missing; run tdoa_amd.build.build() (needs hipcc)")
+    L = C.CDLL(_build.LIB)
+    vp, sz = C.c_void_p, C.c_size_t
+    fp, u8p, dp = C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.POINTER(C.c_double)
+    i32p = C.POINTER(C.c_int32)
+    L.tdoa_default_params.argtypes = [C.POINTER(Params)]
+    L.tdoa_default_params.restype = None
+    L.tdoa_create.argtypes = [C.POINTER(Params), C.POINTER(vp)]
+    L.tdoa_destroy.argtypes = [vp]
+    L.tdoa_destroy.restype = None
+    L.tdoa_strerror.argtypes = [C.c_int]
+    L.tdoa_strerror.restype = C.c_char_p
+    L.tdoa_last_error.argtypes = [vp]
+    L.tdoa_last_error.restype = C.c_char_p
+    L.tdoa_kernel_name.argtypes = [C.c_int]
+    L.tdoa_kernel_name.restype = C.c_char_p
+    L.tdoa_load_iq_u8.argtypes = [vp, u8p, sz, fp]
+    L.tdoa_preprocess_c64.argtypes = [vp, fp, sz, fp, C.POINTER(C.c_int)]
+    L.tdoa_time_domain_correlation_c64.argtypes = [vp, fp, sz, fp, sz, C.c_int, i32p, dp]
+    L.tdoa_cross_correlate_c64.argtypes = [vp, fp, sz, fp, sz, i32p, dp]
+    L.tdoa_simple_correlate_c64.argtypes = [vp, fp, sz, fp, sz, i32p, fp]
+    L.tdoa_fast_snr_u8.argtypes = [vp, u8p, C.c_int, dp]
+    L.tdoa_capture_upload.argtypes = [vp, C.c_int, u8p, sz]
+    L.tdoa_capture_attach_device.argtypes = [vp, C.c_int, vp, sz]
+    L.tdoa_capture_clear.argtypes = [vp]
+    L.tdoa_num_windows.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.tdoa_num_pairs.argtypes = [vp]
+    L.tdoa_process.argtypes = [vp, C.c_int, C.c_int, vp, vp]
+    L.tdoa_process_u8.argtypes = [vp, C.POINTER(u8p), C.POINTER(sz), C.c_int, vp]
+    L.tdoa_fm_xcorr_u8.argtypes = [vp, u8p, sz, u8p, sz, C.c_int, C.POINTER(Peak)]
+    L.tdoa_fm_preprocess_u8.argtypes = [vp, u8p, sz, fp, C.POINTER(FmStats)]
+    L.tdoa_fm_xcorr_lags_u8.argtypes = [vp, u8p, sz, u8p, sz, C.c_int, dp]
+    L.tdoa_latlon_to_ecef.argtypes = [C.c_double, C.c_double, C.c_double, dp]
+    L.tdoa_latlon_to_ecef.restype = None
+    L.tdoa_ecef_to_latlon.argtypes = [C.c_double, C.c_double, C.c_double, dp]
+    L.tdoa_ecef_to_latlon.restype = None
+    L.tdoa_solve_3station.argtypes = [dp, dp, dp, C.POINTER(C.c_int)]
+    L.tdoa_profile_enable.argtypes = [vp, C.c_int]
+    L.tdoa_profile_reset.argtypes = [vp]
+    L.tdoa_profile_get.argtypes = [vp, C.c_int, dp, C.POINTER(C.c_int64), dp]
+    L.tdoa_plan_info.argtypes = [vp, C.POINTER(C.c_int64), i32p, i32p]
+    _lib = L
+    return L
+
+
+def default_params():
+    p = Params()
+    load().tdoa_default_params(C.byref(p))
+    return p
+
+
+def _u8(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint8))
+
+
+def _f(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _d(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _c64(x):
+    a = np.ascontiguousarray(x, dtype=np.complex64)
+    return a, a.view(np.float32)
+
+
+class Context:
+    """One tdoa_ctx (one GPU, single caller)."""
+
+    def __init__(self, **kw):
+        self._L = load()
+        p = default_params()
+        for k, v in kw.items():
+            if not hasattr(p, k):
+                raise TypeError("unknown parameter %r" % k)
+            setattr(p, k, v)
+        self.params = p
+        h = C.c_void_p()
+        rc = self._L.tdoa_create(C.byref(p), C.byref(h))
+        if rc != OK:
+            raise TdoaError(rc, self._L.tdoa_strerror(rc).decode())
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.tdoa_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _chk(self, rc):
+        if rc != OK:
+            detail = self._L.tdoa_last_error(self._h).decode()
+            raise TdoaError(rc, "%s (%s)" % (self._L.tdoa_strerror(rc).decode(), detail))
+
+    # ---- mode A ------------------------------------------------------------
+    def load_iq_u8(self, raw):
+        raw = np.ascontiguousarray(raw, dtype=np.uint8)
+        n = raw.size // 2
+        out = np.empty(n, dtype=np.complex64)
+        self._chk(self._L.tdoa_load_iq_u8(self._h, _u8(raw), n, _f(out.view(np.float32))))
+        return out
+
+    def preprocess(self, sig):
+        a, v = _c64(sig)
+        out = np.empty_like(a)
+        weak = C.c_int()
+        self._chk(self._L.tdoa_preprocess_c64(self._h, _f(v), a.size, _f(out.view(np.float32)), C.byref(weak)))
+        return out, bool(weak.value)
+
+    def time_domain_correlation(self, s1, s2, max_lag):
+        a, va = _c64(s1)
+        b, vb = _c64(s2)
+        d, c = C.c_int32(), C.c_double()
+        self._chk(self._L.tdoa_time_domain_correlation_c64(self._h, _f(va), a.size, _f(vb), b.size, int(max_lag),
+                                                           C.byref(d), C.byref(c)))
+        return d.value, c.value
+
+    def cross_correlate(self, s1, s2):
+        a, va = _c64(s1)
+        b, vb = _c64(s2)
+        d, c = C.c_int32(), C.c_double()
+        self._chk(self._L.tdoa_cross_correlate_c64(self._h, _f(va), a.size, _f(vb), b.size, C.byref(d), C.byref(c)))
+        return d.value, c.value
+
+    def simple_correlate(self, s1, s2):
+        a, va = _c64(s1)
+        b, vb = _c64(s2)
+        d, c = C.c_int32(), C.c_float()
+        self._chk(self._L.tdoa_simple_correlate_c64(self._h, _f(va), a.size, _f(vb), b.size, C.byref(d), C.byref(c)))
+        return d.value, c.value
+
+    def fast_snr(self, samples_u8, total_samples):
+        s = np.ascontiguousarray(samples_u8, dtype=np.uint8)
+        out = C.c_double()
+        self._chk(self._L.tdoa_fast_snr_u8(self._h, _u8(s), int(total_samples), C.byref(out)))
+        return out.value
+
+    # ---- mode B ------------------------------------------------------------
+    def capture_upload(self, station, iq_u8):
+        s = np.ascontiguousarray(iq_u8, dtype=np.uint8)
+        self._chk(self._L.tdoa_capture_upload(self._h, int(station), _u8(s), s.size // 2))
+
+    def capture_attach_device(self, station, dev_ptr, n_samples):
+        self._chk(self._L.tdoa_capture_attach_device(self._h, int(station), C.c_void_p(int(dev_ptr)), int(n_samples)))
+
+    def capture_clear(self):
+        self._chk(self._L.tdoa_capture_clear(self._h))
+
+    def num_windows(self):
+        a, b = C.c_int(), C.c_int()
+        self._chk(self._L.tdoa_num_windows(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def num_pairs(self):
+        return self._L.tdoa_num_pairs(self._h)
+
+    def process(self, rank=0, world=1, out_dev_ptr=None, want_host=True):
+        wpb, w = self.num_windows()
+        p = self.num_pairs()
+        out = np.zeros((w, p), dtype=PEAK_DTYPE) if want_host else None
+        self._chk(self._L.tdoa_process(self._h, int(rank), int(world),
+                                       out.ctypes.data_as(C.c_void_p) if want_host else None,
+                                       C.c_void_p(int(out_dev_ptr)) if out_dev_ptr else None))
+        return out
+
+    def process_u8(self, captures):
+        caps = [np.ascontiguousarray(c, dtype=np.uint8) for c in captures]
+        n = len(caps)
+        ptrs = (C.POINTER(C.c_uint8) * n)(*[_u8(c) for c in caps])
+        sizes = (C.c_size_t * n)(*[c.size // 2 for c in caps])
+        blk = min(c.size // 2 for c in caps) // 3
+        wl = min(self.params.window_len, blk)
+        w = 3 * max(1, blk // wl) if blk >= 2 else 0
+        out = np.zeros((w, n * (n - 1) // 2), dtype=PEAK_DTYPE)
+        self._chk(self._L.tdoa_process_u8(self._h, ptrs, sizes, n, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def fm_xcorr(self, iq1, iq2, max_lag):
+        a = np.ascontiguousarray(iq1, dtype=np.uint8)
+        b = np.ascontiguousarray(iq2, dtype=np.uint8)
+        pk = Peak()
+        self._chk(self._L.tdoa_fm_xcorr_u8(self._h, _u8(a), a.size // 2, _u8(b), b.size // 2, int(max_lag), C.byref(pk)))
+        return pk.lag, pk.corr
+
+    def fm_xcorr_lags(self, iq1, iq2, max_lag):
+        a = np.ascontiguousarray(iq1, dtype=np.uint8)
+        b = np.ascontiguousarray(iq2, dtype=np.uint8)
+        out = np.zeros(2 * max_lag - 1, dtype=np.float64)
+        self._chk(self._L.tdoa_fm_xcorr_lags_u8(self._h, _u8(a), a.size // 2, _u8(b), b.size // 2, int(max_lag), _d(out)))
+        return out
+
+    def fm_preprocess(self, iq):
+        a = np.ascontiguousarray(iq, dtype=np.uint8)
+        out = np.empty(a.size // 2, dtype=np.float32)
+        st = FmStats()
+        self._chk(self._L.tdoa_fm_preprocess_u8(self._h, _u8(a), a.size // 2, _f(out), C.byref(st)))
+        return out, st
+
+    # ---- measurement -------------------------------------------------------
+    def profile_enable(self, on=True):
+        self._chk(self._L.tdoa_profile_enable(self._h, 1 if on else 0))
+
+    def profile_reset(self):
+        self._chk(self._L.tdoa_profile_reset(self._h))
+
+    def profile(self):
+        out = {}
+        for k, name in enumerate(KERNELS):
+            ms, n, b = C.c_double(), C.c_int64(), C.c_double()
+            self._chk(self._L.tdoa_profile_get(self._h, k, C.byref(ms), C.byref(n), C.byref(b)))
+            out[self._L.tdoa_kernel_name(k).decode()] = {"ms": ms.value, "launches": n.value, "bytes": b.value}
+        return out
+
+    def plan_info(self):
+        n, n1, n2 = C.c_int64(), C.c_int32(), C.c_int32()
+        self._chk(self._L.tdoa_plan_info(self._h, C.byref(n), C.byref(n1), C.byref(n2)))
+        return n.value, n1.value, n2.value
+
+
+def latlon_to_ecef(lat, lon, elev):
+    out = np.zeros(3)
+    load().tdoa_latlon_to_ecef(lat, lon, elev, _d(out))
+    return out
+
+
+def ecef_to_latlon(x, y, z):
+    out = np.zeros(3)
+    load().tdoa_ecef_to_latlon(x, y, z, _d(out))
+    return out
+
+
+def solve_3station(stations_lle, range_diff):
+    st = np.ascontiguousarray(stations_lle, dtype=np.float64).reshape(9)
+    rd = np.ascontiguousarray(range_diff, dtype=np.float64)
+    out = np.zeros(3)
+    it = C.c_int()
+    rc = load().tdoa_solve_3station(_d(st), _d(rd), _d(out), C.byref(it))
+    return rc, out, it.value

@@ -1,0 +1,132 @@
+"""GPU parity tests for the north-star (mode B) path, through the C ABI:
+u8 IQ -> K1 discriminator -> K2 Stockham FFT -> K3 conj-multiply -> K4 inverse -> K5 argmax.
+Oracle: oracle/tdoa_oracle.c (ob_* functions, f64 time domain)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-5      # north_star: correlation magnitudes within 1e-5 relative
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import tdoa_amd
+    c = tdoa_amd.Context(max_lag=500, window_len=10000)
+    yield c
+    c.close()
+
+
+def _assert_lags_close(got, want, tol=REL_TOL):
+    peak = np.abs(want).max()
+    assert peak > 0
+    err = np.abs(got - want).max() / peak
+    assert err < tol, "max lag error %.3g of peak" % err
+
+
+def test_k1_discriminator_bit_exact(ctx, oracle):
+    raw = oracle.simulate_station("kx0u", 20000, oracle.SEED_BASE)
+    for lo, n in ((0, 20000), (40000, 12345), (80002, 777)):   # byte offsets: even sample starts
+        iq = raw[lo:lo + 2 * n]
+        got, st = ctx.fm_preprocess(iq)
+        want, ost = oracle.b_preprocess(iq)
+        assert (st.s1, st.s2_lo, st.s2_hi) == (ost.s1, ost.s2_lo, ost.s2_hi)
+        assert np.float32(st.mean).tobytes() == np.float32(ost.mean).tobytes()
+        assert np.float32(st.scale).tobytes() == np.float32(ost.scale).tobytes()
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_k1_bit_exact_on_random_bytes(ctx, oracle):
+    rng = np.random.default_rng(11)
+    iq = rng.integers(0, 256, size=2 * 200000, dtype=np.uint8)
+    iq[:8] = [0, 0, 255, 255, 0, 255, 255, 0]                  # extremes
+    got, st = ctx.fm_preprocess(iq)
+    want, ost = oracle.b_preprocess(iq)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert (st.s1, st.s2_lo, st.s2_hi) == (ost.s1, ost.s2_lo, ost.s2_hi)
+
+
+@pytest.mark.parametrize("n1,n2,max_lag", [
+    (40, 40, 8),            # N = 64: smallest plan (N2 = 2)
+    (1000, 900, 100),       # N = 2048: N2 = 16
+    (3001, 3001, 257),      # odd lengths
+    (30000, 30000, 2000),   # N = 32768
+    (70000, 66000, 600),    # N = 131072: 4096-point rows
+])
+def test_xcorr_all_lags_vs_oracle(ctx, oracle, n1, n2, max_lag):
+    a = oracle.simulate_delayed_fm(n1, 0, 1001, 7)
+    b = oracle.simulate_delayed_fm(n2, 5, 1001, 8)
+    got = ctx.fm_xcorr_lags(a, b, max_lag)
+    ta, _ = oracle.b_preprocess(a)
+    tb, _ = oracle.b_preprocess(b)
+    want = oracle.b_xcorr_all_lags(ta, tb, max_lag)
+    _assert_lags_close(got, want)
+    lag, corr = ctx.fm_xcorr(a, b, max_lag)
+    olag, ocorr = oracle.b_pick_peak(want, max_lag)
+    assert lag == olag
+    assert abs(corr - ocorr) <= REL_TOL * abs(ocorr)
+
+
+@pytest.mark.parametrize("delay", [0, 1, 37, -37, 113, -114, 499])
+def test_peak_finds_true_delay(ctx, oracle, delay):
+    n = 20000
+    # station b delayed by `delay` samples relative to a (negative: a delayed)
+    a = oracle.simulate_delayed_fm(n, max(0, -delay), 4242, 1)
+    b = oracle.simulate_delayed_fm(n, max(0, delay), 4242, 2)
+    lag, corr = ctx.fm_xcorr(a, b, 500)
+    ta, _ = oracle.b_preprocess(a)
+    tb, _ = oracle.b_preprocess(b)
+    olag, ocorr = oracle.b_xcorr_peak(ta, tb, 500)
+    assert lag == delay == olag
+    assert abs(corr - ocorr) <= REL_TOL * abs(ocorr)
+
+
+def test_empty_and_tiny_inputs(ctx, oracle):
+    a = oracle.simulate_delayed_fm(100, 0, 1, 1)
+    assert ctx.fm_xcorr(np.zeros(0, np.uint8), a, 10) == (0, 0.0)     # processor.go:622-625
+    flat = np.full(2 * 64, 128, np.uint8)                              # constant capture: zero phase
+    lag, corr = ctx.fm_xcorr(flat, flat, 10)
+    assert (lag, corr) == (0, 0.0)
+
+
+def test_process_batched_matches_oracle(oracle):
+    import tdoa_amd
+    block, wl, ml = 30000, 10000, 300
+    caps = [oracle.simulate_station(nm, block, oracle.SEED_BASE + i, tx_power=200000.0)
+            for i, nm in enumerate(oracle.COLLECTORS)]
+    with tdoa_amd.Context(max_lag=ml, window_len=wl, windows_per_batch=2) as c:
+        peaks = c.process_u8(caps)
+        assert peaks.shape == (9, 3)
+        pairs = [(0, 1), (0, 2), (1, 2)]                               # processor.go:816-817 order
+        for wid in range(9):
+            off = (wid // 3) * block + (wid % 3) * wl
+            pre = [oracle.b_preprocess(cp[2 * off:2 * (off + wl)])[0] for cp in caps]
+            for p, (i, j) in enumerate(pairs):
+                olag, ocorr = oracle.b_xcorr_peak(pre[i], pre[j], ml)
+                assert peaks[wid, p]["lag"] == olag, (wid, p)
+                assert abs(peaks[wid, p]["corr"] - ocorr) <= REL_TOL * abs(ocorr)
+        # sharded run (rank r of 2) reproduces exactly the windows it owns
+        for r in range(2):
+            part = c.process(rank=r, world=2)
+            for wid in range(9):
+                if wid % 2 == r:
+                    assert np.array_equal(part[wid], peaks[wid])
+                else:
+                    assert not part[wid]["lag"].any() and not part[wid]["corr"].any()
+
+
+def test_full_size_window_vs_f64_fft(oracle):
+    """BASELINE config 2 geometry: L = 2 000 000, max_lag 20000, N = 2^21."""
+    import tdoa_amd
+    n = 2_000_000
+    a = oracle.simulate_delayed_fm(n, 0, 99, 3)
+    b = oracle.simulate_delayed_fm(n, 57, 99, 4)
+    with tdoa_amd.Context() as c:
+        lag, corr = c.fm_xcorr(a, b, 20000)
+        lags = c.fm_xcorr_lags(a, b, 20000)
+    ta, _ = oracle.b_preprocess(a)
+    tb, _ = oracle.b_preprocess(b)
+    olag, ocorr, want = oracle.b_xcorr_peak_fft(ta, tb, 20000)
+    assert lag == olag == 57
+    assert abs(corr - ocorr) <= REL_TOL * abs(ocorr)
+    _assert_lags_close(lags, want)
