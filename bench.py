@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""bench.py -- IQ Msamples/s through demod + xcorr on MI355X (BASELINE.json metric).
+
+A step = one pass of the hot path (u8 IQ -> FM discriminator -> FFT -> conj-multiply ->
+inverse FFT -> peak pick) over one synthetic capture set already resident in HBM:
+BASELINE config 2 -- 3 stations x 2 Msps x 100 s (400 MB each, blocks [ref|target|ref] of
+66 666 666 samples), windows of L = 2 000 000 samples, N = 2^21, all 3 pairs on all 99
+windows.  With N ranks (one per GPU, torch.distributed over RCCL) every rank owns its own
+capture set (weak scaling) and the per-pair peaks are collected with one all-gather.
+
+Prints ONE JSON line on rank 0 (see the contract in the task description).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "tdoa-geolocation_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+# lat-lon-table.csv rows of the three collectors + simulator.go:229 example transmitter
+STATIONS = [
+    (41.18660274289527, -95.96064116595667, 355.69),   # kx0u
+    (41.24669616513154, -96.08366304481238, 329.0),    # n3pay
+    (41.32916620016985, -96.03513381562004, 373.18),   # kf0mtl
+]
+TX = (41.20, -96.00, 400.0)
+SEED_BASE = 0x5D0A0000
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured achievable)
+
+
+def cpu_baseline_leg(ctx, peaks, block, wlen, max_lag, budget_s):
+    """Times the CPU oracle (restatement of processor.go crossCorrelate) on the host cores on a
+    bounded sample of the same bytes, and uses the same oracle to check the GPU peaks of
+    window 0.  This is the only place bench.py touches oracle/."""
+    import numpy as np
+    from oracle import pyoracle as o
+    o.build()
+    cores = os.cpu_count() or 1
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    # --- parity of the timed GPU path on window 0 (mode B oracle, f64 FFT form)
+    w0 = [ctx.capture_download(s, 0, wlen) for s in range(3)]
+    pre = [o.b_preprocess(x)[0] for x in w0]
+    parity = True
+    for p, (i, j) in enumerate([(0, 1), (0, 2), (1, 2)]):
+        olag, ocorr, _ = o.b_xcorr_peak_fft(pre[i], pre[j], max_lag)
+        g = peaks[0, p]
+        if int(g["lag"]) != olag or abs(float(g["corr"]) - ocorr) > 1e-5 * abs(ocorr):
+            parity = False
+    # --- CPU baseline: reference call pattern (3 pairs, reference-frequency block) on the
+    # first n samples of each station's capture; calibrate n to the time budget
+    def run(n):
+        sig = [o.iq_u8_to_c64(x[:2 * n]) for x in w0]
+        t0 = time.perf_counter()
+        for (i, j) in [(0, 1), (0, 2), (1, 2)]:
+            o.cross_correlate(sig[i], sig[j])
+        return time.perf_counter() - t0
+    n = 20000
+    t = run(n)
+    n_big = int(min(wlen, max(n, n * budget_s / max(t, 1e-3))))
+    if n_big > 2 * n:
+        n, t = n_big, run(n_big)
+    return {
+        "value": round(3 * n / t / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
+        "sample": "oracle restatement of processor.go crossCorrelate (weak-signal filter chain + "
+                  "time-domain correlation), 3 pairs on the first %d samples of each station's "
+                  "reference block, same bytes as the GPU run, OpenMP over %d threads, %.1f s" % (n, cores, t),
+    }, parity
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--seconds", type=float, default=100.0, help="capture length per station")
+    ap.add_argument("--batch", type=int, default=0, help="windows per launch group (0 = library default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=15.0)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import tdoa_amd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    fs = 2_000_000
+    wlen, max_lag = 2_000_000, 20000
+    total = int(args.seconds * fs)
+    block = total // 3
+    ctx = tdoa_amd.Context(device=local_rank, window_len=wlen, max_lag=max_lag, windows_per_batch=args.batch)
+    for s in range(3):
+        ctx.synth_capture(s, block, STATIONS[s], TX, SEED_BASE + 16 * rank + s)
+    wpb, n_windows = ctx.num_windows()
+    n_pairs = ctx.num_pairs()
+    samples_per_step = 3 * n_windows * min(wlen, block)
+
+    peak_bytes = n_windows * n_pairs * 16
+    dev_peaks = torch.zeros(peak_bytes, dtype=torch.uint8, device="cuda")
+    gathered = torch.zeros(peak_bytes * world, dtype=torch.uint8, device="cuda") if world > 1 else None
+
+    def step():
+        ctx.process(0, 1, out_dev_ptr=dev_peaks.data_ptr(), want_host=False)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, dev_peaks)      # RCCL over xGMI: per-pair peaks
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ctx.profile_enable(True)
+    ctx.profile_reset()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    ctx.profile_enable(False)
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    prof = ctx.profile()
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = samples_per_step * world / (dt / args.steps) / 1e6
+        dom = max(prof.items(), key=lambda kv: kv[1]["ms"])
+        name, rec = dom
+        roof = None
+        if rec["launches"]:
+            per_launch_bytes = rec["bytes"] / rec["launches"]
+            avg_s = rec["ms"] / rec["launches"] / 1e3
+            achieved = per_launch_bytes / avg_s / 1e9
+            roof = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "algorithmic_bytes_per_launch": per_launch_bytes,
+                    "avg_launch_us": round(avg_s * 1e6, 2), "launches": rec["launches"],
+                    "kernels_ms_per_step": {k: round(v["ms"] / args.steps, 4) for k, v in prof.items()}}
+        n_fft, n1, n2 = ctx.plan_info()
+        # whole-pipeline algorithmic bytes: 2L + 12N per station-window, 16N per pair-window
+        a_bytes = n_windows * (3 * (2 * wlen + 12 * n_fft) + n_pairs * 16 * n_fft)
+        out = {
+            "metric": "IQ Msamples/s through demod+xcorr", "value": round(value, 2), "unit": "Msamples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE config 2: 3 stations x 2 Msps x %g s simulator.go-style capture per GPU, "
+                                   "3 pairs x %d windows of %d samples, FFT N=%d (%dx%d), max_lag %d"
+                                   % (args.seconds, n_windows, wlen, n_fft, n1, n2, max_lag),
+                       "stations": 3, "pairs": n_pairs, "windows": n_windows, "window_len": wlen,
+                       "fft_n": n_fft, "parallelism": "window-sharded x%d + RCCL all-gather of peaks" % world},
+            "pipeline_algorithmic_GBps": round(a_bytes * world / (dt / args.steps) / 1e9, 1),
+            "pipeline_frac_of_hbm_peak": round(a_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            peaks = np.frombuffer(dev_peaks.cpu().numpy().tobytes(), dtype=tdoa_amd.capi.PEAK_DTYPE).reshape(
+                n_windows, n_pairs)
+            out["cpu_baseline"], out["parity_window0"] = cpu_baseline_leg(ctx, peaks, block, min(wlen, block),
+                                                                           max_lag, args.cpu_budget)
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -124,6 +124,13 @@ int tdoa_capture_upload(tdoa_ctx *ctx, int station, const uint8_t *iq, size_t n_
 /* or attach a buffer that is already in this device's memory (not copied, not freed) */
 int tdoa_capture_attach_device(tdoa_ctx *ctx, int station, const void *dev_iq, size_t n_samples);
 int tdoa_capture_clear(tdoa_ctx *ctx);
+/* synthesise a simulator.go-style capture (tones + uniform noise, carrier-phase delay,
+ * [ref | target | ref] blocks of block_samples; simulator.go:100-161) directly in HBM */
+int tdoa_synth_capture(tdoa_ctx *ctx, int station, size_t block_samples, double ref_freq, double tgt_freq,
+                       double noise_level, const double station_lle[3], const double tx_lle[3],
+                       double tx_power, uint64_t seed);
+/* read back part of a capture that lives in HBM */
+int tdoa_capture_download(tdoa_ctx *ctx, int station, size_t first_sample, size_t n_samples, uint8_t *out);
 
 int tdoa_num_windows(const tdoa_ctx *ctx, int *windows_per_block, int *n_windows_total);
 int tdoa_num_pairs(const tdoa_ctx *ctx);

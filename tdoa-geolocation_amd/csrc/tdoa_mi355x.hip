@@ -20,6 +20,7 @@
 #include "k1_discriminator.hpp"
 #include "fft_stockham.hpp"
 #include "exact_reference.hpp"
+#include "synth_capture.hpp"
 #include "host_geodesy.hpp"
 
 using namespace tdoa;
@@ -476,6 +477,62 @@ int tdoa_capture_attach_device(tdoa_ctx *ctx, int station, const void *dev_iq, s
     c.dev = static_cast<const uint8_t *>(dev_iq);
     c.n = n_samples;
     c.owned = false;
+    return TDOA_OK;
+}
+
+int tdoa_synth_capture(tdoa_ctx *ctx, int station, size_t block_samples, double ref_freq, double tgt_freq,
+                       double noise_level, const double station_lle[3], const double tx_lle[3], double tx_power,
+                       uint64_t seed)
+{
+    int rc;
+    if ((rc = check_ctx(ctx))) return rc;
+    if (station < 0 || station > 1023 || block_samples < 2 || !station_lle || !tx_lle)
+        return fail(ctx, TDOA_ERR_INVALID, "bad argument");
+    if ((size_t)station >= ctx->caps.size()) ctx->caps.resize(station + 1);
+    auto &c = ctx->caps[station];
+    if (c.owned && c.dev) (void)hipFree(const_cast<uint8_t *>(c.dev));
+    c = tdoa_ctx::Capture{};
+    void *d = nullptr;
+    hipError_t e = hipMalloc(&d, 6 * block_samples + 64);
+    if (e != hipSuccess) return fail(ctx, TDOA_ERR_NOMEM, "hipMalloc capture", e);
+    // simulator.go:104-120: distance -> travel time -> carrier phase; amplitude power/d*0.1
+    double a[3], b[3];
+    geo::latlon_to_ecef(station_lle[0], station_lle[1], station_lle[2], a);
+    geo::latlon_to_ecef(tx_lle[0], tx_lle[1], tx_lle[2], b);
+    const double dist = geo::range(a, b);
+    const double travel = dist / geo::kC;
+    const double fs = ctx->prm.sample_rate;
+    const double phase = 2 * geo::kPi * tgt_freq * travel;
+    const double amp = tx_power / dist * 0.1;
+    SynthBlock blk[3] = {
+        {2 * geo::kPi * ref_freq / fs, 0.0, 0.01, noise_level, seed, 1},      // simulator.go:126-128
+        {2 * geo::kPi * tgt_freq / fs, phase, amp, noise_level, seed, 2},     // simulator.go:131-133
+        {2 * geo::kPi * ref_freq / fs, 0.0, 0.01, noise_level, seed, 3},      // simulator.go:136-138
+    };
+    const long long n = (long long)block_samples;
+    for (int k = 0; k < 3; k++)
+        hipLaunchKernelGGL(k_synth_tone_block, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                           static_cast<uint8_t *>(d) + 2 * n * k, n, blk[k]);
+    e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        (void)hipFree(d);
+        return fail(ctx, TDOA_ERR_HIP, "synth kernels", e);
+    }
+    c.dev = static_cast<const uint8_t *>(d);
+    c.n = 3 * block_samples;
+    c.owned = true;
+    return TDOA_OK;
+}
+
+int tdoa_capture_download(tdoa_ctx *ctx, int station, size_t first_sample, size_t n_samples, uint8_t *out)
+{
+    int rc;
+    if ((rc = check_ctx(ctx))) return rc;
+    if (station < 0 || (size_t)station >= ctx->caps.size() || !ctx->caps[station].dev || !out)
+        return fail(ctx, TDOA_ERR_INVALID, "no such capture");
+    const auto &c = ctx->caps[station];
+    if (first_sample > c.n || n_samples > c.n - first_sample) return fail(ctx, TDOA_ERR_INVALID, "range outside capture");
+    HIPCHK(ctx, hipMemcpy(out, c.dev + 2 * first_sample, 2 * n_samples, hipMemcpyDeviceToHost));
     return TDOA_OK;
 }
 

@@ -42,6 +42,7 @@ SYMBOLS = [
     "tdoa_load_iq_u8", "tdoa_preprocess_c64", "tdoa_time_domain_correlation_c64",
     "tdoa_cross_correlate_c64", "tdoa_simple_correlate_c64", "tdoa_fast_snr_u8",
     "tdoa_capture_upload", "tdoa_capture_attach_device", "tdoa_capture_clear",
+    "tdoa_synth_capture", "tdoa_capture_download",
     "tdoa_num_windows", "tdoa_num_pairs", "tdoa_process", "tdoa_process_u8",
     "tdoa_fm_xcorr_u8", "tdoa_fm_preprocess_u8", "tdoa_fm_xcorr_lags_u8",
     "tdoa_latlon_to_ecef", "tdoa_ecef_to_latlon", "tdoa_solve_3station",
@@ -89,6 +90,9 @@ def load(build_if_missing=True):
     L.tdoa_capture_upload.argtypes = [vp, C.c_int, u8p, sz]
     L.tdoa_capture_attach_device.argtypes = [vp, C.c_int, vp, sz]
     L.tdoa_capture_clear.argtypes = [vp]
+    L.tdoa_synth_capture.argtypes = [vp, C.c_int, sz, C.c_double, C.c_double, C.c_double, dp, dp, C.c_double,
+                                     C.c_uint64]
+    L.tdoa_capture_download.argtypes = [vp, C.c_int, sz, sz, u8p]
     L.tdoa_num_windows.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.tdoa_num_pairs.argtypes = [vp]
     L.tdoa_process.argtypes = [vp, C.c_int, C.c_int, vp, vp]
@@ -221,6 +225,18 @@ class Context:
 
     def capture_attach_device(self, station, dev_ptr, n_samples):
         self._chk(self._L.tdoa_capture_attach_device(self._h, int(station), C.c_void_p(int(dev_ptr)), int(n_samples)))
+
+    def synth_capture(self, station, block_samples, station_lle, tx_lle, seed, ref_freq=162.4e6,
+                      tgt_freq=101.7e6, noise=0.01, tx_power=1000.0):
+        st = np.ascontiguousarray(station_lle, dtype=np.float64)
+        tx = np.ascontiguousarray(tx_lle, dtype=np.float64)
+        self._chk(self._L.tdoa_synth_capture(self._h, int(station), int(block_samples), ref_freq, tgt_freq, noise,
+                                             _d(st), _d(tx), tx_power, int(seed)))
+
+    def capture_download(self, station, first_sample, n_samples):
+        out = np.empty(2 * int(n_samples), dtype=np.uint8)
+        self._chk(self._L.tdoa_capture_download(self._h, int(station), int(first_sample), int(n_samples), _u8(out)))
+        return out
 
     def capture_clear(self):
         self._chk(self._L.tdoa_capture_clear(self._h))
