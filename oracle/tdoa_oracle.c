@@ -20,6 +20,15 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* Go calls math.Cos and math.Sin separately.  gcc would merge cos(x) and sin(x) of one
+ * argument into a single sincos() call, whose results differ from sin()/cos() in the
+ * last bit for a few arguments; route sin through a volatile copy to keep two calls. */
+static inline double sin_sep(double x)
+{
+    volatile double v = x;
+    return sin(v);
+}
+
 /* ------------------------------------------------------------------------ */
 /* Go complex helpers                                                        */
 /* ------------------------------------------------------------------------ */
@@ -412,7 +421,7 @@ void o_simple_dft(const float *sig, int n, float *out)
         float sr = 0.0f, si = 0.0f;
         for (int j = 0; j < n; j++) {
             double angle = -2.0 * M_PI * (double)((long)k * (long)j) / (double)n;
-            float tr = (float)cos(angle), ti = (float)sin(angle);
+            float tr = (float)cos(angle), ti = (float)sin_sep(angle);
             float pr, pi;
             c64_mul(sig[2 * j], sig[2 * j + 1], tr, ti, &pr, &pi);
             sr = sr + pr;
@@ -508,7 +517,7 @@ void o_fast_dft(const double *in, int n_in, double *out)
     for (int k = 0; k < n; k++) {
         double angle = -2 * M_PI * (double)k / (double)n;
         tw[2 * k] = cos(angle);
-        tw[2 * k + 1] = sin(angle);
+        tw[2 * k + 1] = sin_sep(angle);
     }
 #pragma omp parallel for schedule(static)
     for (int k = 0; k < n; k++) {
@@ -658,7 +667,7 @@ void o_latlon_to_ecef(double lat, double lon, double elev, double xyz[3])
     double e2 = 2 * f - f * f;
     double lat_r = lat * M_PI / 180;
     double lon_r = lon * M_PI / 180;
-    double sl = sin(lat_r), cl = cos(lat_r), so = sin(lon_r), co = cos(lon_r);
+    double sl = sin_sep(lat_r), cl = cos(lat_r), so = sin_sep(lon_r), co = cos(lon_r);
     double N = a / sqrt(1 - e2 * sl * sl);
     xyz[0] = (N + elev) * cl * co;
     xyz[1] = (N + elev) * cl * so;
@@ -682,11 +691,11 @@ void o_ecef_to_latlon(double x, double y, double z, double lle[3])
     double lon = atan2(y, x);
     double lat = atan2(z, p * (1 - e2));
     for (int i = 0; i < 5; i++) {
-        double N = a / sqrt(1 - e2 * sin(lat) * sin(lat));
+        double N = a / sqrt(1 - e2 * sin_sep(lat) * sin_sep(lat));
         double elev = p / cos(lat) - N;
         lat = atan2(z, p * (1 - e2 * N / (N + elev)));
     }
-    double N = a / sqrt(1 - e2 * sin(lat) * sin(lat));
+    double N = a / sqrt(1 - e2 * sin_sep(lat) * sin_sep(lat));
     double elev = p / cos(lat) - N;
     lle[0] = lat * 180.0 / M_PI;
     lle[1] = lon * 180.0 / M_PI;
@@ -799,7 +808,7 @@ static void sim_block_perfect(uint8_t *out, size_t n, double freq, double fs, do
     for (long i = 0; i < (long)n; i++) {
         double t = (double)i / fs;
         float re = (float)(amp * cos(omega * t + phase));
-        float im = (float)(amp * sin(omega * t + phase));
+        float im = (float)(amp * sin_sep(omega * t + phase));
         uint64_t ctr = (block_id << 40) + (uint64_t)i;
         float ni = (float)(noise * (2 * o_rand_float64(seed, 2 * ctr) - 1));
         float nq = (float)(noise * (2 * o_rand_float64(seed, 2 * ctr + 1) - 1));
@@ -843,7 +852,7 @@ static void sim_block_weak(uint8_t *out, size_t n, double freq, double fs, doubl
         double t = (double)i / fs;
         double drift = (double)(i + 1) * (np.drift / fs);
         double cur = omega * t + phase + drift;
-        double re = amp * cos(cur), im = amp * sin(cur);
+        double re = amp * cos(cur), im = amp * sin_sep(cur);
         re += np.dc;
         im += np.dc;
         uint64_t ctr = ((block_id << 40) + (uint64_t)i) * 8;
@@ -868,7 +877,7 @@ static void sim_block_strong(uint8_t *out, size_t n, double freq, double fs, dou
 #pragma omp parallel for schedule(static)
     for (long i = 0; i < (long)n; i++) {
         double t = (double)i / fs;
-        double re = amp * cos(omega * t + phase), im = amp * sin(omega * t + phase);
+        double re = amp * cos(omega * t + phase), im = amp * sin_sep(omega * t + phase);
         uint64_t ctr = ((block_id << 40) + (uint64_t)i) * 8;
         re += 0.001 * rand_norm(seed, ctr);
         im += 0.001 * rand_norm(seed, ctr + 1);
@@ -916,7 +925,7 @@ void o_simulate_delayed_fm(uint8_t *out, size_t n, int delay, double mod_index, 
         if (i < 0)
             continue;
         double theta = mod_index * (s / msg_rms);
-        double re = 0.5 * cos(theta), im = 0.5 * sin(theta);
+        double re = 0.5 * cos(theta), im = 0.5 * sin_sep(theta);
         float fr = (float)re + (float)(noise * (2 * o_rand_float64(noise_seed, 2 * (uint64_t)i) - 1));
         float fi = (float)im + (float)(noise * (2 * o_rand_float64(noise_seed, 2 * (uint64_t)i + 1) - 1));
         out[2 * i] = quantize_u8(fr);
