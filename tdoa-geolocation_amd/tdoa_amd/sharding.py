@@ -1,0 +1,59 @@
+"""Multi-GPU layout of the hot path: (pair, window) units are independent (processor.go:816-850
+is a plain double loop), so windows are dealt round-robin to ranks -- each rank transforms every
+station's window once and reuses the spectrum for all pairs -- and the only exchange is one
+all-gather of the fixed-size per-pair peak records (RCCL over xGMI on GPUs, gloo in CPU tests).
+"""
+import numpy as np
+
+from .capi import PEAK_DTYPE
+
+PEAK_BYTES = PEAK_DTYPE.itemsize  # 16
+
+
+def owned_windows(rank, world, n_windows):
+    """Window ids processed by `rank` (window-major sharding: wid % world == rank)."""
+    if world < 1 or not 0 <= rank < world:
+        raise ValueError("bad rank/world")
+    return list(range(rank, n_windows, world))
+
+
+def owner_of(wid, world):
+    return wid % world
+
+
+def peaks_as_bytes(peaks):
+    """structured peak array -> flat uint8 view (what travels through the collective)."""
+    a = np.ascontiguousarray(peaks, dtype=PEAK_DTYPE)
+    return a.view(np.uint8).reshape(-1)
+
+
+def bytes_as_peaks(buf, n_windows, n_pairs):
+    return np.frombuffer(np.ascontiguousarray(buf, dtype=np.uint8).tobytes(), dtype=PEAK_DTYPE).reshape(
+        n_windows, n_pairs).copy()
+
+
+def all_gather_peaks(local_bytes, dist, group=None):
+    """One all-gather of this rank's peak buffer (torch uint8 tensor, CPU or GPU).
+    Returns a [world, nbytes] tensor on every rank."""
+    import torch
+    world = dist.get_world_size(group)
+    out = torch.empty((world, local_bytes.numel()), dtype=torch.uint8, device=local_bytes.device)
+    if local_bytes.is_cuda:
+        dist.all_gather_into_tensor(out.view(-1), local_bytes.contiguous(), group=group)
+    else:  # gloo: list form
+        parts = [out[r] for r in range(world)]
+        dist.all_gather(parts, local_bytes.contiguous(), group=group)
+    return out
+
+
+def merge_sharded(gathered, n_windows, n_pairs):
+    """gathered[r] = rank r's [n_windows][n_pairs] peaks with other ranks' windows zero-filled
+    (tdoa_process(rank, world)); returns the complete array, each window taken from its owner."""
+    world = gathered.shape[0]
+    out = np.zeros((n_windows, n_pairs), dtype=PEAK_DTYPE)
+    for r in range(world):
+        part = bytes_as_peaks(np.asarray(gathered[r].cpu() if hasattr(gathered[r], "cpu") else gathered[r]),
+                              n_windows, n_pairs)
+        own = owned_windows(r, world, n_windows)
+        out[own] = part[own]
+    return out
