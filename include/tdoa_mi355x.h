@@ -155,6 +155,9 @@ int tdoa_fm_preprocess_u8(tdoa_ctx *ctx, const uint8_t *iq, size_t n, float *out
 int tdoa_fm_xcorr_lags_u8(tdoa_ctx *ctx, const uint8_t *iq1, size_t n1, const uint8_t *iq2, size_t n2,
                           int max_lag, double *lags_out /* [2*max_lag-1] */);
 
+/* tests only: run the any-size fallback kernels even where a hot-size kernel exists */
+int tdoa_debug_force_generic(tdoa_ctx *ctx, int on);
+
 /* ---- downstream (processor.go:125-163, 932-1045), host side ---------------- */
 void tdoa_latlon_to_ecef(double lat, double lon, double elev, double xyz[3]);
 void tdoa_ecef_to_latlon(double x, double y, double z, double lle[3]);

@@ -60,8 +60,10 @@ def lib():
         L.o_fast_snr.restype = C.c_double
         L.o_rand_float64.restype = C.c_double
         L.o_rand_float64.argtypes = [C.c_uint64, C.c_uint64]
-        L.ob_atan2.restype = C.c_float
-        L.ob_atan2.argtypes = [C.c_float, C.c_float]
+        L.ob_theta.restype = C.c_float
+        L.ob_theta.argtypes = [C.c_int, C.c_int]
+        L.ob_wrap_diff.restype = C.c_float
+        L.ob_wrap_diff.argtypes = [C.c_float, C.c_float]
         L.o_lowpass.argtypes = [fp, sz, C.c_int, fp]
         L.o_cutoff_window.argtypes = [C.c_double, C.c_double]
         L.o_lowpass_cutoff.argtypes = [fp, sz, C.c_double, C.c_double, fp]
@@ -340,8 +342,8 @@ def rand_float64(seed, counter):
 
 # --- mode B ------------------------------------------------------------------------
 
-def b_atan2(y, x):
-    return lib().ob_atan2(float(y), float(x))
+def b_theta(i, q):
+    return lib().ob_theta(int(i), int(q))
 
 
 def b_discriminate(iq_u8):

@@ -937,47 +937,51 @@ void o_simulate_delayed_fm(uint8_t *out, size_t n, int delay, double mod_index, 
 /* mode B oracle (north-star pipeline; definition in DESIGN.md section 3)    */
 /* ------------------------------------------------------------------------ */
 
-/* K1 arctangent: an explicit sequence of correctly-rounded f32 operations
- * (div, mul, add, sub; no FMA) so the device kernel can reproduce it bit for
- * bit.  |x|,|y| finite, not both zero.  Range reduction and the degree-9 odd
- * polynomial follow the classic single-precision Cephes form. */
-float ob_atan2(float y, float x)
+/* K1 sample angle: theta = arg(I + iQ) for odd integers I, Q in [-255, 255], as an explicit
+ * sequence of correctly rounded f32 operations that the device kernel repeats bit for bit:
+ *   t = min(|I|,|Q|) * RCP[max(|I|,|Q|)]      RCP[m] = f32(1/m) (table of correctly rounded reciprocals)
+ *   a = t * P(t*t)                              P: degree-7 Horner with fused multiply-adds
+ *   octant fix-ups (pi/2 - a, pi - a, -a)
+ * max error 1.7e-7 rad over all byte pairs. */
+static const float K1_C[8] = {
+    0x1.fffffcp-1f, -0x1.5551bcp-2f, 0x1.98f84ep-3f, -0x1.1f0f46p-3f,
+    0x1.95c0f4p-4f, -0x1.e655d6p-5f, 0x1.8bf058p-6f, -0x1.31f904p-8f,
+};
+#define K1_PI     3.1415927410125732f
+#define K1_PIO2   1.5707963705062866f
+#define K1_TWOPI  6.2831854820251465f
+
+float ob_theta(int I, int Q)
 {
-    float ax = fabsf(x), ay = fabsf(y);
-    float mx = ax > ay ? ax : ay;
-    float mn = ax > ay ? ay : ax;
-    float t = mn / mx;                       /* in [0,1] */
-    float base = 0.0f;
-    if (t > 0.4142135679721832f) {           /* tan(pi/8) */
-        base = 0.7853981852531433f;          /* pi/4 */
-        t = (t - 1.0f) / (t + 1.0f);
-    }
+    int ax = I < 0 ? -I : I, ay = Q < 0 ? -Q : Q;
+    int mx = ax > ay ? ax : ay, mn = ax > ay ? ay : ax;
+    float r = 1.0f / (float)mx;                  /* == RCP[mx] */
+    float t = (float)mn * r;
     float z = t * t;
-    float p = 8.05374449538e-2f * z;
-    p = p - 1.38776856032e-1f;
-    p = p * z;
-    p = p + 1.99777106478e-1f;
-    p = p * z;
-    p = p - 3.33329491539e-1f;
-    p = p * z;
-    p = p * t;
-    p = p + t;
-    float r = base + p;
-    if (ay > ax)
-        r = 1.5707963705062866f - r;         /* pi/2 */
-    if (x < 0.0f)
-        r = 3.1415927410125732f - r;         /* pi */
-    if (y < 0.0f)
-        r = -r;
-    return r;
+    float p = K1_C[7];
+    for (int k = 6; k >= 0; k--)
+        p = fmaf(p, z, K1_C[k]);
+    float a = p * t;
+    if (ay > ax) a = K1_PIO2 - a;
+    if (I < 0) a = K1_PI - a;
+    if (Q < 0) a = -a;
+    return a;
 }
 
-/* K1: u8 IQ -> phase difference.  With I=2b-255, Q=2b'-255 (exact odd
- * integers proportional to (b-127.5)/127.5 of processor.go:198-199):
- *   re = I_i*I_{i-1} + Q_i*Q_{i-1},  im = Q_i*I_{i-1} - I_i*Q_{i-1}
- *   phase_i = atan2(im, re)  (i >= 1),  phase_0 = phase_1.
- * x_i is never 0 for byte data, so the |p|^2 > 1e-10 gate of the prebuilt
- * binary's convertToInstantaneousFrequency never fires. */
+/* wrapped phase step theta1 - theta0 into [-pi, pi] (f32 subtract, one conditional +-2pi) */
+float ob_wrap_diff(float th1, float th0)
+{
+    float d = th1 - th0;
+    if (d > K1_PI) d = d - K1_TWOPI;
+    else if (d < -K1_PI) d = d + K1_TWOPI;
+    return d;
+}
+
+/* K1: u8 IQ -> phase-difference FM discriminator.  With I = 2b_I - 255, Q = 2b_Q - 255 (exact
+ * odd integers proportional to (b-127.5)/127.5 of processor.go:198-199, never zero):
+ *   phase_i = wrap(arg(x_i) - arg(x_{i-1})) = arg(x_i * conj(x_{i-1}))   (i >= 1),  phase_0 = phase_1.
+ * x_i is never 0 for byte data, so the |p|^2 > 1e-10 gate of the prebuilt binary's
+ * convertToInstantaneousFrequency never fires. */
 void ob_discriminate_u8(const uint8_t *iq, size_t n, float *phase)
 {
     if (n == 0)
@@ -988,11 +992,9 @@ void ob_discriminate_u8(const uint8_t *iq, size_t n, float *phase)
     }
 #pragma omp parallel for schedule(static)
     for (long i = 1; i < (long)n; i++) {
-        int I1 = 2 * (int)iq[2 * i] - 255, Q1 = 2 * (int)iq[2 * i + 1] - 255;
-        int I0 = 2 * (int)iq[2 * i - 2] - 255, Q0 = 2 * (int)iq[2 * i - 1] - 255;
-        int re = I1 * I0 + Q1 * Q0;
-        int im = Q1 * I0 - I1 * Q0;
-        phase[i] = ob_atan2((float)im, (float)re);
+        float t1 = ob_theta(2 * (int)iq[2 * i] - 255, 2 * (int)iq[2 * i + 1] - 255);
+        float t0 = ob_theta(2 * (int)iq[2 * i - 2] - 255, 2 * (int)iq[2 * i - 1] - 255);
+        phase[i] = ob_wrap_diff(t1, t0);
     }
     phase[0] = phase[1];
 }

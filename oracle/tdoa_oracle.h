@@ -121,7 +121,8 @@ void   o_simulate_delayed_fm(uint8_t *out, size_t n_samples, int delay_samples,
 double o_rand_float64(uint64_t seed, uint64_t counter);
 
 /* ---- mode B oracle (north-star pipeline) ----------- */
-float  ob_atan2(float y, float x);
+float  ob_theta(int I, int Q);
+float  ob_wrap_diff(float th1, float th0);
 void   ob_discriminate_u8(const uint8_t *iq, size_t n, float *phase);
 typedef struct {
     int64_t  s1;        /* sum of q_i = rint(phase_i * 2^28)            */

@@ -110,6 +110,8 @@ struct FftPlan {
 __global__ __launch_bounds__(256) void k_fwd_col_u8(const SWDesc *sw, const FmStats *stats, float2 *T, FftPlan pl)
 {
     extern __shared__ float2 lds[];
+    __shared__ float rcp[128];
+    k1_init_rcp(rcp);
     const int tile = pl.N2 << pl.logC;
     const SWDesc d = sw[blockIdx.y];
     const uint16_t *p = reinterpret_cast<const uint16_t *>(d.base);
@@ -121,8 +123,8 @@ __global__ __launch_bounds__(256) void k_fwd_col_u8(const SWDesc *sw, const FmSt
         long long m = (long long)n2 * pl.N1 + c0 + c;
         long long i0 = 2 * m;
         float v0 = 0.0f, v1 = 0.0f;
-        if (i0 < len) v0 = k1_normalise(k1_window_phase(p, (int)i0, len), mean, scale);
-        if (i0 + 1 < len) v1 = k1_normalise(k1_window_phase(p, (int)i0 + 1, len), mean, scale);
+        if (i0 < len) v0 = k1_normalise(k1_window_phase(p, (int)i0, len, rcp), mean, scale);
+        if (i0 + 1 < len) v1 = k1_normalise(k1_window_phase(p, (int)i0 + 1, len, rcp), mean, scale);
         lds[e] = make_float2(v0, v1);
     }
     __syncthreads();

@@ -4,62 +4,75 @@
 // Replaces (reference file:line): the u8 -> complex64 conversion of
 // processor.go:195-201 and, for the north-star pipeline, the instantaneous-
 // frequency demodulation that exists only in the prebuilt processor binary
-// (SURVEY.md section 8, row K1).  The arithmetic is an explicit sequence of
-// correctly rounded f32 operations so a CPU restatement can match it bit for bit.
+// (SURVEY.md section 8, row K1): phase_i = arg(x_i * conj(x_{i-1})), evaluated as the
+// wrapped difference of the per-sample angles arg(x_i).  The arithmetic is an explicit
+// sequence of correctly rounded f32 operations (table reciprocal, FMA Horner, no IEEE
+// division in the hot loop) so a CPU restatement can match it bit for bit.
 #pragma once
 
 #include "device_common.hpp"
 
 namespace tdoa {
 
-// atan2 for finite (y, x) not both zero: one or two IEEE divisions and a
-// degree-9 odd polynomial after reduction to |t| <= tan(pi/8).  No FMA.
-__device__ __forceinline__ float k1_atan2(float y, float x)
+// Reciprocal table RCP[k] = f32(1 / (2k+1)), k < 128, kept in LDS (random per-lane index).
+// Every kernel that evaluates K1 calls k1_init_rcp() once (it contains a barrier).
+__device__ __forceinline__ void k1_init_rcp(float *rcp)
 {
 #pragma clang fp contract(off)
-    float ax = fabsf(x), ay = fabsf(y);
-    float mx = ax > ay ? ax : ay;
-    float mn = ax > ay ? ay : ax;
-    float t = mn / mx;
-    float base = 0.0f;
-    if (t > 0.4142135679721832f) {
-        base = 0.7853981852531433f;
-        t = (t - 1.0f) / (t + 1.0f);
-    }
-    float z = t * t;
-    float p = 8.05374449538e-2f * z;
-    p = p - 1.38776856032e-1f;
-    p = p * z;
-    p = p + 1.99777106478e-1f;
-    p = p * z;
-    p = p - 3.33329491539e-1f;
-    p = p * z;
-    p = p * t;
-    p = p + t;
-    float r = base + p;
-    if (ay > ax) r = 1.5707963705062866f - r;
-    if (x < 0.0f) r = 3.1415927410125732f - r;
-    if (y < 0.0f) r = -r;
-    return r;
+    for (int k = threadIdx.x; k < 128; k += blockDim.x) rcp[k] = 1.0f / (float)(2 * k + 1);
+    __syncthreads();
 }
 
-// cur/prev: one IQ sample as uint16 (I | Q << 8).  Phase of x_cur * conj(x_prev)
-// with x = (2b - 255) (exact odd integers, never zero).
-__device__ __forceinline__ float k1_phase(unsigned int cur, unsigned int prev)
+// theta = arg(I + iQ), I = 2 b_I - 255, Q = 2 b_Q - 255, for one IQ sample s = b_I | b_Q << 8:
+// t = min * RCP[max], degree-7 Horner in t^2 with fused multiply-adds, octant fix-ups.
+// The same sequence of correctly rounded f32 operations as the CPU restatement (bit-exact).
+__device__ __forceinline__ float k1_theta(unsigned int s, const float *rcp)
 {
-    int I1 = 2 * (int)(cur & 0xffu) - 255, Q1 = 2 * (int)((cur >> 8) & 0xffu) - 255;
-    int I0 = 2 * (int)(prev & 0xffu) - 255, Q0 = 2 * (int)((prev >> 8) & 0xffu) - 255;
-    int re = I1 * I0 + Q1 * Q0;
-    int im = Q1 * I0 - I1 * Q0;
-    return k1_atan2((float)im, (float)re);
+#pragma clang fp contract(off)
+    // I = 2 b_I - 255 and Q = 2 b_Q - 255 as exact floats (byte -> float conversions)
+    const float fi = __builtin_fmaf(2.0f, (float)(s & 0xffu), -255.0f);
+    const float fq = __builtin_fmaf(2.0f, (float)((s >> 8) & 0xffu), -255.0f);
+    const float ax = fabsf(fi), ay = fabsf(fq);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    const float t = mn * rcp[(unsigned int)mx >> 1];
+    const float z = t * t;
+    float p = -0x1.31f904p-8f;
+    p = __builtin_fmaf(p, z, 0x1.8bf058p-6f);
+    p = __builtin_fmaf(p, z, -0x1.e655d6p-5f);
+    p = __builtin_fmaf(p, z, 0x1.95c0f4p-4f);
+    p = __builtin_fmaf(p, z, -0x1.1f0f46p-3f);
+    p = __builtin_fmaf(p, z, 0x1.98f84ep-3f);
+    p = __builtin_fmaf(p, z, -0x1.5551bcp-2f);
+    p = __builtin_fmaf(p, z, 0x1.fffffcp-1f);
+    float a = p * t;
+    a = ay > ax ? 1.5707963705062866f - a : a;
+    a = (s & 0x80u) ? a : 3.1415927410125732f - a;            // I < 0  <=>  b_I < 128
+    // Q < 0 (b_Q < 128): negate by flipping the sign bit
+    return __uint_as_float(__float_as_uint(a) ^ ((~s & 0x8000u) << 16));
+}
+
+// wrapped phase step theta1 - theta0
+__device__ __forceinline__ float k1_wrap_diff(float th1, float th0)
+{
+#pragma clang fp contract(off)
+    float d = th1 - th0;
+    if (d > 3.1415927410125732f) d = d - 6.2831854820251465f;
+    else if (d < -3.1415927410125732f) d = d + 6.2831854820251465f;
+    return d;
+}
+
+// phase of x_cur * conj(x_prev) for two IQ samples given as uint16 (I | Q << 8)
+__device__ __forceinline__ float k1_phase(unsigned int cur, unsigned int prev, const float *rcp)
+{
+    return k1_wrap_diff(k1_theta(cur, rcp), k1_theta(prev, rcp));
 }
 
 // phase of sample i of a window of len samples; sample 0 repeats sample 1
-__device__ __forceinline__ float k1_window_phase(const uint16_t *p, int i, int len)
+__device__ __forceinline__ float k1_window_phase(const uint16_t *p, int i, int len, const float *rcp)
 {
     if (len < 2) return 0.0f;
     int ii = i == 0 ? 1 : i;
-    return k1_phase(p[ii], p[ii - 1]);
+    return k1_phase(p[ii], p[ii - 1], rcp);
 }
 
 __device__ __forceinline__ float k1_normalise(float phase, float mean, float scale)
@@ -81,6 +94,8 @@ constexpr int kStatsThreads = 256;
 __global__ __launch_bounds__(kStatsThreads) void k_fm_stats(const SWDesc *sw, StatsPartial *partials,
                                                             int chunks_per_window)
 {
+    __shared__ float rcp[128];
+    k1_init_rcp(rcp);
     const SWDesc d = sw[blockIdx.y];
     const uint16_t *p = reinterpret_cast<const uint16_t *>(d.base);
     const int len = d.len;
@@ -88,7 +103,7 @@ __global__ __launch_bounds__(kStatsThreads) void k_fm_stats(const SWDesc *sw, St
     long long s1 = 0;
     unsigned long long lo = 0, hi = 0;
     for (int i = start + threadIdx.x; i < start + kStatsChunk && i < len; i += kStatsThreads) {
-        float ph = k1_window_phase(p, i, len);
+        float ph = k1_window_phase(p, i, len, rcp);
         long long q = (long long)__float2int_rn(ph * 268435456.0f);   // |q| < 2^30
         s1 += q;
         unsigned long long sq = (unsigned long long)(q * q);
@@ -173,11 +188,13 @@ __global__ void k_fm_stats_final(const SWDesc *sw, const StatsPartial *partials,
 // inspection hook: write the normalised discriminator output of one window
 __global__ void k_fm_dump(const SWDesc *sw, const FmStats *stats, float *out)
 {
+    __shared__ float rcp[128];
+    k1_init_rcp(rcp);
     const SWDesc d = sw[blockIdx.y];
     const uint16_t *p = reinterpret_cast<const uint16_t *>(d.base);
     const FmStats st = stats[blockIdx.y];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < d.len) out[i] = k1_normalise(k1_window_phase(p, i, d.len), st.mean, st.scale);
+    if (i < d.len) out[i] = k1_normalise(k1_window_phase(p, i, d.len, rcp), st.mean, st.scale);
 }
 
 }  // namespace tdoa

@@ -19,6 +19,7 @@
 #include "device_common.hpp"
 #include "k1_discriminator.hpp"
 #include "fft_stockham.hpp"
+#include "fft_radix16.hpp"
 #include "exact_reference.hpp"
 #include "synth_capture.hpp"
 #include "host_geodesy.hpp"
@@ -57,6 +58,7 @@ struct tdoa_ctx {
     DevBuf ex_a, ex_b, ex_c, ex_d, ex_part;
 
     bool profiling = false;
+    bool force_generic = false;   // tests: run the any-size kernels even at the hot sizes
     std::vector<ProfRec> recs;
     double prof_ms[TDOA_K_COUNT] = {0};
     int64_t prof_launches[TDOA_K_COUNT] = {0};
@@ -211,10 +213,10 @@ void prof_collect(tdoa_ctx *ctx)
 // sw/pw descriptors are already in device memory; maxlen = longest window.
 int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const PWDesc *d_pw, int n_pw,
                  unsigned long long *d_keys, const FftPlan &pl, int lag_lo, int lag_hi, float *lag_dump,
-                 float dump_scale, double sum_len)
+                 float dump_scale, double sum_len, unsigned align, bool even_len)
 {
     int rc;
-    const int chunks = std::max(1, (maxlen + kStatsChunk - 1) / kStatsChunk);
+    const int chunks = std::max(1, (maxlen + 7 + kStatsChunk - 1) / kStatsChunk);
     if ((rc = ensure(ctx, ctx->partials, sizeof(StatsPartial) * (size_t)chunks * n_sw))) return rc;
     if ((rc = ensure(ctx, ctx->stats, sizeof(FmStats) * (size_t)n_sw))) return rc;
     if ((rc = ensure(ctx, ctx->tz, sizeof(float2) * (size_t)pl.Nc * n_sw))) return rc;
@@ -226,36 +228,76 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
     hipStream_t st = ctx->stream;
     const double nc8 = 8.0 * (double)pl.Nc;
 
+    // hot-size kernels (fft_radix16.hpp) when the plan and the window alignment allow, else the
+    // any-size kernels of fft_stockham.hpp
+    const bool row16 = pl.N1 == 4096 && !ctx->force_generic;
+    const bool col16 = row16 && pl.N2 == 256 && (align & 3) == 0 && even_len;
+    const bool vec_stats = !ctx->force_generic;
+    int np = 0, nn = 0;
+    {
+        const long long n_real = 2 * pl.Nc;
+        np = lag_hi >= 0 ? (int)((lag_hi / 2) / pl.N1) + 1 : 0;
+        nn = lag_lo < 0 ? pl.N2 - (int)(((n_real + lag_lo) / 2) / pl.N1) : 0;
+    }
+    const bool pruned = !ctx->force_generic && pl.N1 >= 32 && pl.N2 <= 512 && np + nn <= kPruneMax && np + nn <= pl.N2 &&
+                        lag_hi < pl.Nc && lag_lo > -pl.Nc;
     {
         ProfScope ps(ctx, TDOA_K_STATS, 2.0 * sum_len);
-        hipLaunchKernelGGL(k_fm_stats, dim3(chunks, n_sw), dim3(kStatsThreads), 0, st, d_sw, partials, chunks);
-        hipLaunchKernelGGL(k_fm_stats_final, dim3((n_sw + 63) / 64), dim3(64), 0, st, d_sw, partials, chunks, stats,
-                           n_sw);
+        if (vec_stats) {
+            hipLaunchKernelGGL(k_fm_stats_vec, dim3(chunks, n_sw), dim3(kStatsThreads), 0, st, d_sw, partials, chunks);
+            hipLaunchKernelGGL(k_fm_stats_final_wave, dim3(n_sw), dim3(64), 0, st, d_sw, partials, chunks, stats);
+        } else {
+            hipLaunchKernelGGL(k_fm_stats, dim3(chunks, n_sw), dim3(kStatsThreads), 0, st, d_sw, partials, chunks);
+            hipLaunchKernelGGL(k_fm_stats_final, dim3((n_sw + 63) / 64), dim3(64), 0, st, d_sw, partials, chunks,
+                               stats, n_sw);
+        }
     }
     const size_t lds_col = sizeof(float2) * 2 * (size_t)pl.N2 * pl.C;
     const size_t lds_row = sizeof(float2) * 2 * (size_t)pl.N1;
     const size_t lds_row2 = sizeof(float2) * 4 * (size_t)pl.N1;
+    const size_t lds_col16 = sizeof(float2) * 256 * 32;
+    const size_t lds_pair16 = sizeof(float2) * 2 * kRowLds;
     if ((rc = set_lds(ctx, k_fwd_col_u8, lds_col))) return rc;
     if ((rc = set_lds(ctx, k_fwd_row, lds_row))) return rc;
     if ((rc = set_lds(ctx, k_inv_row_pair, lds_row2))) return rc;
     if ((rc = set_lds(ctx, k_inv_col_peak<true>, lds_col))) return rc;
+    if ((rc = set_lds(ctx, k_fwd_col256_u8, lds_col16))) return rc;
+    if ((rc = set_lds(ctx, k_inv_row_pair4096, lds_pair16))) return rc;
     {
         ProfScope ps(ctx, TDOA_K_FWD_COL, 2.0 * sum_len + nc8 * n_sw);
-        hipLaunchKernelGGL(k_fwd_col_u8, dim3(pl.N1 / pl.C, n_sw), dim3(256), lds_col, st, d_sw, stats, tz, pl);
+        if (col16)
+            hipLaunchKernelGGL(k_fwd_col256_u8, dim3(pl.N1 / 32, n_sw), dim3(512), lds_col16, st, d_sw, stats, tz, pl);
+        else
+            hipLaunchKernelGGL(k_fwd_col_u8, dim3(pl.N1 / pl.C, n_sw), dim3(256), lds_col, st, d_sw, stats, tz, pl);
     }
     {
         ProfScope ps(ctx, TDOA_K_FWD_ROW, 2.0 * nc8 * n_sw);
-        hipLaunchKernelGGL(k_fwd_row, dim3(pl.N2, n_sw), dim3(256), lds_row, st, tz, pl);
+        if (row16)
+            hipLaunchKernelGGL(k_fwd_row4096, dim3(pl.N2, n_sw), dim3(256), 0, st, tz, pl);
+        else
+            hipLaunchKernelGGL(k_fwd_row, dim3(pl.N2, n_sw), dim3(256), lds_row, st, tz, pl);
     }
     if (n_pw) {
         {
             ProfScope ps(ctx, TDOA_K_INV_ROW, 3.0 * nc8 * n_pw);
-            hipLaunchKernelGGL(k_inv_row_pair, dim3(pl.N2 / 2, n_pw), dim3(256), lds_row2, st, d_pw, tz, v, pl);
+            if (row16) {
+                if (pl.N2 > 2)
+                    hipLaunchKernelGGL(k_inv_row_pair4096, dim3(pl.N2 / 2 - 1, n_pw), dim3(256), lds_pair16, st, d_pw,
+                                       tz, v, pl);
+                // the two self-mirrored rows (0 and N2/2) stay with the generic kernel (block a = 0)
+                hipLaunchKernelGGL(k_inv_row_pair, dim3(1, n_pw), dim3(256), lds_row2, st, d_pw, tz, v, pl);
+            } else {
+                hipLaunchKernelGGL(k_inv_row_pair, dim3(pl.N2 / 2, n_pw), dim3(256), lds_row2, st, d_pw, tz, v, pl);
+            }
         }
         {
             ProfScope ps(ctx, TDOA_K_INV_COL, nc8 * n_pw);
-            hipLaunchKernelGGL(k_inv_col_peak<true>, dim3(pl.N1 / pl.C, n_pw), dim3(256), lds_col, st, v, d_keys,
-                               d_pw, pl, lag_lo, lag_hi, lag_dump, dump_scale);
+            if (pruned)
+                hipLaunchKernelGGL(k_inv_col_pruned, dim3(pl.N1 / 32, n_pw), dim3(256), 0, st, v, d_keys, d_pw, pl,
+                                   lag_lo, lag_hi, np, nn, lag_dump, dump_scale);
+            else
+                hipLaunchKernelGGL(k_inv_col_peak<true>, dim3(pl.N1 / pl.C, n_pw), dim3(256), lds_col, st, v, d_keys,
+                                   d_pw, pl, lag_lo, lag_hi, lag_dump, dump_scale);
         }
     }
     HIPCHK(ctx, hipGetLastError());
@@ -324,7 +366,8 @@ int fm_pair(tdoa_ctx *ctx, const uint8_t *iq1, size_t n1, const uint8_t *iq2, si
     HIPCHK(ctx, hipMemsetAsync(ctx->keys.p, 0, sizeof(unsigned long long), ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(ctx->scales.p, &scale, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     rc = run_fm_batch(ctx, d_sw, 2, (int)std::max(n1, n2), d_pw, 1, static_cast<unsigned long long *>(ctx->keys.p),
-                      pl, -(max_lag - 1), max_lag - 1, dump, 1.0f, (double)(n1 + n2));
+                      pl, -(max_lag - 1), max_lag - 1, dump, 1.0f, (double)(n1 + n2), 0u,
+                      n1 >= 2 && n2 >= 2 && !((n1 | n2) & 1));
     if (rc) return rc;
     hipLaunchKernelGGL(k_decode_peaks, dim3(1), dim3(64), 0, ctx->stream,
                        static_cast<unsigned long long *>(ctx->keys.p), static_cast<double *>(ctx->scales.p),
@@ -617,11 +660,15 @@ int tdoa_process(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host, void *
     // all descriptors, uploaded once
     std::vector<SWDesc> sw(mine.size() * (size_t)S);
     std::vector<PWDesc> pw(mine.size() * (size_t)P);
+    unsigned align = 0;   // OR of the low address bits of every window start
     for (size_t wi = 0; wi < mine.size(); wi++) {
         int wid = mine[wi];
         long long off = (long long)(wid / wpb) * block + (long long)(wid % wpb) * wlen;
         int local = (int)(wi % per_batch);
-        for (int s = 0; s < S; s++) sw[wi * S + s] = SWDesc{ctx->caps[s].dev + 2 * off, (int32_t)wlen, 0};
+        for (int s = 0; s < S; s++) {
+            sw[wi * S + s] = SWDesc{ctx->caps[s].dev + 2 * off, (int32_t)wlen, 0};
+            align |= (unsigned)((uintptr_t)(ctx->caps[s].dev + 2 * off) & 15u);
+        }
         int p = 0;
         for (int i = 0; i < S; i++)
             for (int j = i + 1; j < S; j++, p++)
@@ -648,7 +695,7 @@ int tdoa_process(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host, void *
         rc = run_fm_batch(ctx, static_cast<SWDesc *>(ctx->sw_desc.p) + w0 * S, nw * S, (int)wlen,
                           static_cast<PWDesc *>(ctx->pw_desc.p) + w0 * P, nw * P,
                           static_cast<unsigned long long *>(ctx->keys.p), pl, -(ctx->prm.max_lag - 1),
-                          ctx->prm.max_lag - 1, nullptr, 1.0f, (double)wlen * nw * S);
+                          ctx->prm.max_lag - 1, nullptr, 1.0f, (double)wlen * nw * S, align, wlen >= 2 && !(wlen & 1));
         if (rc) return rc;
     }
     {
@@ -723,6 +770,13 @@ int tdoa_fm_preprocess_u8(tdoa_ctx *ctx, const uint8_t *iq, size_t n, float *out
 // ===========================================================================
 // measurement
 // ===========================================================================
+int tdoa_debug_force_generic(tdoa_ctx *ctx, int on)
+{
+    if (!ctx) return TDOA_ERR_INVALID;
+    ctx->force_generic = on != 0;
+    return TDOA_OK;
+}
+
 int tdoa_profile_enable(tdoa_ctx *ctx, int on)
 {
     if (!ctx) return TDOA_ERR_INVALID;

@@ -44,7 +44,7 @@ SYMBOLS = [
     "tdoa_capture_upload", "tdoa_capture_attach_device", "tdoa_capture_clear",
     "tdoa_synth_capture", "tdoa_capture_download",
     "tdoa_num_windows", "tdoa_num_pairs", "tdoa_process", "tdoa_process_u8",
-    "tdoa_fm_xcorr_u8", "tdoa_fm_preprocess_u8", "tdoa_fm_xcorr_lags_u8",
+    "tdoa_fm_xcorr_u8", "tdoa_fm_preprocess_u8", "tdoa_fm_xcorr_lags_u8", "tdoa_debug_force_generic",
     "tdoa_latlon_to_ecef", "tdoa_ecef_to_latlon", "tdoa_solve_3station",
     "tdoa_profile_enable", "tdoa_profile_reset", "tdoa_profile_get", "tdoa_kernel_name",
     "tdoa_plan_info",
@@ -100,6 +100,7 @@ def load(build_if_missing=True):
     L.tdoa_fm_xcorr_u8.argtypes = [vp, u8p, sz, u8p, sz, C.c_int, C.POINTER(Peak)]
     L.tdoa_fm_preprocess_u8.argtypes = [vp, u8p, sz, fp, C.POINTER(FmStats)]
     L.tdoa_fm_xcorr_lags_u8.argtypes = [vp, u8p, sz, u8p, sz, C.c_int, dp]
+    L.tdoa_debug_force_generic.argtypes = [vp, C.c_int]
     L.tdoa_latlon_to_ecef.argtypes = [C.c_double, C.c_double, C.c_double, dp]
     L.tdoa_latlon_to_ecef.restype = None
     L.tdoa_ecef_to_latlon.argtypes = [C.c_double, C.c_double, C.c_double, dp]
@@ -290,6 +291,9 @@ class Context:
         st = FmStats()
         self._chk(self._L.tdoa_fm_preprocess_u8(self._h, _u8(a), a.size // 2, _f(out), C.byref(st)))
         return out, st
+
+    def force_generic(self, on=True):
+        self._chk(self._L.tdoa_debug_force_generic(self._h, 1 if on else 0))
 
     # ---- measurement -------------------------------------------------------
     def profile_enable(self, on=True):

@@ -130,3 +130,43 @@ def test_full_size_window_vs_f64_fft(oracle):
     assert lag == olag == 57
     assert abs(corr - ocorr) <= REL_TOL * abs(ocorr)
     _assert_lags_close(lags, want)
+
+
+def test_hot_size_and_fallback_kernels_agree(oracle):
+    """N = 2^21: radix-16 register kernels + pruned inverse vs the any-size LDS kernels."""
+    import tdoa_amd
+    n = 2_000_000
+    a = oracle.simulate_delayed_fm(n, 3, 123, 5)
+    b = oracle.simulate_delayed_fm(n, 0, 123, 6)          # a is the delayed one: lag -3
+    with tdoa_amd.Context() as c:
+        hot = c.fm_xcorr_lags(a, b, 20000)
+        lag_h, corr_h = c.fm_xcorr(a, b, 20000)
+        c.force_generic(True)
+        gen = c.fm_xcorr_lags(a, b, 20000)
+        lag_g, corr_g = c.fm_xcorr(a, b, 20000)
+    _assert_lags_close(hot, gen)
+    assert lag_h == lag_g == -3
+    assert abs(corr_h - corr_g) <= REL_TOL * abs(corr_g)
+    ta, _ = oracle.b_preprocess(a)
+    tb, _ = oracle.b_preprocess(b)
+    olag, ocorr, want = oracle.b_xcorr_peak_fft(ta, tb, 20000)
+    assert olag == -3
+    _assert_lags_close(hot, want)
+    print("max |hot - f64| / peak = %.3g" % (np.abs(hot - want).max() / np.abs(want).max()))
+
+
+def test_odd_and_unaligned_windows_use_fallback(oracle):
+    """window starts that are not 4-byte aligned / odd lengths go through the generic kernels"""
+    import tdoa_amd
+    blk, wl, ml = 30001, 9999, 200                           # odd block -> windows at odd sample offsets
+    caps = [oracle.simulate_delayed_fm(3 * blk, d, 55, 20 + i) for i, d in enumerate((0, 9))]
+    with tdoa_amd.Context(max_lag=ml, window_len=wl) as c:
+        peaks = c.process_u8(caps)
+    wpb = blk // wl
+    assert peaks.shape == (3 * wpb, 1)
+    for wid in range(3 * wpb):
+        off = (wid // wpb) * blk + (wid % wpb) * wl
+        pre = [oracle.b_preprocess(cp[2 * off:2 * (off + wl)])[0] for cp in caps]
+        olag, ocorr = oracle.b_xcorr_peak(pre[0], pre[1], ml)
+        assert peaks[wid, 0]["lag"] == olag == 9
+        assert abs(peaks[wid, 0]["corr"] - ocorr) <= REL_TOL * abs(ocorr)
