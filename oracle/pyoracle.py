@@ -347,17 +347,18 @@ def b_theta(i, q):
 
 
 def b_discriminate(iq_u8):
+    """u8 IQ -> int16 phase codes (pi == 32768)."""
     s = np.ascontiguousarray(iq_u8, dtype=np.uint8)
     n = s.size // 2
-    out = np.empty(n, dtype=np.float32)
-    lib().ob_discriminate_u8(_u8(s), C.c_size_t(n), _f(out))
+    out = np.empty(n, dtype=np.int16)
+    lib().ob_discriminate_u8(_u8(s), C.c_size_t(n), out.ctypes.data_as(C.POINTER(C.c_int16)))
     return out
 
 
-def b_phase_stats(phase):
-    p = np.ascontiguousarray(phase, dtype=np.float32)
+def b_phase_stats(code):
+    p = np.ascontiguousarray(code, dtype=np.int16)
     st = BStats()
-    lib().ob_phase_stats(_f(p), C.c_size_t(p.size), C.byref(st))
+    lib().ob_phase_stats(p.ctypes.data_as(C.POINTER(C.c_int16)), C.c_size_t(p.size), C.byref(st))
     return st
 
 

@@ -977,65 +977,76 @@ float ob_wrap_diff(float th1, float th0)
     return d;
 }
 
-/* K1: u8 IQ -> phase-difference FM discriminator.  With I = 2b_I - 255, Q = 2b_Q - 255 (exact
- * odd integers proportional to (b-127.5)/127.5 of processor.go:198-199, never zero):
- *   phase_i = wrap(arg(x_i) - arg(x_{i-1})) = arg(x_i * conj(x_{i-1}))   (i >= 1),  phase_0 = phase_1.
+/* K1: u8 IQ -> phase-difference FM discriminator -> 16-bit phase code.
+ * With I = 2b_I - 255, Q = 2b_Q - 255 (exact odd integers proportional to (b-127.5)/127.5 of
+ * processor.go:198-199, never zero):
+ *   phase_i = wrap(arg(x_i) - arg(x_{i-1})) = arg(x_i * conj(x_{i-1}))   (i >= 1),  phase_0 = phase_1
+ *   code_i  = int16(rint(phase_i * 32768/pi))      (+pi wraps to -32768: the phase circle)
  * x_i is never 0 for byte data, so the |p|^2 > 1e-10 gate of the prebuilt binary's
- * convertToInstantaneousFrequency never fires. */
-void ob_discriminate_u8(const uint8_t *iq, size_t n, float *phase)
+ * convertToInstantaneousFrequency never fires.  The code step (9.6e-5 rad) is far below the
+ * phase noise that 8-bit I/Q quantisation itself causes (>= 2e-3 rad at full scale). */
+#define K1_CODE_SCALE 10430.3779296875f   /* f32(32768/pi) */
+
+int16_t ob_phase_code(float phase)
+{
+    long q = lrintf(phase * K1_CODE_SCALE);
+    return (int16_t)(uint16_t)(q & 0xffff);
+}
+
+void ob_discriminate_u8(const uint8_t *iq, size_t n, int16_t *code)
 {
     if (n == 0)
         return;
     if (n == 1) {
-        phase[0] = 0.0f;
+        code[0] = 0;
         return;
     }
 #pragma omp parallel for schedule(static)
     for (long i = 1; i < (long)n; i++) {
         float t1 = ob_theta(2 * (int)iq[2 * i] - 255, 2 * (int)iq[2 * i + 1] - 255);
         float t0 = ob_theta(2 * (int)iq[2 * i - 2] - 255, 2 * (int)iq[2 * i - 1] - 255);
-        phase[i] = ob_wrap_diff(t1, t0);
+        code[i] = ob_phase_code(ob_wrap_diff(t1, t0));
     }
-    phase[0] = phase[1];
+    code[0] = code[1];
 }
 
-/* exact, order-independent statistics of the quantised phase q=rint(p*2^28) */
-void ob_phase_stats(const float *phase, size_t n, ob_stats *st)
+/* exact, order-independent statistics of the phase codes */
+void ob_phase_stats(const int16_t *code, size_t n, ob_stats *st)
 {
     int64_t s1 = 0;
-    unsigned __int128 s2 = 0;
+    uint64_t s2 = 0;
     for (size_t i = 0; i < n; i++) {
-        int64_t q = (int64_t)lrintf(phase[i] * 268435456.0f);
+        int64_t q = code[i];
         s1 += q;
-        s2 += (unsigned __int128)((uint64_t)(q * q));
+        s2 += (uint64_t)(q * q);
     }
     st->s1 = s1;
-    st->s2_lo = (uint64_t)s2;
-    st->s2_hi = (uint64_t)(s2 >> 64);
+    st->s2_lo = s2;
+    st->s2_hi = 0;
     if (n == 0) {
         st->mean = 0.0f; st->scale = 1.0f; st->var = 0.0;
         return;
     }
     double dn = (double)n;
-    double mean_q = (double)s1 / dn;
-    st->mean = (float)(mean_q / 268435456.0);
-    double s2d = (double)st->s2_hi * 18446744073709551616.0 + (double)st->s2_lo;
+    st->mean = (float)((double)s1 / dn);
     double m2 = ((double)s1 * (double)s1) / dn;
-    double var = ((s2d - m2) / dn) / 72057594037927936.0; /* 2^56 */
+    double var = ((double)s2 - m2) / dn;
     st->var = var;
     st->scale = (var > 0) ? (float)(1.0 / sqrt(var)) : 1.0f;
 }
 
-/* mode B preprocessing: phase -> (phase - mean) * scale, f32 sub then f32 mul */
+/* mode B preprocessing: code -> (float(code) - mean) * scale, f32 sub then f32 mul */
 void ob_preprocess_u8(const uint8_t *iq, size_t n, float *out, ob_stats *st_out)
 {
     ob_stats st;
-    ob_discriminate_u8(iq, n, out);
-    ob_phase_stats(out, n, &st);
+    int16_t *code = (int16_t *)malloc((n ? n : 1) * sizeof(int16_t));
+    ob_discriminate_u8(iq, n, code);
+    ob_phase_stats(code, n, &st);
     for (size_t i = 0; i < n; i++) {
-        float d = out[i] - st.mean;
+        float d = (float)code[i] - st.mean;
         out[i] = d * st.scale;
     }
+    free(code);
     if (st_out) *st_out = st;
 }
 

@@ -123,16 +123,17 @@ double o_rand_float64(uint64_t seed, uint64_t counter);
 /* ---- mode B oracle (north-star pipeline) ----------- */
 float  ob_theta(int I, int Q);
 float  ob_wrap_diff(float th1, float th0);
-void   ob_discriminate_u8(const uint8_t *iq, size_t n, float *phase);
+int16_t ob_phase_code(float phase);
+void   ob_discriminate_u8(const uint8_t *iq, size_t n, int16_t *code);
 typedef struct {
-    int64_t  s1;        /* sum of q_i = rint(phase_i * 2^28)            */
-    uint64_t s2_lo;     /* sum of q_i^2, 128-bit                        */
-    uint64_t s2_hi;
-    float    mean;      /* f32((double)s1 / (n * 2^28))                 */
+    int64_t  s1;        /* sum of the 16-bit phase codes               */
+    uint64_t s2_lo;     /* sum of code^2                                */
+    uint64_t s2_hi;     /* always 0 (kept for layout)                   */
+    float    mean;      /* f32((double)s1 / n), in code units           */
     float    scale;     /* f32(1/sqrt(var)), 1.0f if var <= 0           */
     double   var;
 } ob_stats;
-void   ob_phase_stats(const float *phase, size_t n, ob_stats *st);
+void   ob_phase_stats(const int16_t *code, size_t n, ob_stats *st);
 void   ob_preprocess_u8(const uint8_t *iq, size_t n, float *out, ob_stats *st);
 /* c[d] = sum_i t[i]*s[i+d] (f64, zero outside), lags -(max_lag-1)..max_lag-1,
  * out[d + max_lag - 1]; scaled by 1/sqrt(nt). */

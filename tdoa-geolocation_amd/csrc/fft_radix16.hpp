@@ -136,57 +136,23 @@ __global__ __launch_bounds__(256) void k_fwd_row4096(float2 *TZ, FftPlan pl)
 }
 
 // ---------------------------------------------------------------------------
-// forward column pass fused with K1, N2 = 256, 32 columns per workgroup; windows 4-byte aligned, even length.
-// grid (N1/32, n_sw), 512 threads (c = t & 31 column, j = t >> 5 item), LDS 64 KB
+// forward column pass, N2 = 256, 32 columns per workgroup: phase codes -> normalise -> pack ->
+// two radix-16 stages down the columns -> twiddle -> T[k2][n1].
+// grid (N1/32, n_sw), 512 threads (c = t & 31 column, j = t >> 5 item), dynamic LDS 64 KB
 // ---------------------------------------------------------------------------
-// Branch-free element fetch for windows of EVEN length >= 2 whose start is 4-byte aligned:
-// the two loads are issued unconditionally (addresses clamped into the window) so that all 32
-// loads of a thread are in flight together; out-of-window elements are zeroed afterwards.
-struct K1Raw {
-    unsigned int cur, prev;
-    bool valid, first;
-};
-
-__device__ __forceinline__ K1Raw k1_fetch(const uint8_t *base, long long m, int len)
-{
-    K1Raw r;
-    r.valid = 2 * m < len;
-    const long long mm = r.valid ? m : 0;
-    r.first = mm == 0;
-    r.cur = *reinterpret_cast<const unsigned int *>(base + 4 * mm);            // samples 2m, 2m+1
-    r.prev = *reinterpret_cast<const uint16_t *>(base + 4 * mm - (r.first ? 0 : 2));   // sample 2m-1
-    return r;
-}
-
-__device__ __forceinline__ float2 k1_finish(const K1Raw r, float mean, float scale, const float *rcp)
-{
-    const float th0 = k1_theta(r.cur & 0xffffu, rcp), th1 = k1_theta(r.cur >> 16, rcp);
-    const float thp = k1_theta(r.prev, rcp);
-    const float v1 = k1_normalise(k1_wrap_diff(th1, th0), mean, scale);
-    float v0 = k1_normalise(k1_wrap_diff(th0, thp), mean, scale);
-    v0 = r.first ? v1 : v0;                                  // phase_0 := phase_1
-    return r.valid ? make_float2(v0, v1) : make_float2(0.0f, 0.0f);
-}
-
-__global__ __launch_bounds__(512) void k_fwd_col256_u8(const SWDesc *sw, const FmStats *stats, float2 *T, FftPlan pl)
+__global__ __launch_bounds__(512) void k_fwd_col256_c16(const SWDesc *sw, const short *codes, long long code_stride,
+                                                        const FmStats *stats, float2 *T, FftPlan pl)
 {
     extern __shared__ float2 lds[];   // [256][32]
-    __shared__ float rcp[128];
-    k1_init_rcp(rcp);
-    const SWDesc d = sw[blockIdx.y];
-    const int len = d.len;
+    const int len = sw[blockIdx.y].len;
+    const short *row = codes + (size_t)blockIdx.y * code_stride;
     const float mean = stats[blockIdx.y].mean, scale = stats[blockIdx.y].scale;
     const int c = threadIdx.x & 31, j = threadIdx.x >> 5;     // column, item (0..15)
     const int n1 = (blockIdx.x << 5) + c;
     const int N1 = pl.N1;
     float2 v[16];
-    {
-        K1Raw raw[16];
 #pragma unroll
-        for (int r = 0; r < 16; r++) raw[r] = k1_fetch(d.base, (long long)(j + 16 * r) * N1 + n1, len);
-#pragma unroll
-        for (int r = 0; r < 16; r++) v[r] = k1_finish(raw[r], mean, scale, rcp);
-    }
+    for (int r = 0; r < 16; r++) v[r] = code_element(row, (long long)(j + 16 * r) * N1 + n1, len, mean, scale);
     fft16<false>(v);
 #pragma unroll
     for (int k = 0; k < 16; k++) lds[((16 * j + k) << 5) + c] = v[oreg(k)];
@@ -310,33 +276,35 @@ __global__ __launch_bounds__(256) void k_inv_row_pair4096(const PWDesc *pw, cons
 // pruned inverse column pass + K5.  Only the outputs n2 that can hold a searched lag are
 // evaluated, as direct DFT sums over k2 (lags 2m, 2m+1 with m = n2*N1 + n1; |lag| <= max):
 //   n2 in [0, NP)  (non-negative lags)  and  n2 in [N2 - NN, N2)  (negative lags), NP + NN <= 8.
-// grid (N1/32, n_pw), 256 threads: c = t & 31 (column), g = t >> 5 (row group, rows g, g+8, ...)
 // ---------------------------------------------------------------------------
 constexpr int kPruneMax = 8;
 
+// grid (N1/64, n_pw), 256 threads: cp = t & 31 (column PAIR: n1 = 64*bx + 2cp, +1), g = t >> 5
+// (row group: rows g, g+8, ...); 16-byte loads, 8 rows in flight per thread
 __global__ __launch_bounds__(256) void k_inv_col_pruned(const float2 *V, unsigned long long *keys, const PWDesc *pw,
                                                        FftPlan pl, int lag_lo, int lag_hi, int np, int nn,
                                                        float *lag_dump, float dump_scale)
 {
     __shared__ float2 wtab[512];                   // e^{+2 pi i k/N2}, N2 <= 512
-    __shared__ float2 part[8][kPruneMax][32];
+    __shared__ float4 part[8][kPruneMax][32];
     __shared__ unsigned long long red[4];
     const int N2 = pl.N2, N1 = pl.N1;
     for (int k = threadIdx.x; k < N2; k += 256) wtab[k] = unit_root((float)k, 2.0f / (float)N2, true);
     __syncthreads();
-    const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
-    const int n1 = (blockIdx.x << 5) + c;
-    const float2 *in = V + (size_t)blockIdx.y * pl.Nc + n1;
-    float2 acc[kPruneMax];
+    const int cp = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int n1 = (blockIdx.x << 6) + 2 * cp;
+    const float4 *in = reinterpret_cast<const float4 *>(V + (size_t)blockIdx.y * pl.Nc + n1);
+    const size_t row_stride = (size_t)N1 / 2;      // in float4 units
+    float4 acc[kPruneMax];
 #pragma unroll
-    for (int o = 0; o < kPruneMax; o++) acc[o] = make_float2(0.0f, 0.0f);
+    for (int o = 0; o < kPruneMax; o++) acc[o] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     const int nout = np + nn;
     for (int kb = g; kb < N2; kb += 64) {          // 8 rows per trip, all loads issued first
-        float2 x[8];
+        float4 x[8];
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const int k2 = kb + 8 * u;
-            x[u] = k2 < N2 ? in[(size_t)k2 * N1] : make_float2(0.0f, 0.0f);
+            x[u] = k2 < N2 ? in[(size_t)k2 * row_stride] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         }
 #pragma unroll
         for (int u = 0; u < 8; u++) {
@@ -349,36 +317,36 @@ __global__ __launch_bounds__(256) void k_inv_col_pruned(const float2 *V, unsigne
                     const float2 w = wtab[(n2 * k2) & (N2 - 1)];
                     acc[o].x += x[u].x * w.x - x[u].y * w.y;
                     acc[o].y += x[u].x * w.y + x[u].y * w.x;
+                    acc[o].z += x[u].z * w.x - x[u].w * w.y;
+                    acc[o].w += x[u].z * w.y + x[u].w * w.x;
                 }
             }
         }
     }
 #pragma unroll
-    for (int o = 0; o < kPruneMax; o++) part[g][o][c] = acc[o];
+    for (int o = 0; o < kPruneMax; o++) part[g][o][cp] = acc[o];
     __syncthreads();
     unsigned long long best = 0;
     if (threadIdx.x < 32 * nout) {
-        const int o = threadIdx.x >> 5;             // wave-uniform for 32-lane halves
-        float2 s = part[0][o][c];
+        const int o = threadIdx.x >> 5;
+        float4 s = part[0][o][cp];
 #pragma unroll
         for (int gg = 1; gg < 8; gg++) {
-            s.x += part[gg][o][c].x;
-            s.y += part[gg][o][c].y;
+            const float4 q = part[gg][o][cp];
+            s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
         }
         const int n2 = o < np ? o : N2 - nn + (o - np);
-        const long long m = (long long)n2 * N1 + n1;
-        long long d0 = 2 * m;
-        if (d0 >= pl.Nc) d0 -= 2 * pl.Nc;
-        const long long d1 = d0 + 1;
-        if (d0 >= lag_lo && d0 <= lag_hi && s.x == s.x) {
-            const unsigned long long k = peak_key(s.x, (int)d0);
-            best = k > best ? k : best;
-            if (lag_dump) lag_dump[d0 - lag_lo] = s.x * dump_scale;
-        }
-        if (d1 >= lag_lo && d1 <= lag_hi && s.y == s.y) {
-            const unsigned long long k = peak_key(s.y, (int)d1);
-            best = k > best ? k : best;
-            if (lag_dump) lag_dump[d1 - lag_lo] = s.y * dump_scale;
+        const float vals[4] = {s.x, s.y, s.z, s.w};   // lags 2m, 2m+1, 2m+2, 2m+3 with m = n2*N1 + n1
+        long long d = 2 * ((long long)n2 * N1 + n1);
+        if (d >= pl.Nc) d -= 2 * pl.Nc;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const long long dq = d + q;
+            if (dq >= lag_lo && dq <= lag_hi && vals[q] == vals[q]) {
+                const unsigned long long k = peak_key(vals[q], (int)dq);
+                best = k > best ? k : best;
+                if (lag_dump) lag_dump[dq - lag_lo] = vals[q] * dump_scale;
+            }
         }
     }
     best = wave_max_u64(best);
@@ -389,141 +357,6 @@ __global__ __launch_bounds__(256) void k_inv_col_pruned(const float2 *V, unsigne
         for (int w = 1; w < 4; w++) bb = red[w] > bb ? red[w] : bb;
         if (bb) atomicMax(&keys[pw[blockIdx.y].out_index], bb);
     }
-}
-
-// ---------------------------------------------------------------------------
-// K1 statistics, vectorised: each thread takes 8 consecutive samples from one aligned 16-byte
-// load.  The thread grid is shifted back by a = (base mod 16)/2 samples so that every load is
-// 16-byte aligned whatever the window start; partial sums are exact integers, so it does not
-// matter which block accounts for a sample.  grid (chunks, n_sw) with chunks*kStatsChunk >= len + 7.
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(kStatsThreads) void k_fm_stats_vec(const SWDesc *sw, StatsPartial *partials,
-                                                                int chunks_per_window)
-{
-    __shared__ float rcp[128];
-    k1_init_rcp(rcp);
-    const SWDesc d = sw[blockIdx.y];
-    const uint16_t *p = reinterpret_cast<const uint16_t *>(d.base);
-    const int len = d.len;
-    const int shift = (int)(((uintptr_t)d.base & 15u) >> 1);
-    const int start = blockIdx.x * kStatsChunk - shift;
-    long long s1 = 0;
-    unsigned long long lo = 0, hi = 0;
-    for (int i0 = start + threadIdx.x * 8; i0 < start + kStatsChunk && i0 < len; i0 += kStatsThreads * 8) {
-        long long ls1 = 0;
-        unsigned long long ls2 = 0;                 // 8 squares < 2^60 each: no overflow
-        if (i0 >= 1 && i0 + 8 <= len) {
-            // interior: one aligned 16-byte load + the previous sample, no per-sample conditions
-            const uint4 q = *reinterpret_cast<const uint4 *>(p + i0);
-            const unsigned int prev = p[i0 - 1];
-            float th[9];
-            th[0] = k1_theta(prev, rcp);
-            th[1] = k1_theta(q.x & 0xffffu, rcp);
-            th[2] = k1_theta(q.x >> 16, rcp);
-            th[3] = k1_theta(q.y & 0xffffu, rcp);
-            th[4] = k1_theta(q.y >> 16, rcp);
-            th[5] = k1_theta(q.z & 0xffffu, rcp);
-            th[6] = k1_theta(q.z >> 16, rcp);
-            th[7] = k1_theta(q.w & 0xffffu, rcp);
-            th[8] = k1_theta(q.w >> 16, rcp);
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const int qi = __float2int_rn(k1_wrap_diff(th[k + 1], th[k]) * 268435456.0f);
-                ls1 += qi;
-                const unsigned int aq = (unsigned int)(qi < 0 ? -qi : qi);
-                ls2 += (unsigned long long)aq * aq;
-            }
-        } else {
-            for (int k = 0; k < 8; k++) {
-                const int i = i0 + k;
-                if (i >= 0 && i < len) {
-                    const int qi = __float2int_rn(k1_window_phase(p, i, len, rcp) * 268435456.0f);
-                    ls1 += qi;
-                    const unsigned int aq = (unsigned int)(qi < 0 ? -qi : qi);
-                    ls2 += (unsigned long long)aq * aq;
-                }
-            }
-        }
-        s1 += ls1;
-        const unsigned long long nlo = lo + ls2;
-        hi += nlo < lo ? 1ull : 0ull;
-        lo = nlo;
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const long long o1 = __shfl_xor(s1, off, kWave);
-        const unsigned long long olo = __shfl_xor(lo, off, kWave);
-        const unsigned long long ohi = __shfl_xor(hi, off, kWave);
-        s1 += o1;
-        const unsigned long long nlo = lo + olo;
-        hi += ohi + (nlo < lo ? 1ull : 0ull);
-        lo = nlo;
-    }
-    __shared__ StatsPartial red[kStatsThreads / kWave];
-    const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
-    if (lane == 0) {
-        red[wid].s1 = s1;
-        red[wid].s2_lo = lo;
-        red[wid].s2_hi = hi;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        StatsPartial t = red[0];
-        for (int w = 1; w < kStatsThreads / kWave; w++) {
-            t.s1 += red[w].s1;
-            const unsigned long long nlo = t.s2_lo + red[w].s2_lo;
-            t.s2_hi += red[w].s2_hi + (nlo < t.s2_lo ? 1ull : 0ull);
-            t.s2_lo = nlo;
-        }
-        partials[(size_t)blockIdx.y * chunks_per_window + blockIdx.x] = t;
-    }
-}
-
-// fold the partials with one wave per station-window (exact integers: order-free)
-__global__ __launch_bounds__(64) void k_fm_stats_final_wave(const SWDesc *sw, const StatsPartial *partials,
-                                                            int chunks_per_window, FmStats *stats)
-{
-#pragma clang fp contract(off)
-    const int id = blockIdx.x;
-    const int len = sw[id].len;
-    const int chunks = chunks_per_window;          // every block wrote its (possibly empty) partial
-    long long s1 = 0;
-    unsigned long long lo = 0, hi = 0;
-    for (int c = threadIdx.x; c < chunks; c += 64) {
-        const StatsPartial t = partials[(size_t)id * chunks_per_window + c];
-        s1 += t.s1;
-        const unsigned long long nlo = lo + t.s2_lo;
-        hi += t.s2_hi + (nlo < lo ? 1ull : 0ull);
-        lo = nlo;
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const long long o1 = __shfl_xor(s1, off, kWave);
-        const unsigned long long olo = __shfl_xor(lo, off, kWave);
-        const unsigned long long ohi = __shfl_xor(hi, off, kWave);
-        s1 += o1;
-        const unsigned long long nlo = lo + olo;
-        hi += ohi + (nlo < lo ? 1ull : 0ull);
-        lo = nlo;
-    }
-    if (threadIdx.x != 0) return;
-    FmStats out;
-    out.s1 = s1;
-    out.s2_lo = lo;
-    out.s2_hi = hi;
-    if (len == 0) {
-        out.mean = 0.0f;
-        out.scale = 1.0f;
-    } else {
-        const double dn = (double)len;
-        const double mean_q = (double)s1 / dn;
-        out.mean = (float)(mean_q / 268435456.0);
-        const double s2d = (double)hi * 18446744073709551616.0 + (double)lo;
-        const double m2 = ((double)s1 * (double)s1) / dn;
-        const double var = ((s2d - m2) / dn) / 72057594037927936.0;
-        out.scale = var > 0 ? (float)(1.0 / sqrt(var)) : 1.0f;
-    }
-    stats[id] = out;
 }
 
 }  // namespace tdoa

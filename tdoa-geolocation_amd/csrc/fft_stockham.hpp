@@ -103,29 +103,35 @@ struct FftPlan {
 };
 
 // ---------------------------------------------------------------------------
-// forward column pass, fused with K1: u8 IQ -> discriminator -> normalise ->
-// pack -> length-N2 FFT down C adjacent columns -> twiddle -> T[k2][n1]
+// element m of the packed window: phase codes (2m, 2m+1) -> normalised float2, zero beyond len
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float2 code_element(const short *codes, long long m, int len, float mean, float scale)
+{
+    const long long i0 = 2 * m;
+    const bool ok0 = i0 < len, ok1 = i0 + 1 < len;
+    const unsigned int w = reinterpret_cast<const unsigned int *>(codes)[ok0 ? m : 0];
+    const float v0 = k1_normalise((int)(short)(w & 0xffffu), mean, scale);
+    const float v1 = k1_normalise((int)(short)(w >> 16), mean, scale);
+    return make_float2(ok0 ? v0 : 0.0f, ok1 ? v1 : 0.0f);
+}
+
+// ---------------------------------------------------------------------------
+// forward column pass: phase codes -> normalise -> pack -> length-N2 FFT down C adjacent
+// columns -> twiddle -> T[k2][n1]
 // grid: (N1 / C, n_station_windows), dynamic LDS: 2 * N2 * C * 8 bytes
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_fwd_col_u8(const SWDesc *sw, const FmStats *stats, float2 *T, FftPlan pl)
+__global__ __launch_bounds__(256) void k_fwd_col_c16(const SWDesc *sw, const short *codes, long long code_stride,
+                                                     const FmStats *stats, float2 *T, FftPlan pl)
 {
     extern __shared__ float2 lds[];
-    __shared__ float rcp[128];
-    k1_init_rcp(rcp);
     const int tile = pl.N2 << pl.logC;
-    const SWDesc d = sw[blockIdx.y];
-    const uint16_t *p = reinterpret_cast<const uint16_t *>(d.base);
-    const int len = d.len;
+    const int len = sw[blockIdx.y].len;
+    const short *row = codes + (size_t)blockIdx.y * code_stride;
     const float mean = stats[blockIdx.y].mean, scale = stats[blockIdx.y].scale;
     const int c0 = blockIdx.x << pl.logC;
     for (int e = threadIdx.x; e < tile; e += blockDim.x) {
         int c = e & (pl.C - 1), n2 = e >> pl.logC;
-        long long m = (long long)n2 * pl.N1 + c0 + c;
-        long long i0 = 2 * m;
-        float v0 = 0.0f, v1 = 0.0f;
-        if (i0 < len) v0 = k1_normalise(k1_window_phase(p, (int)i0, len, rcp), mean, scale);
-        if (i0 + 1 < len) v1 = k1_normalise(k1_window_phase(p, (int)i0 + 1, len, rcp), mean, scale);
-        lds[e] = make_float2(v0, v1);
+        lds[e] = code_element(row, (long long)n2 * pl.N1 + c0 + c, len, mean, scale);
     }
     __syncthreads();
     float2 *r = lds_fft<false>(lds, lds + tile, pl.N2, pl.logN2, pl.C, pl.logC);

@@ -54,7 +54,7 @@ struct tdoa_ctx {
     };
     std::vector<Capture> caps;
 
-    DevBuf sw_desc, pw_desc, partials, stats, tz, v, keys, scales, peaks, scratch_a, scratch_b, lagdump;
+    DevBuf sw_desc, pw_desc, partials, stats, codes, tz, v, keys, scales, peaks, scratch_a, scratch_b, lagdump;
     DevBuf ex_a, ex_b, ex_c, ex_d, ex_part;
 
     bool profiling = false;
@@ -213,62 +213,62 @@ void prof_collect(tdoa_ctx *ctx)
 // sw/pw descriptors are already in device memory; maxlen = longest window.
 int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const PWDesc *d_pw, int n_pw,
                  unsigned long long *d_keys, const FftPlan &pl, int lag_lo, int lag_hi, float *lag_dump,
-                 float dump_scale, double sum_len, unsigned align, bool even_len)
+                 float dump_scale, double sum_len)
 {
     int rc;
-    const int chunks = std::max(1, (maxlen + 7 + kStatsChunk - 1) / kStatsChunk);
+    const int chunks = std::max(1, (maxlen + kStatsChunk - 1) / kStatsChunk);
+    const long long code_stride = ((long long)maxlen + 15) / 8 * 8;      // rows stay 16-byte aligned
     if ((rc = ensure(ctx, ctx->partials, sizeof(StatsPartial) * (size_t)chunks * n_sw))) return rc;
     if ((rc = ensure(ctx, ctx->stats, sizeof(FmStats) * (size_t)n_sw))) return rc;
+    if ((rc = ensure(ctx, ctx->codes, sizeof(short) * (size_t)code_stride * n_sw))) return rc;
     if ((rc = ensure(ctx, ctx->tz, sizeof(float2) * (size_t)pl.Nc * n_sw))) return rc;
     if (n_pw && (rc = ensure(ctx, ctx->v, sizeof(float2) * (size_t)pl.Nc * n_pw))) return rc;
     auto *partials = static_cast<StatsPartial *>(ctx->partials.p);
     auto *stats = static_cast<FmStats *>(ctx->stats.p);
+    auto *codes = static_cast<short *>(ctx->codes.p);
     auto *tz = static_cast<float2 *>(ctx->tz.p);
     auto *v = static_cast<float2 *>(ctx->v.p);
     hipStream_t st = ctx->stream;
     const double nc8 = 8.0 * (double)pl.Nc;
 
-    // hot-size kernels (fft_radix16.hpp) when the plan and the window alignment allow, else the
-    // any-size kernels of fft_stockham.hpp
+    // hot-size kernels (fft_radix16.hpp) when the plan allows, else the any-size kernels of
+    // fft_stockham.hpp
     const bool row16 = pl.N1 == 4096 && !ctx->force_generic;
-    const bool col16 = row16 && pl.N2 == 256 && (align & 3) == 0 && even_len;
-    const bool vec_stats = !ctx->force_generic;
+    const bool col16 = row16 && pl.N2 == 256;
     int np = 0, nn = 0;
     {
         const long long n_real = 2 * pl.Nc;
         np = lag_hi >= 0 ? (int)((lag_hi / 2) / pl.N1) + 1 : 0;
         nn = lag_lo < 0 ? pl.N2 - (int)(((n_real + lag_lo) / 2) / pl.N1) : 0;
     }
-    const bool pruned = !ctx->force_generic && pl.N1 >= 32 && pl.N2 <= 512 && np + nn <= kPruneMax && np + nn <= pl.N2 &&
+    const bool pruned = !ctx->force_generic && pl.N1 >= 64 && pl.N2 <= 512 && np + nn <= kPruneMax && np + nn <= pl.N2 &&
                         lag_hi < pl.Nc && lag_lo > -pl.Nc;
     {
-        ProfScope ps(ctx, TDOA_K_STATS, 2.0 * sum_len);
-        if (vec_stats) {
-            hipLaunchKernelGGL(k_fm_stats_vec, dim3(chunks, n_sw), dim3(kStatsThreads), 0, st, d_sw, partials, chunks);
-            hipLaunchKernelGGL(k_fm_stats_final_wave, dim3(n_sw), dim3(64), 0, st, d_sw, partials, chunks, stats);
-        } else {
-            hipLaunchKernelGGL(k_fm_stats, dim3(chunks, n_sw), dim3(kStatsThreads), 0, st, d_sw, partials, chunks);
-            hipLaunchKernelGGL(k_fm_stats_final, dim3((n_sw + 63) / 64), dim3(64), 0, st, d_sw, partials, chunks,
-                               stats, n_sw);
-        }
+        // K1: capture bytes -> 16-bit phase codes + exact window statistics
+        ProfScope ps(ctx, TDOA_K_STATS, 4.0 * sum_len);
+        hipLaunchKernelGGL(k_fm_demod, dim3(chunks, n_sw), dim3(kStatsThreads), 0, st, d_sw, codes, code_stride,
+                           partials, chunks);
+        hipLaunchKernelGGL(k_fm_stats_final, dim3(n_sw), dim3(64), 0, st, d_sw, partials, chunks, stats);
     }
     const size_t lds_col = sizeof(float2) * 2 * (size_t)pl.N2 * pl.C;
     const size_t lds_row = sizeof(float2) * 2 * (size_t)pl.N1;
     const size_t lds_row2 = sizeof(float2) * 4 * (size_t)pl.N1;
     const size_t lds_col16 = sizeof(float2) * 256 * 32;
     const size_t lds_pair16 = sizeof(float2) * 2 * kRowLds;
-    if ((rc = set_lds(ctx, k_fwd_col_u8, lds_col))) return rc;
+    if ((rc = set_lds(ctx, k_fwd_col_c16, lds_col))) return rc;
     if ((rc = set_lds(ctx, k_fwd_row, lds_row))) return rc;
     if ((rc = set_lds(ctx, k_inv_row_pair, lds_row2))) return rc;
     if ((rc = set_lds(ctx, k_inv_col_peak<true>, lds_col))) return rc;
-    if ((rc = set_lds(ctx, k_fwd_col256_u8, lds_col16))) return rc;
+    if ((rc = set_lds(ctx, k_fwd_col256_c16, lds_col16))) return rc;
     if ((rc = set_lds(ctx, k_inv_row_pair4096, lds_pair16))) return rc;
     {
         ProfScope ps(ctx, TDOA_K_FWD_COL, 2.0 * sum_len + nc8 * n_sw);
         if (col16)
-            hipLaunchKernelGGL(k_fwd_col256_u8, dim3(pl.N1 / 32, n_sw), dim3(512), lds_col16, st, d_sw, stats, tz, pl);
+            hipLaunchKernelGGL(k_fwd_col256_c16, dim3(pl.N1 / 32, n_sw), dim3(512), lds_col16, st, d_sw, codes,
+                               code_stride, stats, tz, pl);
         else
-            hipLaunchKernelGGL(k_fwd_col_u8, dim3(pl.N1 / pl.C, n_sw), dim3(256), lds_col, st, d_sw, stats, tz, pl);
+            hipLaunchKernelGGL(k_fwd_col_c16, dim3(pl.N1 / pl.C, n_sw), dim3(256), lds_col, st, d_sw, codes,
+                               code_stride, stats, tz, pl);
     }
     {
         ProfScope ps(ctx, TDOA_K_FWD_ROW, 2.0 * nc8 * n_sw);
@@ -293,7 +293,7 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
         {
             ProfScope ps(ctx, TDOA_K_INV_COL, nc8 * n_pw);
             if (pruned)
-                hipLaunchKernelGGL(k_inv_col_pruned, dim3(pl.N1 / 32, n_pw), dim3(256), 0, st, v, d_keys, d_pw, pl,
+                hipLaunchKernelGGL(k_inv_col_pruned, dim3(pl.N1 / 64, n_pw), dim3(256), 0, st, v, d_keys, d_pw, pl,
                                    lag_lo, lag_hi, np, nn, lag_dump, dump_scale);
             else
                 hipLaunchKernelGGL(k_inv_col_peak<true>, dim3(pl.N1 / pl.C, n_pw), dim3(256), lds_col, st, v, d_keys,
@@ -366,8 +366,7 @@ int fm_pair(tdoa_ctx *ctx, const uint8_t *iq1, size_t n1, const uint8_t *iq2, si
     HIPCHK(ctx, hipMemsetAsync(ctx->keys.p, 0, sizeof(unsigned long long), ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(ctx->scales.p, &scale, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     rc = run_fm_batch(ctx, d_sw, 2, (int)std::max(n1, n2), d_pw, 1, static_cast<unsigned long long *>(ctx->keys.p),
-                      pl, -(max_lag - 1), max_lag - 1, dump, 1.0f, (double)(n1 + n2), 0u,
-                      n1 >= 2 && n2 >= 2 && !((n1 | n2) & 1));
+                      pl, -(max_lag - 1), max_lag - 1, dump, 1.0f, (double)(n1 + n2));
     if (rc) return rc;
     hipLaunchKernelGGL(k_decode_peaks, dim3(1), dim3(64), 0, ctx->stream,
                        static_cast<unsigned long long *>(ctx->keys.p), static_cast<double *>(ctx->scales.p),
@@ -436,7 +435,7 @@ const char *tdoa_last_error(const tdoa_ctx *ctx) { return ctx ? ctx->last_error.
 
 const char *tdoa_kernel_name(int k)
 {
-    static const char *names[TDOA_K_COUNT] = {"k_fm_stats", "k_fwd_col_u8", "k_fwd_row", "k_inv_row_pair",
+    static const char *names[TDOA_K_COUNT] = {"k_fm_demod", "k_fwd_col", "k_fwd_row", "k_inv_row_pair",
                                               "k_inv_col_peak", "k_decode_peaks"};
     return (k >= 0 && k < TDOA_K_COUNT) ? names[k] : "";
 }
@@ -474,7 +473,7 @@ void tdoa_destroy(tdoa_ctx *ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     prof_collect(ctx);
     tdoa_capture_clear(ctx);
-    DevBuf *bufs[] = {&ctx->sw_desc, &ctx->pw_desc, &ctx->partials, &ctx->stats, &ctx->tz, &ctx->v, &ctx->keys,
+    DevBuf *bufs[] = {&ctx->sw_desc, &ctx->pw_desc, &ctx->partials, &ctx->stats, &ctx->codes, &ctx->tz, &ctx->v, &ctx->keys,
                       &ctx->scales, &ctx->peaks, &ctx->scratch_a, &ctx->scratch_b, &ctx->lagdump,
                       &ctx->ex_a, &ctx->ex_b, &ctx->ex_c, &ctx->ex_d, &ctx->ex_part};
     for (DevBuf *b : bufs) release(*b);
@@ -652,23 +651,20 @@ int tdoa_process(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host, void *
 
     std::vector<int> mine;
     for (int w = rank; w < W; w += world) mine.push_back(w);
-    int per_batch = ctx->prm.windows_per_batch > 0 ? ctx->prm.windows_per_batch : 8;
-    // keep the batch workspace under ~24 GiB
-    const double bytes_per_window = 8.0 * (double)pl.Nc * (S + P);
+    // default: every window of this rank in one launch group (launch tails cost more than cache
+    // residency gains), bounded by ~24 GiB of workspace
+    int per_batch = ctx->prm.windows_per_batch > 0 ? ctx->prm.windows_per_batch : (int)std::max<size_t>(mine.size(), 1);
+    const double bytes_per_window = 8.0 * (double)pl.Nc * (S + P) + 2.0 * (double)(wlen + 16) * S;
     per_batch = (int)std::max(1.0, std::min<double>(per_batch, 24.0 * 1073741824.0 / bytes_per_window));
 
     // all descriptors, uploaded once
     std::vector<SWDesc> sw(mine.size() * (size_t)S);
     std::vector<PWDesc> pw(mine.size() * (size_t)P);
-    unsigned align = 0;   // OR of the low address bits of every window start
     for (size_t wi = 0; wi < mine.size(); wi++) {
         int wid = mine[wi];
         long long off = (long long)(wid / wpb) * block + (long long)(wid % wpb) * wlen;
         int local = (int)(wi % per_batch);
-        for (int s = 0; s < S; s++) {
-            sw[wi * S + s] = SWDesc{ctx->caps[s].dev + 2 * off, (int32_t)wlen, 0};
-            align |= (unsigned)((uintptr_t)(ctx->caps[s].dev + 2 * off) & 15u);
-        }
+        for (int s = 0; s < S; s++) sw[wi * S + s] = SWDesc{ctx->caps[s].dev + 2 * off, (int32_t)wlen, 0};
         int p = 0;
         for (int i = 0; i < S; i++)
             for (int j = i + 1; j < S; j++, p++)
@@ -695,7 +691,7 @@ int tdoa_process(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host, void *
         rc = run_fm_batch(ctx, static_cast<SWDesc *>(ctx->sw_desc.p) + w0 * S, nw * S, (int)wlen,
                           static_cast<PWDesc *>(ctx->pw_desc.p) + w0 * P, nw * P,
                           static_cast<unsigned long long *>(ctx->keys.p), pl, -(ctx->prm.max_lag - 1),
-                          ctx->prm.max_lag - 1, nullptr, 1.0f, (double)wlen * nw * S, align, wlen >= 2 && !(wlen & 1));
+                          ctx->prm.max_lag - 1, nullptr, 1.0f, (double)wlen * nw * S);
         if (rc) return rc;
     }
     {
@@ -746,20 +742,23 @@ int tdoa_fm_preprocess_u8(tdoa_ctx *ctx, const uint8_t *iq, size_t n, float *out
     if ((rc = ensure(ctx, ctx->scratch_b, sizeof(float) * n))) return rc;
     if ((rc = ensure(ctx, ctx->sw_desc, sizeof(SWDesc)))) return rc;
     const int chunks = (int)((n + kStatsChunk - 1) / kStatsChunk);
+    const long long code_stride = ((long long)n + 15) / 8 * 8;
     if ((rc = ensure(ctx, ctx->partials, sizeof(StatsPartial) * (size_t)chunks))) return rc;
     if ((rc = ensure(ctx, ctx->stats, sizeof(FmStats)))) return rc;
+    if ((rc = ensure(ctx, ctx->codes, sizeof(short) * (size_t)code_stride))) return rc;
     hipStream_t st = ctx->stream;
     SWDesc sw = {static_cast<uint8_t *>(ctx->scratch_a.p), (int32_t)n, 0};
     HIPCHK(ctx, hipMemcpyAsync(ctx->scratch_a.p, iq, 2 * n, hipMemcpyHostToDevice, st));
     HIPCHK(ctx, hipMemcpyAsync(ctx->sw_desc.p, &sw, sizeof(sw), hipMemcpyHostToDevice, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
     auto *d_sw = static_cast<SWDesc *>(ctx->sw_desc.p);
-    hipLaunchKernelGGL(k_fm_stats, dim3(chunks, 1), dim3(kStatsThreads), 0, st, d_sw,
-                       static_cast<StatsPartial *>(ctx->partials.p), chunks);
+    hipLaunchKernelGGL(k_fm_demod, dim3(chunks, 1), dim3(kStatsThreads), 0, st, d_sw, static_cast<short *>(ctx->codes.p),
+                       code_stride, static_cast<StatsPartial *>(ctx->partials.p), chunks);
     hipLaunchKernelGGL(k_fm_stats_final, dim3(1), dim3(64), 0, st, d_sw, static_cast<StatsPartial *>(ctx->partials.p),
-                       chunks, static_cast<FmStats *>(ctx->stats.p), 1);
+                       chunks, static_cast<FmStats *>(ctx->stats.p));
     hipLaunchKernelGGL(k_fm_dump, dim3((unsigned)((n + 255) / 256), 1), dim3(256), 0, st, d_sw,
-                       static_cast<FmStats *>(ctx->stats.p), static_cast<float *>(ctx->scratch_b.p));
+                       static_cast<short *>(ctx->codes.p), static_cast<FmStats *>(ctx->stats.p),
+                       static_cast<float *>(ctx->scratch_b.p));
     HIPCHK(ctx, hipGetLastError());
     if (out_f32) HIPCHK(ctx, hipMemcpyAsync(out_f32, ctx->scratch_b.p, sizeof(float) * n, hipMemcpyDeviceToHost, st));
     if (stats) HIPCHK(ctx, hipMemcpyAsync(stats, ctx->stats.p, sizeof(FmStats), hipMemcpyDeviceToHost, st));

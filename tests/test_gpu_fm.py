@@ -170,3 +170,21 @@ def test_odd_and_unaligned_windows_use_fallback(oracle):
         olag, ocorr = oracle.b_xcorr_peak(pre[0], pre[1], ml)
         assert peaks[wid, 0]["lag"] == olag == 9
         assert abs(peaks[wid, 0]["corr"] - ocorr) <= REL_TOL * abs(ocorr)
+
+
+@pytest.mark.parametrize("n,delay,label", [
+    (4_000_000, -41, "cfg5 window: 1 s at 4 Msps, N = 2^22 (4096 x 512)"),
+    (20_000_000, 88, "cfg3 window: 10 s at 2 Msps, N = 2^25 (4096 x 4096)"),
+])
+def test_long_windows_vs_f64_fft(oracle, n, delay, label):
+    """BASELINE configs 3 and 5 window geometries through the any-size column kernels."""
+    import tdoa_amd
+    a = oracle.simulate_delayed_fm(n, max(0, -delay), 31, 1)
+    b = oracle.simulate_delayed_fm(n, max(0, delay), 31, 2)
+    with tdoa_amd.Context() as c:
+        lag, corr = c.fm_xcorr(a, b, 20000)
+    ta, _ = oracle.b_preprocess(a)
+    tb, _ = oracle.b_preprocess(b)
+    olag, ocorr, _ = oracle.b_xcorr_peak_fft(ta, tb, 20000)
+    assert lag == olag == delay, label
+    assert abs(corr - ocorr) <= REL_TOL * abs(ocorr), label
