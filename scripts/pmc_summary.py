@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Folds the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; KiB units) into per-kernel HBM-side
+traffic per launch.  gfx950 correction: FETCH_SIZE counts 128-byte requests as 64 bytes for wide
+coalesced loads.  Calibration on this pipeline's own kernels (known byte counts, no reuse possible):
+  k_fwd_row4096 (8 B/lane float2 rows)  : FETCH_SIZE*1024 / bytes read = 0.500  -> x2
+  k_inv_col_pruned (16 B/lane)          : 0.500 -> x2      k_fm_demod (16 B/lane): 0.504 -> x2
+  k_fwd_col256_c16 (4 B/lane, 128-B runs): 0.94 -> x1 (left uncorrected)
+  WRITE_SIZE*1024 / bytes written = 1.000 for every kernel -> x1
+usage: pmc_summary.py <fetch_dir> <write_dir> <out.json>"""
+import collections
+import csv
+import glob
+import json
+import sys
+
+FETCH_CORRECTION = {"k_fm_demod": 2.0, "k_fwd_row4096": 2.0, "k_inv_row_pair4096": 2.0, "k_inv_col_pruned": 2.0,
+                    "k_fwd_col256_c16": 1.0}
+
+
+def load(d):
+    out = collections.defaultdict(list)
+    for path in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(path)):
+            name = r["Kernel_Name"].split("(")[0].replace("tdoa::", "").replace("void ", "")
+            out[name].append(float(r["Counter_Value"]))
+    return out
+
+
+def main():
+    fetch, write = load(sys.argv[1]), load(sys.argv[2])
+    res = {}
+    for k in sorted(set(fetch) & set(write)):
+        if not k.startswith("k_") or k.startswith("k_synth"):
+            continue
+        f, w = fetch[k][-1], write[k][-1]           # last launch = a timed step
+        corr = FETCH_CORRECTION.get(k, 1.0)
+        res[k] = {"FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "fetch_correction": corr,
+                  "traffic_bytes_per_launch": f * 1024 * corr + w * 1024}
+    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py cfg2, batch = all windows",
+               "kernels": res}, open(sys.argv[3], "w"), indent=1, sort_keys=True)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -175,26 +175,42 @@ __global__ __launch_bounds__(512) void k_fwd_col256_c16(const SWDesc *sw, const 
 // inverse row pass with K3 fused, N1 = 4096: one workgroup owns rows a and N2 - a (a >= 1).
 // Thread t builds Q[a][t + 256 r] and its mirror Q[N2-a][4095 - t - 256 r] from the same four
 // spectrum values, so stage 1 of row a (item t) and of row N2-a (item 255 - t) need no exchange.
-// grid (N2/2 - 1, n_pw), 256 threads, dynamic LDS 2*kRowLds*8 = 68 KB.  Row pair a = 0 is left to k_inv_row_pair.
+// grid (N2/2, n_pw), 256 threads, dynamic LDS 2*kRowLds*8 = 68 KB.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_inv_row_pair4096(const PWDesc *pw, const float2 *Z, float2 *V, FftPlan pl)
 {
     extern __shared__ float2 lds[];   // 2 * kRowLds
     const PWDesc d = pw[blockIdx.y];
     const int N2 = pl.N2;
-    const int a = blockIdx.x + 1, b = N2 - a;
+    // block 0 owns the two self-mirrored rows (0, N2/2); block a >= 1 the mirrored pair (a, N2 - a)
+    const bool self = blockIdx.x == 0;
+    const int a = self ? 0 : blockIdx.x, b = self ? N2 / 2 : N2 - a;
     const float2 *ZaA = Z + (size_t)d.sw_a * pl.Nc + (size_t)a * 4096;
     const float2 *ZaB = Z + (size_t)d.sw_a * pl.Nc + (size_t)b * 4096;
     const float2 *ZbA = Z + (size_t)d.sw_b * pl.Nc + (size_t)a * 4096;
     const float2 *ZbB = Z + (size_t)d.sw_b * pl.Nc + (size_t)b * 4096;
     const int t = threadIdx.x;
+    const float invNc = 1.0f / (float)pl.Nc;
     float2 va[16], vb[16];
-    {
+    if (self) {
+        // each row mirrors onto itself: row 0 by k1 -> (4096 - k1) mod 4096, row N2/2 by k1 -> 4095 - k1;
+        // every thread builds only its own Q values (the mirror operand is re-read)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int k1 = t + 256 * r;
+            float2 q, qm;
+            const int m0 = (4096 - k1) & 4095;
+            pair_q(ZaA[k1], ZaA[m0], ZbA[k1], ZbA[m0], unit_root((float)((long long)k1 * N2), invNc, false), q, qm);
+            va[r] = q;
+            const int m1 = 4095 - k1;
+            pair_q(ZaB[k1], ZaB[m1], ZbB[k1], ZbB[m1], unit_root((float)((long long)k1 * N2 + b), invNc, false), q, qm);
+            vb[r] = q;
+        }
+    } else {
         // w(k) = W_N^k, k = (t + 256 r) N2 + a  =>  w = w0 * W_32^r
         const long long k0 = (long long)t * N2 + a;
-        const float2 w0 = unit_root((float)k0, 1.0f / (float)pl.Nc, false);
         const float2 st = make_float2(0.98078528040323043f, -0.19509032201612825f);   // e^{-2 pi i/32}
-        float2 w = w0;
+        float2 w = unit_root((float)k0, invNc, false);
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int k1 = t + 256 * r;
@@ -202,23 +218,20 @@ __global__ __launch_bounds__(256) void k_inv_row_pair4096(const PWDesc *pw, cons
             pair_q(ZaA[k1], ZaB[4095 - k1], ZbA[k1], ZbB[4095 - k1], w, q, qm);
             va[r] = q;
             vb[15 - r] = qm;
-            if ((r & 3) == 3) {
-                // re-anchor every 4 steps to keep the running product short
-                const float x = (float)(k0 + (long long)(r + 1) * 256 * N2);
-                w = unit_root(x, 1.0f / (float)pl.Nc, false);
-            } else {
+            if ((r & 3) == 3)   // re-anchor every 4 steps to keep the running product short
+                w = unit_root((float)(k0 + (long long)(r + 1) * 256 * N2), invNc, false);
+            else
                 w = cmul(w, st);
-            }
         }
     }
+    const int item_b = self ? t : 255 - t;   // which item of row b this thread's stage-1 butterfly is
     fft16<true>(va);
     fft16<true>(vb);
-    // row a: item t; row b: item 255 - t
     float2 *la = lds, *lb = lds + kRowLds;
 #pragma unroll
     for (int k = 0; k < 16; k++) {
         la[pad16(16 * t + k)] = va[oreg(k)];
-        lb[pad16(16 * (255 - t) + k)] = vb[oreg(k)];
+        lb[pad16(16 * item_b + k)] = vb[oreg(k)];
     }
     __syncthreads();
     const int j = t;

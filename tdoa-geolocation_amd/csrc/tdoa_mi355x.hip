@@ -281,11 +281,8 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
         {
             ProfScope ps(ctx, TDOA_K_INV_ROW, 3.0 * nc8 * n_pw);
             if (row16) {
-                if (pl.N2 > 2)
-                    hipLaunchKernelGGL(k_inv_row_pair4096, dim3(pl.N2 / 2 - 1, n_pw), dim3(256), lds_pair16, st, d_pw,
-                                       tz, v, pl);
-                // the two self-mirrored rows (0 and N2/2) stay with the generic kernel (block a = 0)
-                hipLaunchKernelGGL(k_inv_row_pair, dim3(1, n_pw), dim3(256), lds_row2, st, d_pw, tz, v, pl);
+                hipLaunchKernelGGL(k_inv_row_pair4096, dim3(pl.N2 / 2, n_pw), dim3(256), lds_pair16, st, d_pw, tz, v,
+                                   pl);
             } else {
                 hipLaunchKernelGGL(k_inv_row_pair, dim3(pl.N2 / 2, n_pw), dim3(256), lds_row2, st, d_pw, tz, v, pl);
             }
