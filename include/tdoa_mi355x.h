@@ -164,6 +164,11 @@ void tdoa_ecef_to_latlon(double x, double y, double z, double lle[3]);
 /* reference 3-station solver, bit-compatible call: range_diff[0]=(0,1), [1]=(0,2) */
 int  tdoa_solve_3station(const double stations_lle[9], const double *range_diff,
                          double out_lle[3], int *iterations);
+/* N-station generalisation: all n(n-1)/2 range differences (pairs i<j), optional weights,
+ * X,Y (Z frozen, like the reference) or X,Y,Z unknowns; centroid start, 0.5 damping,
+ * 10 iterations, 1 m stop rule as processor.go:950-1010. */
+int  tdoa_solve_nstation(const double *stations_lle, int n_stations, const double *range_diff,
+                         const double *weights, int solve_z, double out_lle[3], int *iterations);
 
 /* ---- measurement ----------------------------------------------------------- */
 enum {

@@ -78,4 +78,66 @@ inline int solve_3station(const double st[9], const double *rd, double out[3], i
     return 0;
 }
 
+// N-station generalisation: Gauss-Newton over ALL pair range differences
+// rd[p], pairs ordered i<j like processor.go:816-817, optional weights (e.g. |corr|), unknowns
+// ECEF X,Y (Z frozen at the centroid like the reference, processor.go:1004) or X,Y,Z when
+// solve_z is set.  Same start (centroid), damping (0.5), iteration cap (10) and 1 m stop rule as
+// the reference; with n = 3 and weights {1,1,0} it solves the reference's own 2x2 system.
+// returns 0 ok, -1 singular normal matrix.
+inline int solve_nstation(const double *st_lle, int n, const double *rd, const double *wt, int solve_z,
+                          int max_iter, double damping, double tol_m, double out[3], int *iters)
+{
+    if (n < 3 || n > 64) return -2;
+    double s[64][3], x[3], c[3] = {0, 0, 0};
+    for (int i = 0; i < n; i++) {
+        latlon_to_ecef(st_lle[3 * i], st_lle[3 * i + 1], st_lle[3 * i + 2], s[i]);
+        for (int k = 0; k < 3; k++) c[k] += st_lle[3 * i + k] / n;
+    }
+    latlon_to_ecef(c[0], c[1], c[2], x);
+    const int nu = solve_z ? 3 : 2;
+    int it = 0;
+    for (; it < max_iter; it++) {
+        double r[64], u[64][3];
+        for (int i = 0; i < n; i++) {
+            r[i] = range(x, s[i]);
+            for (int k = 0; k < 3; k++) u[i][k] = (x[k] - s[i][k]) / r[i];
+        }
+        double A[3][3] = {{0}}, g[3] = {0, 0, 0}, worst = 0;
+        int p = 0;
+        for (int i = 0; i < n; i++)
+            for (int j = i + 1; j < n; j++, p++) {
+                const double w = wt ? wt[p] : 1.0;
+                if (w == 0) continue;
+                const double f = (r[j] - r[i]) - rd[p];
+                worst = std::fmax(worst, std::fabs(f));
+                double jr[3];
+                for (int k = 0; k < 3; k++) jr[k] = u[j][k] - u[i][k];
+                for (int a = 0; a < nu; a++) {
+                    g[a] += w * jr[a] * f;
+                    for (int b = 0; b < nu; b++) A[a][b] += w * jr[a] * jr[b];
+                }
+            }
+        if (worst < tol_m) break;
+        double d[3] = {0, 0, 0};
+        if (nu == 2) {
+            const double det = A[0][0] * A[1][1] - A[0][1] * A[1][0];
+            if (std::fabs(det) < 1e-20) { if (iters) *iters = it; return -1; }
+            d[0] = (-g[0] * A[1][1] + g[1] * A[0][1]) / det;
+            d[1] = (g[0] * A[1][0] - g[1] * A[0][0]) / det;
+        } else {
+            const double det = A[0][0] * (A[1][1] * A[2][2] - A[1][2] * A[2][1]) - A[0][1] * (A[1][0] * A[2][2] - A[1][2] * A[2][0]) +
+                               A[0][2] * (A[1][0] * A[2][1] - A[1][1] * A[2][0]);
+            if (std::fabs(det) < 1e-30) { if (iters) *iters = it; return -1; }
+            const double b0 = -g[0], b1 = -g[1], b2 = -g[2];
+            d[0] = (b0 * (A[1][1] * A[2][2] - A[1][2] * A[2][1]) - A[0][1] * (b1 * A[2][2] - A[1][2] * b2) + A[0][2] * (b1 * A[2][1] - A[1][1] * b2)) / det;
+            d[1] = (A[0][0] * (b1 * A[2][2] - A[1][2] * b2) - b0 * (A[1][0] * A[2][2] - A[1][2] * A[2][0]) + A[0][2] * (A[1][0] * b2 - b1 * A[2][0])) / det;
+            d[2] = (A[0][0] * (A[1][1] * b2 - b1 * A[2][1]) - A[0][1] * (A[1][0] * b2 - b1 * A[2][0]) + b0 * (A[1][0] * A[2][1] - A[1][1] * A[2][0])) / det;
+        }
+        for (int k = 0; k < 3; k++) x[k] += damping * d[k];
+    }
+    if (iters) *iters = it;
+    ecef_to_latlon(x[0], x[1], x[2], out);
+    return 0;
+}
+
 }  // namespace geo

@@ -812,6 +812,15 @@ int tdoa_solve_3station(const double stations_lle[9], const double *range_diff, 
     return geo::solve_3station(stations_lle, range_diff, out_lle, iterations) ? TDOA_ERR_INVALID : TDOA_OK;
 }
 
+int tdoa_solve_nstation(const double *stations_lle, int n_stations, const double *range_diff, const double *weights,
+                        int solve_z, double out_lle[3], int *iterations)
+{
+    if (!stations_lle || !range_diff || !out_lle) return TDOA_ERR_INVALID;
+    const int rc = geo::solve_nstation(stations_lle, n_stations, range_diff, weights, solve_z, 10, 0.5, 1.0, out_lle,
+                                       iterations);
+    return rc == 0 ? TDOA_OK : (rc == -2 ? TDOA_ERR_UNSUPPORTED : TDOA_ERR_INVALID);
+}
+
 }  // extern "C"
 
 #include "exact_reference_api.inc"

@@ -6,6 +6,8 @@ import subprocess
 PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(PKG_ROOT, "csrc")
 LIB = os.path.join(PKG_ROOT, "libtdoa_mi355x.so")
+CLI = os.path.join(PKG_ROOT, "tdoa_processor")
+CLI_SRC = os.path.join(CSRC, "host", "tdoa_processor.cpp")
 HEADER = os.path.join(os.path.dirname(PKG_ROOT), "include", "tdoa_mi355x.h")
 
 
@@ -40,7 +42,21 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    build_cli(force=True, verbose=verbose)
     return LIB
+
+
+def build_cli(force=False, verbose=False):
+    """tdoa_processor: C++ host harness with the reference processor's command line, linked
+    against the C-ABI library only (no HIP headers)."""
+    if (not force and os.path.exists(CLI) and os.path.getmtime(CLI) >= max(os.path.getmtime(CLI_SRC), os.path.getmtime(HEADER))):
+        return CLI
+    cmd = [shutil.which("g++") or "g++", "-O2", "-std=c++17", "-Wall", "-o", CLI, CLI_SRC,
+           "-L" + PKG_ROOT, "-ltdoa_mi355x", "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return CLI
 
 
 if __name__ == "__main__":

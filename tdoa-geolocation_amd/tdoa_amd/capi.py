@@ -45,7 +45,7 @@ SYMBOLS = [
     "tdoa_synth_capture", "tdoa_capture_download",
     "tdoa_num_windows", "tdoa_num_pairs", "tdoa_process", "tdoa_process_u8",
     "tdoa_fm_xcorr_u8", "tdoa_fm_preprocess_u8", "tdoa_fm_xcorr_lags_u8", "tdoa_debug_force_generic",
-    "tdoa_latlon_to_ecef", "tdoa_ecef_to_latlon", "tdoa_solve_3station",
+    "tdoa_latlon_to_ecef", "tdoa_ecef_to_latlon", "tdoa_solve_3station", "tdoa_solve_nstation",
     "tdoa_profile_enable", "tdoa_profile_reset", "tdoa_profile_get", "tdoa_kernel_name",
     "tdoa_plan_info",
 ]
@@ -106,6 +106,7 @@ def load(build_if_missing=True):
     L.tdoa_ecef_to_latlon.argtypes = [C.c_double, C.c_double, C.c_double, dp]
     L.tdoa_ecef_to_latlon.restype = None
     L.tdoa_solve_3station.argtypes = [dp, dp, dp, C.POINTER(C.c_int)]
+    L.tdoa_solve_nstation.argtypes = [dp, C.c_int, dp, dp, C.c_int, dp, C.POINTER(C.c_int)]
     L.tdoa_profile_enable.argtypes = [vp, C.c_int]
     L.tdoa_profile_reset.argtypes = [vp]
     L.tdoa_profile_get.argtypes = [vp, C.c_int, dp, C.POINTER(C.c_int64), dp]
@@ -334,4 +335,16 @@ def solve_3station(stations_lle, range_diff):
     out = np.zeros(3)
     it = C.c_int()
     rc = load().tdoa_solve_3station(_d(st), _d(rd), _d(out), C.byref(it))
+    return rc, out, it.value
+
+
+def solve_nstation(stations_lle, range_diff, weights=None, solve_z=False):
+    st = np.ascontiguousarray(stations_lle, dtype=np.float64)
+    n = st.size // 3
+    rd = np.ascontiguousarray(range_diff, dtype=np.float64)
+    wt = None if weights is None else np.ascontiguousarray(weights, dtype=np.float64)
+    out = np.zeros(3)
+    it = C.c_int()
+    rc = load().tdoa_solve_nstation(_d(st.reshape(-1)), n, _d(rd), _d(wt) if wt is not None else None,
+                                    1 if solve_z else 0, _d(out), C.byref(it))
     return rc, out, it.value

@@ -89,3 +89,25 @@ def test_sharding_covers_every_window_once():
             assert seen == list(range(n))
     with pytest.raises(ValueError):
         sharding.owned_windows(2, 2, 5)
+
+
+def test_nstation_solver_reduces_to_reference_and_uses_all_pairs(capi, oracle):
+    st = [oracle.STATIONS[k] for k in oracle.COLLECTORS]
+    # n = 3 with weights {1,1,0}: the reference's own 2x2 system (processor.go:967-1003)
+    for rd in ([0.0, 0.0, 0.0], [1500.0, -2500.0, 0.0]):
+        rc, lle, it = capi.solve_nstation(st, rd, weights=[1, 1, 0])
+        orc, olle, oit = oracle.solve_tdoa(st, rd)
+        assert rc == 0 and it == oit and np.allclose(lle, olle, rtol=0, atol=1e-6)
+    # 8 stations on a ring, transmitter inside, exact range differences, X/Y/Z unknowns
+    rng = np.random.default_rng(4)
+    c = np.mean(np.array(st), axis=0)
+    ring = [(c[0] + 0.11 * np.cos(a), c[1] + 0.14 * np.sin(a), 300 + 100 * rng.random())
+            for a in np.linspace(0, 2 * np.pi, 8, endpoint=False)]
+    tx = (c[0] + 0.02, c[1] - 0.03, 420.0)
+    e = [capi.latlon_to_ecef(*s) for s in ring]
+    te = capi.latlon_to_ecef(*tx)
+    r = [float(np.linalg.norm(x - te)) for x in e]
+    rd = [r[j] - r[i] for i in range(8) for j in range(i + 1, 8)]
+    rc, lle, it = capi.solve_nstation(ring, rd, solve_z=False)
+    assert rc == 0 and abs(lle[0] - tx[0]) < 2e-3 and abs(lle[1] - tx[1]) < 2e-3
+    assert capi.solve_nstation(st[:2], [0.0])[0] != 0       # needs >= 3 stations
