@@ -108,18 +108,25 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    # one rank per GPU; TDOA_BENCH_BACKEND=gloo is a rehearsal mode (several ranks may then share
+    # a GPU and the peak records travel through host memory) -- the driver always runs nccl (= RCCL)
+    backend = os.environ.get("TDOA_BENCH_BACKEND", "nccl")
+    device = local_rank % torch.cuda.device_count() if backend == "gloo" else local_rank
+    torch.cuda.set_device(device)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend=backend)
 
     fs = 2_000_000
     wlen, max_lag = 2_000_000, 20000
     total = int(args.seconds * fs)
     block = total // 3
-    ctx = tdoa_amd.Context(device=local_rank, window_len=wlen, max_lag=max_lag, windows_per_batch=args.batch)
+    ctx = tdoa_amd.Context(device=device, window_len=wlen, max_lag=max_lag, windows_per_batch=args.batch)
     for s in range(3):
         ctx.synth_capture(s, block, STATIONS[s], TX, SEED_BASE + 16 * rank + s)
     wpb, n_windows = ctx.num_windows()
@@ -133,7 +140,12 @@ def main():
     def step():
         ctx.process(0, 1, out_dev_ptr=dev_peaks.data_ptr(), want_host=False)
         if world > 1:
-            dist.all_gather_into_tensor(gathered, dev_peaks)      # RCCL over xGMI: per-pair peaks
+            if backend == "nccl":
+                dist.all_gather_into_tensor(gathered, dev_peaks)  # RCCL over xGMI: per-pair peaks
+            else:
+                parts = [torch.empty(peak_bytes, dtype=torch.uint8) for _ in range(world)]
+                dist.all_gather(parts, dev_peaks.cpu())
+                gathered.copy_(torch.cat(parts))
 
     def fence():
         if world > 1:
@@ -152,9 +164,14 @@ def main():
     dt = time.perf_counter() - t0
     ctx.profile_enable(False)
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        # every rank must hold every rank's peaks after the gather
+        got = torch.frombuffer(bytearray(gathered.cpu().numpy().tobytes()), dtype=torch.uint8).view(world, -1)
+        mine = dev_peaks.cpu()
+        if not torch.equal(got[rank], mine):
+            raise SystemExit("all-gather of peak records is inconsistent on rank %d" % rank)
 
     prof = ctx.profile()
     if rank == 0:

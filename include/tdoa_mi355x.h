@@ -40,7 +40,8 @@ enum {
     TDOA_ERR_HIP = 3,         /* a HIP runtime call failed (tdoa_last_error)   */
     TDOA_ERR_NOMEM = 4,
     TDOA_ERR_UNSUPPORTED = 5, /* size outside the supported range              */
-    TDOA_ERR_STATE = 6        /* call order (e.g. process before upload)       */
+    TDOA_ERR_STATE = 6,       /* call order (e.g. process before upload)       */
+    TDOA_ERR_SINGULAR = 7     /* solver: singular Jacobian (processor.go:997-999) */
 };
 
 /* The constants the reference hard-codes, as parameters. */

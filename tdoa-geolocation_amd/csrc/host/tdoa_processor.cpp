@@ -255,7 +255,11 @@ int main(int argc, char **argv)
     int iters = 0;
     if (S == 3) rc = tdoa_solve_3station(lle.data(), rd.data(), out, &iters);
     else rc = tdoa_solve_nstation(lle.data(), S, rd.data(), nullptr, 0, out, &iters);
-    if (rc != TDOA_OK) return die("TDOA solution failed", rc);
+    if (rc != TDOA_OK) {                                       // processor.go:919-921
+        std::fprintf(stderr, "TDOA solution failed: %s at iteration %d\n", tdoa_strerror(rc), iters);
+        tdoa_destroy(ctx);
+        return 3;
+    }
     std::printf("\n*** CALCULATED TRANSMITTER LOCATION ***\nLatitude:  %.6f°\nLongitude: %.6f°\nElevation: %.1f m\n", out[0], out[1], out[2]);
     tdoa_destroy(ctx);
     return 0;

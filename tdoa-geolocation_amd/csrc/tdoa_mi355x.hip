@@ -424,6 +424,7 @@ const char *tdoa_strerror(int status)
         case TDOA_ERR_NOMEM: return "out of device memory";
         case TDOA_ERR_UNSUPPORTED: return "unsupported size";
         case TDOA_ERR_STATE: return "invalid call order";
+        case TDOA_ERR_SINGULAR: return "singular Jacobian matrix";
         default: return "unknown status";
     }
 }
@@ -809,7 +810,7 @@ void tdoa_ecef_to_latlon(double x, double y, double z, double lle[3]) { geo::ece
 int tdoa_solve_3station(const double stations_lle[9], const double *range_diff, double out_lle[3], int *iterations)
 {
     if (!stations_lle || !range_diff || !out_lle) return TDOA_ERR_INVALID;
-    return geo::solve_3station(stations_lle, range_diff, out_lle, iterations) ? TDOA_ERR_INVALID : TDOA_OK;
+    return geo::solve_3station(stations_lle, range_diff, out_lle, iterations) ? TDOA_ERR_SINGULAR : TDOA_OK;
 }
 
 int tdoa_solve_nstation(const double *stations_lle, int n_stations, const double *range_diff, const double *weights,
@@ -818,7 +819,7 @@ int tdoa_solve_nstation(const double *stations_lle, int n_stations, const double
     if (!stations_lle || !range_diff || !out_lle) return TDOA_ERR_INVALID;
     const int rc = geo::solve_nstation(stations_lle, n_stations, range_diff, weights, solve_z, 10, 0.5, 1.0, out_lle,
                                        iterations);
-    return rc == 0 ? TDOA_OK : (rc == -2 ? TDOA_ERR_UNSUPPORTED : TDOA_ERR_INVALID);
+    return rc == 0 ? TDOA_OK : (rc == -2 ? TDOA_ERR_UNSUPPORTED : TDOA_ERR_SINGULAR);
 }
 
 }  // extern "C"

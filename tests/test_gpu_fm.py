@@ -188,3 +188,22 @@ def test_long_windows_vs_f64_fft(oracle, n, delay, label):
     olag, ocorr, _ = oracle.b_xcorr_peak_fft(ta, tb, 20000)
     assert lag == olag == delay, label
     assert abs(corr - ocorr) <= REL_TOL * abs(ocorr), label
+
+
+def test_eight_stations_28_pairs(oracle):
+    """BASELINE config 4 geometry in miniature: 8 collectors, 28 pairs ordered i<j."""
+    import tdoa_amd
+    blk, wl, ml = 12000, 6000, 120
+    delays = [0, 7, 19, 33, 2, 51, 40, 11]
+    caps = [oracle.simulate_delayed_fm(3 * blk, d, 808, 100 + i) for i, d in enumerate(delays)]
+    with tdoa_amd.Context(max_lag=ml, window_len=wl) as c:
+        peaks = c.process_u8(caps)
+    assert peaks.shape == (6, 28)
+    pairs = [(i, j) for i in range(8) for j in range(i + 1, 8)]
+    for wid in (0, 3, 5):
+        off = (wid // 2) * blk + (wid % 2) * wl
+        pre = [oracle.b_preprocess(cp[2 * off:2 * (off + wl)])[0] for cp in caps]
+        for p, (i, j) in enumerate(pairs):
+            olag, ocorr = oracle.b_xcorr_peak(pre[i], pre[j], ml)
+            assert peaks[wid, p]["lag"] == olag == delays[j] - delays[i], (wid, i, j)
+            assert abs(peaks[wid, p]["corr"] - ocorr) <= REL_TOL * abs(ocorr)
