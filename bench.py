@@ -154,7 +154,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    ctx.profile_enable(True)
+    ctx.profile_enable(os.environ.get("TDOA_BENCH_NOPROF", "0") != "1")
     ctx.profile_reset()
     fence()
     t0 = time.perf_counter()

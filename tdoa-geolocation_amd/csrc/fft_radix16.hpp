@@ -40,54 +40,40 @@ __device__ __forceinline__ void fft16(float2 (&v)[16])
     for (int k2 = 0; k2 < 4; k2++) bfly4<INV>(v[4 * k2], v[4 * k2 + 1], v[4 * k2 + 2], v[4 * k2 + 3]);
 }
 
-// v[r] *= w^r, r = 1..15, powers by a depth-4 product tree
+// v[r] *= w^r, r = 1..15.  w^r = g_q * w^(r mod 4) with g_q = w^(4q): products of depth <= 4,
+// and only w, w^2, w^3 and the current g_q are live at any time.
 __device__ __forceinline__ void mul_powers16(float2 (&v)[16], float2 w)
 {
-    float2 w2 = cmul(w, w), w3 = cmul(w2, w), w4 = cmul(w2, w2);
-    float2 w5 = cmul(w4, w), w6 = cmul(w4, w2), w7 = cmul(w4, w3), w8 = cmul(w4, w4);
+    const float2 w2 = cmul(w, w), w3 = cmul(w2, w), w4 = cmul(w2, w2);
     v[1] = cmul(v[1], w);
     v[2] = cmul(v[2], w2);
     v[3] = cmul(v[3], w3);
-    v[4] = cmul(v[4], w4);
-    v[5] = cmul(v[5], w5);
-    v[6] = cmul(v[6], w6);
-    v[7] = cmul(v[7], w7);
-    v[8] = cmul(v[8], w8);
-    v[9] = cmul(v[9], cmul(w8, w));
-    v[10] = cmul(v[10], cmul(w8, w2));
-    v[11] = cmul(v[11], cmul(w8, w3));
-    v[12] = cmul(v[12], cmul(w8, w4));
-    v[13] = cmul(v[13], cmul(w8, w5));
-    v[14] = cmul(v[14], cmul(w8, w6));
-    v[15] = cmul(v[15], cmul(w8, w7));
+    float2 g = w4;
+#pragma unroll
+    for (int q = 1; q < 4; q++) {
+        v[4 * q] = cmul(v[4 * q], g);
+        v[4 * q + 1] = cmul(v[4 * q + 1], cmul(g, w));
+        v[4 * q + 2] = cmul(v[4 * q + 2], cmul(g, w2));
+        v[4 * q + 3] = cmul(v[4 * q + 3], cmul(g, w3));
+        if (q == 1) g = cmul(w4, w4);
+        if (q == 2) g = cmul(g, w4);
+    }
 }
 
-// same, but applied to the outputs X[k] (which live in v[oreg(k)]) with a separate base factor:
+// the same for the outputs X[k] (which live in v[oreg(k)]) with a separate base factor:
 // X[k] *= base * step^k
 __device__ __forceinline__ void mul_base_step16(float2 (&v)[16], float2 base, float2 step)
 {
-    float2 s2 = cmul(step, step), s3 = cmul(s2, step), s4 = cmul(s2, s2);
-    float2 s5 = cmul(s4, step), s6 = cmul(s4, s2), s7 = cmul(s4, s3), s8 = cmul(s4, s4);
-    float2 p[16];
-    p[0] = base;
-    p[1] = cmul(base, step);
-    p[2] = cmul(base, s2);
-    p[3] = cmul(base, s3);
-    p[4] = cmul(base, s4);
-    p[5] = cmul(base, s5);
-    p[6] = cmul(base, s6);
-    p[7] = cmul(base, s7);
-    float2 b8 = cmul(base, s8);
-    p[8] = b8;
-    p[9] = cmul(b8, step);
-    p[10] = cmul(b8, s2);
-    p[11] = cmul(b8, s3);
-    p[12] = cmul(b8, s4);
-    p[13] = cmul(b8, s5);
-    p[14] = cmul(b8, s6);
-    p[15] = cmul(b8, s7);
+    const float2 s2 = cmul(step, step), s3 = cmul(s2, step), s4 = cmul(s2, s2);
+    float2 g = base;
 #pragma unroll
-    for (int k = 0; k < 16; k++) v[oreg(k)] = cmul(v[oreg(k)], p[k]);
+    for (int q = 0; q < 4; q++) {
+        v[oreg(4 * q)] = cmul(v[oreg(4 * q)], g);
+        v[oreg(4 * q + 1)] = cmul(v[oreg(4 * q + 1)], cmul(g, step));
+        v[oreg(4 * q + 2)] = cmul(v[oreg(4 * q + 2)], cmul(g, s2));
+        v[oreg(4 * q + 3)] = cmul(v[oreg(4 * q + 3)], cmul(g, s3));
+        g = cmul(g, s4);
+    }
 }
 
 __device__ __forceinline__ int pad16(int i) { return i + (i >> 4); }
@@ -175,16 +161,23 @@ __global__ __launch_bounds__(512) void k_fwd_col256_c16(const SWDesc *sw, const 
 // inverse row pass with K3 fused, N1 = 4096: one workgroup owns rows a and N2 - a (a >= 1).
 // Thread t builds Q[a][t + 256 r] and its mirror Q[N2-a][4095 - t - 256 r] from the same four
 // spectrum values, so stage 1 of row a (item t) and of row N2-a (item 255 - t) need no exchange.
-// grid (N2/2, n_pw), 256 threads, dynamic LDS 2*kRowLds*8 = 68 KB.
+// grid (N2/2 - 1, n_pw) [+ (1, n_pw) for the SELF instance], 256 threads, dynamic LDS 68 KB.
 // ---------------------------------------------------------------------------
+template <bool SELF>
 __global__ __launch_bounds__(256) void k_inv_row_pair4096(const PWDesc *pw, const float2 *Z, float2 *V, FftPlan pl)
 {
     extern __shared__ float2 lds[];   // 2 * kRowLds
-    const PWDesc d = pw[blockIdx.y];
     const int N2 = pl.N2;
-    // block 0 owns the two self-mirrored rows (0, N2/2); block a >= 1 the mirrored pair (a, N2 - a)
-    const bool self = blockIdx.x == 0;
-    const int a = self ? 0 : blockIdx.x, b = self ? N2 / 2 : N2 - a;
+    // SELF: the two self-mirrored rows (0, N2/2), grid (1, n_pw); else the mirrored pair (a, N2 - a),
+    // a = blockIdx.x + 1, grid (N2/2 - 1, n_pw).  (Two instantiations: the self-mirrored loader needs
+    // twice the loads and would cost the paired kernel its occupancy.)
+    // An XCD-aware 1-D remap that puts the station pairs sharing a spectrum row on one XCD (staggered or
+    // not) measured 4-8 % SLOWER than this plain grid on cfg2, so the plain grid stays.
+    constexpr bool self = SELF;
+    const int pw_index = blockIdx.y;
+    const int a = self ? 0 : blockIdx.x + 1;
+    const PWDesc d = pw[pw_index];
+    const int b = self ? N2 / 2 : N2 - a;
     const float2 *ZaA = Z + (size_t)d.sw_a * pl.Nc + (size_t)a * 4096;
     const float2 *ZaB = Z + (size_t)d.sw_a * pl.Nc + (size_t)b * 4096;
     const float2 *ZbA = Z + (size_t)d.sw_b * pl.Nc + (size_t)a * 4096;
@@ -192,7 +185,7 @@ __global__ __launch_bounds__(256) void k_inv_row_pair4096(const PWDesc *pw, cons
     const int t = threadIdx.x;
     const float invNc = 1.0f / (float)pl.Nc;
     float2 va[16], vb[16];
-    if (self) {
+    if constexpr (self) {
         // each row mirrors onto itself: row 0 by k1 -> (4096 - k1) mod 4096, row N2/2 by k1 -> 4095 - k1;
         // every thread builds only its own Q values (the mirror operand is re-read)
 #pragma unroll
@@ -227,6 +220,9 @@ __global__ __launch_bounds__(256) void k_inv_row_pair4096(const PWDesc *pw, cons
     const int item_b = self ? t : 255 - t;   // which item of row b this thread's stage-1 butterfly is
     fft16<true>(va);
     fft16<true>(vb);
+    // Both rows go through stages 2 and 3 together, each in its own LDS image.  (Sending them through
+    // one 34 KB image one after the other would fit three workgroups per CU, but the compiler then
+    // needs > 170 VGPRs or spills: measured 2.4 ms against 1.6 ms for this form.)
     float2 *la = lds, *lb = lds + kRowLds;
 #pragma unroll
     for (int k = 0; k < 16; k++) {
@@ -270,7 +266,7 @@ __global__ __launch_bounds__(256) void k_inv_row_pair4096(const PWDesc *pw, cons
     fft16<true>(va);
     fft16<true>(vb);
     // V[k2][n1] = y[n1] * W_Nc^(-n1 k2), n1 = j + 256 k
-    float2 *out = V + (size_t)blockIdx.y * pl.Nc;
+    float2 *out = V + (size_t)pw_index * pl.Nc;
     const float inv2 = 2.0f / (float)pl.Nc;
     {
         const long long e0 = ((long long)j * a) & (pl.Nc - 1), e1 = ((long long)256 * a) & (pl.Nc - 1);

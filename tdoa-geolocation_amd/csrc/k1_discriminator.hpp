@@ -55,10 +55,10 @@ __device__ __forceinline__ float k1_theta(unsigned int s, const float *rcp)
 __device__ __forceinline__ float k1_wrap_diff(float th1, float th0)
 {
 #pragma clang fp contract(off)
-    float d = th1 - th0;
-    if (d > 3.1415927410125732f) d = d - 6.2831854820251465f;
-    else if (d < -3.1415927410125732f) d = d + 6.2831854820251465f;
-    return d;
+    const float d = th1 - th0;
+    // branch-free: add -2pi, +2pi or 0 (the codes derived from d are unaffected by d + 0.0f)
+    const float adj = d > 3.1415927410125732f ? -6.2831854820251465f : (d < -3.1415927410125732f ? 6.2831854820251465f : 0.0f);
+    return d + adj;
 }
 
 // phase -> 16-bit code, pi == 32768 (wraps to -32768)
@@ -117,7 +117,9 @@ __global__ __launch_bounds__(kStatsThreads) void k_fm_demod(const SWDesc *sw, sh
     __shared__ float rcp[128];
     k1_init_rcp(rcp);
     const SWDesc d = sw[blockIdx.y];
-    const uint16_t *p = reinterpret_cast<const uint16_t *>(d.base);
+    // the pointer comes out of a descriptor in memory: tell the compiler it is global, not flat
+    typedef const __attribute__((address_space(1))) uint16_t *global_u16;
+    const uint16_t *p = (const uint16_t *)(global_u16)(const uint16_t *)d.base;
     short *out = codes + (size_t)blockIdx.y * code_stride;
     const int len = d.len;
     const int start = blockIdx.x * kStatsChunk;
@@ -126,15 +128,25 @@ __global__ __launch_bounds__(kStatsThreads) void k_fm_demod(const SWDesc *sw, sh
     for (int i0 = start + threadIdx.x * 8; i0 < start + kStatsChunk && i0 < len; i0 += kStatsThreads * 8) {
         int c[8];
         if (i0 >= 1 && i0 + 8 <= len) {
+            // interior: no per-sample conditions
             unsigned int s[9];
             k1_load9(p, i0, s);
             float th[9];
 #pragma unroll
             for (int k = 0; k < 9; k++) th[k] = k1_theta(s[k], rcp);
+            int t1 = 0;
+            unsigned long long t2 = 0;
 #pragma unroll
-            for (int k = 0; k < 8; k++) c[k] = k1_code(k1_wrap_diff(th[k + 1], th[k]));
+            for (int k = 0; k < 8; k++) {
+                c[k] = k1_code(k1_wrap_diff(th[k + 1], th[k]));
+                t1 += c[k];
+                t2 += (unsigned int)(c[k] * c[k]);     // <= 2^30 each
+            }
+            s1 += t1;
+            s2 += t2;
         } else {
-            // window head (code_0 := code_1) and tail
+            // window head (code_0 := code_1) and tail; samples beyond len carry code 0 in memory
+            // and do not enter the sums
 #pragma unroll
             for (int k = 0; k < 8; k++) {
                 const int i = i0 + k;
@@ -144,14 +156,10 @@ __global__ __launch_bounds__(kStatsThreads) void k_fm_demod(const SWDesc *sw, sh
                     v = k1_code(k1_wrap_diff(k1_theta(p[ii], rcp), k1_theta(p[ii - 1], rcp)));
                 }
                 c[k] = v;
-            }
-        }
-        // samples beyond len carry code 0 in memory but do not enter the sums
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            if (i0 + k < len) {
-                s1 += c[k];
-                s2 += (unsigned long long)(unsigned int)(c[k] * c[k]);
+                if (i < len) {
+                    s1 += v;
+                    s2 += (unsigned long long)(unsigned int)(v * v);
+                }
             }
         }
         uint4 w;

@@ -66,6 +66,14 @@ struct tdoa_ctx {
 
     FftPlan plan{};
     int64_t plan_n = 0;
+
+    // whole-step hipGraph of tdoa_process (launch-bound when windows are processed in many groups)
+    bool use_graph = true;
+    uint64_t alloc_gen = 0;                 // bumped whenever a workspace buffer moves
+    std::vector<uint64_t> graph_key;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    DevBuf g_sw_desc, g_pw_desc, g_scales, g_keys;
 };
 
 namespace {
@@ -108,6 +116,7 @@ int ensure(tdoa_ctx *ctx, DevBuf &b, size_t bytes)
         return fail(ctx, TDOA_ERR_NOMEM, "hipMalloc", e);
     }
     b.cap = want;
+    ctx->alloc_gen++;
     return TDOA_OK;
 }
 
@@ -209,6 +218,21 @@ void prof_collect(tdoa_ctx *ctx)
     ctx->recs.clear();
 }
 
+// make every workspace buffer of run_fm_batch large enough (no allocation may happen while a
+// stream capture is open)
+int reserve_fm_batch(tdoa_ctx *ctx, int n_sw, int maxlen, int n_pw, const FftPlan &pl)
+{
+    int rc;
+    const int chunks = std::max(1, (maxlen + kStatsChunk - 1) / kStatsChunk);
+    const long long code_stride = ((long long)maxlen + 15) / 8 * 8;
+    if ((rc = ensure(ctx, ctx->partials, sizeof(StatsPartial) * (size_t)chunks * n_sw))) return rc;
+    if ((rc = ensure(ctx, ctx->stats, sizeof(FmStats) * (size_t)n_sw))) return rc;
+    if ((rc = ensure(ctx, ctx->codes, sizeof(short) * (size_t)code_stride * n_sw))) return rc;
+    if ((rc = ensure(ctx, ctx->tz, sizeof(float2) * (size_t)pl.Nc * n_sw))) return rc;
+    if (n_pw && (rc = ensure(ctx, ctx->v, sizeof(float2) * (size_t)pl.Nc * n_pw))) return rc;
+    return TDOA_OK;
+}
+
 // ---- mode B core: run stats + forward + inverse + peak over prepared descriptors
 // sw/pw descriptors are already in device memory; maxlen = longest window.
 int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const PWDesc *d_pw, int n_pw,
@@ -255,12 +279,6 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
     const size_t lds_row2 = sizeof(float2) * 4 * (size_t)pl.N1;
     const size_t lds_col16 = sizeof(float2) * 256 * 32;
     const size_t lds_pair16 = sizeof(float2) * 2 * kRowLds;
-    if ((rc = set_lds(ctx, k_fwd_col_c16, lds_col))) return rc;
-    if ((rc = set_lds(ctx, k_fwd_row, lds_row))) return rc;
-    if ((rc = set_lds(ctx, k_inv_row_pair, lds_row2))) return rc;
-    if ((rc = set_lds(ctx, k_inv_col_peak<true>, lds_col))) return rc;
-    if ((rc = set_lds(ctx, k_fwd_col256_c16, lds_col16))) return rc;
-    if ((rc = set_lds(ctx, k_inv_row_pair4096, lds_pair16))) return rc;
     {
         ProfScope ps(ctx, TDOA_K_FWD_COL, 2.0 * sum_len + nc8 * n_sw);
         if (col16)
@@ -281,8 +299,10 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
         {
             ProfScope ps(ctx, TDOA_K_INV_ROW, 3.0 * nc8 * n_pw);
             if (row16) {
-                hipLaunchKernelGGL(k_inv_row_pair4096, dim3(pl.N2 / 2, n_pw), dim3(256), lds_pair16, st, d_pw, tz, v,
-                                   pl);
+                if (pl.N2 > 2)
+                    hipLaunchKernelGGL(k_inv_row_pair4096<false>, dim3(pl.N2 / 2 - 1, n_pw), dim3(256), lds_pair16, st,
+                                       d_pw, tz, v, pl);
+                hipLaunchKernelGGL(k_inv_row_pair4096<true>, dim3(1, n_pw), dim3(256), lds_pair16, st, d_pw, tz, v, pl);
             } else {
                 hipLaunchKernelGGL(k_inv_row_pair, dim3(pl.N2 / 2, n_pw), dim3(256), lds_row2, st, d_pw, tz, v, pl);
             }
@@ -298,6 +318,24 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
         }
     }
     HIPCHK(ctx, hipGetLastError());
+    return TDOA_OK;
+}
+
+// raise the dynamic-LDS limit of every kernel that needs more than the default once per context
+int allow_big_lds(tdoa_ctx *ctx)
+{
+    int rc;
+    const size_t all = 136 * 1024;   // largest dynamic request: 128 KiB (kLdsCap tiles, generic row pair); static LDS comes on top
+    if ((rc = set_lds(ctx, k_fwd_col_c16, all))) return rc;
+    if ((rc = set_lds(ctx, k_fwd_col_c64, all))) return rc;
+    if ((rc = set_lds(ctx, k_fwd_row, all))) return rc;
+    if ((rc = set_lds(ctx, k_inv_row_pair, all))) return rc;
+    if ((rc = set_lds(ctx, k_inv_row_c64, all))) return rc;
+    if ((rc = set_lds(ctx, k_inv_col_peak<true>, all))) return rc;
+    if ((rc = set_lds(ctx, k_inv_col_peak<false>, all))) return rc;
+    if ((rc = set_lds(ctx, k_fwd_col256_c16, all))) return rc;
+    if ((rc = set_lds(ctx, k_inv_row_pair4096<false>, all))) return rc;
+    if ((rc = set_lds(ctx, k_inv_row_pair4096<true>, all))) return rc;
     return TDOA_OK;
 }
 
@@ -460,6 +498,12 @@ int tdoa_create(const tdoa_params *p, tdoa_ctx **out)
         delete ctx;
         return TDOA_ERR_HIP;
     }
+    if (allow_big_lds(ctx) != TDOA_OK) {
+        (void)hipStreamDestroy(ctx->stream);
+        delete ctx;
+        return TDOA_ERR_HIP;
+    }
+    if (const char *e = std::getenv("TDOA_NO_GRAPH")) ctx->use_graph = !(e[0] == '1');
     *out = ctx;
     return TDOA_OK;
 }
@@ -470,10 +514,13 @@ void tdoa_destroy(tdoa_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     prof_collect(ctx);
+    if (ctx->graph_exec) (void)hipGraphExecDestroy(ctx->graph_exec);
+    if (ctx->graph) (void)hipGraphDestroy(ctx->graph);
     tdoa_capture_clear(ctx);
     DevBuf *bufs[] = {&ctx->sw_desc, &ctx->pw_desc, &ctx->partials, &ctx->stats, &ctx->codes, &ctx->tz, &ctx->v, &ctx->keys,
                       &ctx->scales, &ctx->peaks, &ctx->scratch_a, &ctx->scratch_b, &ctx->lagdump,
-                      &ctx->ex_a, &ctx->ex_b, &ctx->ex_c, &ctx->ex_d, &ctx->ex_part};
+                      &ctx->ex_a, &ctx->ex_b, &ctx->ex_c, &ctx->ex_d, &ctx->ex_part,
+                      &ctx->g_sw_desc, &ctx->g_pw_desc, &ctx->g_scales, &ctx->g_keys};
     for (DevBuf *b : bufs) release(*b);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -669,34 +716,73 @@ int tdoa_process(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host, void *
                 pw[wi * P + p] = PWDesc{local * S + i, local * S + j, wid * P + p, (int32_t)wlen};
     }
     const size_t slots = (size_t)W * P;
-    if ((rc = ensure(ctx, ctx->keys, sizeof(unsigned long long) * slots))) return rc;
-    if ((rc = ensure(ctx, ctx->scales, sizeof(double) * slots))) return rc;
-    if ((rc = ensure(ctx, ctx->peaks, sizeof(PeakOut) * slots))) return rc;
-    if ((rc = ensure(ctx, ctx->sw_desc, sizeof(SWDesc) * std::max<size_t>(sw.size(), 1)))) return rc;
-    if ((rc = ensure(ctx, ctx->pw_desc, sizeof(PWDesc) * std::max<size_t>(pw.size(), 1)))) return rc;
-    std::vector<double> scales(slots, 1.0 / (4.0 * (double)n * std::sqrt((double)wlen)));
     hipStream_t st = ctx->stream;
-    HIPCHK(ctx, hipMemsetAsync(ctx->keys.p, 0, sizeof(unsigned long long) * slots, st));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->scales.p, scales.data(), sizeof(double) * slots, hipMemcpyHostToDevice, st));
-    if (!sw.empty()) {
-        HIPCHK(ctx, hipMemcpyAsync(ctx->sw_desc.p, sw.data(), sizeof(SWDesc) * sw.size(), hipMemcpyHostToDevice, st));
-        HIPCHK(ctx, hipMemcpyAsync(ctx->pw_desc.p, pw.data(), sizeof(PWDesc) * pw.size(), hipMemcpyHostToDevice, st));
-    }
-    HIPCHK(ctx, hipStreamSynchronize(st));   // host vectors go out of scope below
+    const int n_first = (int)std::min<size_t>(per_batch, mine.size());
+    if ((rc = ensure(ctx, ctx->peaks, sizeof(PeakOut) * slots))) return rc;
+    if ((rc = ensure(ctx, ctx->g_keys, sizeof(unsigned long long) * slots))) return rc;
+    if ((rc = ensure(ctx, ctx->g_scales, sizeof(double) * slots))) return rc;
+    if ((rc = ensure(ctx, ctx->g_sw_desc, sizeof(SWDesc) * std::max<size_t>(sw.size(), 1)))) return rc;
+    if ((rc = ensure(ctx, ctx->g_pw_desc, sizeof(PWDesc) * std::max<size_t>(pw.size(), 1)))) return rc;
+    if (n_first && (rc = reserve_fm_batch(ctx, n_first * S, (int)wlen, n_first * P, pl))) return rc;
+    auto *d_sw = static_cast<SWDesc *>(ctx->g_sw_desc.p);
+    auto *d_pw = static_cast<PWDesc *>(ctx->g_pw_desc.p);
+    auto *d_keys = static_cast<unsigned long long *>(ctx->g_keys.p);
+    auto *d_scales = static_cast<double *>(ctx->g_scales.p);
 
-    for (size_t w0 = 0; w0 < mine.size(); w0 += per_batch) {
-        int nw = (int)std::min<size_t>(per_batch, mine.size() - w0);
-        rc = run_fm_batch(ctx, static_cast<SWDesc *>(ctx->sw_desc.p) + w0 * S, nw * S, (int)wlen,
-                          static_cast<PWDesc *>(ctx->pw_desc.p) + w0 * P, nw * P,
-                          static_cast<unsigned long long *>(ctx->keys.p), pl, -(ctx->prm.max_lag - 1),
-                          ctx->prm.max_lag - 1, nullptr, 1.0f, (double)wlen * nw * S);
-        if (rc) return rc;
+    // everything the launches depend on: same key => the captured graph can be replayed as is
+    std::vector<uint64_t> key = {(uint64_t)S, (uint64_t)rank, (uint64_t)world, (uint64_t)per_batch, (uint64_t)wlen,
+                                 (uint64_t)ctx->prm.max_lag, (uint64_t)block, (uint64_t)ctx->force_generic,
+                                 ctx->alloc_gen};
+    for (auto &c : ctx->caps) {
+        key.push_back((uint64_t)(uintptr_t)c.dev);
+        key.push_back((uint64_t)c.n);
     }
-    {
+    const bool graph_ok = ctx->use_graph && !ctx->profiling;
+    const bool replay = graph_ok && ctx->graph_exec && key == ctx->graph_key;
+
+    if (!replay) {
+        std::vector<double> scales(slots, 1.0 / (4.0 * (double)n * std::sqrt((double)wlen)));
+        HIPCHK(ctx, hipMemcpyAsync(d_scales, scales.data(), sizeof(double) * slots, hipMemcpyHostToDevice, st));
+        if (!sw.empty()) {
+            HIPCHK(ctx, hipMemcpyAsync(d_sw, sw.data(), sizeof(SWDesc) * sw.size(), hipMemcpyHostToDevice, st));
+            HIPCHK(ctx, hipMemcpyAsync(d_pw, pw.data(), sizeof(PWDesc) * pw.size(), hipMemcpyHostToDevice, st));
+        }
+        HIPCHK(ctx, hipStreamSynchronize(st));   // host vectors go out of scope below
+    }
+
+    auto enqueue = [&]() -> int {
+        HIPCHK(ctx, hipMemsetAsync(d_keys, 0, sizeof(unsigned long long) * slots, st));
+        for (size_t w0 = 0; w0 < mine.size(); w0 += per_batch) {
+            const int nw = (int)std::min<size_t>(per_batch, mine.size() - w0);
+            const int r = run_fm_batch(ctx, d_sw + w0 * S, nw * S, (int)wlen, d_pw + w0 * P, nw * P, d_keys, pl,
+                                       -(ctx->prm.max_lag - 1), ctx->prm.max_lag - 1, nullptr, 1.0f,
+                                       (double)wlen * nw * S);
+            if (r) return r;
+        }
         ProfScope ps(ctx, TDOA_K_PEAK, 32.0 * (double)slots);
-        hipLaunchKernelGGL(k_decode_peaks, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, st,
-                           static_cast<unsigned long long *>(ctx->keys.p), static_cast<double *>(ctx->scales.p),
+        hipLaunchKernelGGL(k_decode_peaks, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, st, d_keys, d_scales,
                            static_cast<PeakOut *>(ctx->peaks.p), (int)slots);
+        return TDOA_OK;
+    };
+
+    if (replay) {
+        HIPCHK(ctx, hipGraphLaunch(ctx->graph_exec, st));
+    } else if (graph_ok) {
+        if (ctx->graph_exec) { (void)hipGraphExecDestroy(ctx->graph_exec); ctx->graph_exec = nullptr; }
+        if (ctx->graph) { (void)hipGraphDestroy(ctx->graph); ctx->graph = nullptr; }
+        ctx->graph_key.clear();
+        HIPCHK(ctx, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        rc = enqueue();
+        hipGraph_t g = nullptr;
+        hipError_t e = hipStreamEndCapture(st, &g);
+        if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+        if (e != hipSuccess) return fail(ctx, TDOA_ERR_HIP, "hipStreamEndCapture", e);
+        ctx->graph = g;
+        HIPCHK(ctx, hipGraphInstantiate(&ctx->graph_exec, g, nullptr, nullptr, 0));
+        ctx->graph_key = key;
+        HIPCHK(ctx, hipGraphLaunch(ctx->graph_exec, st));
+    } else {
+        if ((rc = enqueue())) return rc;
     }
     if (out_dev)
         HIPCHK(ctx, hipMemcpyAsync(out_dev, ctx->peaks.p, sizeof(PeakOut) * slots, hipMemcpyDeviceToDevice, st));
