@@ -22,7 +22,7 @@ def load(d):
     for path in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(path)):
             name = r["Kernel_Name"].split("(")[0].replace("tdoa::", "").replace("void ", "")
-            out[name].append(float(r["Counter_Value"]))
+            out[name].append(float(r["Counter_Value"]))   # template instances keep their <...> suffix
     return out
 
 
@@ -32,10 +32,14 @@ def main():
     for k in sorted(set(fetch) & set(write)):
         if not k.startswith("k_") or k.startswith("k_synth"):
             continue
+        base = k.split("<")[0]                      # template instances of one kernel are summed
         f, w = fetch[k][-1], write[k][-1]           # last launch = a timed step
-        corr = FETCH_CORRECTION.get(k, 1.0)
-        res[k] = {"FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "fetch_correction": corr,
-                  "traffic_bytes_per_launch": f * 1024 * corr + w * 1024}
+        corr = FETCH_CORRECTION.get(base, 1.0)
+        rec = res.setdefault(base, {"FETCH_SIZE_KiB": 0.0, "WRITE_SIZE_KiB": 0.0, "fetch_correction": corr,
+                                    "traffic_bytes_per_launch": 0.0})
+        rec["FETCH_SIZE_KiB"] += f
+        rec["WRITE_SIZE_KiB"] += w
+        rec["traffic_bytes_per_launch"] += f * 1024 * corr + w * 1024
     json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py cfg2, batch = all windows",
                "kernels": res}, open(sys.argv[3], "w"), indent=1, sort_keys=True)
     print(json.dumps(res, indent=1))

@@ -288,36 +288,36 @@ __global__ __launch_bounds__(256) void k_inv_row_pair4096(const PWDesc *pw, cons
 // ---------------------------------------------------------------------------
 constexpr int kPruneMax = 8;
 
-// grid (N1/64, n_pw), 256 threads: cp = t & 31 (column PAIR: n1 = 64*bx + 2cp, +1), g = t >> 5
-// (row group: rows g, g+8, ...); 16-byte loads, 8 rows in flight per thread
+// grid (N1/128, n_pw), 256 threads: cp = t & 63 (column PAIR: n1 = 128*bx + 2cp, +1), g = t >> 6
+// (row group: rows g, g+4, ...); 16-byte loads -> 1 KB contiguous per row, 8 rows in flight per thread
 __global__ __launch_bounds__(256) void k_inv_col_pruned(const float2 *V, unsigned long long *keys, const PWDesc *pw,
                                                        FftPlan pl, int lag_lo, int lag_hi, int np, int nn,
                                                        float *lag_dump, float dump_scale)
 {
     __shared__ float2 wtab[512];                   // e^{+2 pi i k/N2}, N2 <= 512
-    __shared__ float4 part[8][kPruneMax][32];
+    __shared__ float4 part[4][kPruneMax][64];
     __shared__ unsigned long long red[4];
     const int N2 = pl.N2, N1 = pl.N1;
     for (int k = threadIdx.x; k < N2; k += 256) wtab[k] = unit_root((float)k, 2.0f / (float)N2, true);
     __syncthreads();
-    const int cp = threadIdx.x & 31, g = threadIdx.x >> 5;
-    const int n1 = (blockIdx.x << 6) + 2 * cp;
+    const int cp = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int n1 = (blockIdx.x << 7) + 2 * cp;
     const float4 *in = reinterpret_cast<const float4 *>(V + (size_t)blockIdx.y * pl.Nc + n1);
     const size_t row_stride = (size_t)N1 / 2;      // in float4 units
     float4 acc[kPruneMax];
 #pragma unroll
     for (int o = 0; o < kPruneMax; o++) acc[o] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     const int nout = np + nn;
-    for (int kb = g; kb < N2; kb += 64) {          // 8 rows per trip, all loads issued first
+    for (int kb = g; kb < N2; kb += 32) {          // 8 rows per trip, all loads issued first
         float4 x[8];
 #pragma unroll
         for (int u = 0; u < 8; u++) {
-            const int k2 = kb + 8 * u;
+            const int k2 = kb + 4 * u;
             x[u] = k2 < N2 ? in[(size_t)k2 * row_stride] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         }
 #pragma unroll
         for (int u = 0; u < 8; u++) {
-            const int k2 = kb + 8 * u;
+            const int k2 = kb + 4 * u;
 #pragma unroll
             for (int o = 0; o < kPruneMax; o++) {
                 if (o < nout) {
@@ -336,17 +336,17 @@ __global__ __launch_bounds__(256) void k_inv_col_pruned(const float2 *V, unsigne
     for (int o = 0; o < kPruneMax; o++) part[g][o][cp] = acc[o];
     __syncthreads();
     unsigned long long best = 0;
-    if (threadIdx.x < 32 * nout) {
-        const int o = threadIdx.x >> 5;
-        float4 s = part[0][o][cp];
+    for (int e = threadIdx.x; e < 64 * nout; e += 256) {
+        const int o = e >> 6, c = e & 63;
+        float4 s = part[0][o][c];
 #pragma unroll
-        for (int gg = 1; gg < 8; gg++) {
-            const float4 q = part[gg][o][cp];
+        for (int gg = 1; gg < 4; gg++) {
+            const float4 q = part[gg][o][c];
             s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
         }
         const int n2 = o < np ? o : N2 - nn + (o - np);
-        const float vals[4] = {s.x, s.y, s.z, s.w};   // lags 2m, 2m+1, 2m+2, 2m+3 with m = n2*N1 + n1
-        long long d = 2 * ((long long)n2 * N1 + n1);
+        const float vals[4] = {s.x, s.y, s.z, s.w};   // lags 2m .. 2m+3 with m = n2*N1 + n1
+        long long d = 2 * ((long long)n2 * N1 + (blockIdx.x << 7) + 2 * c);
         if (d >= pl.Nc) d -= 2 * pl.Nc;
 #pragma unroll
         for (int q = 0; q < 4; q++) {

@@ -265,7 +265,7 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
         np = lag_hi >= 0 ? (int)((lag_hi / 2) / pl.N1) + 1 : 0;
         nn = lag_lo < 0 ? pl.N2 - (int)(((n_real + lag_lo) / 2) / pl.N1) : 0;
     }
-    const bool pruned = !ctx->force_generic && pl.N1 >= 64 && pl.N2 <= 512 && np + nn <= kPruneMax && np + nn <= pl.N2 &&
+    const bool pruned = !ctx->force_generic && pl.N1 >= 128 && pl.N2 <= 512 && np + nn <= kPruneMax && np + nn <= pl.N2 &&
                         lag_hi < pl.Nc && lag_lo > -pl.Nc;
     {
         // K1: capture bytes -> 16-bit phase codes + exact window statistics
@@ -310,7 +310,7 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
         {
             ProfScope ps(ctx, TDOA_K_INV_COL, nc8 * n_pw);
             if (pruned)
-                hipLaunchKernelGGL(k_inv_col_pruned, dim3(pl.N1 / 64, n_pw), dim3(256), 0, st, v, d_keys, d_pw, pl,
+                hipLaunchKernelGGL(k_inv_col_pruned, dim3(pl.N1 / 128, n_pw), dim3(256), 0, st, v, d_keys, d_pw, pl,
                                    lag_lo, lag_hi, np, nn, lag_dump, dump_scale);
             else
                 hipLaunchKernelGGL(k_inv_col_peak<true>, dim3(pl.N1 / pl.C, n_pw), dim3(256), lds_col, st, v, d_keys,
