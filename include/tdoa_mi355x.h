@@ -109,6 +109,22 @@ int tdoa_simple_correlate_c64(tdoa_ctx *ctx, const float *s1, size_t n1,
 /* fast_analyzer.go:163-227 fastSNRCalculation(samples, totalSamples) -> dB */
 int tdoa_fast_snr_u8(tdoa_ctx *ctx, const uint8_t *samples, int total_samples, double *snr_db);
 
+/* fast_analyzer.go:15-24 FastAnalysis / :113-161 fastAnalyzeSamples */
+typedef struct {
+    int32_t total_samples;
+    int32_t has_clipping;     /* any I or Q byte equal to 0 or 255 (:154) */
+    int32_t has_overload;     /* I or Q standard deviation below 2 (:155)  */
+    int32_t reserved;
+    double  i_avg, q_avg, i_std, q_std;
+    double  snr_estimate;     /* dB, fastSNRCalculation                    */
+    double  power_level;      /* 20*log10(sqrt(i_std^2+q_std^2)), floor -100 (:146-151) */
+} tdoa_fast_analysis;
+int tdoa_fast_analyze_u8(tdoa_ctx *ctx, const uint8_t *samples, int total_samples, tdoa_fast_analysis *out);
+/* fast_analyzer.go:53-111 fastAnalyzeDualFrequencyFile on capture bytes in memory: the first 32768
+ * samples of blocks 1 and 3 -> ref, of block 2 -> tgt; TDOA_ERR_INVALID if the capture has < 3 samples */
+int tdoa_fast_analyze_capture_u8(tdoa_ctx *ctx, const uint8_t *raw, size_t n_bytes,
+                                 tdoa_fast_analysis *ref, tdoa_fast_analysis *tgt);
+
 /* ---- mode B: the north-star pipeline ---------------------------------------
  * u8 IQ -> FM discriminator -> Stockham FFT -> conj-multiply -> inverse FFT
  * -> argmax, batched over (station, window) and (pair, window).
@@ -122,6 +138,10 @@ int tdoa_fast_snr_u8(tdoa_ctx *ctx, const uint8_t *samples, int total_samples, d
 
 /* copy one station's capture into HBM (ctx-owned) */
 int tdoa_capture_upload(tdoa_ctx *ctx, int station, const uint8_t *iq, size_t n_samples);
+/* stream a .dat file (collector.go:61 naming, raw u8 I,Q; any size, > 1 GiB safe) into HBM through two
+ * pinned staging buffers so that the read of chunk i+1 overlaps the DMA of chunk i;
+ * *n_samples (may be NULL) receives size/2 like processor.go:182 */
+int tdoa_capture_upload_file(tdoa_ctx *ctx, int station, const char *path, size_t *n_samples);
 /* or attach a buffer that is already in this device's memory (not copied, not freed) */
 int tdoa_capture_attach_device(tdoa_ctx *ctx, int station, const void *dev_iq, size_t n_samples);
 int tdoa_capture_clear(tdoa_ctx *ctx);

@@ -215,8 +215,8 @@ int main(int argc, char **argv)
         }
     } else {
         // ---- north-star path: raw bytes in, one peak per (window, pair) out
-        for (int s = 0; s < S; s++)
-            if ((rc = tdoa_capture_upload(ctx, s, caps[s].raw.data(), caps[s].raw.size() / 2))) return die("tdoa_capture_upload", rc);
+        for (int s = 0; s < S; s++)   // file -> pinned staging -> HBM (the bytes read above are only used for the listing)
+            if ((rc = tdoa_capture_upload_file(ctx, s, caps[s].path.c_str(), nullptr))) return die("tdoa_capture_upload_file", rc);
         int wpb = 0, W = 0;
         if ((rc = tdoa_num_windows(ctx, &wpb, &W))) return die("tdoa_num_windows", rc);
         const int P = tdoa_num_pairs(ctx);

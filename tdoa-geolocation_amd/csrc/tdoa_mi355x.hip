@@ -553,6 +553,63 @@ int tdoa_capture_upload(tdoa_ctx *ctx, int station, const uint8_t *iq, size_t n_
     return TDOA_OK;
 }
 
+int tdoa_capture_upload_file(tdoa_ctx *ctx, int station, const char *path, size_t *n_samples)
+{
+    int rc;
+    if ((rc = check_ctx(ctx))) return rc;
+    if (station < 0 || station > 1023 || !path) return fail(ctx, TDOA_ERR_INVALID, "bad station/path");
+    FILE *f = std::fopen(path, "rb");
+    if (!f) return fail(ctx, TDOA_ERR_INVALID, "failed to open file");
+    if (std::fseek(f, 0, SEEK_END) != 0) { std::fclose(f); return fail(ctx, TDOA_ERR_INVALID, "failed to get file size"); }
+    const long long size = std::ftell(f);
+    std::fseek(f, 0, SEEK_SET);
+    if (size < 0) { std::fclose(f); return fail(ctx, TDOA_ERR_INVALID, "failed to get file size"); }
+    const size_t n = (size_t)size / 2;                       // processor.go:182
+    if ((size_t)station >= ctx->caps.size()) ctx->caps.resize(station + 1);
+    auto &c = ctx->caps[station];
+    if (c.owned && c.dev) (void)hipFree(const_cast<uint8_t *>(c.dev));
+    c = tdoa_ctx::Capture{};
+    void *d = nullptr;
+    hipError_t e = hipMalloc(&d, 2 * n + 64);
+    if (e != hipSuccess) { std::fclose(f); return fail(ctx, TDOA_ERR_NOMEM, "hipMalloc capture", e); }
+    const size_t chunk = 32u << 20;                          // 2 x 32 MiB pinned staging
+    void *stage[2] = {nullptr, nullptr};
+    hipEvent_t done[2] = {nullptr, nullptr};
+    bool ok = true;
+    for (int k = 0; k < 2 && ok; k++)
+        ok = hipHostMalloc(&stage[k], chunk, hipHostMallocDefault) == hipSuccess && hipEventCreate(&done[k]) == hipSuccess;
+    size_t off = 0;
+    int k = 0;
+    bool used[2] = {false, false};
+    while (ok && off < 2 * n) {
+        if (used[k]) ok = hipEventSynchronize(done[k]) == hipSuccess;          // staging buffer k is free again
+        const size_t want = std::min(chunk, 2 * n - off);
+        const size_t got = ok ? std::fread(stage[k], 1, want, f) : 0;
+        if (got != want) { ok = false; break; }
+        ok = hipMemcpyAsync(static_cast<uint8_t *>(d) + off, stage[k], got, hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
+             hipEventRecord(done[k], ctx->stream) == hipSuccess;
+        used[k] = true;
+        off += got;
+        k ^= 1;
+    }
+    if (ok) ok = hipStreamSynchronize(ctx->stream) == hipSuccess;
+    std::fclose(f);
+    for (int q = 0; q < 2; q++) {
+        if (stage[q]) (void)hipHostFree(stage[q]);
+        if (done[q]) (void)hipEventDestroy(done[q]);
+    }
+    if (!ok) {
+        (void)hipGetLastError();
+        (void)hipFree(d);
+        return fail(ctx, TDOA_ERR_HIP, "failed to read or upload file");
+    }
+    c.dev = static_cast<const uint8_t *>(d);
+    c.n = n;
+    c.owned = true;
+    if (n_samples) *n_samples = n;
+    return TDOA_OK;
+}
+
 int tdoa_capture_attach_device(tdoa_ctx *ctx, int station, const void *dev_iq, size_t n_samples)
 {
     int rc;

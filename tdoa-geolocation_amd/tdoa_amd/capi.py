@@ -30,6 +30,12 @@ class Peak(C.Structure):
 PEAK_DTYPE = np.dtype([("lag", np.int32), ("abs_corr", np.float32), ("corr", np.float64)])
 
 
+class FastAnalysis(C.Structure):
+    _fields_ = [("total_samples", C.c_int32), ("has_clipping", C.c_int32), ("has_overload", C.c_int32),
+                ("reserved", C.c_int32), ("i_avg", C.c_double), ("q_avg", C.c_double), ("i_std", C.c_double),
+                ("q_std", C.c_double), ("snr_estimate", C.c_double), ("power_level", C.c_double)]
+
+
 class FmStats(C.Structure):
     _fields_ = [("s1", C.c_int64), ("s2_lo", C.c_uint64), ("s2_hi", C.c_uint64),
                 ("mean", C.c_float), ("scale", C.c_float)]
@@ -41,7 +47,8 @@ SYMBOLS = [
     "tdoa_abi_version", "tdoa_device_count",
     "tdoa_load_iq_u8", "tdoa_preprocess_c64", "tdoa_time_domain_correlation_c64",
     "tdoa_cross_correlate_c64", "tdoa_simple_correlate_c64", "tdoa_fast_snr_u8",
-    "tdoa_capture_upload", "tdoa_capture_attach_device", "tdoa_capture_clear",
+    "tdoa_fast_analyze_u8", "tdoa_fast_analyze_capture_u8",
+    "tdoa_capture_upload", "tdoa_capture_upload_file", "tdoa_capture_attach_device", "tdoa_capture_clear",
     "tdoa_synth_capture", "tdoa_capture_download",
     "tdoa_num_windows", "tdoa_num_pairs", "tdoa_process", "tdoa_process_u8",
     "tdoa_fm_xcorr_u8", "tdoa_fm_preprocess_u8", "tdoa_fm_xcorr_lags_u8", "tdoa_debug_force_generic",
@@ -87,7 +94,10 @@ def load(build_if_missing=True):
     L.tdoa_cross_correlate_c64.argtypes = [vp, fp, sz, fp, sz, i32p, dp]
     L.tdoa_simple_correlate_c64.argtypes = [vp, fp, sz, fp, sz, i32p, fp]
     L.tdoa_fast_snr_u8.argtypes = [vp, u8p, C.c_int, dp]
+    L.tdoa_fast_analyze_u8.argtypes = [vp, u8p, C.c_int, C.POINTER(FastAnalysis)]
+    L.tdoa_fast_analyze_capture_u8.argtypes = [vp, u8p, sz, C.POINTER(FastAnalysis), C.POINTER(FastAnalysis)]
     L.tdoa_capture_upload.argtypes = [vp, C.c_int, u8p, sz]
+    L.tdoa_capture_upload_file.argtypes = [vp, C.c_int, C.c_char_p, C.POINTER(sz)]
     L.tdoa_capture_attach_device.argtypes = [vp, C.c_int, vp, sz]
     L.tdoa_capture_clear.argtypes = [vp]
     L.tdoa_synth_capture.argtypes = [vp, C.c_int, sz, C.c_double, C.c_double, C.c_double, dp, dp, C.c_double,
@@ -220,10 +230,28 @@ class Context:
         self._chk(self._L.tdoa_fast_snr_u8(self._h, _u8(s), int(total_samples), C.byref(out)))
         return out.value
 
+    def fast_analyze(self, samples_u8, total_samples):
+        s = np.ascontiguousarray(samples_u8, dtype=np.uint8)
+        fa = FastAnalysis()
+        self._chk(self._L.tdoa_fast_analyze_u8(self._h, _u8(s), int(total_samples), C.byref(fa)))
+        return fa
+
+    def fast_analyze_capture(self, raw_u8):
+        """fast_analyzer's two output lines: (ref, tgt) analyses of one .dat capture."""
+        s = np.ascontiguousarray(raw_u8, dtype=np.uint8)
+        ref, tgt = FastAnalysis(), FastAnalysis()
+        self._chk(self._L.tdoa_fast_analyze_capture_u8(self._h, _u8(s), s.size, C.byref(ref), C.byref(tgt)))
+        return ref, tgt
+
     # ---- mode B ------------------------------------------------------------
     def capture_upload(self, station, iq_u8):
         s = np.ascontiguousarray(iq_u8, dtype=np.uint8)
         self._chk(self._L.tdoa_capture_upload(self._h, int(station), _u8(s), s.size // 2))
+
+    def capture_upload_file(self, station, path):
+        n = C.c_size_t()
+        self._chk(self._L.tdoa_capture_upload_file(self._h, int(station), os.fsencode(path), C.byref(n)))
+        return n.value
 
     def capture_attach_device(self, station, dev_ptr, n_samples):
         self._chk(self._L.tdoa_capture_attach_device(self._h, int(station), C.c_void_p(int(dev_ptr)), int(n_samples)))

@@ -207,3 +207,18 @@ def test_eight_stations_28_pairs(oracle):
             olag, ocorr = oracle.b_xcorr_peak(pre[i], pre[j], ml)
             assert peaks[wid, p]["lag"] == olag == delays[j] - delays[i], (wid, i, j)
             assert abs(peaks[wid, p]["corr"] - ocorr) <= REL_TOL * abs(ocorr)
+
+
+def test_capture_upload_file_roundtrip(tmp_path, oracle):
+    import tdoa_amd
+    rng = np.random.default_rng(21)
+    raw = rng.integers(0, 256, size=2 * (40 * 1024 * 1024 // 2) + 6, dtype=np.uint8)    # > one 32 MiB staging chunk
+    path = tmp_path / "kx0u-1754900000.dat"
+    raw.tofile(path)
+    with tdoa_amd.Context() as c:
+        n = c.capture_upload_file(0, str(path))
+        assert n == raw.size // 2
+        for first, cnt in ((0, 1000), (n - 777, 777), (16 * 1024 * 1024 - 5, 10)):
+            assert np.array_equal(c.capture_download(0, first, cnt), raw[2 * first:2 * (first + cnt)])
+        with pytest.raises(tdoa_amd.TdoaError):
+            c.capture_upload_file(1, str(tmp_path / "missing.dat"))

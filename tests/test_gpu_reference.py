@@ -161,3 +161,21 @@ def test_fast_snr_matches_oracle(ctx, oracle):
     for samples, total in ((ref, 65536), (raw[2 * 40000:2 * 40000 + 2 * 32768], 32768), (raw[:2 * 3000], 3000)):
         assert ctx.fast_snr(samples, total) == oracle.fast_snr(samples, total)
     assert ctx.fast_snr(np.array([128, 128], np.uint8), 1) == -20.0
+
+
+def test_fast_analyzer_capture_matches_oracle(ctx, oracle):
+    # fast_analyzer.go main: "REF,<snr>,<power>,<clip>,<overload>" / "TGT,..." (:44-50)
+    raw = oracle.simulate_station("n3pay", 40000, oracle.SEED_BASE + 1, tx_power=60000.0)
+    ref, tgt = ctx.fast_analyze_capture(raw)
+    rc, oref, otgt = oracle.fast_analyze_capture(raw)
+    assert rc == 0
+    for g, o in ((ref, oref), (tgt, otgt)):
+        assert g.total_samples == o.total_samples
+        assert (g.i_avg, g.q_avg, g.i_std, g.q_std) == (o.i_avg, o.q_avg, o.i_std, o.q_std)
+        assert g.power_level == o.power_level and g.snr_estimate == o.snr_estimate
+        assert (g.has_clipping, g.has_overload) == (o.has_clipping, o.has_overload)
+        line = "%.1f,%.1f,%s,%s" % (g.snr_estimate, g.power_level, bool(g.has_clipping), bool(g.has_overload))
+        assert line == "%.1f,%.1f,%s,%s" % (o.snr_estimate, o.power_level, bool(o.has_clipping), bool(o.has_overload))
+    flat = np.full(2 * 9000, 128, dtype=np.uint8)
+    fa = ctx.fast_analyze(flat, 9000)
+    assert fa.power_level == -100.0 and fa.has_overload == 1 and fa.has_clipping == 0
