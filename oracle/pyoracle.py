@@ -62,8 +62,8 @@ def lib():
         L.o_rand_float64.argtypes = [C.c_uint64, C.c_uint64]
         L.ob_theta.restype = C.c_float
         L.ob_theta.argtypes = [C.c_int, C.c_int]
-        L.ob_wrap_diff.restype = C.c_float
-        L.ob_wrap_diff.argtypes = [C.c_float, C.c_float]
+        L.ob_angle_code.restype = C.c_int
+        L.ob_angle_code.argtypes = [C.c_int, C.c_int]
         L.o_lowpass.argtypes = [fp, sz, C.c_int, fp]
         L.o_cutoff_window.argtypes = [C.c_double, C.c_double]
         L.o_lowpass_cutoff.argtypes = [fp, sz, C.c_double, C.c_double, fp]
@@ -344,6 +344,10 @@ def rand_float64(seed, counter):
 
 def b_theta(i, q):
     return lib().ob_theta(int(i), int(q))
+
+
+def b_angle_code(i, q):
+    return lib().ob_angle_code(int(i), int(q))
 
 
 def b_discriminate(iq_u8):

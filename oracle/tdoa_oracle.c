@@ -949,7 +949,6 @@ static const float K1_C[8] = {
 };
 #define K1_PI     3.1415927410125732f
 #define K1_PIO2   1.5707963705062866f
-#define K1_TWOPI  6.2831854820251465f
 
 float ob_theta(int I, int Q)
 {
@@ -968,29 +967,21 @@ float ob_theta(int I, int Q)
     return a;
 }
 
-/* wrapped phase step theta1 - theta0 into [-pi, pi] (f32 subtract, one conditional +-2pi) */
-float ob_wrap_diff(float th1, float th0)
-{
-    float d = th1 - th0;
-    if (d > K1_PI) d = d - K1_TWOPI;
-    else if (d < -K1_PI) d = d + K1_TWOPI;
-    return d;
-}
-
 /* K1: u8 IQ -> phase-difference FM discriminator -> 16-bit phase code.
  * With I = 2b_I - 255, Q = 2b_Q - 255 (exact odd integers proportional to (b-127.5)/127.5 of
  * processor.go:198-199, never zero):
- *   phase_i = wrap(arg(x_i) - arg(x_{i-1})) = arg(x_i * conj(x_{i-1}))   (i >= 1),  phase_0 = phase_1
- *   code_i  = int16(rint(phase_i * 32768/pi))      (+pi wraps to -32768: the phase circle)
+ *   a_i    = rint(arg(x_i) * 32768/pi)                 angle code of one sample, |a_i| < 32768
+ *   code_i = int16(a_i - a_{i-1})  (two's-complement wrap = the phase circle)   (i >= 1)
+ *          = arg(x_i * conj(x_{i-1})) in units of pi/32768,   code_0 = code_1
  * x_i is never 0 for byte data, so the |p|^2 > 1e-10 gate of the prebuilt binary's
  * convertToInstantaneousFrequency never fires.  The code step (9.6e-5 rad) is far below the
- * phase noise that 8-bit I/Q quantisation itself causes (>= 2e-3 rad at full scale). */
+ * phase noise that 8-bit I/Q quantisation itself causes (>= 2e-3 rad at full scale).
+ * a_i depends only on the two bytes of sample i: the device keeps it as a 65536-entry table. */
 #define K1_CODE_SCALE 10430.3779296875f   /* f32(32768/pi) */
 
-int16_t ob_phase_code(float phase)
+int ob_angle_code(int I, int Q)
 {
-    long q = lrintf(phase * K1_CODE_SCALE);
-    return (int16_t)(uint16_t)(q & 0xffff);
+    return (int)lrintf(ob_theta(I, Q) * K1_CODE_SCALE);
 }
 
 void ob_discriminate_u8(const uint8_t *iq, size_t n, int16_t *code)
@@ -1003,9 +994,9 @@ void ob_discriminate_u8(const uint8_t *iq, size_t n, int16_t *code)
     }
 #pragma omp parallel for schedule(static)
     for (long i = 1; i < (long)n; i++) {
-        float t1 = ob_theta(2 * (int)iq[2 * i] - 255, 2 * (int)iq[2 * i + 1] - 255);
-        float t0 = ob_theta(2 * (int)iq[2 * i - 2] - 255, 2 * (int)iq[2 * i - 1] - 255);
-        code[i] = ob_phase_code(ob_wrap_diff(t1, t0));
+        int a1 = ob_angle_code(2 * (int)iq[2 * i] - 255, 2 * (int)iq[2 * i + 1] - 255);
+        int a0 = ob_angle_code(2 * (int)iq[2 * i - 2] - 255, 2 * (int)iq[2 * i - 1] - 255);
+        code[i] = (int16_t)(uint16_t)((a1 - a0) & 0xffff);
     }
     code[0] = code[1];
 }

@@ -122,8 +122,7 @@ double o_rand_float64(uint64_t seed, uint64_t counter);
 
 /* ---- mode B oracle (north-star pipeline) ----------- */
 float  ob_theta(int I, int Q);
-float  ob_wrap_diff(float th1, float th0);
-int16_t ob_phase_code(float phase);
+int    ob_angle_code(int I, int Q);
 void   ob_discriminate_u8(const uint8_t *iq, size_t n, int16_t *code);
 typedef struct {
     int64_t  s1;        /* sum of the 16-bit phase codes               */

@@ -4,13 +4,13 @@
 // Replaces (reference file:line): the u8 -> complex64 conversion of processor.go:195-201 and,
 // for the north-star pipeline, the instantaneous-frequency demodulation that exists only in
 // the prebuilt processor binary:
-//   phase_i = arg(x_i * conj(x_{i-1})) = wrap(arg(x_i) - arg(x_{i-1})),  phase_0 := phase_1
-//   code_i  = int16(rint(phase_i * 32768/pi))
-// One streaming pass (k_fm_demod) reads the capture bytes once, writes 2 bytes of code per
-// sample and accumulates sum(code), sum(code^2) as exact integers; the FFT pass then reads
-// the codes.  The arithmetic is an explicit sequence of correctly rounded f32 operations
-// (table reciprocal, FMA Horner, no IEEE division in the loop) so the CPU restatement matches
-// it bit for bit.
+//   a_i    = rint(arg(x_i) * 32768/pi)          angle code of one IQ sample (depends on its 2 bytes)
+//   code_i = int16(a_i - a_{i-1})               = arg(x_i * conj(x_{i-1})), wrapped;  code_0 := code_1
+// a_i comes from a 65536-entry int16 table (k_k1_build_table, built once per context with the
+// explicit f32 arithmetic of k1_theta, which the CPU restatement repeats bit for bit).  One
+// streaming pass (k_fm_demod) reads the capture bytes once, looks the angles up in an LDS copy of
+// the table, writes 2 bytes of code per sample and accumulates sum(code), sum(code^2) as exact
+// integers; the FFT pass then reads the codes.
 #pragma once
 
 #include "device_common.hpp"
@@ -51,21 +51,25 @@ __device__ __forceinline__ float k1_theta(unsigned int s, const float *rcp)
     return __uint_as_float(__float_as_uint(a) ^ ((~s & 0x8000u) << 16));   // Q < 0: negate
 }
 
-// wrapped phase step theta1 - theta0
-__device__ __forceinline__ float k1_wrap_diff(float th1, float th0)
+// angle code of one sample: rint(theta * 32768/pi), |code| < 32768
+__device__ __forceinline__ int k1_angle_code(unsigned int s, const float *rcp)
 {
 #pragma clang fp contract(off)
-    const float d = th1 - th0;
-    // branch-free: add -2pi, +2pi or 0 (the codes derived from d are unaffected by d + 0.0f)
-    const float adj = d > 3.1415927410125732f ? -6.2831854820251465f : (d < -3.1415927410125732f ? 6.2831854820251465f : 0.0f);
-    return d + adj;
+    return __float2int_rn(k1_theta(s, rcp) * 10430.3779296875f);
 }
 
-// phase -> 16-bit code, pi == 32768 (wraps to -32768)
-__device__ __forceinline__ int k1_code(float phase)
+// Table slot of sample s = b_I | b_Q << 8.  LDS banks are picked by bits 1..5 of a 2-byte index;
+// captures vary in b_I AND b_Q over a few codes around 127, and b_Q alone would not change the
+// bank (stride 512 B), so b_Q's low bits are folded into the bank bits.
+__device__ __forceinline__ unsigned int k1_slot(unsigned int s) { return s ^ (((s >> 8) & 31u) << 1); }
+
+// table[k1_slot(s)] = angle code of the IQ sample s;  grid 256 x 256 threads
+__global__ __launch_bounds__(256) void k_k1_build_table(short *table)
 {
-#pragma clang fp contract(off)
-    return (int)(short)__float2int_rn(phase * 10430.3779296875f);
+    __shared__ float rcp[128];
+    k1_init_rcp(rcp);
+    const unsigned int s = blockIdx.x * 256 + threadIdx.x;
+    table[k1_slot(s)] = (short)k1_angle_code(s, rcp);
 }
 
 __device__ __forceinline__ float k1_normalise(int code, float mean, float scale)
@@ -86,11 +90,12 @@ struct FmStats {          // mirrors tdoa_fm_stats
     float mean, scale;
 };
 
-constexpr int kStatsChunk = 16384;   // samples per block
-constexpr int kStatsThreads = 256;
+constexpr int kDemodThreads = 1024;
+constexpr int kDemodPiece = 1024;    // samples per wave step: 64 lanes x 2 x 8
+constexpr int kDemodRun = 16;        // pieces per work item (one pair of atomics per 16384 samples)
 
-// nine consecutive IQ samples p[i0-1 .. i0+7] with whatever alignment the window start has
-__device__ __forceinline__ void k1_load9(const uint16_t *p, int i0, unsigned int (&s)[9])
+// eight consecutive IQ samples p[i0 .. i0+7] with whatever alignment the window start has
+__device__ __forceinline__ void k1_load8(const uint16_t *p, int i0, unsigned int (&s)[9])
 {
     const uintptr_t a = reinterpret_cast<uintptr_t>(p + i0);
     if ((a & 15u) == 0) {
@@ -106,112 +111,118 @@ __device__ __forceinline__ void k1_load9(const uint16_t *p, int i0, unsigned int
 #pragma unroll
         for (int k = 0; k < 8; k++) s[k + 1] = p[i0 + k];
     }
-    s[0] = p[i0 - 1];
 }
 
-// K1 demodulation pass.  grid (chunks, n_sw), chunks * kStatsChunk >= maxlen.
-// codes: [n_sw][code_stride] int16, code_stride a multiple of 8 (rows 16-byte aligned).
-__global__ __launch_bounds__(kStatsThreads) void k_fm_demod(const SWDesc *sw, short *codes, long long code_stride,
-                                                            StatsPartial *partials, int chunks_per_window)
+// K1 demodulation pass: persistent 1024-thread workgroups (one per CU) keep the 128 KB angle
+// table in LDS; after loading it the 16 waves of a workgroup run independently, each taking
+// (station-window, 1024-sample piece) work items round-robin.  Window sums go straight into
+// per-window integer accumulators with atomic adds: exact, hence independent of arrival order.
+// codes: [n_sw][code_stride] int16, code_stride a multiple of 8 (rows 16-byte aligned);
+// acc: [n_sw] {s1, s2}, zeroed before the launch.
+__global__ __launch_bounds__(kDemodThreads) void k_fm_demod(const SWDesc *sw, int n_sw, int pieces_per_window,
+                                                            const short *table, short *codes, long long code_stride,
+                                                            StatsPartial *acc)
 {
-    __shared__ float rcp[128];
-    k1_init_rcp(rcp);
-    const SWDesc d = sw[blockIdx.y];
-    // the pointer comes out of a descriptor in memory: tell the compiler it is global, not flat
-    typedef const __attribute__((address_space(1))) uint16_t *global_u16;
-    const uint16_t *p = (const uint16_t *)(global_u16)(const uint16_t *)d.base;
-    short *out = codes + (size_t)blockIdx.y * code_stride;
-    const int len = d.len;
-    const int start = blockIdx.x * kStatsChunk;
-    long long s1 = 0;
-    unsigned long long s2 = 0;
-    for (int i0 = start + threadIdx.x * 8; i0 < start + kStatsChunk && i0 < len; i0 += kStatsThreads * 8) {
-        int c[8];
-        if (i0 >= 1 && i0 + 8 <= len) {
-            // interior: no per-sample conditions
-            unsigned int s[9];
-            k1_load9(p, i0, s);
-            float th[9];
-#pragma unroll
-            for (int k = 0; k < 9; k++) th[k] = k1_theta(s[k], rcp);
-            int t1 = 0;
-            unsigned long long t2 = 0;
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                c[k] = k1_code(k1_wrap_diff(th[k + 1], th[k]));
-                t1 += c[k];
-                t2 += (unsigned int)(c[k] * c[k]);     // <= 2^30 each
-            }
-            s1 += t1;
-            s2 += t2;
-        } else {
-            // window head (code_0 := code_1) and tail; samples beyond len carry code 0 in memory
-            // and do not enter the sums
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const int i = i0 + k;
-                int v = 0;
-                if (i < len && len >= 2) {
-                    const int ii = i == 0 ? 1 : i;
-                    v = k1_code(k1_wrap_diff(k1_theta(p[ii], rcp), k1_theta(p[ii - 1], rcp)));
-                }
-                c[k] = v;
-                if (i < len) {
-                    s1 += v;
-                    s2 += (unsigned long long)(unsigned int)(v * v);
-                }
-            }
-        }
-        uint4 w;
-        w.x = (unsigned int)(c[0] & 0xffff) | ((unsigned int)c[1] << 16);
-        w.y = (unsigned int)(c[2] & 0xffff) | ((unsigned int)c[3] << 16);
-        w.z = (unsigned int)(c[4] & 0xffff) | ((unsigned int)c[5] << 16);
-        w.w = (unsigned int)(c[6] & 0xffff) | ((unsigned int)c[7] << 16);
-        *reinterpret_cast<uint4 *>(out + i0) = w;
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        s1 += __shfl_xor(s1, off, kWave);
-        s2 += __shfl_xor(s2, off, kWave);
-    }
-    __shared__ StatsPartial red[kStatsThreads / kWave];
-    const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
-    if (lane == 0) {
-        red[wid].s1 = s1;
-        red[wid].s2 = s2;
+    extern __shared__ short lut[];               // 65536 angle codes
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(table);
+        uint4 *dst = reinterpret_cast<uint4 *>(lut);
+        for (int k = threadIdx.x; k < 8192; k += kDemodThreads) dst[k] = src[k];
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        StatsPartial t = red[0];
-        for (int w = 1; w < kStatsThreads / kWave; w++) {
-            t.s1 += red[w].s1;
-            t.s2 += red[w].s2;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = blockIdx.x * (kDemodThreads / kWave) + threadIdx.x / kWave;
+    const int n_waves = gridDim.x * (kDemodThreads / kWave);
+    // work item = kDemodRun consecutive pieces of one window; consecutive items belong to DIFFERENT
+    // windows, so the waves that run together add into different accumulators
+    const int runs_per_window = (pieces_per_window + kDemodRun - 1) / kDemodRun;
+    const int n_items = n_sw * runs_per_window;
+    for (int item = wave; item < n_items; item += n_waves) {
+        const int w = item % n_sw, run = item / n_sw;
+        const SWDesc d = sw[w];
+        const int len = d.len;
+        // the pointer comes out of a descriptor in memory: tell the compiler it is global, not flat
+        typedef const __attribute__((address_space(1))) uint16_t *global_u16;
+        const uint16_t *p = (const uint16_t *)(global_u16)(const uint16_t *)d.base;
+        short *out = codes + (size_t)w * code_stride;
+        long long s1 = 0;
+        unsigned long long s2 = 0;
+        for (int piece = run * kDemodRun; piece < (run + 1) * kDemodRun; piece++) {
+            const int start = piece * kDemodPiece;
+            if (start >= len) break;
+            // a lane owns samples [ia, ia+8) and [ib, ib+8); both loads are issued before either is used
+            const int ia = start + lane * 8, ib = ia + 512;
+            const bool fa = ia >= 1 && ia + 8 <= len, fb = ib + 8 <= len;     // interior (fast) pieces
+            unsigned int sa[9], sb[9];
+            if (fa) { k1_load8(p, ia, sa); sa[0] = p[ia - 1]; }
+            if (fb) { k1_load8(p, ib, sb); sb[0] = p[ib - 1]; }
+#pragma unroll
+            for (int half = 0; half < 2; half++) {
+                const int i0 = half ? ib : ia;
+                const bool fast = half ? fb : fa;
+                if (i0 >= len) continue;
+                int c[8];
+                if (fast) {
+                    int a[9];
+#pragma unroll
+                    for (int k = 0; k < 9; k++) a[k] = lut[k1_slot(half ? sb[k] : sa[k])];
+                    int t1 = 0;
+                    unsigned long long t2 = 0;
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        c[k] = (int)(short)(a[k + 1] - a[k]);
+                        t1 += c[k];
+                        t2 += (unsigned int)(c[k] * c[k]);     // <= 2^30 each
+                    }
+                    s1 += t1;
+                    s2 += t2;
+                } else {
+                    // window head (code_0 := code_1) and tail; samples beyond len carry code 0 in memory
+                    // and do not enter the sums
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        const int i = i0 + k;
+                        int v = 0;
+                        if (i < len && len >= 2) {
+                            const int ii = i == 0 ? 1 : i;
+                            v = (int)(short)(lut[k1_slot(p[ii])] - lut[k1_slot(p[ii - 1])]);
+                        }
+                        c[k] = v;
+                        if (i < len) {
+                            s1 += v;
+                            s2 += (unsigned long long)(unsigned int)(v * v);
+                        }
+                    }
+                }
+                uint4 wv;
+                wv.x = (unsigned int)(c[0] & 0xffff) | ((unsigned int)c[1] << 16);
+                wv.y = (unsigned int)(c[2] & 0xffff) | ((unsigned int)c[3] << 16);
+                wv.z = (unsigned int)(c[4] & 0xffff) | ((unsigned int)c[5] << 16);
+                wv.w = (unsigned int)(c[6] & 0xffff) | ((unsigned int)c[7] << 16);
+                *reinterpret_cast<uint4 *>(out + i0) = wv;
+            }
         }
-        partials[(size_t)blockIdx.y * chunks_per_window + blockIdx.x] = t;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            s1 += __shfl_xor(s1, off, kWave);
+            s2 += __shfl_xor(s2, off, kWave);
+        }
+        if (lane == 0) {
+            atomicAdd(reinterpret_cast<unsigned long long *>(&acc[w].s1), (unsigned long long)s1);   // two's complement
+            atomicAdd(&acc[w].s2, s2);
+        }
     }
 }
 
-// one wave per station-window folds the partials (exact integers: order-free) and derives
-// mean and scale in f64
-__global__ __launch_bounds__(64) void k_fm_stats_final(const SWDesc *sw, const StatsPartial *partials,
-                                                       int chunks_per_window, FmStats *stats)
+// mean and scale of every station-window from its exact sums, in f64
+__global__ void k_fm_stats_final(const SWDesc *sw, const StatsPartial *acc, FmStats *stats, int n_sw)
 {
 #pragma clang fp contract(off)
-    const int id = blockIdx.x;
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n_sw) return;
     const int len = sw[id].len;
-    long long s1 = 0;
-    unsigned long long s2 = 0;
-    for (int c = threadIdx.x; c < chunks_per_window; c += 64) {
-        const StatsPartial t = partials[(size_t)id * chunks_per_window + c];
-        s1 += t.s1;
-        s2 += t.s2;
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        s1 += __shfl_xor(s1, off, kWave);
-        s2 += __shfl_xor(s2, off, kWave);
-    }
-    if (threadIdx.x != 0) return;
+    const long long s1 = acc[id].s1;
+    const unsigned long long s2 = acc[id].s2;
     FmStats out;
     out.s1 = s1;
     out.s2_lo = s2;

@@ -54,6 +54,7 @@ struct tdoa_ctx {
     };
     std::vector<Capture> caps;
 
+    DevBuf k1_table;                        // 65536 int16 angle codes (k_k1_build_table)
     DevBuf sw_desc, pw_desc, partials, stats, codes, tz, v, keys, scales, peaks, scratch_a, scratch_b, lagdump;
     DevBuf ex_a, ex_b, ex_c, ex_d, ex_part;
 
@@ -68,6 +69,7 @@ struct tdoa_ctx {
     int64_t plan_n = 0;
 
     // whole-step hipGraph of tdoa_process (launch-bound when windows are processed in many groups)
+    int n_cu = 256;                         // multiprocessors of this device
     bool use_graph = true;
     uint64_t alloc_gen = 0;                 // bumped whenever a workspace buffer moves
     std::vector<uint64_t> graph_key;
@@ -223,9 +225,8 @@ void prof_collect(tdoa_ctx *ctx)
 int reserve_fm_batch(tdoa_ctx *ctx, int n_sw, int maxlen, int n_pw, const FftPlan &pl)
 {
     int rc;
-    const int chunks = std::max(1, (maxlen + kStatsChunk - 1) / kStatsChunk);
     const long long code_stride = ((long long)maxlen + 15) / 8 * 8;
-    if ((rc = ensure(ctx, ctx->partials, sizeof(StatsPartial) * (size_t)chunks * n_sw))) return rc;
+    if ((rc = ensure(ctx, ctx->partials, sizeof(StatsPartial) * (size_t)n_sw))) return rc;
     if ((rc = ensure(ctx, ctx->stats, sizeof(FmStats) * (size_t)n_sw))) return rc;
     if ((rc = ensure(ctx, ctx->codes, sizeof(short) * (size_t)code_stride * n_sw))) return rc;
     if ((rc = ensure(ctx, ctx->tz, sizeof(float2) * (size_t)pl.Nc * n_sw))) return rc;
@@ -240,9 +241,9 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
                  float dump_scale, double sum_len)
 {
     int rc;
-    const int chunks = std::max(1, (maxlen + kStatsChunk - 1) / kStatsChunk);
+    const int pieces = std::max(1, (maxlen + kDemodPiece - 1) / kDemodPiece);
     const long long code_stride = ((long long)maxlen + 15) / 8 * 8;      // rows stay 16-byte aligned
-    if ((rc = ensure(ctx, ctx->partials, sizeof(StatsPartial) * (size_t)chunks * n_sw))) return rc;
+    if ((rc = ensure(ctx, ctx->partials, sizeof(StatsPartial) * (size_t)n_sw))) return rc;
     if ((rc = ensure(ctx, ctx->stats, sizeof(FmStats) * (size_t)n_sw))) return rc;
     if ((rc = ensure(ctx, ctx->codes, sizeof(short) * (size_t)code_stride * n_sw))) return rc;
     if ((rc = ensure(ctx, ctx->tz, sizeof(float2) * (size_t)pl.Nc * n_sw))) return rc;
@@ -270,9 +271,13 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
     {
         // K1: capture bytes -> 16-bit phase codes + exact window statistics
         ProfScope ps(ctx, TDOA_K_STATS, 4.0 * sum_len);
-        hipLaunchKernelGGL(k_fm_demod, dim3(chunks, n_sw), dim3(kStatsThreads), 0, st, d_sw, codes, code_stride,
-                           partials, chunks);
-        hipLaunchKernelGGL(k_fm_stats_final, dim3(n_sw), dim3(64), 0, st, d_sw, partials, chunks, stats);
+        HIPCHK(ctx, hipMemsetAsync(partials, 0, sizeof(StatsPartial) * (size_t)n_sw, st));
+        const long long items = (long long)pieces * n_sw;
+        const int waves_per_block = kDemodThreads / kWave;
+        const int blocks = (int)std::max<long long>(1, std::min<long long>((items + waves_per_block - 1) / waves_per_block, ctx->n_cu));
+        hipLaunchKernelGGL(k_fm_demod, dim3(blocks), dim3(kDemodThreads), 65536 * sizeof(short), st, d_sw, n_sw, pieces,
+                           static_cast<const short *>(ctx->k1_table.p), codes, code_stride, partials);
+        hipLaunchKernelGGL(k_fm_stats_final, dim3((n_sw + 63) / 64), dim3(64), 0, st, d_sw, partials, stats, n_sw);
     }
     const size_t lds_col = sizeof(float2) * 2 * (size_t)pl.N2 * pl.C;
     const size_t lds_row = sizeof(float2) * 2 * (size_t)pl.N1;
@@ -309,9 +314,20 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
         }
         {
             ProfScope ps(ctx, TDOA_K_INV_COL, nc8 * n_pw);
-            if (pruned)
-                hipLaunchKernelGGL(k_inv_col_pruned, dim3(pl.N1 / 128, n_pw), dim3(256), 0, st, v, d_keys, d_pw, pl,
-                                   lag_lo, lag_hi, np, nn, lag_dump, dump_scale);
+            if (pruned) {
+                const dim3 grid(pl.N1 / 128, n_pw), blk(256);
+#define TDOA_PRUNED(NP, NN)                                                                                      \
+    hipLaunchKernelGGL((k_inv_col_pruned<NP, NN>), grid, blk, 0, st, v, d_keys, d_pw, pl, lag_lo, lag_hi, lag_dump, \
+                       dump_scale)
+                if (np == 3 && nn == 3) TDOA_PRUNED(3, 3);
+                else if (np == 1 && nn == 1) TDOA_PRUNED(1, 1);
+                else if (np == 2 && nn == 2) TDOA_PRUNED(2, 2);
+                else if (np == 4 && nn == 4) TDOA_PRUNED(4, 4);
+                else
+                    hipLaunchKernelGGL(k_inv_col_pruned_any, grid, blk, 0, st, v, d_keys, d_pw, pl, lag_lo, lag_hi, np,
+                                       nn, lag_dump, dump_scale);
+#undef TDOA_PRUNED
+            }
             else
                 hipLaunchKernelGGL(k_inv_col_peak<true>, dim3(pl.N1 / pl.C, n_pw), dim3(256), lds_col, st, v, d_keys,
                                    d_pw, pl, lag_lo, lag_hi, lag_dump, dump_scale);
@@ -326,6 +342,7 @@ int allow_big_lds(tdoa_ctx *ctx)
 {
     int rc;
     const size_t all = 136 * 1024;   // largest dynamic request: 128 KiB (kLdsCap tiles, generic row pair); static LDS comes on top
+    if ((rc = set_lds(ctx, k_fm_demod, all))) return rc;
     if ((rc = set_lds(ctx, k_fwd_col_c16, all))) return rc;
     if ((rc = set_lds(ctx, k_fwd_col_c64, all))) return rc;
     if ((rc = set_lds(ctx, k_fwd_row, all))) return rc;
@@ -494,6 +511,11 @@ int tdoa_create(const tdoa_params *p, tdoa_ctx **out)
     if (!ctx) return TDOA_ERR_NOMEM;
     ctx->prm = prm;
     ctx->device = prm.device;
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, prm.device) == hipSuccess && cus > 0)
+            ctx->n_cu = cus;
+    }
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
         return TDOA_ERR_HIP;
@@ -502,6 +524,21 @@ int tdoa_create(const tdoa_params *p, tdoa_ctx **out)
         (void)hipStreamDestroy(ctx->stream);
         delete ctx;
         return TDOA_ERR_HIP;
+    }
+    {   // K1 angle table, once per context
+        void *t = nullptr;
+        if (hipMalloc(&t, 65536 * sizeof(short)) != hipSuccess) {
+            (void)hipStreamDestroy(ctx->stream);
+            delete ctx;
+            return TDOA_ERR_NOMEM;
+        }
+        ctx->k1_table.p = t;
+        ctx->k1_table.cap = 65536 * sizeof(short);
+        hipLaunchKernelGGL(k_k1_build_table, dim3(256), dim3(256), 0, ctx->stream, static_cast<short *>(t));
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
+            tdoa_destroy(ctx);
+            return TDOA_ERR_HIP;
+        }
     }
     if (const char *e = std::getenv("TDOA_NO_GRAPH")) ctx->use_graph = !(e[0] == '1');
     *out = ctx;
@@ -517,7 +554,7 @@ void tdoa_destroy(tdoa_ctx *ctx)
     if (ctx->graph_exec) (void)hipGraphExecDestroy(ctx->graph_exec);
     if (ctx->graph) (void)hipGraphDestroy(ctx->graph);
     tdoa_capture_clear(ctx);
-    DevBuf *bufs[] = {&ctx->sw_desc, &ctx->pw_desc, &ctx->partials, &ctx->stats, &ctx->codes, &ctx->tz, &ctx->v, &ctx->keys,
+    DevBuf *bufs[] = {&ctx->k1_table, &ctx->sw_desc, &ctx->pw_desc, &ctx->partials, &ctx->stats, &ctx->codes, &ctx->tz, &ctx->v, &ctx->keys,
                       &ctx->scales, &ctx->peaks, &ctx->scratch_a, &ctx->scratch_b, &ctx->lagdump,
                       &ctx->ex_a, &ctx->ex_b, &ctx->ex_c, &ctx->ex_d, &ctx->ex_part,
                       &ctx->g_sw_desc, &ctx->g_pw_desc, &ctx->g_scales, &ctx->g_keys};
@@ -882,21 +919,23 @@ int tdoa_fm_preprocess_u8(tdoa_ctx *ctx, const uint8_t *iq, size_t n, float *out
     if ((rc = ensure(ctx, ctx->scratch_a, 2 * n + 16))) return rc;
     if ((rc = ensure(ctx, ctx->scratch_b, sizeof(float) * n))) return rc;
     if ((rc = ensure(ctx, ctx->sw_desc, sizeof(SWDesc)))) return rc;
-    const int chunks = (int)((n + kStatsChunk - 1) / kStatsChunk);
+    const int pieces = (int)((n + kDemodPiece - 1) / kDemodPiece);
     const long long code_stride = ((long long)n + 15) / 8 * 8;
-    if ((rc = ensure(ctx, ctx->partials, sizeof(StatsPartial) * (size_t)chunks))) return rc;
+    if ((rc = ensure(ctx, ctx->partials, sizeof(StatsPartial)))) return rc;
     if ((rc = ensure(ctx, ctx->stats, sizeof(FmStats)))) return rc;
     if ((rc = ensure(ctx, ctx->codes, sizeof(short) * (size_t)code_stride))) return rc;
     hipStream_t st = ctx->stream;
     SWDesc sw = {static_cast<uint8_t *>(ctx->scratch_a.p), (int32_t)n, 0};
     HIPCHK(ctx, hipMemcpyAsync(ctx->scratch_a.p, iq, 2 * n, hipMemcpyHostToDevice, st));
     HIPCHK(ctx, hipMemcpyAsync(ctx->sw_desc.p, &sw, sizeof(sw), hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemsetAsync(ctx->partials.p, 0, sizeof(StatsPartial), st));
     HIPCHK(ctx, hipStreamSynchronize(st));
     auto *d_sw = static_cast<SWDesc *>(ctx->sw_desc.p);
-    hipLaunchKernelGGL(k_fm_demod, dim3(chunks, 1), dim3(kStatsThreads), 0, st, d_sw, static_cast<short *>(ctx->codes.p),
-                       code_stride, static_cast<StatsPartial *>(ctx->partials.p), chunks);
+    hipLaunchKernelGGL(k_fm_demod, dim3(std::max(1, std::min((pieces + 15) / 16, ctx->n_cu))), dim3(kDemodThreads),
+                       65536 * sizeof(short), st, d_sw, 1, pieces, static_cast<const short *>(ctx->k1_table.p),
+                       static_cast<short *>(ctx->codes.p), code_stride, static_cast<StatsPartial *>(ctx->partials.p));
     hipLaunchKernelGGL(k_fm_stats_final, dim3(1), dim3(64), 0, st, d_sw, static_cast<StatsPartial *>(ctx->partials.p),
-                       chunks, static_cast<FmStats *>(ctx->stats.p));
+                       static_cast<FmStats *>(ctx->stats.p), 1);
     hipLaunchKernelGGL(k_fm_dump, dim3((unsigned)((n + 255) / 256), 1), dim3(256), 0, st, d_sw,
                        static_cast<short *>(ctx->codes.p), static_cast<FmStats *>(ctx->stats.p),
                        static_cast<float *>(ctx->scratch_b.p));
