@@ -222,7 +222,7 @@ void prof_collect(tdoa_ctx *ctx)
 
 // make every workspace buffer of run_fm_batch large enough (no allocation may happen while a
 // stream capture is open)
-int reserve_fm_batch(tdoa_ctx *ctx, int n_sw, int maxlen, int n_pw, const FftPlan &pl)
+int reserve_fm_batch(tdoa_ctx *ctx, int n_sw, int maxlen, int n_pw, const FftPlan &pl, int lag_lo, int lag_hi)
 {
     int rc;
     const long long code_stride = ((long long)maxlen + 15) / 8 * 8;
@@ -230,6 +230,8 @@ int reserve_fm_batch(tdoa_ctx *ctx, int n_sw, int maxlen, int n_pw, const FftPla
     if ((rc = ensure(ctx, ctx->stats, sizeof(FmStats) * (size_t)n_sw))) return rc;
     if ((rc = ensure(ctx, ctx->codes, sizeof(short) * (size_t)code_stride * n_sw))) return rc;
     if ((rc = ensure(ctx, ctx->tz, sizeof(float2) * (size_t)pl.Nc * n_sw))) return rc;
+    (void)lag_lo;
+    (void)lag_hi;
     if (n_pw && (rc = ensure(ctx, ctx->v, sizeof(float2) * (size_t)pl.Nc * n_pw))) return rc;
     return TDOA_OK;
 }
@@ -247,7 +249,7 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
     if ((rc = ensure(ctx, ctx->stats, sizeof(FmStats) * (size_t)n_sw))) return rc;
     if ((rc = ensure(ctx, ctx->codes, sizeof(short) * (size_t)code_stride * n_sw))) return rc;
     if ((rc = ensure(ctx, ctx->tz, sizeof(float2) * (size_t)pl.Nc * n_sw))) return rc;
-    if (n_pw && (rc = ensure(ctx, ctx->v, sizeof(float2) * (size_t)pl.Nc * n_pw))) return rc;
+    if ((rc = reserve_fm_batch(ctx, n_sw, maxlen, n_pw, pl, lag_lo, lag_hi))) return rc;
     auto *partials = static_cast<StatsPartial *>(ctx->partials.p);
     auto *stats = static_cast<FmStats *>(ctx->stats.p);
     auto *codes = static_cast<short *>(ctx->codes.p);
@@ -817,7 +819,9 @@ int tdoa_process(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host, void *
     if ((rc = ensure(ctx, ctx->g_scales, sizeof(double) * slots))) return rc;
     if ((rc = ensure(ctx, ctx->g_sw_desc, sizeof(SWDesc) * std::max<size_t>(sw.size(), 1)))) return rc;
     if ((rc = ensure(ctx, ctx->g_pw_desc, sizeof(PWDesc) * std::max<size_t>(pw.size(), 1)))) return rc;
-    if (n_first && (rc = reserve_fm_batch(ctx, n_first * S, (int)wlen, n_first * P, pl))) return rc;
+    if (n_first && (rc = reserve_fm_batch(ctx, n_first * S, (int)wlen, n_first * P, pl, -(ctx->prm.max_lag - 1),
+                                          ctx->prm.max_lag - 1)))
+        return rc;
     auto *d_sw = static_cast<SWDesc *>(ctx->g_sw_desc.p);
     auto *d_pw = static_cast<PWDesc *>(ctx->g_pw_desc.p);
     auto *d_keys = static_cast<unsigned long long *>(ctx->g_keys.p);

@@ -1,6 +1,8 @@
 """GPU parity tests for the north-star (mode B) path, through the C ABI:
 u8 IQ -> K1 discriminator -> K2 Stockham FFT -> K3 conj-multiply -> K4 inverse -> K5 argmax.
 Oracle: oracle/tdoa_oracle.c (ob_* functions, f64 time domain)."""
+import os
+
 import numpy as np
 import pytest
 
