@@ -146,29 +146,6 @@ __global__ __launch_bounds__(256) void k_fwd_col_c16(const SWDesc *sw, const sho
     }
 }
 
-// forward column pass for a complex64 signal already in HBM (mode A correlation):
-// z[m] = sig[m], zero padded beyond len.  Same grid/LDS as above.
-__global__ __launch_bounds__(256) void k_fwd_col_c64(const float2 *sig, int len, float2 *T, FftPlan pl)
-{
-    extern __shared__ float2 lds[];
-    const int tile = pl.N2 << pl.logC;
-    const int c0 = blockIdx.x << pl.logC;
-    for (int e = threadIdx.x; e < tile; e += blockDim.x) {
-        int c = e & (pl.C - 1), n2 = e >> pl.logC;
-        long long m = (long long)n2 * pl.N1 + c0 + c;
-        lds[e] = m < len ? sig[m] : make_float2(0.0f, 0.0f);
-    }
-    __syncthreads();
-    float2 *r = lds_fft<false>(lds, lds + tile, pl.N2, pl.logN2, pl.C, pl.logC);
-    const float inv2 = 2.0f / (float)pl.Nc;
-    for (int e = threadIdx.x; e < tile; e += blockDim.x) {
-        int c = e & (pl.C - 1), k2 = e >> pl.logC;
-        int n1 = c0 + c;
-        long long ex = ((long long)n1 * k2) & (pl.Nc - 1);
-        T[(size_t)k2 * pl.N1 + n1] = cmul(r[e], unit_root((float)ex, inv2, false));
-    }
-}
-
 // ---------------------------------------------------------------------------
 // forward row pass: length-N1 FFT of each contiguous row, in place (T -> Zs)
 // grid: (N2, n_station_windows), dynamic LDS: 2 * N1 * 8 bytes
@@ -260,35 +237,13 @@ __global__ __launch_bounds__(256) void k_inv_row_pair(const PWDesc *pw, const fl
     }
 }
 
-// inverse row pass for complex (unpacked) spectra, mode A: Q = conj(Za) * Zb
-// grid: (N2, 1), dynamic LDS: 2 * N1 * 8 bytes
-__global__ __launch_bounds__(256) void k_inv_row_c64(const float2 *Za, const float2 *Zb, float2 *V, FftPlan pl)
-{
-    extern __shared__ float2 lds[];
-    const int N1 = pl.N1;
-    const int k2 = blockIdx.x;
-    for (int e = threadIdx.x; e < N1; e += blockDim.x) {
-        size_t i = (size_t)k2 * N1 + e;
-        lds[e] = cmulc(Za[i], Zb[i]);
-    }
-    __syncthreads();
-    float2 *r = lds_fft<true>(lds, lds + N1, N1, pl.logN1, 1, 0);
-    const float inv2 = 2.0f / (float)pl.Nc;
-    for (int n1 = threadIdx.x; n1 < N1; n1 += blockDim.x) {
-        long long ex = ((long long)n1 * k2) & (pl.Nc - 1);
-        V[(size_t)k2 * N1 + n1] = cmul(r[n1], unit_root((float)ex, inv2, true));
-    }
-}
-
 // ---------------------------------------------------------------------------
 // inverse column pass + K5 argmax.  After the length-N2 IFFT down a column,
 // element (n2, n1) is q[m], m = n2*N1 + n1.
-//   packed-real mode: lags 2m (real part) and 2m+1 (imag part), minus N when >= N/2
-//   complex mode    : lag m (real part only: Re(conj(t) s), processor.go:705)
+// lags 2m (real part) and 2m+1 (imag part), minus N when >= N/2.
 // Candidates with lag_lo <= lag <= lag_hi enter a 64-bit atomicMax key.
 // grid: (N1 / C, n_pair_windows), dynamic LDS: 2 * N2 * C * 8 bytes
 // ---------------------------------------------------------------------------
-template <bool PACKED>
 __global__ __launch_bounds__(256) void k_inv_col_peak(const float2 *V, unsigned long long *keys, const PWDesc *pw,
                                                       FftPlan pl, int lag_lo, int lag_hi, float *lag_dump,
                                                       float dump_scale)
@@ -309,28 +264,18 @@ __global__ __launch_bounds__(256) void k_inv_col_peak(const float2 *V, unsigned 
         int c = e & (pl.C - 1), n2 = e >> pl.logC;
         long long m = (long long)n2 * pl.N1 + c0 + c;
         float2 v = r[e];
-        if (PACKED) {
-            long long d0 = 2 * m;
-            if (d0 >= Nc) d0 -= 2 * Nc;
-            long long d1 = d0 + 1;
-            if (d0 >= lag_lo && d0 <= lag_hi && v.x == v.x) {
-                unsigned long long k = peak_key(v.x, (int)d0);
-                best = k > best ? k : best;
-                if (lag_dump) lag_dump[d0 - lag_lo] = v.x * dump_scale;
-            }
-            if (d1 >= lag_lo && d1 <= lag_hi && v.y == v.y) {
-                unsigned long long k = peak_key(v.y, (int)d1);
-                best = k > best ? k : best;
-                if (lag_dump) lag_dump[d1 - lag_lo] = v.y * dump_scale;
-            }
-        } else {
-            long long d0 = m;
-            if (d0 >= Nc / 2) d0 -= Nc;
-            if (d0 >= lag_lo && d0 <= lag_hi && v.x == v.x) {
-                unsigned long long k = peak_key(v.x, (int)d0);
-                best = k > best ? k : best;
-                if (lag_dump) lag_dump[d0 - lag_lo] = v.x * dump_scale;
-            }
+        long long d0 = 2 * m;
+        if (d0 >= Nc) d0 -= 2 * Nc;
+        long long d1 = d0 + 1;
+        if (d0 >= lag_lo && d0 <= lag_hi && v.x == v.x) {
+            unsigned long long k = peak_key(v.x, (int)d0);
+            best = k > best ? k : best;
+            if (lag_dump) lag_dump[d0 - lag_lo] = v.x * dump_scale;
+        }
+        if (d1 >= lag_lo && d1 <= lag_hi && v.y == v.y) {
+            unsigned long long k = peak_key(v.y, (int)d1);
+            best = k > best ? k : best;
+            if (lag_dump) lag_dump[d1 - lag_lo] = v.y * dump_scale;
         }
     }
     best = wave_max_u64(best);
@@ -351,7 +296,7 @@ struct PeakOut {      // mirrors tdoa_peak
     double corr;
 };
 
-// decode keys -> peaks; scale = 1 / (4 N sqrt(len_a)) (packed) or 1 / (Nc sqrt(M)) (complex)
+// decode keys -> peaks; scale = 1 / (4 N sqrt(len_a))
 __global__ void k_decode_peaks(const unsigned long long *keys, const double *scales, PeakOut *out, int n)
 {
     int id = blockIdx.x * blockDim.x + threadIdx.x;

@@ -331,7 +331,7 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
 #undef TDOA_PRUNED
             }
             else
-                hipLaunchKernelGGL(k_inv_col_peak<true>, dim3(pl.N1 / pl.C, n_pw), dim3(256), lds_col, st, v, d_keys,
+                hipLaunchKernelGGL(k_inv_col_peak, dim3(pl.N1 / pl.C, n_pw), dim3(256), lds_col, st, v, d_keys,
                                    d_pw, pl, lag_lo, lag_hi, lag_dump, dump_scale);
         }
     }
@@ -346,12 +346,9 @@ int allow_big_lds(tdoa_ctx *ctx)
     const size_t all = 136 * 1024;   // largest dynamic request: 128 KiB (kLdsCap tiles, generic row pair); static LDS comes on top
     if ((rc = set_lds(ctx, k_fm_demod, all))) return rc;
     if ((rc = set_lds(ctx, k_fwd_col_c16, all))) return rc;
-    if ((rc = set_lds(ctx, k_fwd_col_c64, all))) return rc;
     if ((rc = set_lds(ctx, k_fwd_row, all))) return rc;
     if ((rc = set_lds(ctx, k_inv_row_pair, all))) return rc;
-    if ((rc = set_lds(ctx, k_inv_row_c64, all))) return rc;
-    if ((rc = set_lds(ctx, k_inv_col_peak<true>, all))) return rc;
-    if ((rc = set_lds(ctx, k_inv_col_peak<false>, all))) return rc;
+    if ((rc = set_lds(ctx, k_inv_col_peak, all))) return rc;
     if ((rc = set_lds(ctx, k_fwd_col256_c16, all))) return rc;
     if ((rc = set_lds(ctx, k_inv_row_pair4096<false>, all))) return rc;
     if ((rc = set_lds(ctx, k_inv_row_pair4096<true>, all))) return rc;

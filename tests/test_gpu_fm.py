@@ -224,3 +224,26 @@ def test_capture_upload_file_roundtrip(tmp_path, oracle):
             assert np.array_equal(c.capture_download(0, first, cnt), raw[2 * first:2 * (first + cnt)])
         with pytest.raises(tdoa_amd.TdoaError):
             c.capture_upload_file(1, str(tmp_path / "missing.dat"))
+
+
+def test_attach_device_buffer_from_torch(oracle):
+    """captures that already live in HBM (e.g. a torch tensor) are used in place, and the peaks can be
+    written into a device buffer for the RCCL all-gather."""
+    torch = pytest.importorskip("torch")
+    import tdoa_amd
+    from tdoa_amd.capi import PEAK_DTYPE
+    blk, wl, ml = 9000, 3000, 100
+    caps = [oracle.simulate_delayed_fm(3 * blk, d, 99, 40 + i) for i, d in enumerate((0, 21, 5))]
+    dev = [torch.from_numpy(c.copy()).cuda() for c in caps]
+    with tdoa_amd.Context(max_lag=ml, window_len=wl) as c:
+        for s, t in enumerate(dev):
+            c.capture_attach_device(s, t.data_ptr(), t.numel() // 2)
+        wpb, W = c.num_windows()
+        out_dev = torch.zeros(W * 3 * 16, dtype=torch.uint8, device="cuda")
+        host = c.process(out_dev_ptr=out_dev.data_ptr())
+        torch.cuda.synchronize()
+        got = np.frombuffer(out_dev.cpu().numpy().tobytes(), dtype=PEAK_DTYPE).reshape(W, 3)
+        assert np.array_equal(got, host)
+        assert (host["lag"] == np.array([21, 5, -16])).all()
+        ref = c.process_u8(caps)                       # same bytes through the upload path
+        assert np.array_equal(ref, host)
