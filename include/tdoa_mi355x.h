@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TDOA_ABI_VERSION 1
+#define TDOA_ABI_VERSION 2
 
 typedef struct tdoa_ctx tdoa_ctx;
 
@@ -170,6 +170,27 @@ int tdoa_process_u8(tdoa_ctx *ctx, const uint8_t *const *station_iq, const size_
 /* single pair of raw IQ windows -> peak (lags -(max_lag-1) .. max_lag-1) */
 int tdoa_fm_xcorr_u8(tdoa_ctx *ctx, const uint8_t *iq1, size_t n1, const uint8_t *iq2, size_t n2,
                      int max_lag, tdoa_peak *peak);
+
+/* Sub-sample refinement and physical-plausibility gate (SURVEY section 8 row (f)-4;
+ * PROJECT_NOTES.md:29-32: one sample is 500 ns = 150 m of range, max |TDOA| of the
+ * deployed stations about 57 us = 114 samples).  Around the integer peak lag d:
+ * y_q = s*c[d-1+q], s = sign(c[d]); frac = vertex of the parabola through the three
+ * points, (y_m - y_p) / (2 (y_m - 2 y_0 + y_p)) when that curvature is negative, clamped to
+ * [-1/2, 1/2], else 0.  The integer peak of tdoa_process is untouched (index parity). */
+typedef struct {
+    double  delay;      /* lag + frac, samples                               */
+    float   frac;       /* vertex offset in [-1/2, 1/2]                      */
+    float   y[3];       /* s*c[lag-1], s*c[lag], s*c[lag+1], reference scale */
+    int32_t plausible;  /* |delay| <= gate_samples                           */
+    int32_t reserved;
+} tdoa_fine_peak;
+/* tdoa_process + refinement: fine_host [n_windows_total][n_pairs] (zero delay, plausible
+ * for windows of other ranks), out_host may be NULL */
+int tdoa_process_fine(tdoa_ctx *ctx, int rank, int world, double gate_samples, tdoa_peak *out_host,
+                      tdoa_fine_peak *fine_host);
+int tdoa_fm_xcorr_fine_u8(tdoa_ctx *ctx, const uint8_t *iq1, size_t n1, const uint8_t *iq2, size_t n2,
+                          int max_lag, double gate_samples, tdoa_peak *peak /* may be NULL */,
+                          tdoa_fine_peak *fine);
 
 /* inspection hooks used by the parity tests */
 int tdoa_fm_preprocess_u8(tdoa_ctx *ctx, const uint8_t *iq, size_t n, float *out_f32, tdoa_fm_stats *stats);

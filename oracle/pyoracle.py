@@ -86,6 +86,9 @@ def lib():
         L.o_ecef_to_latlon.argtypes = [C.c_double, C.c_double, C.c_double, dp]
         L.ob_xcorr_all_lags.argtypes = [fp, sz, fp, sz, C.c_int, dp]
         L.ob_xcorr_peak.argtypes = [fp, sz, fp, sz, C.c_int, ip, dp]
+        L.ob_parabola_vertex.argtypes = [C.c_double, C.c_double, C.c_double]
+        L.ob_parabola_vertex.restype = C.c_double
+        L.ob_refine_peak.argtypes = [fp, sz, fp, sz, C.c_int, C.c_double, C.POINTER(Fine)]
     return _lib
 
 
@@ -396,6 +399,23 @@ def b_xcorr_peak(t, s, max_lag):
     lag, corr = C.c_int(), C.c_double()
     lib().ob_xcorr_peak(_f(t), t.size, _f(s), s.size, int(max_lag), C.byref(lag), C.byref(corr))
     return lag.value, corr.value
+
+
+class Fine(C.Structure):
+    _fields_ = [("delay", C.c_double), ("frac", C.c_double), ("y", C.c_double * 3), ("plausible", C.c_int)]
+
+
+def b_parabola_vertex(ym, y0, yp):
+    return lib().ob_parabola_vertex(float(ym), float(y0), float(yp))
+
+
+def b_refine_peak(t, s, lag, gate):
+    """ob_refine_peak -> dict(delay, frac, y[3], plausible)"""
+    t = np.ascontiguousarray(t, dtype=np.float32)
+    s = np.ascontiguousarray(s, dtype=np.float32)
+    f = Fine()
+    lib().ob_refine_peak(_f(t), t.size, _f(s), s.size, int(lag), float(gate), C.byref(f))
+    return dict(delay=f.delay, frac=f.frac, y=np.array(list(f.y)), plausible=bool(f.plausible))
 
 
 def b_xcorr_peak_fft(t, s, max_lag):

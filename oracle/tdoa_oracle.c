@@ -1079,3 +1079,44 @@ void ob_xcorr_peak(const float *t, size_t nt, const float *s, size_t ns, int max
     ob_pick_peak(c, max_lag, lag, corr);
     free(c);
 }
+
+/* ---- (f)-4 sub-sample refinement and plausibility gate --------------------
+ * Not in any .go file: PROJECT_NOTES.md:29-32 gives the physical bound (max |TDOA| about 57 us
+ * = 114 samples at 2 Msps; the prebuilt ELF restricts a second search to lags < 120) and the
+ * 500 ns sample period (150 m of range) is the reason to interpolate.  Definition (DESIGN.md
+ * section 3): y_q = s * c[lag-1+q], s = sign(c[lag]); vertex of the parabola through the three
+ * points, frac = (y_m - y_p) / (2 (y_m - 2 y_0 + y_p)) if that curvature is negative, clamped
+ * to [-1/2, 1/2], else 0; delay = lag + frac; plausible <=> |delay| <= gate. */
+double ob_parabola_vertex(double ym, double y0, double yp)
+{
+    double den = ym - 2.0 * y0 + yp;
+    if (!(den < 0.0)) return 0.0;
+    double f = 0.5 * (ym - yp) / den;
+    if (f > 0.5) f = 0.5;
+    if (f < -0.5) f = -0.5;
+    return f;
+}
+
+static double ob_one_lag(const float *t, size_t nt, const float *s, size_t ns, long d)
+{
+    long i0 = d < 0 ? -d : 0;
+    long i1 = (long)nt;
+    if ((long)ns - d < i1) i1 = (long)ns - d;
+    double acc = 0.0;
+    for (long i = i0; i < i1; i++) acc += (double)t[i] * (double)s[i + d];
+    return nt ? acc / sqrt((double)nt) : 0.0;
+}
+
+void ob_refine_peak(const float *t, size_t nt, const float *s, size_t ns, int lag, double gate, ob_fine *out)
+{
+    double c0 = ob_one_lag(t, nt, s, ns, lag);
+    double sg = c0 < 0.0 ? -1.0 : 1.0;
+    out->y[0] = sg * ob_one_lag(t, nt, s, ns, (long)lag - 1);
+    out->y[1] = sg * c0;
+    out->y[2] = sg * ob_one_lag(t, nt, s, ns, (long)lag + 1);
+    if (c0 == 0.0) out->y[0] = out->y[1] = out->y[2] = 0.0;      /* the all-zero result (0, 0.0) */
+    out->frac = ob_parabola_vertex(out->y[0], out->y[1], out->y[2]);
+    out->delay = (double)lag + out->frac;
+    out->plausible = fabs(out->delay) <= gate;
+}
+

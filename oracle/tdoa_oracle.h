@@ -142,6 +142,16 @@ void   ob_xcorr_all_lags(const float *t, size_t nt, const float *s, size_t ns,
 void   ob_pick_peak(const double *c, int max_lag, int *lag, double *corr);
 void   ob_xcorr_peak(const float *t, size_t nt, const float *s, size_t ns,
                      int max_lag, int *lag, double *corr);
+/* (f)-4: parabolic sub-sample refinement around a peak lag and the plausibility gate */
+typedef struct {
+    double delay;       /* lag + frac, samples                          */
+    double frac;        /* vertex offset in [-1/2, 1/2]                 */
+    double y[3];        /* s*c[lag-1], s*c[lag], s*c[lag+1], s=sign(c[lag]) */
+    int    plausible;   /* |delay| <= gate                              */
+} ob_fine;
+double ob_parabola_vertex(double ym, double y0, double yp);
+void   ob_refine_peak(const float *t, size_t nt, const float *s, size_t ns, int lag,
+                      double gate, ob_fine *out);
 
 #ifdef __cplusplus
 }

@@ -320,4 +320,84 @@ __global__ void k_decode_peaks(const unsigned long long *keys, const double *sca
     out[id] = p;
 }
 
+// ---------------------------------------------------------------------------
+// (f)-4 sub-sample refinement.  For the peak lag d of every pair-window the three correlation
+// values c[d-1], c[d], c[d+1] are re-evaluated as direct column sums over V (V[k2][n1] is the
+// inverse row pass including its twiddle in every plan, so element m = n2*N1 + n1 of the packed
+// result is sum_k2 V[k2][n1] e^{+2 pi i n2 k2/N2}; lag 2m is its real part, 2m+1 its imaginary
+// part).  3*N2 scattered reads per unit -- nothing next to the passes that produced V.
+// grid n_pw, 64 threads; raw[3*slot + q] unscaled like the keys.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_refine_peaks(const float2 *V, const unsigned long long *keys,
+                                                    const PWDesc *pw, FftPlan pl, float *raw)
+{
+    const int slot = pw[blockIdx.x].out_index;
+    const unsigned long long k = keys[slot];
+    if (k == 0 || (unsigned int)(k >> 32) == 0) {
+        if (threadIdx.x < 3) raw[3 * (size_t)slot + threadIdx.x] = 0.0f;
+        return;
+    }
+    const unsigned int rank = 0x7fffffffu - ((unsigned int)k >> 1);
+    const int lag = rank == 0 ? 0 : ((rank & 1u) ? (int)((rank + 1u) >> 1) : -(int)(rank >> 1));
+    const float2 *in = V + (size_t)blockIdx.x * pl.Nc;
+    const float inv2 = 2.0f / (float)pl.N2;
+    for (int q = 0; q < 3; q++) {
+        long long l = (long long)lag - 1 + q;
+        if (l < 0) l += 2 * pl.Nc;
+        const long long m = l >> 1;
+        const int n2 = (int)(m >> pl.logN1), n1 = (int)(m & (pl.N1 - 1));
+        float acc = 0.0f;
+        for (int k2 = threadIdx.x; k2 < pl.N2; k2 += kWave) {
+            const float2 x = in[(size_t)k2 * pl.N1 + n1];
+            const float2 w = unit_root((float)((n2 * k2) & (pl.N2 - 1)), inv2, true);
+            acc += (l & 1) ? x.x * w.y + x.y * w.x : x.x * w.x - x.y * w.y;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, kWave);
+        if (threadIdx.x == 0) raw[3 * (size_t)slot + q] = acc;
+    }
+}
+
+struct FineOut {      // mirrors tdoa_fine_peak
+    double delay;
+    float frac;
+    float y[3];
+    int32_t plausible;
+    int32_t reserved;
+};
+
+// raw neighbours -> parabola vertex (f64), delay = lag + frac, plausibility gate
+__global__ void k_decode_fine(const unsigned long long *keys, const double *scales, const float *raw, FineOut *out,
+                              double gate, int n)
+{
+    int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n) return;
+    const unsigned long long k = keys[id];
+    FineOut f;
+    f.delay = 0.0;
+    f.frac = 0.0f;
+    f.y[0] = f.y[1] = f.y[2] = 0.0f;
+    f.reserved = 0;
+    int lag = 0;
+    if (k != 0 && (unsigned int)(k >> 32) != 0) {
+        const unsigned int low = (unsigned int)k;
+        const unsigned int rank = 0x7fffffffu - (low >> 1);
+        lag = rank == 0 ? 0 : ((rank & 1u) ? (int)((rank + 1u) >> 1) : -(int)(rank >> 1));
+        const double sc = (low & 1u) ? -scales[id] : scales[id];
+        const double ym = (double)raw[3 * (size_t)id] * sc, y0 = (double)raw[3 * (size_t)id + 1] * sc,
+                     yp = (double)raw[3 * (size_t)id + 2] * sc;
+        const double den = ym - 2.0 * y0 + yp;
+        double fr = 0.0;
+        if (den < 0.0) {
+            fr = 0.5 * (ym - yp) / den;
+            fr = fr > 0.5 ? 0.5 : (fr < -0.5 ? -0.5 : fr);
+        }
+        f.frac = (float)fr;
+        f.delay = (double)lag + fr;
+        f.y[0] = (float)ym; f.y[1] = (float)y0; f.y[2] = (float)yp;
+    }
+    f.plausible = fabs(f.delay) <= gate ? 1 : 0;
+    out[id] = f;
+}
+
 }  // namespace tdoa

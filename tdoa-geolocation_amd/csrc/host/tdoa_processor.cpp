@@ -92,7 +92,7 @@ bool read_file(const std::string &path, std::vector<uint8_t> *out, std::string *
 
 void usage(const char *argv0)
 {
-    std::printf("Usage: %s [--fm] [--device N] [--window SAMPLES] [--max-lag SAMPLES] "
+    std::printf("Usage: %s [--fm] [--fine] [--gate SAMPLES] [--device N] [--window SAMPLES] [--max-lag SAMPLES] "
                 "<ref_freq_hz> <target_freq_hz> <csv_file> <dat_file1> [dat_file2] [dat_file3] ...\n", argv0);
     std::printf("Example: %s 162400000 101700000 lat-lon-table.csv kx0u-data.dat n3pay-data.dat kf0mtl-data.dat\n", argv0);
 }
@@ -108,13 +108,16 @@ double median(std::vector<double> v)
 
 int main(int argc, char **argv)
 {
-    bool fm = false;
+    bool fm = false, fine = false;
+    double gate = 120.0;     // samples; PROJECT_NOTES.md:29-32 (max |TDOA| about 57 us = 114 samples at 2 Msps)
     tdoa_params prm;
     tdoa_default_params(&prm);
     std::vector<std::string> pos;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         if (a == "--fm") fm = true;
+        else if (a == "--fine") fm = fine = true;              // sub-sample refinement + plausibility gate (implies --fm)
+        else if (a == "--gate" && i + 1 < argc) gate = std::atof(argv[++i]);
         else if (a == "--device" && i + 1 < argc) prm.device = std::atoi(argv[++i]);
         else if (a == "--window" && i + 1 < argc) prm.window_len = std::atoll(argv[++i]);
         else if (a == "--max-lag" && i + 1 < argc) prm.max_lag = std::atoi(argv[++i]);
@@ -221,7 +224,11 @@ int main(int argc, char **argv)
         if ((rc = tdoa_num_windows(ctx, &wpb, &W))) return die("tdoa_num_windows", rc);
         const int P = tdoa_num_pairs(ctx);
         std::vector<tdoa_peak> peaks((size_t)W * P);
-        if ((rc = tdoa_process(ctx, 0, 1, peaks.data(), nullptr))) return die("tdoa_process", rc);
+        std::vector<tdoa_fine_peak> fines;
+        if (fine) {
+            fines.resize((size_t)W * P);
+            if ((rc = tdoa_process_fine(ctx, 0, 1, gate, peaks.data(), fines.data()))) return die("tdoa_process_fine", rc);
+        } else if ((rc = tdoa_process(ctx, 0, 1, peaks.data(), nullptr))) return die("tdoa_process", rc);
         std::printf("\n=== FM-DISCRIMINATOR CROSS-CORRELATION: %d windows x %d pairs ===\n", W, P);
         int p = 0;
         for (int i = 0; i < S; i++)
@@ -237,7 +244,21 @@ int main(int argc, char **argv)
                             caps[j].st.name.c_str(), median(lr), lr.size(), median(cr));
                 std::printf("TGT %s - %s: median lag=%.0f samples over %zu windows, median |corr|=%.6f\n", caps[i].st.name.c_str(),
                             caps[j].st.name.c_str(), median(lt), lt.size(), median(ct));
-                tgt_dt.push_back(median(lt) / prm.sample_rate);
+                double lag_used = median(lt);
+                if (fine) {
+                    // refined delays of the target windows that pass the gate (all of them if none does)
+                    std::vector<double> ok, all;
+                    for (int w = 0; w < W; w++) {
+                        if ((w / wpb) != 1) continue;
+                        const tdoa_fine_peak &fk = fines[(size_t)w * P + p];
+                        all.push_back(fk.delay);
+                        if (fk.plausible) ok.push_back(fk.delay);
+                    }
+                    lag_used = median(ok.empty() ? all : ok);
+                    std::printf("TGT %s - %s: refined delay=%.3f samples, %zu of %zu windows within +-%.1f samples\n",
+                                caps[i].st.name.c_str(), caps[j].st.name.c_str(), lag_used, ok.size(), all.size(), gate);
+                }
+                tgt_dt.push_back(lag_used / prm.sample_rate);
                 tgt_w.push_back(median(ct));
             }
     }

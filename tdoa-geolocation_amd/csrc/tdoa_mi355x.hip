@@ -76,6 +76,7 @@ struct tdoa_ctx {
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     DevBuf g_sw_desc, g_pw_desc, g_scales, g_keys;
+    DevBuf fine_raw, fine;                  // (f)-4 refinement: 3 raw neighbours and tdoa_fine_peak per slot
 };
 
 namespace {
@@ -240,7 +241,7 @@ int reserve_fm_batch(tdoa_ctx *ctx, int n_sw, int maxlen, int n_pw, const FftPla
 // sw/pw descriptors are already in device memory; maxlen = longest window.
 int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const PWDesc *d_pw, int n_pw,
                  unsigned long long *d_keys, const FftPlan &pl, int lag_lo, int lag_hi, float *lag_dump,
-                 float dump_scale, double sum_len)
+                 float dump_scale, double sum_len, float *fine_raw = nullptr)
 {
     int rc;
     const int pieces = std::max(1, (maxlen + kDemodPiece - 1) / kDemodPiece);
@@ -335,6 +336,8 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
                                    d_pw, pl, lag_lo, lag_hi, lag_dump, dump_scale);
         }
     }
+    if (n_pw && fine_raw)   // V of this batch is still in place: peak neighbours for the parabola
+        hipLaunchKernelGGL(k_refine_peaks, dim3(n_pw), dim3(64), 0, st, v, d_keys, d_pw, pl, fine_raw);
     HIPCHK(ctx, hipGetLastError());
     return TDOA_OK;
 }
@@ -386,13 +389,14 @@ int stage_pair_u8(tdoa_ctx *ctx, const uint8_t *iq1, size_t n1, const uint8_t *i
 }
 
 int fm_pair(tdoa_ctx *ctx, const uint8_t *iq1, size_t n1, const uint8_t *iq2, size_t n2, int max_lag,
-            tdoa_peak *peak, double *lags_out)
+            tdoa_peak *peak, double *lags_out, tdoa_fine_peak *fine = nullptr, double gate = 0.0)
 {
     int rc;
     if ((rc = check_ctx(ctx))) return rc;
-    if (max_lag < 1 || (!peak && !lags_out)) return fail(ctx, TDOA_ERR_INVALID, "bad argument");
+    if (max_lag < 1 || (!peak && !lags_out && !fine)) return fail(ctx, TDOA_ERR_INVALID, "bad argument");
     if (n1 == 0 || n2 == 0) {   // processor.go:622-625 behaviour: (0, 0.0)
         if (peak) *peak = tdoa_peak{0, 0.0f, 0.0};
+        if (fine) *fine = tdoa_fine_peak{0.0, 0.0f, {0.0f, 0.0f, 0.0f}, gate >= 0.0 ? 1 : 0, 0};
         if (lags_out) std::fill(lags_out, lags_out + (2 * max_lag - 1), 0.0);
         return TDOA_OK;
     }
@@ -406,6 +410,10 @@ int fm_pair(tdoa_ctx *ctx, const uint8_t *iq1, size_t n1, const uint8_t *iq2, si
     if ((rc = ensure(ctx, ctx->keys, sizeof(unsigned long long)))) return rc;
     if ((rc = ensure(ctx, ctx->scales, sizeof(double)))) return rc;
     if ((rc = ensure(ctx, ctx->peaks, sizeof(PeakOut)))) return rc;
+    if (fine) {
+        if ((rc = ensure(ctx, ctx->fine_raw, 3 * sizeof(float)))) return rc;
+        if ((rc = ensure(ctx, ctx->fine, sizeof(FineOut)))) return rc;
+    }
     const int nl = 2 * max_lag - 1;
     float *dump = nullptr;
     if (lags_out) {
@@ -417,13 +425,21 @@ int fm_pair(tdoa_ctx *ctx, const uint8_t *iq1, size_t n1, const uint8_t *iq2, si
     HIPCHK(ctx, hipMemsetAsync(ctx->keys.p, 0, sizeof(unsigned long long), ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(ctx->scales.p, &scale, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     rc = run_fm_batch(ctx, d_sw, 2, (int)std::max(n1, n2), d_pw, 1, static_cast<unsigned long long *>(ctx->keys.p),
-                      pl, -(max_lag - 1), max_lag - 1, dump, 1.0f, (double)(n1 + n2));
+                      pl, -(max_lag - 1), max_lag - 1, dump, 1.0f, (double)(n1 + n2),
+                      fine ? static_cast<float *>(ctx->fine_raw.p) : nullptr);
     if (rc) return rc;
     hipLaunchKernelGGL(k_decode_peaks, dim3(1), dim3(64), 0, ctx->stream,
                        static_cast<unsigned long long *>(ctx->keys.p), static_cast<double *>(ctx->scales.p),
                        static_cast<PeakOut *>(ctx->peaks.p), 1);
     tdoa_peak pk;
     HIPCHK(ctx, hipMemcpyAsync(&pk, ctx->peaks.p, sizeof(pk), hipMemcpyDeviceToHost, ctx->stream));
+    tdoa_fine_peak fk;
+    if (fine) {
+        hipLaunchKernelGGL(k_decode_fine, dim3(1), dim3(64), 0, ctx->stream,
+                           static_cast<unsigned long long *>(ctx->keys.p), static_cast<double *>(ctx->scales.p),
+                           static_cast<float *>(ctx->fine_raw.p), static_cast<FineOut *>(ctx->fine.p), gate, 1);
+        HIPCHK(ctx, hipMemcpyAsync(&fk, ctx->fine.p, sizeof(fk), hipMemcpyDeviceToHost, ctx->stream));
+    }
     std::vector<float> hl;
     if (lags_out) {
         hl.resize(nl);
@@ -432,6 +448,7 @@ int fm_pair(tdoa_ctx *ctx, const uint8_t *iq1, size_t n1, const uint8_t *iq2, si
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     prof_collect(ctx);
     if (peak) *peak = pk;
+    if (fine) *fine = fk;
     if (lags_out)
         for (int i = 0; i < nl; i++) lags_out[i] = (double)hl[i] * scale;
     return TDOA_OK;
@@ -556,7 +573,7 @@ void tdoa_destroy(tdoa_ctx *ctx)
     DevBuf *bufs[] = {&ctx->k1_table, &ctx->sw_desc, &ctx->pw_desc, &ctx->partials, &ctx->stats, &ctx->codes, &ctx->tz, &ctx->v, &ctx->keys,
                       &ctx->scales, &ctx->peaks, &ctx->scratch_a, &ctx->scratch_b, &ctx->lagdump,
                       &ctx->ex_a, &ctx->ex_b, &ctx->ex_c, &ctx->ex_d, &ctx->ex_part,
-                      &ctx->g_sw_desc, &ctx->g_pw_desc, &ctx->g_scales, &ctx->g_keys};
+                      &ctx->g_sw_desc, &ctx->g_pw_desc, &ctx->g_scales, &ctx->g_keys, &ctx->fine_raw, &ctx->fine};
     for (DevBuf *b : bufs) release(*b);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -770,7 +787,8 @@ int tdoa_plan_info(const tdoa_ctx *ctx, int64_t *fft_n, int32_t *n1, int32_t *n2
     return TDOA_OK;
 }
 
-int tdoa_process(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host, void *out_dev)
+static int process_impl(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host, void *out_dev,
+                        tdoa_fine_peak *fine_host, double gate)
 {
     int rc;
     if ((rc = check_ctx(ctx))) return rc;
@@ -816,6 +834,10 @@ int tdoa_process(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host, void *
     if ((rc = ensure(ctx, ctx->g_scales, sizeof(double) * slots))) return rc;
     if ((rc = ensure(ctx, ctx->g_sw_desc, sizeof(SWDesc) * std::max<size_t>(sw.size(), 1)))) return rc;
     if ((rc = ensure(ctx, ctx->g_pw_desc, sizeof(PWDesc) * std::max<size_t>(pw.size(), 1)))) return rc;
+    if (fine_host) {
+        if ((rc = ensure(ctx, ctx->fine_raw, 3 * sizeof(float) * slots))) return rc;
+        if ((rc = ensure(ctx, ctx->fine, sizeof(FineOut) * slots))) return rc;
+    }
     if (n_first && (rc = reserve_fm_batch(ctx, n_first * S, (int)wlen, n_first * P, pl, -(ctx->prm.max_lag - 1),
                                           ctx->prm.max_lag - 1)))
         return rc;
@@ -827,7 +849,8 @@ int tdoa_process(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host, void *
     // everything the launches depend on: same key => the captured graph can be replayed as is
     std::vector<uint64_t> key = {(uint64_t)S, (uint64_t)rank, (uint64_t)world, (uint64_t)per_batch, (uint64_t)wlen,
                                  (uint64_t)ctx->prm.max_lag, (uint64_t)block, (uint64_t)ctx->force_generic,
-                                 ctx->alloc_gen};
+                                 ctx->alloc_gen, (uint64_t)(fine_host != nullptr), 0};
+    std::memcpy(&key.back(), &gate, sizeof(double));
     for (auto &c : ctx->caps) {
         key.push_back((uint64_t)(uintptr_t)c.dev);
         key.push_back((uint64_t)c.n);
@@ -847,13 +870,17 @@ int tdoa_process(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host, void *
 
     auto enqueue = [&]() -> int {
         HIPCHK(ctx, hipMemsetAsync(d_keys, 0, sizeof(unsigned long long) * slots, st));
+        float *fine_raw = fine_host ? static_cast<float *>(ctx->fine_raw.p) : nullptr;
         for (size_t w0 = 0; w0 < mine.size(); w0 += per_batch) {
             const int nw = (int)std::min<size_t>(per_batch, mine.size() - w0);
             const int r = run_fm_batch(ctx, d_sw + w0 * S, nw * S, (int)wlen, d_pw + w0 * P, nw * P, d_keys, pl,
                                        -(ctx->prm.max_lag - 1), ctx->prm.max_lag - 1, nullptr, 1.0f,
-                                       (double)wlen * nw * S);
+                                       (double)wlen * nw * S, fine_raw);
             if (r) return r;
         }
+        if (fine_raw)
+            hipLaunchKernelGGL(k_decode_fine, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, st, d_keys, d_scales,
+                               fine_raw, static_cast<FineOut *>(ctx->fine.p), gate, (int)slots);
         ProfScope ps(ctx, TDOA_K_PEAK, 32.0 * (double)slots);
         hipLaunchKernelGGL(k_decode_peaks, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, st, d_keys, d_scales,
                            static_cast<PeakOut *>(ctx->peaks.p), (int)slots);
@@ -883,9 +910,30 @@ int tdoa_process(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host, void *
         HIPCHK(ctx, hipMemcpyAsync(out_dev, ctx->peaks.p, sizeof(PeakOut) * slots, hipMemcpyDeviceToDevice, st));
     if (out_host)
         HIPCHK(ctx, hipMemcpyAsync(out_host, ctx->peaks.p, sizeof(PeakOut) * slots, hipMemcpyDeviceToHost, st));
+    if (fine_host)
+        HIPCHK(ctx, hipMemcpyAsync(fine_host, ctx->fine.p, sizeof(FineOut) * slots, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
     prof_collect(ctx);
     return TDOA_OK;
+}
+
+int tdoa_process(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host, void *out_dev)
+{
+    return process_impl(ctx, rank, world, out_host, out_dev, nullptr, 0.0);
+}
+
+int tdoa_process_fine(tdoa_ctx *ctx, int rank, int world, double gate_samples, tdoa_peak *out_host,
+                      tdoa_fine_peak *fine_host)
+{
+    if (!fine_host || !(gate_samples >= 0.0)) return fail(ctx, TDOA_ERR_INVALID, "fine_host is NULL or gate < 0");
+    return process_impl(ctx, rank, world, out_host, nullptr, fine_host, gate_samples);
+}
+
+int tdoa_fm_xcorr_fine_u8(tdoa_ctx *ctx, const uint8_t *iq1, size_t n1, const uint8_t *iq2, size_t n2, int max_lag,
+                          double gate_samples, tdoa_peak *peak, tdoa_fine_peak *fine)
+{
+    if (!fine || !(gate_samples >= 0.0)) return fail(ctx, TDOA_ERR_INVALID, "fine is NULL or gate < 0");
+    return fm_pair(ctx, iq1, n1, iq2, n2, max_lag, peak, nullptr, fine, gate_samples);
 }
 
 int tdoa_process_u8(tdoa_ctx *ctx, const uint8_t *const *station_iq, const size_t *n_samples, int n_stations,

@@ -30,6 +30,15 @@ class Peak(C.Structure):
 PEAK_DTYPE = np.dtype([("lag", np.int32), ("abs_corr", np.float32), ("corr", np.float64)])
 
 
+class FinePeak(C.Structure):
+    _fields_ = [("delay", C.c_double), ("frac", C.c_float), ("y", C.c_float * 3), ("plausible", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+FINE_DTYPE = np.dtype([("delay", np.float64), ("frac", np.float32), ("y", np.float32, (3,)), ("plausible", np.int32),
+                       ("reserved", np.int32)])
+
+
 class FastAnalysis(C.Structure):
     _fields_ = [("total_samples", C.c_int32), ("has_clipping", C.c_int32), ("has_overload", C.c_int32),
                 ("reserved", C.c_int32), ("i_avg", C.c_double), ("q_avg", C.c_double), ("i_std", C.c_double),
@@ -51,6 +60,7 @@ SYMBOLS = [
     "tdoa_capture_upload", "tdoa_capture_upload_file", "tdoa_capture_attach_device", "tdoa_capture_clear",
     "tdoa_synth_capture", "tdoa_capture_download",
     "tdoa_num_windows", "tdoa_num_pairs", "tdoa_process", "tdoa_process_u8",
+    "tdoa_process_fine", "tdoa_fm_xcorr_fine_u8",
     "tdoa_fm_xcorr_u8", "tdoa_fm_preprocess_u8", "tdoa_fm_xcorr_lags_u8", "tdoa_debug_force_generic",
     "tdoa_latlon_to_ecef", "tdoa_ecef_to_latlon", "tdoa_solve_3station", "tdoa_solve_nstation",
     "tdoa_profile_enable", "tdoa_profile_reset", "tdoa_profile_get", "tdoa_kernel_name",
@@ -108,6 +118,9 @@ def load(build_if_missing=True):
     L.tdoa_process.argtypes = [vp, C.c_int, C.c_int, vp, vp]
     L.tdoa_process_u8.argtypes = [vp, C.POINTER(u8p), C.POINTER(sz), C.c_int, vp]
     L.tdoa_fm_xcorr_u8.argtypes = [vp, u8p, sz, u8p, sz, C.c_int, C.POINTER(Peak)]
+    L.tdoa_process_fine.argtypes = [vp, C.c_int, C.c_int, C.c_double, vp, vp]
+    L.tdoa_fm_xcorr_fine_u8.argtypes = [vp, u8p, sz, u8p, sz, C.c_int, C.c_double, C.POINTER(Peak),
+                                        C.POINTER(FinePeak)]
     L.tdoa_fm_preprocess_u8.argtypes = [vp, u8p, sz, fp, C.POINTER(FmStats)]
     L.tdoa_fm_xcorr_lags_u8.argtypes = [vp, u8p, sz, u8p, sz, C.c_int, dp]
     L.tdoa_debug_force_generic.argtypes = [vp, C.c_int]
@@ -287,6 +300,25 @@ class Context:
                                        out.ctypes.data_as(C.c_void_p) if want_host else None,
                                        C.c_void_p(int(out_dev_ptr)) if out_dev_ptr else None))
         return out
+
+    def process_fine(self, gate_samples, rank=0, world=1):
+        """tdoa_process_fine -> (peaks [W][P], fine [W][P])"""
+        wpb, w = self.num_windows()
+        p = self.num_pairs()
+        out = np.zeros((w, p), dtype=PEAK_DTYPE)
+        fine = np.zeros((w, p), dtype=FINE_DTYPE)
+        self._chk(self._L.tdoa_process_fine(self._h, int(rank), int(world), float(gate_samples),
+                                            out.ctypes.data_as(C.c_void_p), fine.ctypes.data_as(C.c_void_p)))
+        return out, fine
+
+    def fm_xcorr_fine(self, iq1, iq2, max_lag, gate_samples):
+        a = np.ascontiguousarray(iq1, dtype=np.uint8)
+        b = np.ascontiguousarray(iq2, dtype=np.uint8)
+        pk, fk = Peak(), FinePeak()
+        self._chk(self._L.tdoa_fm_xcorr_fine_u8(self._h, _u8(a), a.size // 2, _u8(b), b.size // 2, int(max_lag),
+                                                float(gate_samples), C.byref(pk), C.byref(fk)))
+        return (pk.lag, pk.corr), dict(delay=fk.delay, frac=fk.frac, y=np.array(list(fk.y)),
+                                       plausible=bool(fk.plausible))
 
     def process_u8(self, captures):
         caps = [np.ascontiguousarray(c, dtype=np.uint8) for c in captures]

@@ -82,6 +82,9 @@ def main():
     pb, _ = o.b_preprocess(fm_b[:2 * 6000])
     lag, corr = o.b_xcorr_peak(pa, pb, MAX_LAG)
     mode_b["fm_pair"] = {"n": 6000, "lag": lag, "corr": float(corr).hex()}
+    fine = o.b_refine_peak(pa, pb, lag, 20.0)     # gate 20 < lag 23: implausible on purpose
+    mode_b["fm_pair_fine"] = {"gate": 20.0, "frac": float(fine["frac"]).hex(), "delay": float(fine["delay"]).hex(),
+                              "y": [float(v).hex() for v in fine["y"]], "plausible": bool(fine["plausible"])}
     out["mode_b"] = mode_b
 
     # simple_corr / fast analyzer

@@ -51,6 +51,11 @@ def test_oracle_reproduces_golden(gold, oracle):
     lag, corr = oracle.b_xcorr_peak(pa, pb, g["max_lag"])
     assert lag == g["mode_b"]["fm_pair"]["lag"] == g["files"]["fm-b"]["delay"]
     assert corr == float.fromhex(g["mode_b"]["fm_pair"]["corr"])
+    rec = g["mode_b"]["fm_pair_fine"]
+    fine = oracle.b_refine_peak(pa, pb, lag, rec["gate"])
+    assert fine["frac"] == float.fromhex(rec["frac"]) and fine["delay"] == float.fromhex(rec["delay"])
+    assert [float(v) for v in fine["y"]] == [float.fromhex(v) for v in rec["y"]]
+    assert fine["plausible"] == rec["plausible"]
 
 
 @pytest.mark.gpu
@@ -105,3 +110,8 @@ def test_gpu_mode_b_reproduces_golden(gold):
         lag, corr = c.fm_xcorr(g["fm_a"][:12000], g["fm_b"][:12000], g["max_lag"])
         want = float.fromhex(g["mode_b"]["fm_pair"]["corr"])
         assert lag == g["mode_b"]["fm_pair"]["lag"] and abs(corr - want) <= 1e-5 * abs(want)
+        rec = g["mode_b"]["fm_pair_fine"]
+        _, fine = c.fm_xcorr_fine(g["fm_a"][:12000], g["fm_b"][:12000], g["max_lag"], rec["gate"])
+        assert abs(fine["frac"] - float.fromhex(rec["frac"])) < 1e-4
+        assert max(abs(a - float.fromhex(b)) for a, b in zip(fine["y"], rec["y"])) <= 1e-5 * abs(want)
+        assert fine["plausible"] == rec["plausible"]
