@@ -392,19 +392,20 @@ __global__ __launch_bounds__(256) void k_inv_col_pruned(const float2 *V, unsigne
     float4 acc[NOUT];
 #pragma unroll
     for (int o = 0; o < NOUT; o++) acc[o] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    for (int kb = g; kb < N2; kb += 32) {          // 8 rows per trip, all loads issued first
-        float4 x[8];
+    // software pipeline: the 8 loads of trip i+1 are in flight while trip i is accumulated
+    float4 x[8], xn[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) x[u] = in[(size_t)(g + 4 * u) * row_stride];        // N2 % 32 == 0 (host checks)
+#pragma unroll 1
+    for (int kb = g; kb < N2; kb += 32) {
+        const int kn = kb + 32 < N2 ? kb + 32 : kb;                                   // last trip: harmless re-read
+#pragma unroll
+        for (int u = 0; u < 8; u++) xn[u] = in[(size_t)(kn + 4 * u) * row_stride];
 #pragma unroll
         for (int u = 0; u < 8; u++) {
-            const int k2 = kb + 4 * u;
-            x[u] = k2 < N2 ? in[(size_t)k2 * row_stride] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        }
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int k2 = kb + 4 * u;
             float2 wp[NPW];
             wp[0] = make_float2(1.0f, 0.0f);
-            if (NPW > 1) wp[1] = wtab[k2 & (N2 - 1)];
+            if (NPW > 1) wp[1] = wtab[kb + 4 * u];
 #pragma unroll
             for (int q = 2; q < NPW; q++) wp[q] = cmul(wp[q - 1], wp[1]);
 #pragma unroll
@@ -420,6 +421,8 @@ __global__ __launch_bounds__(256) void k_inv_col_pruned(const float2 *V, unsigne
                 }
             }
         }
+#pragma unroll
+        for (int u = 0; u < 8; u++) x[u] = xn[u];
     }
 #pragma unroll
     for (int o = 0; o < NOUT; o++) part[g][o][cp] = acc[o];

@@ -322,10 +322,11 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
 #define TDOA_PRUNED(NP, NN)                                                                                      \
     hipLaunchKernelGGL((k_inv_col_pruned<NP, NN>), grid, blk, 0, st, v, d_keys, d_pw, pl, lag_lo, lag_hi, lag_dump, \
                        dump_scale)
-                if (np == 3 && nn == 3) TDOA_PRUNED(3, 3);
-                else if (np == 1 && nn == 1) TDOA_PRUNED(1, 1);
-                else if (np == 2 && nn == 2) TDOA_PRUNED(2, 2);
-                else if (np == 4 && nn == 4) TDOA_PRUNED(4, 4);
+                const bool fixed = (pl.N2 & 31) == 0;     // the compile-time forms read 32 rows per trip unguarded
+                if (fixed && np == 3 && nn == 3) TDOA_PRUNED(3, 3);
+                else if (fixed && np == 1 && nn == 1) TDOA_PRUNED(1, 1);
+                else if (fixed && np == 2 && nn == 2) TDOA_PRUNED(2, 2);
+                else if (fixed && np == 4 && nn == 4) TDOA_PRUNED(4, 4);
                 else
                     hipLaunchKernelGGL(k_inv_col_pruned_any, grid, blk, 0, st, v, d_keys, d_pw, pl, lag_lo, lag_hi, np,
                                        nn, lag_dump, dump_scale);
