@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Per-kernel table of the SQ counters collected by collect_sq.sh (last launch of each kernel).
+usage: sq_summary.py <dir prefix> <n groups>"""
+import collections
+import csv
+import glob
+import sys
+
+
+def main():
+    prefix, n = sys.argv[1], int(sys.argv[2])
+    table = collections.defaultdict(dict)
+    for i in range(n):
+        for path in glob.glob("%s%d/**/*counter_collection.csv" % (prefix, i), recursive=True):
+            for r in csv.DictReader(open(path)):
+                name = r["Kernel_Name"].split("(")[0].replace("tdoa::", "").replace("void ", "")
+                if name.startswith("k_") and not name.startswith("k_synth"):
+                    table[name][r["Counter_Name"]] = float(r["Counter_Value"])     # last launch wins
+    ctrs = sorted({c for v in table.values() for c in v})
+    print("kernel," + ",".join(ctrs))
+    for k in sorted(table):
+        print(k + "," + ",".join("%.6g" % table[k].get(c, float("nan")) for c in ctrs))
+
+
+if __name__ == "__main__":
+    main()
