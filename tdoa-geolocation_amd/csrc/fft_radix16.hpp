@@ -158,6 +158,73 @@ __global__ __launch_bounds__(512) void k_fwd_col256_c16(const SWDesc *sw, const 
 }
 
 // ---------------------------------------------------------------------------
+// forward column pass, N2 = 256 F (F = 2: 1 s windows at 4 Msps, N = 2^22; F = 4: N = 2^23).
+// Decimation in time by F: thread group `par` runs the 256-point transform of the rows
+// n2 = par (mod F) exactly as above in its own LDS image; a last radix-F butterfly across the
+// images, X[k + 256 q] = sum_p W_F^(qp) W_(256F)^(kp) Y_p[k], is done by group q.
+// 32/F columns per workgroup: grid (N1 F/32, n_sw), 512 threads, dynamic LDS 64 KB.
+// ---------------------------------------------------------------------------
+template <int F>
+__global__ __launch_bounds__(512) void k_fwd_colx_c16(const SWDesc *sw, const short *codes, long long code_stride,
+                                                      const FmStats *stats, float2 *T, FftPlan pl)
+{
+    static_assert(F == 2 || F == 4, "last stage is radix 2 or 4");
+    constexpr int C = 32 / F, LOGC = F == 2 ? 4 : 3;
+    extern __shared__ float2 lds[];   // [F][256][C]
+    const int len = sw[blockIdx.y].len;
+    const short *row = codes + (size_t)blockIdx.y * code_stride;
+    const float mean = stats[blockIdx.y].mean, scale = stats[blockIdx.y].scale;
+    const int c = threadIdx.x & (C - 1), j = (threadIdx.x >> LOGC) & 15, par = threadIdx.x >> (LOGC + 4);
+    const int n1 = blockIdx.x * C + c;
+    const int N1 = pl.N1;
+    float2 *img = lds + par * 256 * C;
+    float2 v[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++)
+        v[r] = code_element(row, (long long)(F * (j + 16 * r) + par) * N1 + n1, len, mean, scale);
+    fft16<false>(v);
+#pragma unroll
+    for (int k = 0; k < 16; k++) img[(16 * j + k) * C + c] = v[oreg(k)];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; r++) v[r] = img[(j + 16 * r) * C + c];
+    mul_powers16(v, unit_root((float)j, 2.0f / 256.0f, false));
+    fft16<false>(v);
+    // Y_par[k = j + 16 kk] *= W_(256F)^(k par)
+    if (par)      // uniform per wave
+        mul_base_step16(v, unit_root((float)(j * par), 2.0f / (256.0f * F), false),
+                        unit_root((float)(16 * par), 2.0f / (256.0f * F), false));
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; k++) img[(j + 16 * k) * C + c] = v[oreg(k)];
+    __syncthreads();
+    const int q = par;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int idx = (j + 16 * k) * C + c;
+        const float2 a0 = lds[idx], a1 = lds[256 * C + idx];
+        if (F == 2) {
+            v[oreg(k)] = q ? csub(a0, a1) : cadd(a0, a1);
+        } else {
+            const float2 a2 = lds[2 * 256 * C + idx], a3 = lds[3 * 256 * C + idx];
+            const float2 s02 = (q & 1) ? csub(a0, a2) : cadd(a0, a2);
+            const float2 e13 = (q & 1) ? csub(a1, a3) : cadd(a1, a3);
+            // W_4^q = (-i)^q on the odd pair: q = 0, 2: +-(a1 + a3);  q = 1: -i (a1 - a3);  q = 3: +i (a1 - a3)
+            const float2 o = (q & 1) ? make_float2(e13.y, -e13.x) : e13;
+            v[oreg(k)] = (q & 2) ? csub(s02, o) : cadd(s02, o);
+        }
+    }
+    // X[k2 = j + 16 k + 256 q] *= W_Nc^(n1 k2) = W^(n1 (j + 256 q)) * (W^(16 n1))^k
+    float2 *out = T + (size_t)blockIdx.y * pl.Nc;
+    const float inv2 = 2.0f / (float)pl.Nc;
+    const long long e0 = ((long long)n1 * (j + 256 * q)) & (pl.Nc - 1);
+    const long long e1 = ((long long)n1 * 16) & (pl.Nc - 1);
+    mul_base_step16(v, unit_root((float)e0, inv2, false), unit_root((float)e1, inv2, false));
+#pragma unroll
+    for (int k = 0; k < 16; k++) out[(size_t)(j + 16 * k + 256 * q) * N1 + n1] = v[oreg(k)];
+}
+
+// ---------------------------------------------------------------------------
 // inverse row pass with K3 fused, N1 = 4096: one workgroup owns rows a and N2 - a (a >= 1).
 // Thread t builds Q[a][t + 256 r] and its mirror Q[N2-a][4095 - t - 256 r] from the same four
 // spectrum values, so stage 1 of row a (item t) and of row N2-a (item 255 - t) need no exchange.

@@ -263,6 +263,7 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
     // fft_stockham.hpp
     const bool row16 = pl.N1 == 4096 && !ctx->force_generic;
     const bool col16 = row16 && pl.N2 == 256;
+    const int colx = row16 && (pl.N2 == 512 || pl.N2 == 1024) ? pl.N2 / 256 : 0;   // last radix of k_fwd_colx_c16
     int np = 0, nn = 0;
     {
         const long long n_real = 2 * pl.Nc;
@@ -291,6 +292,12 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
         ProfScope ps(ctx, TDOA_K_FWD_COL, 2.0 * sum_len + nc8 * n_sw);
         if (col16)
             hipLaunchKernelGGL(k_fwd_col256_c16, dim3(pl.N1 / 32, n_sw), dim3(512), lds_col16, st, d_sw, codes,
+                               code_stride, stats, tz, pl);
+        else if (colx == 2)
+            hipLaunchKernelGGL(k_fwd_colx_c16<2>, dim3(pl.N1 / 16, n_sw), dim3(512), lds_col16, st, d_sw, codes,
+                               code_stride, stats, tz, pl);
+        else if (colx == 4)
+            hipLaunchKernelGGL(k_fwd_colx_c16<4>, dim3(pl.N1 / 8, n_sw), dim3(512), lds_col16, st, d_sw, codes,
                                code_stride, stats, tz, pl);
         else
             hipLaunchKernelGGL(k_fwd_col_c16, dim3(pl.N1 / pl.C, n_sw), dim3(256), lds_col, st, d_sw, codes,
@@ -354,6 +361,8 @@ int allow_big_lds(tdoa_ctx *ctx)
     if ((rc = set_lds(ctx, k_inv_row_pair, all))) return rc;
     if ((rc = set_lds(ctx, k_inv_col_peak, all))) return rc;
     if ((rc = set_lds(ctx, k_fwd_col256_c16, all))) return rc;
+    if ((rc = set_lds(ctx, k_fwd_colx_c16<2>, all))) return rc;
+    if ((rc = set_lds(ctx, k_fwd_colx_c16<4>, all))) return rc;
     if ((rc = set_lds(ctx, k_inv_row_pair4096<false>, all))) return rc;
     if ((rc = set_lds(ctx, k_inv_row_pair4096<true>, all))) return rc;
     return TDOA_OK;

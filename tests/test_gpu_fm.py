@@ -175,21 +175,27 @@ def test_odd_and_unaligned_windows_use_fallback(oracle):
 
 
 @pytest.mark.parametrize("n,delay,label", [
-    (4_000_000, -41, "cfg5 window: 1 s at 4 Msps, N = 2^22 (4096 x 512)"),
-    (20_000_000, 88, "cfg3 window: 10 s at 2 Msps, N = 2^25 (4096 x 4096)"),
+    (4_000_000, -41, "cfg5 window: 1 s at 4 Msps, N = 2^22 (4096 x 512, radix-2 last column stage)"),
+    (8_000_000, 123, "2 s at 4 Msps, N = 2^23 (4096 x 1024, radix-4 last column stage)"),
+    (20_000_000, 88, "cfg3 window: 10 s at 2 Msps, N = 2^25 (4096 x 4096, any-size column kernels)"),
 ])
 def test_long_windows_vs_f64_fft(oracle, n, delay, label):
-    """BASELINE configs 3 and 5 window geometries through the any-size column kernels."""
+    """BASELINE configs 3 and 5 window geometries (and the size between them)."""
     import tdoa_amd
     a = oracle.simulate_delayed_fm(n, max(0, -delay), 31, 1)
     b = oracle.simulate_delayed_fm(n, max(0, delay), 31, 2)
-    with tdoa_amd.Context() as c:
-        lag, corr = c.fm_xcorr(a, b, 20000)
     ta, _ = oracle.b_preprocess(a)
     tb, _ = oracle.b_preprocess(b)
-    olag, ocorr, _ = oracle.b_xcorr_peak_fft(ta, tb, 20000)
-    assert lag == olag == delay, label
-    assert abs(corr - ocorr) <= REL_TOL * abs(ocorr), label
+    olag, ocorr, want = oracle.b_xcorr_peak_fft(ta, tb, 20000)
+    with tdoa_amd.Context() as c:
+        lag, corr = c.fm_xcorr(a, b, 20000)
+        assert lag == olag == delay, label
+        assert abs(corr - ocorr) <= REL_TOL * abs(ocorr), label
+        if n <= 8_000_000:
+            hot = c.fm_xcorr_lags(a, b, 20000)
+            _assert_lags_close(hot, want)
+            c.force_generic(True)
+            _assert_lags_close(c.fm_xcorr_lags(a, b, 20000), hot)
 
 
 def test_eight_stations_28_pairs(oracle):
