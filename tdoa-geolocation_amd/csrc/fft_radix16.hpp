@@ -125,10 +125,16 @@ __global__ __launch_bounds__(256) void k_fwd_row4096(float2 *TZ, FftPlan pl)
 // forward column pass, N2 = 256, 32 columns per workgroup: phase codes -> normalise -> pack ->
 // two radix-16 stages down the columns -> twiddle -> T[k2][n1].
 // grid (N1/32, n_sw), 512 threads (c = t & 31 column, j = t >> 5 item), dynamic LDS 64 KB
+//
+// SUB = true is the first half of a column pass of N2 = 256 G points (G = 16: 10 s windows, N = 2^25; G = 8),
+// decimated in time by G: blockIdx.z = a transforms the rows n2 = a (mod G), applies W_(256G)^(a kb)
+// and leaves Y_a[kb] in row a*256 + kb; k_fwd_col_finish<G> then runs the G-point transforms over a.
 // ---------------------------------------------------------------------------
+template <bool SUB>
 __global__ __launch_bounds__(512) void k_fwd_col256_c16(const SWDesc *sw, const short *codes, long long code_stride,
                                                         const FmStats *stats, float2 *T, FftPlan pl)
 {
+    const int G = SUB ? pl.N2 >> 8 : 1, a = SUB ? (int)blockIdx.z : 0;
     extern __shared__ float2 lds[];   // [256][32]
     const int len = sw[blockIdx.y].len;
     const short *row = codes + (size_t)blockIdx.y * code_stride;
@@ -138,7 +144,8 @@ __global__ __launch_bounds__(512) void k_fwd_col256_c16(const SWDesc *sw, const 
     const int N1 = pl.N1;
     float2 v[16];
 #pragma unroll
-    for (int r = 0; r < 16; r++) v[r] = code_element(row, (long long)(j + 16 * r) * N1 + n1, len, mean, scale);
+    for (int r = 0; r < 16; r++)
+        v[r] = code_element(row, (long long)(a + G * (j + 16 * r)) * N1 + n1, len, mean, scale);
     fft16<false>(v);
 #pragma unroll
     for (int k = 0; k < 16; k++) lds[((16 * j + k) << 5) + c] = v[oreg(k)];
@@ -147,14 +154,47 @@ __global__ __launch_bounds__(512) void k_fwd_col256_c16(const SWDesc *sw, const 
     for (int r = 0; r < 16; r++) v[r] = lds[((j + 16 * r) << 5) + c];
     mul_powers16(v, unit_root((float)j, 2.0f / 256.0f, false));
     fft16<false>(v);
-    // Y[k2 = j + 16k] *= W_Nc^(n1*k2) = W^(n1*j) * (W^(16*n1))^k
     float2 *out = T + (size_t)blockIdx.y * pl.Nc;
+    if (SUB) {
+        // Y_a[kb = j + 16k] *= W_(256G)^(a kb) = W^(a j) * (W^(16 a))^k
+        const float invg = 2.0f / (float)pl.N2;
+        if (a) mul_base_step16(v, unit_root((float)(a * j), invg, false), unit_root((float)(16 * a), invg, false));
+#pragma unroll
+        for (int k = 0; k < 16; k++) out[(size_t)(a * 256 + j + 16 * k) * N1 + n1] = v[oreg(k)];
+    } else {
+        // Y[k2 = j + 16k] *= W_Nc^(n1*k2) = W^(n1*j) * (W^(16*n1))^k
+        const float inv2 = 2.0f / (float)pl.Nc;
+        const long long e0 = ((long long)n1 * j) & (pl.Nc - 1);
+        const long long e1 = ((long long)n1 * 16) & (pl.Nc - 1);
+        mul_base_step16(v, unit_root((float)e0, inv2, false), unit_root((float)e1, inv2, false));
+#pragma unroll
+        for (int k = 0; k < 16; k++) out[(size_t)(j + 16 * k) * N1 + n1] = v[oreg(k)];
+    }
+}
+
+// second half, G = 16 (N2 = 4096) or 8 (N2 = 2048): X[kb + 256 ka] = sum_a W_G^(a ka) Y_a[kb] in registers
+// (G = 8 runs the 16-point butterfly on inputs spread to the even slots: W_16^(2a k) = W_8^(a k)), then the
+// four-step twiddle W_Nc^(n1 k2) = W^(n1 kb) * (W^(256 n1))^ka; in place (a thread rewrites the rows it read).
+// grid (N1/256, 256, n_sw), 256 threads = 256 adjacent columns.
+template <int G>
+__global__ __launch_bounds__(256) void k_fwd_col_finish(float2 *T, FftPlan pl)
+{
+    static_assert(G == 8 || G == 16, "two-sweep column pass: N2 = 2048 or 4096");
+    const int n1 = (blockIdx.x << 8) + threadIdx.x, kb = blockIdx.y;
+    float2 *base = T + (size_t)blockIdx.z * pl.Nc + (size_t)kb * pl.N1 + n1;
+    const size_t stride = (size_t)256 * pl.N1;
+    float2 v[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) v[r] = make_float2(0.0f, 0.0f);
+#pragma unroll
+    for (int a = 0; a < G; a++) v[(16 / G) * a] = base[a * stride];
+    fft16<false>(v);
     const float inv2 = 2.0f / (float)pl.Nc;
-    const long long e0 = ((long long)n1 * j) & (pl.Nc - 1);
-    const long long e1 = ((long long)n1 * 16) & (pl.Nc - 1);
+    const long long e0 = ((long long)n1 * kb) & (pl.Nc - 1);
+    const long long e1 = ((long long)n1 * 256) & (pl.Nc - 1);
     mul_base_step16(v, unit_root((float)e0, inv2, false), unit_root((float)e1, inv2, false));
 #pragma unroll
-    for (int k = 0; k < 16; k++) out[(size_t)(j + 16 * k) * N1 + n1] = v[oreg(k)];
+    for (int ka = 0; ka < G; ka++) base[ka * stride] = v[oreg(ka)];
 }
 
 // ---------------------------------------------------------------------------
@@ -361,7 +401,7 @@ __global__ __launch_bounds__(256) void k_inv_col_pruned_any(const float2 *V, uns
                                                        FftPlan pl, int lag_lo, int lag_hi, int np, int nn,
                                                        float *lag_dump, float dump_scale)
 {
-    __shared__ float2 wtab[512];                   // e^{+2 pi i k/N2}, N2 <= 512
+    extern __shared__ float2 wtab[];               // e^{+2 pi i k/N2}, N2 entries (dynamic LDS)
     __shared__ float4 part[4][kPruneMax][64];
     __shared__ unsigned long long red[4];
     const int N2 = pl.N2, N1 = pl.N1;
@@ -446,7 +486,7 @@ __global__ __launch_bounds__(256) void k_inv_col_pruned(const float2 *V, unsigne
 {
     constexpr int NOUT = NP + NN;
     constexpr int NPW = (NP - 1 > NN ? NP - 1 : NN) + 1;     // powers w^0 .. w^(NPW-1)
-    __shared__ float2 wtab[512];                   // e^{+2 pi i k/N2}, N2 <= 512
+    extern __shared__ float2 wtab[];               // e^{+2 pi i k/N2}, N2 entries (dynamic LDS)
     __shared__ float4 part[4][NOUT][64];
     __shared__ unsigned long long red[4];
     const int N2 = pl.N2, N1 = pl.N1;

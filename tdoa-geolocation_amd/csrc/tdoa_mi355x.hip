@@ -263,6 +263,7 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
     // fft_stockham.hpp
     const bool row16 = pl.N1 == 4096 && !ctx->force_generic;
     const bool col16 = row16 && pl.N2 == 256;
+    const bool col2pass = row16 && (pl.N2 == 4096 || pl.N2 == 2048);   // 256-point sub-transforms + 16-point finish (two sweeps)
     const int colx = row16 && (pl.N2 == 512 || pl.N2 == 1024) ? pl.N2 / 256 : 0;   // last radix of k_fwd_colx_c16
     int np = 0, nn = 0;
     {
@@ -270,7 +271,7 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
         np = lag_hi >= 0 ? (int)((lag_hi / 2) / pl.N1) + 1 : 0;
         nn = lag_lo < 0 ? pl.N2 - (int)(((n_real + lag_lo) / 2) / pl.N1) : 0;
     }
-    const bool pruned = !ctx->force_generic && pl.N1 >= 128 && pl.N2 <= 512 && np + nn <= kPruneMax && np + nn <= pl.N2 &&
+    const bool pruned = !ctx->force_generic && pl.N1 >= 128 && pl.N2 <= 4096 && np + nn <= kPruneMax && np + nn <= pl.N2 &&
                         lag_hi < pl.Nc && lag_lo > -pl.Nc;
     {
         // K1: capture bytes -> 16-bit phase codes + exact window statistics
@@ -291,8 +292,16 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
     {
         ProfScope ps(ctx, TDOA_K_FWD_COL, 2.0 * sum_len + nc8 * n_sw);
         if (col16)
-            hipLaunchKernelGGL(k_fwd_col256_c16, dim3(pl.N1 / 32, n_sw), dim3(512), lds_col16, st, d_sw, codes,
+            hipLaunchKernelGGL(k_fwd_col256_c16<false>, dim3(pl.N1 / 32, n_sw), dim3(512), lds_col16, st, d_sw, codes,
                                code_stride, stats, tz, pl);
+        else if (col2pass) {
+            hipLaunchKernelGGL(k_fwd_col256_c16<true>, dim3(pl.N1 / 32, n_sw, pl.N2 / 256), dim3(512), lds_col16, st,
+                               d_sw, codes, code_stride, stats, tz, pl);
+            if (pl.N2 == 4096)
+                hipLaunchKernelGGL(k_fwd_col_finish<16>, dim3(pl.N1 / 256, 256, n_sw), dim3(256), 0, st, tz, pl);
+            else
+                hipLaunchKernelGGL(k_fwd_col_finish<8>, dim3(pl.N1 / 256, 256, n_sw), dim3(256), 0, st, tz, pl);
+        }
         else if (colx == 2)
             hipLaunchKernelGGL(k_fwd_colx_c16<2>, dim3(pl.N1 / 16, n_sw), dim3(512), lds_col16, st, d_sw, codes,
                                code_stride, stats, tz, pl);
@@ -326,16 +335,17 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
             ProfScope ps(ctx, TDOA_K_INV_COL, nc8 * n_pw);
             if (pruned) {
                 const dim3 grid(pl.N1 / 128, n_pw), blk(256);
+                const size_t lds_wtab = sizeof(float2) * (size_t)pl.N2;
 #define TDOA_PRUNED(NP, NN)                                                                                      \
-    hipLaunchKernelGGL((k_inv_col_pruned<NP, NN>), grid, blk, 0, st, v, d_keys, d_pw, pl, lag_lo, lag_hi, lag_dump, \
-                       dump_scale)
+    hipLaunchKernelGGL((k_inv_col_pruned<NP, NN>), grid, blk, lds_wtab, st, v, d_keys, d_pw, pl, lag_lo, lag_hi, \
+                       lag_dump, dump_scale)
                 const bool fixed = (pl.N2 & 31) == 0;     // the compile-time forms read 32 rows per trip unguarded
                 if (fixed && np == 3 && nn == 3) TDOA_PRUNED(3, 3);
                 else if (fixed && np == 1 && nn == 1) TDOA_PRUNED(1, 1);
                 else if (fixed && np == 2 && nn == 2) TDOA_PRUNED(2, 2);
                 else if (fixed && np == 4 && nn == 4) TDOA_PRUNED(4, 4);
                 else
-                    hipLaunchKernelGGL(k_inv_col_pruned_any, grid, blk, 0, st, v, d_keys, d_pw, pl, lag_lo, lag_hi, np,
+                    hipLaunchKernelGGL(k_inv_col_pruned_any, grid, blk, lds_wtab, st, v, d_keys, d_pw, pl, lag_lo, lag_hi, np,
                                        nn, lag_dump, dump_scale);
 #undef TDOA_PRUNED
             }
@@ -360,7 +370,8 @@ int allow_big_lds(tdoa_ctx *ctx)
     if ((rc = set_lds(ctx, k_fwd_row, all))) return rc;
     if ((rc = set_lds(ctx, k_inv_row_pair, all))) return rc;
     if ((rc = set_lds(ctx, k_inv_col_peak, all))) return rc;
-    if ((rc = set_lds(ctx, k_fwd_col256_c16, all))) return rc;
+    if ((rc = set_lds(ctx, k_fwd_col256_c16<false>, all))) return rc;
+    if ((rc = set_lds(ctx, k_fwd_col256_c16<true>, all))) return rc;
     if ((rc = set_lds(ctx, k_fwd_colx_c16<2>, all))) return rc;
     if ((rc = set_lds(ctx, k_fwd_colx_c16<4>, all))) return rc;
     if ((rc = set_lds(ctx, k_inv_row_pair4096<false>, all))) return rc;

@@ -177,7 +177,8 @@ def test_odd_and_unaligned_windows_use_fallback(oracle):
 @pytest.mark.parametrize("n,delay,label", [
     (4_000_000, -41, "cfg5 window: 1 s at 4 Msps, N = 2^22 (4096 x 512, radix-2 last column stage)"),
     (8_000_000, 123, "2 s at 4 Msps, N = 2^23 (4096 x 1024, radix-4 last column stage)"),
-    (20_000_000, 88, "cfg3 window: 10 s at 2 Msps, N = 2^25 (4096 x 4096, any-size column kernels)"),
+    (10_000_000, -7, "5 s at 2 Msps, N = 2^24 (4096 x 2048, two-sweep column pass, 8-point finish)"),
+    (20_000_000, 88, "cfg3 window: 10 s at 2 Msps, N = 2^25 (4096 x 4096, two-sweep column pass, 16-point finish)"),
 ])
 def test_long_windows_vs_f64_fft(oracle, n, delay, label):
     """BASELINE configs 3 and 5 window geometries (and the size between them)."""
@@ -191,7 +192,7 @@ def test_long_windows_vs_f64_fft(oracle, n, delay, label):
         lag, corr = c.fm_xcorr(a, b, 20000)
         assert lag == olag == delay, label
         assert abs(corr - ocorr) <= REL_TOL * abs(ocorr), label
-        if n <= 8_000_000:
+        if n <= 10_000_000:
             hot = c.fm_xcorr_lags(a, b, 20000)
             _assert_lags_close(hot, want)
             c.force_generic(True)
