@@ -192,6 +192,23 @@ int tdoa_fm_xcorr_fine_u8(tdoa_ctx *ctx, const uint8_t *iq1, size_t n1, const ui
                           int max_lag, double gate_samples, tdoa_peak *peak /* may be NULL */,
                           tdoa_fine_peak *fine);
 
+/* Capture-quality statistics of every (window, station) in one streaming pass over the bytes
+ * in HBM: the byte statistics of fastAnalyzeSamples
+ * (fast_analyzer.go:117-155) and the block power of validateDataFile (collector.go:219-224).
+ * Exact integer sums on the GPU, so every field equals the reference's float64 result. */
+typedef struct {
+    int64_t n_samples;
+    double  i_avg, q_avg, i_std, q_std;   /* fast_analyzer.go:139-142                     */
+    double  power_level;                  /* dB, floor -100 (:146-151)                    */
+    double  mean_power;                   /* mean of (I-127.5)^2+(Q-127.5)^2 (collector.go:219-224) */
+    int32_t i_min, i_max, q_min, q_max;
+    int32_t has_clipping, has_overload;   /* :154-155                                     */
+} tdoa_window_quality;
+/* out_host [n_windows_total][n_stations]; windows of other ranks are zero-filled */
+int tdoa_window_quality_all(tdoa_ctx *ctx, int rank, int world, tdoa_window_quality *out_host);
+/* the same statistics of one host buffer of raw IQ */
+int tdoa_window_quality_u8(tdoa_ctx *ctx, const uint8_t *iq, size_t n_samples, tdoa_window_quality *out);
+
 /* inspection hooks used by the parity tests */
 int tdoa_fm_preprocess_u8(tdoa_ctx *ctx, const uint8_t *iq, size_t n, float *out_f32, tdoa_fm_stats *stats);
 int tdoa_fm_xcorr_lags_u8(tdoa_ctx *ctx, const uint8_t *iq1, size_t n1, const uint8_t *iq2, size_t n2,

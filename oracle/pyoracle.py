@@ -266,6 +266,13 @@ def fast_analyze(samples_u8, total_samples):
     return fa
 
 
+def block_power(iq_u8):
+    s = np.ascontiguousarray(iq_u8, dtype=np.uint8)
+    f = lib().o_block_power
+    f.restype = C.c_double
+    return f(_u8(s), C.c_size_t(s.size // 2))
+
+
 def fast_analyze_capture(raw_u8):
     s = np.ascontiguousarray(raw_u8, dtype=np.uint8)
     ref, tgt = FastAnalysis(), FastAnalysis()

@@ -633,6 +633,19 @@ void o_fast_analyze(const uint8_t *s, int total, o_fast_analysis *a)
     a->snr_estimate = o_fast_snr(s, total);
 }
 
+/* collector.go:219-224 validateDataFile block power: mean of (I-127.5)^2 + (Q-127.5)^2 over the
+ * first n samples, float64 running sum in sample order. */
+double o_block_power(const uint8_t *iq, size_t n)
+{
+    double sum_sq = 0.0;
+    for (size_t j = 0; j < n; j++) {
+        double iv = (double)iq[2 * j] - 127.5;
+        double qv = (double)iq[2 * j + 1] - 127.5;
+        sum_sq += iv * iv + qv * qv;
+    }
+    return sum_sq / (double)n;
+}
+
 /* fast_analyzer.go:53-111 fastAnalyzeDualFrequencyFile on bytes in memory. */
 int o_fast_analyze_capture(const uint8_t *raw, size_t n_bytes,
                            o_fast_analysis *ref, o_fast_analysis *tgt)

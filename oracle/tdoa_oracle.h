@@ -88,6 +88,7 @@ void   o_fast_dft(const double *in_c128, int n, double *out_c128);
 double o_fast_snr(const uint8_t *samples, int total_samples);
 void   o_fast_analyze(const uint8_t *samples, int total_samples, o_fast_analysis *out);
 /* fastAnalyzeDualFrequencyFile on an in-memory capture; returns -1 if too small */
+double o_block_power(const uint8_t *iq, size_t n_samples);   /* collector.go:219-224 */
 int    o_fast_analyze_capture(const uint8_t *raw, size_t n_bytes,
                               o_fast_analysis *ref, o_fast_analysis *tgt);
 

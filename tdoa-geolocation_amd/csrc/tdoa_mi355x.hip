@@ -22,6 +22,7 @@
 #include "fft_radix16.hpp"
 #include "exact_reference.hpp"
 #include "synth_capture.hpp"
+#include "window_quality.hpp"
 #include "host_geodesy.hpp"
 
 using namespace tdoa;
@@ -76,6 +77,7 @@ struct tdoa_ctx {
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     DevBuf g_sw_desc, g_pw_desc, g_scales, g_keys;
+    DevBuf qual;                            // QualAcc per (window, station)
     DevBuf fine_raw, fine;                  // (f)-4 refinement: 3 raw neighbours and tdoa_fine_peak per slot
 };
 
@@ -594,7 +596,7 @@ void tdoa_destroy(tdoa_ctx *ctx)
     DevBuf *bufs[] = {&ctx->k1_table, &ctx->sw_desc, &ctx->pw_desc, &ctx->partials, &ctx->stats, &ctx->codes, &ctx->tz, &ctx->v, &ctx->keys,
                       &ctx->scales, &ctx->peaks, &ctx->scratch_a, &ctx->scratch_b, &ctx->lagdump,
                       &ctx->ex_a, &ctx->ex_b, &ctx->ex_c, &ctx->ex_d, &ctx->ex_part,
-                      &ctx->g_sw_desc, &ctx->g_pw_desc, &ctx->g_scales, &ctx->g_keys, &ctx->fine_raw, &ctx->fine};
+                      &ctx->g_sw_desc, &ctx->g_pw_desc, &ctx->g_scales, &ctx->g_keys, &ctx->fine_raw, &ctx->fine, &ctx->qual};
     for (DevBuf *b : bufs) release(*b);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -955,6 +957,93 @@ int tdoa_fm_xcorr_fine_u8(tdoa_ctx *ctx, const uint8_t *iq1, size_t n1, const ui
 {
     if (!fine || !(gate_samples >= 0.0)) return fail(ctx, TDOA_ERR_INVALID, "fine is NULL or gate < 0");
     return fm_pair(ctx, iq1, n1, iq2, n2, max_lag, peak, nullptr, fine, gate_samples);
+}
+
+// fast_analyzer.go:139-155 and collector.go:224 from the exact integer sums, in the reference's expression order
+static void finalize_quality(const QualAcc &q, long long n_samples, tdoa_window_quality *out)
+{
+    std::memset(out, 0, sizeof(*out));
+    out->n_samples = n_samples;
+    if (n_samples <= 0) return;
+    const double n = (double)n_samples;
+    const double isum = (double)q.si, qsum = (double)q.sq, isq = (double)q.sii, qsq = (double)q.sqq;   // exact (< 2^53)
+    out->i_avg = isum / n;
+    out->q_avg = qsum / n;
+    out->i_std = std::sqrt((isq / n) - (out->i_avg * out->i_avg));
+    out->q_std = std::sqrt((qsq / n) - (out->q_avg * out->q_avg));
+    const double pm = std::sqrt(out->i_std * out->i_std + out->q_std * out->q_std);
+    out->power_level = pm <= 1e-10 ? -100.0 : 20 * std::log10(pm);
+    // sum of (b-127.5)^2 over both components: every term is a multiple of 1/4, so the f64 running sum is exact
+    const double sumsq = (isq + qsq) - 255.0 * (isum + qsum) + 2.0 * n * 16256.25;
+    out->mean_power = sumsq / n;
+    out->i_min = (int32_t)q.imin; out->i_max = (int32_t)q.imax; out->q_min = (int32_t)q.qmin; out->q_max = (int32_t)q.qmax;
+    out->has_clipping = (q.imin == 0 || q.imax == 255 || q.qmin == 0 || q.qmax == 255) ? 1 : 0;
+    out->has_overload = (out->i_std < 2 || out->q_std < 2) ? 1 : 0;
+}
+
+static int run_quality(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, long long max_len, std::vector<QualAcc> *host)
+{
+    int rc;
+    if ((rc = ensure(ctx, ctx->qual, sizeof(QualAcc) * (size_t)std::max(n_sw, 1)))) return rc;
+    auto *acc = static_cast<QualAcc *>(ctx->qual.p);
+    host->resize(n_sw);
+    if (n_sw == 0) return TDOA_OK;
+    hipStream_t st = ctx->stream;
+    hipLaunchKernelGGL(k_quality_init, dim3((n_sw + 255) / 256), dim3(256), 0, st, acc, n_sw);
+    const unsigned chunks = (unsigned)std::max<long long>(1, (max_len + kQualChunk - 1) / kQualChunk);
+    hipLaunchKernelGGL(k_window_quality, dim3(chunks, n_sw), dim3(256), 0, st, d_sw, acc);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(host->data(), acc, sizeof(QualAcc) * (size_t)n_sw, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    return TDOA_OK;
+}
+
+int tdoa_window_quality_all(tdoa_ctx *ctx, int rank, int world, tdoa_window_quality *out_host)
+{
+    int rc;
+    if ((rc = check_ctx(ctx))) return rc;
+    if (world < 1 || rank < 0 || rank >= world || !out_host) return fail(ctx, TDOA_ERR_INVALID, "bad rank/world/out");
+    long long block, wlen;
+    int wpb;
+    if ((rc = window_geometry(ctx, &block, &wlen, &wpb))) return fail(ctx, rc, "captures missing or too small");
+    const int S = (int)ctx->caps.size();
+    const int W = 3 * wpb;
+    std::vector<int> mine;
+    for (int w = rank; w < W; w += world) mine.push_back(w);
+    std::vector<SWDesc> sw(mine.size() * (size_t)S);
+    for (size_t wi = 0; wi < mine.size(); wi++) {
+        const int wid = mine[wi];
+        const long long off = (long long)(wid / wpb) * block + (long long)(wid % wpb) * wlen;
+        for (int s = 0; s < S; s++) sw[wi * S + s] = SWDesc{ctx->caps[s].dev + 2 * off, (int32_t)wlen, 0};
+    }
+    if ((rc = ensure(ctx, ctx->g_sw_desc, sizeof(SWDesc) * std::max<size_t>(sw.size(), 1)))) return rc;
+    ctx->graph_key.clear();     // the descriptor buffer of a captured tdoa_process graph is being rewritten
+    if (!sw.empty())
+        HIPCHK(ctx, hipMemcpyAsync(ctx->g_sw_desc.p, sw.data(), sizeof(SWDesc) * sw.size(), hipMemcpyHostToDevice, ctx->stream));
+    std::vector<QualAcc> acc;
+    if ((rc = run_quality(ctx, static_cast<const SWDesc *>(ctx->g_sw_desc.p), (int)sw.size(), wlen, &acc))) return rc;
+    std::memset(out_host, 0, sizeof(tdoa_window_quality) * (size_t)W * S);
+    for (size_t wi = 0; wi < mine.size(); wi++)
+        for (int s = 0; s < S; s++) finalize_quality(acc[wi * S + s], wlen, &out_host[(size_t)mine[wi] * S + s]);
+    return TDOA_OK;
+}
+
+int tdoa_window_quality_u8(tdoa_ctx *ctx, const uint8_t *iq, size_t n_samples, tdoa_window_quality *out)
+{
+    int rc;
+    if ((rc = check_ctx(ctx))) return rc;
+    if (!out || (!iq && n_samples) || n_samples > 0x7fffffff) return fail(ctx, TDOA_ERR_INVALID, "bad argument");
+    if (n_samples == 0) { finalize_quality(QualAcc{}, 0, out); return TDOA_OK; }
+    if ((rc = ensure(ctx, ctx->scratch_a, 2 * n_samples + 16))) return rc;
+    if ((rc = ensure(ctx, ctx->sw_desc, sizeof(SWDesc)))) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->scratch_a.p, iq, 2 * n_samples, hipMemcpyHostToDevice, ctx->stream));
+    const SWDesc d{static_cast<const uint8_t *>(ctx->scratch_a.p), (int32_t)n_samples, 0};
+    HIPCHK(ctx, hipMemcpyAsync(ctx->sw_desc.p, &d, sizeof(d), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // d is a stack object
+    std::vector<QualAcc> acc;
+    if ((rc = run_quality(ctx, static_cast<const SWDesc *>(ctx->sw_desc.p), 1, (long long)n_samples, &acc))) return rc;
+    finalize_quality(acc[0], (long long)n_samples, out);
+    return TDOA_OK;
 }
 
 int tdoa_process_u8(tdoa_ctx *ctx, const uint8_t *const *station_iq, const size_t *n_samples, int n_stations,

@@ -30,6 +30,12 @@ class Peak(C.Structure):
 PEAK_DTYPE = np.dtype([("lag", np.int32), ("abs_corr", np.float32), ("corr", np.float64)])
 
 
+QUALITY_DTYPE = np.dtype([("n_samples", np.int64), ("i_avg", np.float64), ("q_avg", np.float64), ("i_std", np.float64),
+                          ("q_std", np.float64), ("power_level", np.float64), ("mean_power", np.float64),
+                          ("i_min", np.int32), ("i_max", np.int32), ("q_min", np.int32), ("q_max", np.int32),
+                          ("has_clipping", np.int32), ("has_overload", np.int32)])
+
+
 class FinePeak(C.Structure):
     _fields_ = [("delay", C.c_double), ("frac", C.c_float), ("y", C.c_float * 3), ("plausible", C.c_int32),
                 ("reserved", C.c_int32)]
@@ -60,7 +66,7 @@ SYMBOLS = [
     "tdoa_capture_upload", "tdoa_capture_upload_file", "tdoa_capture_attach_device", "tdoa_capture_clear",
     "tdoa_synth_capture", "tdoa_capture_download",
     "tdoa_num_windows", "tdoa_num_pairs", "tdoa_process", "tdoa_process_u8",
-    "tdoa_process_fine", "tdoa_fm_xcorr_fine_u8",
+    "tdoa_process_fine", "tdoa_fm_xcorr_fine_u8", "tdoa_window_quality_all", "tdoa_window_quality_u8",
     "tdoa_fm_xcorr_u8", "tdoa_fm_preprocess_u8", "tdoa_fm_xcorr_lags_u8", "tdoa_debug_force_generic",
     "tdoa_latlon_to_ecef", "tdoa_ecef_to_latlon", "tdoa_solve_3station", "tdoa_solve_nstation",
     "tdoa_profile_enable", "tdoa_profile_reset", "tdoa_profile_get", "tdoa_kernel_name",
@@ -118,6 +124,8 @@ def load(build_if_missing=True):
     L.tdoa_process.argtypes = [vp, C.c_int, C.c_int, vp, vp]
     L.tdoa_process_u8.argtypes = [vp, C.POINTER(u8p), C.POINTER(sz), C.c_int, vp]
     L.tdoa_fm_xcorr_u8.argtypes = [vp, u8p, sz, u8p, sz, C.c_int, C.POINTER(Peak)]
+    L.tdoa_window_quality_all.argtypes = [vp, C.c_int, C.c_int, vp]
+    L.tdoa_window_quality_u8.argtypes = [vp, u8p, sz, vp]
     L.tdoa_process_fine.argtypes = [vp, C.c_int, C.c_int, C.c_double, vp, vp]
     L.tdoa_fm_xcorr_fine_u8.argtypes = [vp, u8p, sz, u8p, sz, C.c_int, C.c_double, C.POINTER(Peak),
                                         C.POINTER(FinePeak)]
@@ -292,6 +300,10 @@ class Context:
     def num_pairs(self):
         return self._L.tdoa_num_pairs(self._h)
 
+    def num_stations(self):
+        p = self.num_pairs()
+        return (1 + int(round((1 + 8 * p) ** 0.5))) // 2
+
     def process(self, rank=0, world=1, out_dev_ptr=None, want_host=True):
         wpb, w = self.num_windows()
         p = self.num_pairs()
@@ -300,6 +312,19 @@ class Context:
                                        out.ctypes.data_as(C.c_void_p) if want_host else None,
                                        C.c_void_p(int(out_dev_ptr)) if out_dev_ptr else None))
         return out
+
+    def window_quality_all(self, rank=0, world=1):
+        """tdoa_window_quality_all -> [W][S] QUALITY_DTYPE"""
+        wpb, w = self.num_windows()
+        out = np.zeros((w, self.num_stations()), dtype=QUALITY_DTYPE)
+        self._chk(self._L.tdoa_window_quality_all(self._h, int(rank), int(world), out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def window_quality(self, iq_u8):
+        s = np.ascontiguousarray(iq_u8, dtype=np.uint8)
+        out = np.zeros(1, dtype=QUALITY_DTYPE)
+        self._chk(self._L.tdoa_window_quality_u8(self._h, _u8(s), s.size // 2, out.ctypes.data_as(C.c_void_p)))
+        return out[0]
 
     def process_fine(self, gate_samples, rank=0, world=1):
         """tdoa_process_fine -> (peaks [W][P], fine [W][P])"""
