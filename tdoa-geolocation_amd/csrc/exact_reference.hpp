@@ -90,53 +90,68 @@ __global__ __launch_bounds__(256) void k_ex_power_final(const double *partials, 
 }
 
 // ---- removeDCBias: the f32 running sum is order-dependent at the 1e-5 level for 2e6
-// samples, so it is reproduced as ONE sequential chain (lane 0 of one wave; the other
-// lanes only help with loads).  ~8 cycles per sample; independent signals run in parallel.
-__global__ __launch_bounds__(64) void k_ex_seq_sum(const float2 *sig, size_t n, float2 *mean_out)
+// samples, so it is reproduced as ONE sequential chain per component: lane 0 adds the real
+// parts, lane 1 the imaginary parts (one v_add_f32 per sample for both), all 64 lanes stage the
+// next 1024 samples through registers into split re/im LDS planes while the chain runs.
+// The chain is latency-bound at one dependent add per sample; LDS reads are batched 32 ahead.
+// Samples beyond n are +0.0: x + (+0.0) is exact and a running sum that starts at +0.0 can
+// never be -0.0, so padding equals stopping.  One wave: program order replaces barriers.
+// blockIdx.x selects one of several independent signals (sig/n/mean_out arrays of descriptors).
+struct SeqSumJob {
+    const float2 *sig;
+    size_t n;
+    float2 *mean_out;
+};
+
+__global__ __launch_bounds__(64) void k_ex_seq_sum(SeqSumJob j0, SeqSumJob j1)
 {
 #pragma clang fp contract(off)
-    __shared__ float2 buf[1024];
+    __shared__ float plane[2][2][1024];          // [buffer][re | im][sample]
+    const SeqSumJob job = blockIdx.x ? j1 : j0;
+    const float2 *sig = job.sig;
+    const size_t n = job.n;
     const int lane = threadIdx.x;
-    float sr = 0.0f, si = 0.0f;
+    float acc = 0.0f;
     const size_t nchunks = (n + 1023) / 1024;
     float2 regs[16];
-    // chunk c+1 is fetched into registers while lane 0 walks chunk c in LDS
 #pragma unroll
     for (int q = 0; q < 16; q++) {
-        size_t idx = (size_t)q * 64 + lane;
+        const size_t idx = (size_t)q * 64 + lane;
         regs[q] = idx < n ? sig[idx] : make_float2(0.0f, 0.0f);
     }
     for (size_t c = 0; c < nchunks; c++) {
+        const int b = (int)(c & 1);
 #pragma unroll
-        for (int q = 0; q < 16; q++) buf[q * 64 + lane] = regs[q];
-        __syncthreads();
+        for (int q = 0; q < 16; q++) {
+            plane[b][0][q * 64 + lane] = regs[q].x;
+            plane[b][1][q * 64 + lane] = regs[q].y;
+        }
         if (c + 1 < nchunks) {
 #pragma unroll
             for (int q = 0; q < 16; q++) {
-                size_t idx = (c + 1) * 1024 + (size_t)q * 64 + lane;
+                const size_t idx = (c + 1) * 1024 + (size_t)q * 64 + lane;
                 regs[q] = idx < n ? sig[idx] : make_float2(0.0f, 0.0f);
             }
         }
-        if (lane == 0) {
-            size_t base = c * 1024;
-            int m = (int)((n - base) < 1024 ? (n - base) : 1024);
-            const float4 *b4 = reinterpret_cast<const float4 *>(buf);
-            int k = 0;
-            for (; k + 1 < m; k += 2) {
-                float4 v = b4[k >> 1];
-                sr = sr + v.x;
-                si = si + v.y;
-                sr = sr + v.z;
-                si = si + v.w;
-            }
-            if (k < m) {
-                sr = sr + buf[k].x;
-                si = si + buf[k].y;
+        __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): the plane writes above have landed
+        if (lane < 2) {
+            const float4 *p4 = reinterpret_cast<const float4 *>(plane[b][lane]);
+            for (int k = 0; k < 256; k += 8) {   // 32 samples per trip: 8 LDS reads issued together
+                float4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) v[u] = p4[k + u];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    acc = acc + v[u].x;
+                    acc = acc + v[u].y;
+                    acc = acc + v[u].z;
+                    acc = acc + v[u].w;
+                }
             }
         }
-        __syncthreads();
     }
-    if (lane == 0) *mean_out = n ? go_div_real(make_float2(sr, si), (float)n) : make_float2(0.0f, 0.0f);
+    const float sr = __shfl(acc, 0, kWave), si = __shfl(acc, 1, kWave);
+    if (lane == 0) *job.mean_out = n ? go_div_real(make_float2(sr, si), (float)n) : make_float2(0.0f, 0.0f);
 }
 
 __global__ void k_ex_sub_const(const float2 *in, size_t n, const float2 *c, float2 *out)
