@@ -136,10 +136,13 @@ int tdoa_fast_analyze_capture_u8(tdoa_ctx *ctx, const uint8_t *raw, size_t n_byt
  * frequency, blocks 0 and 2 the reference frequency (processor.go:211-233).
  * Pairs are ordered i<j as in processor.go:816-850.                          */
 
-/* copy one station's capture into HBM (ctx-owned) */
+/* copy one station's capture into HBM (ctx-owned).  A few host threads stage the bytes through pinned
+ * buffers onto their own copy streams (about 40 GB/s from pageable memory against 15 GB/s for one
+ * hipMemcpy); a station's previous buffer is reused when the new capture fits, so repeated
+ * uploads of equal-sized captures keep their device addresses (TDOA_UPLOAD_THREADS overrides 4). */
 int tdoa_capture_upload(tdoa_ctx *ctx, int station, const uint8_t *iq, size_t n_samples);
-/* stream a .dat file (collector.go:61 naming, raw u8 I,Q; any size, > 1 GiB safe) into HBM through two
- * pinned staging buffers so that the read of chunk i+1 overlaps the DMA of chunk i;
+/* the same from a .dat file (collector.go:61 naming, raw u8 I,Q; any size, > 1 GiB safe): the threads
+ * pread their chunks straight into the pinned buffers;
  * *n_samples (may be NULL) receives size/2 like processor.go:182 */
 int tdoa_capture_upload_file(tdoa_ctx *ctx, int station, const char *path, size_t *n_samples);
 /* or attach a buffer that is already in this device's memory (not copied, not freed) */

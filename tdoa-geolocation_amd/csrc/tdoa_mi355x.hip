@@ -24,6 +24,7 @@
 #include "synth_capture.hpp"
 #include "window_quality.hpp"
 #include "host_geodesy.hpp"
+#include "host_upload.hpp"
 
 using namespace tdoa;
 
@@ -52,6 +53,7 @@ struct tdoa_ctx {
         const uint8_t *dev = nullptr;
         size_t n = 0;
         bool owned = false;
+        size_t cap_bytes = 0;               // size of an owned allocation (reused by the next upload if it fits)
     };
     std::vector<Capture> caps;
 
@@ -78,6 +80,7 @@ struct tdoa_ctx {
     hipGraphExec_t graph_exec = nullptr;
     DevBuf g_sw_desc, g_pw_desc, g_scales, g_keys;
     DevBuf qual;                            // QualAcc per (window, station)
+    StagedUploader uploader;                // pinned staging buffers + copy streams, created on first use
     DevBuf fine_raw, fine;                  // (f)-4 refinement: 3 raw neighbours and tdoa_fine_peak per slot
 };
 
@@ -606,26 +609,62 @@ void tdoa_destroy(tdoa_ctx *ctx)
 // mode B
 // ===========================================================================
 
+// device buffer of `bytes` for a station's capture: the station's previous owned buffer when it is large enough
+// (re-uploading captures of the same size keeps the pointers, hence the captured graph), else a new allocation
+static int capture_buffer(tdoa_ctx *ctx, int station, size_t bytes, uint8_t **out)
+{
+    if ((size_t)station >= ctx->caps.size()) ctx->caps.resize(station + 1);
+    auto &c = ctx->caps[station];
+    if (c.owned && c.dev && c.cap_bytes >= bytes) {
+        *out = const_cast<uint8_t *>(c.dev);
+        return TDOA_OK;
+    }
+    if (c.owned && c.dev) (void)hipFree(const_cast<uint8_t *>(c.dev));
+    c = tdoa_ctx::Capture{};
+    void *d = nullptr;
+    const hipError_t e = hipMalloc(&d, bytes + 64);
+    if (e != hipSuccess) return fail(ctx, TDOA_ERR_NOMEM, "hipMalloc capture", e);
+    c.dev = static_cast<const uint8_t *>(d);
+    c.owned = true;
+    c.cap_bytes = bytes;
+    c.n = 0;
+    *out = static_cast<uint8_t *>(d);
+    return TDOA_OK;
+}
+
+// host memory (src) or file (fd, from offset 0) -> device, through the context's staged uploader
+static int staged_upload(tdoa_ctx *ctx, uint8_t *dst, const uint8_t *src, int fd, size_t bytes)
+{
+    if (bytes == 0) return TDOA_OK;
+    if (bytes < (1u << 20) && src) {   // small: one plain copy beats waking threads
+        HIPCHK(ctx, hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+        return TDOA_OK;
+    }
+    int n_threads = 4;   // measured: 2-4 copy threads reach ~40 GB/s on the bench node, 12 fall back to 25
+    if (const char *e = std::getenv("TDOA_UPLOAD_THREADS")) n_threads = std::atoi(e);
+    if (!ctx->uploader.init(ctx->device, n_threads)) {
+        (void)hipGetLastError();
+        return fail(ctx, TDOA_ERR_HIP, "staging buffers for the uploader");
+    }
+    const int st = ctx->uploader.run(dst, src, fd, bytes);
+    if (st == 2) return fail(ctx, TDOA_ERR_INVALID, "failed to read data");
+    if (st) {
+        (void)hipGetLastError();
+        return fail(ctx, TDOA_ERR_HIP, "host to device copy failed");
+    }
+    return TDOA_OK;
+}
+
 int tdoa_capture_upload(tdoa_ctx *ctx, int station, const uint8_t *iq, size_t n_samples)
 {
     int rc;
     if ((rc = check_ctx(ctx))) return rc;
     if (station < 0 || station > 1023 || (!iq && n_samples)) return fail(ctx, TDOA_ERR_INVALID, "bad station/iq");
-    if ((size_t)station >= ctx->caps.size()) ctx->caps.resize(station + 1);
-    auto &c = ctx->caps[station];
-    if (c.owned && c.dev) (void)hipFree(const_cast<uint8_t *>(c.dev));
-    c = tdoa_ctx::Capture{};
-    void *d = nullptr;
-    hipError_t e = hipMalloc(&d, 2 * n_samples + 64);
-    if (e != hipSuccess) return fail(ctx, TDOA_ERR_NOMEM, "hipMalloc capture", e);
-    e = hipMemcpy(d, iq, 2 * n_samples, hipMemcpyHostToDevice);
-    if (e != hipSuccess) {
-        (void)hipFree(d);
-        return fail(ctx, TDOA_ERR_HIP, "hipMemcpy capture", e);
-    }
-    c.dev = static_cast<const uint8_t *>(d);
-    c.n = n_samples;
-    c.owned = true;
+    uint8_t *d = nullptr;
+    if ((rc = capture_buffer(ctx, station, 2 * n_samples, &d))) return rc;
+    ctx->caps[station].n = 0;                                  // not valid until the copy has finished
+    if ((rc = staged_upload(ctx, d, iq, -1, 2 * n_samples))) return rc;
+    ctx->caps[station].n = n_samples;
     return TDOA_OK;
 }
 
@@ -641,47 +680,13 @@ int tdoa_capture_upload_file(tdoa_ctx *ctx, int station, const char *path, size_
     std::fseek(f, 0, SEEK_SET);
     if (size < 0) { std::fclose(f); return fail(ctx, TDOA_ERR_INVALID, "failed to get file size"); }
     const size_t n = (size_t)size / 2;                       // processor.go:182
-    if ((size_t)station >= ctx->caps.size()) ctx->caps.resize(station + 1);
-    auto &c = ctx->caps[station];
-    if (c.owned && c.dev) (void)hipFree(const_cast<uint8_t *>(c.dev));
-    c = tdoa_ctx::Capture{};
-    void *d = nullptr;
-    hipError_t e = hipMalloc(&d, 2 * n + 64);
-    if (e != hipSuccess) { std::fclose(f); return fail(ctx, TDOA_ERR_NOMEM, "hipMalloc capture", e); }
-    const size_t chunk = 32u << 20;                          // 2 x 32 MiB pinned staging
-    void *stage[2] = {nullptr, nullptr};
-    hipEvent_t done[2] = {nullptr, nullptr};
-    bool ok = true;
-    for (int k = 0; k < 2 && ok; k++)
-        ok = hipHostMalloc(&stage[k], chunk, hipHostMallocDefault) == hipSuccess && hipEventCreate(&done[k]) == hipSuccess;
-    size_t off = 0;
-    int k = 0;
-    bool used[2] = {false, false};
-    while (ok && off < 2 * n) {
-        if (used[k]) ok = hipEventSynchronize(done[k]) == hipSuccess;          // staging buffer k is free again
-        const size_t want = std::min(chunk, 2 * n - off);
-        const size_t got = ok ? std::fread(stage[k], 1, want, f) : 0;
-        if (got != want) { ok = false; break; }
-        ok = hipMemcpyAsync(static_cast<uint8_t *>(d) + off, stage[k], got, hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
-             hipEventRecord(done[k], ctx->stream) == hipSuccess;
-        used[k] = true;
-        off += got;
-        k ^= 1;
-    }
-    if (ok) ok = hipStreamSynchronize(ctx->stream) == hipSuccess;
+    uint8_t *d = nullptr;
+    if ((rc = capture_buffer(ctx, station, 2 * n, &d))) { std::fclose(f); return rc; }
+    ctx->caps[station].n = 0;
+    rc = staged_upload(ctx, d, nullptr, fileno(f), 2 * n);
     std::fclose(f);
-    for (int q = 0; q < 2; q++) {
-        if (stage[q]) (void)hipHostFree(stage[q]);
-        if (done[q]) (void)hipEventDestroy(done[q]);
-    }
-    if (!ok) {
-        (void)hipGetLastError();
-        (void)hipFree(d);
-        return fail(ctx, TDOA_ERR_HIP, "failed to read or upload file");
-    }
-    c.dev = static_cast<const uint8_t *>(d);
-    c.n = n;
-    c.owned = true;
+    if (rc) return rc;
+    ctx->caps[station].n = n;
     if (n_samples) *n_samples = n;
     return TDOA_OK;
 }
@@ -697,6 +702,7 @@ int tdoa_capture_attach_device(tdoa_ctx *ctx, int station, const void *dev_iq, s
     c.dev = static_cast<const uint8_t *>(dev_iq);
     c.n = n_samples;
     c.owned = false;
+    c.cap_bytes = 0;
     return TDOA_OK;
 }
 
@@ -708,13 +714,9 @@ int tdoa_synth_capture(tdoa_ctx *ctx, int station, size_t block_samples, double 
     if ((rc = check_ctx(ctx))) return rc;
     if (station < 0 || station > 1023 || block_samples < 2 || !station_lle || !tx_lle)
         return fail(ctx, TDOA_ERR_INVALID, "bad argument");
-    if ((size_t)station >= ctx->caps.size()) ctx->caps.resize(station + 1);
-    auto &c = ctx->caps[station];
-    if (c.owned && c.dev) (void)hipFree(const_cast<uint8_t *>(c.dev));
-    c = tdoa_ctx::Capture{};
-    void *d = nullptr;
-    hipError_t e = hipMalloc(&d, 6 * block_samples + 64);
-    if (e != hipSuccess) return fail(ctx, TDOA_ERR_NOMEM, "hipMalloc capture", e);
+    uint8_t *d = nullptr;
+    if ((rc = capture_buffer(ctx, station, 6 * block_samples, &d))) return rc;
+    ctx->caps[station].n = 0;
     // simulator.go:104-120: distance -> travel time -> carrier phase; amplitude power/d*0.1
     double a[3], b[3];
     geo::latlon_to_ecef(station_lle[0], station_lle[1], station_lle[2], a);
@@ -732,15 +734,9 @@ int tdoa_synth_capture(tdoa_ctx *ctx, int station, size_t block_samples, double 
     const long long n = (long long)block_samples;
     for (int k = 0; k < 3; k++)
         hipLaunchKernelGGL(k_synth_tone_block, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
-                           static_cast<uint8_t *>(d) + 2 * n * k, n, blk[k]);
-    e = hipStreamSynchronize(ctx->stream);
-    if (e != hipSuccess) {
-        (void)hipFree(d);
-        return fail(ctx, TDOA_ERR_HIP, "synth kernels", e);
-    }
-    c.dev = static_cast<const uint8_t *>(d);
-    c.n = 3 * block_samples;
-    c.owned = true;
+                           d + 2 * n * k, n, blk[k]);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->caps[station].n = 3 * block_samples;
     return TDOA_OK;
 }
 
@@ -1050,7 +1046,8 @@ int tdoa_process_u8(tdoa_ctx *ctx, const uint8_t *const *station_iq, const size_
                     tdoa_peak *out)
 {
     if (!ctx || !station_iq || !n_samples || n_stations < 2 || !out) return fail(ctx, TDOA_ERR_INVALID, "bad argument");
-    int rc = tdoa_capture_clear(ctx);
+    int rc = TDOA_OK;
+    if ((int)ctx->caps.size() != n_stations) rc = tdoa_capture_clear(ctx);   // else the uploads reuse the buffers
     for (int s = 0; s < n_stations && !rc; s++) rc = tdoa_capture_upload(ctx, s, station_iq[s], n_samples[s]);
     if (rc) return rc;
     return tdoa_process(ctx, 0, 1, out, nullptr);

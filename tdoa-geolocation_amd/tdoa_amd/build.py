@@ -37,7 +37,7 @@ def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wall", "-Wno-unused-function", "-Xarch_host", "-ffp-contract=off",
+           "-Wall", "-Wno-unused-function", "-pthread", "-Xarch_host", "-ffp-contract=off",
            "-o", LIB, os.path.join(CSRC, "tdoa_mi355x.hip")]
     if verbose:
         print(" ".join(cmd))
