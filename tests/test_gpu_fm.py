@@ -221,7 +221,7 @@ def test_eight_stations_28_pairs(oracle):
 def test_capture_upload_file_roundtrip(tmp_path, oracle):
     import tdoa_amd
     rng = np.random.default_rng(21)
-    raw = rng.integers(0, 256, size=2 * (40 * 1024 * 1024 // 2) + 6, dtype=np.uint8)    # > one 32 MiB staging chunk
+    raw = rng.integers(0, 256, size=2 * (40 * 1024 * 1024 // 2) + 6, dtype=np.uint8)    # several 8 MiB staging chunks + a ragged tail
     path = tmp_path / "kx0u-1754900000.dat"
     raw.tofile(path)
     with tdoa_amd.Context() as c:
@@ -231,6 +231,18 @@ def test_capture_upload_file_roundtrip(tmp_path, oracle):
             assert np.array_equal(c.capture_download(0, first, cnt), raw[2 * first:2 * (first + cnt)])
         with pytest.raises(tdoa_amd.TdoaError):
             c.capture_upload_file(1, str(tmp_path / "missing.dat"))
+        # whole capture, every 8 MiB staging chunk of every copy thread
+        assert np.array_equal(c.capture_download(0, 0, n), raw[:2 * n])
+        # host-memory path through the same uploader; then a shorter capture into the same (reused) buffer
+        c.capture_upload(1, raw)
+        assert np.array_equal(c.capture_download(1, 0, n), raw[:2 * n])
+        short = raw[5_000_000:5_000_000 + 2 * 3_000_001]
+        c.capture_upload(1, short)
+        assert np.array_equal(c.capture_download(1, 0, 3_000_001), short)
+        with pytest.raises(tdoa_amd.TdoaError):
+            c.capture_download(1, 3_000_001, 1)               # beyond the new, shorter capture
+        c.capture_upload(1, raw[:2 * 100])                    # small copies take the plain path
+        assert np.array_equal(c.capture_download(1, 0, 100), raw[:200])
 
 
 def test_attach_device_buffer_from_torch(oracle):
