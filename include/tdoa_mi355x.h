@@ -129,9 +129,11 @@ int tdoa_fast_analyze_capture_u8(tdoa_ctx *ctx, const uint8_t *raw, size_t n_byt
  * u8 IQ -> FM discriminator -> Stockham FFT -> conj-multiply -> inverse FFT
  * -> argmax, batched over (station, window) and (pair, window).
  *
- * A capture is 3 blocks of n = floor(total/3) samples.  Windows of
- * window_len samples tile each block: windows_per_block = max(1, n /
- * window_len) (a block shorter than window_len is one window of n samples).
+ * A capture is 3 blocks of n = floor(total/3) samples (each capture its own
+ * n, as processor.go:214 does per file).  Windows of window_len samples tile
+ * each block from its start; the window grid comes from the shortest capture:
+ * windows_per_block = max(1, n_min / window_len) (a block shorter than
+ * window_len is one window of n_min samples).
  * Window id wid = block * windows_per_block + w; block 1 is the target
  * frequency, blocks 0 and 2 the reference frequency (processor.go:211-233).
  * Pairs are ordered i<j as in processor.go:816-850.                          */

@@ -769,7 +769,9 @@ static int window_geometry(const tdoa_ctx *ctx, long long *block, long long *wle
         if (!c.dev) return TDOA_ERR_STATE;
         nmin = std::min(nmin, c.n);
     }
-    long long b = (long long)(nmin / 3);   // processor.go:214
+    // every capture is cut into its OWN thirds (processor.go:214 takes len(signal)/3 per file); the window grid
+    // comes from the shortest one, so captures of unequal length still pair block k window w with block k window w
+    long long b = (long long)(nmin / 3);
     if (b < 2) return TDOA_ERR_UNSUPPORTED;
     long long l = std::min<long long>(ctx->prm.window_len, b);
     *block = b;
@@ -837,9 +839,11 @@ static int process_impl(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host,
     std::vector<PWDesc> pw(mine.size() * (size_t)P);
     for (size_t wi = 0; wi < mine.size(); wi++) {
         int wid = mine[wi];
-        long long off = (long long)(wid / wpb) * block + (long long)(wid % wpb) * wlen;
         int local = (int)(wi % per_batch);
-        for (int s = 0; s < S; s++) sw[wi * S + s] = SWDesc{ctx->caps[s].dev + 2 * off, (int32_t)wlen, 0};
+        for (int s = 0; s < S; s++) {
+            const long long off = (long long)(wid / wpb) * (long long)(ctx->caps[s].n / 3) + (long long)(wid % wpb) * wlen;
+            sw[wi * S + s] = SWDesc{ctx->caps[s].dev + 2 * off, (int32_t)wlen, 0};
+        }
         int p = 0;
         for (int i = 0; i < S; i++)
             for (int j = i + 1; j < S; j++, p++)
@@ -1009,8 +1013,10 @@ int tdoa_window_quality_all(tdoa_ctx *ctx, int rank, int world, tdoa_window_qual
     std::vector<SWDesc> sw(mine.size() * (size_t)S);
     for (size_t wi = 0; wi < mine.size(); wi++) {
         const int wid = mine[wi];
-        const long long off = (long long)(wid / wpb) * block + (long long)(wid % wpb) * wlen;
-        for (int s = 0; s < S; s++) sw[wi * S + s] = SWDesc{ctx->caps[s].dev + 2 * off, (int32_t)wlen, 0};
+        for (int s = 0; s < S; s++) {
+            const long long off = (long long)(wid / wpb) * (long long)(ctx->caps[s].n / 3) + (long long)(wid % wpb) * wlen;
+            sw[wi * S + s] = SWDesc{ctx->caps[s].dev + 2 * off, (int32_t)wlen, 0};
+        }
     }
     if ((rc = ensure(ctx, ctx->g_sw_desc, sizeof(SWDesc) * std::max<size_t>(sw.size(), 1)))) return rc;
     ctx->graph_key.clear();     // the descriptor buffer of a captured tdoa_process graph is being rewritten

@@ -1,0 +1,116 @@
+"""Edge cases and error behaviour of the batched path at the C ABI: call order, ragged captures,
+tiny captures, lag ranges longer than the window, argument checks.  Status codes instead of
+aborts (the reference log.Fatalf's, processor.go:1067-1075; a library must not)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-5
+ERR_INVALID, ERR_UNSUPPORTED, ERR_STATE = 1, 5, 6
+
+
+def test_call_order_and_argument_errors(oracle):
+    import tdoa_amd
+    with tdoa_amd.Context(max_lag=50, window_len=1000) as c:
+        with pytest.raises(tdoa_amd.TdoaError) as e:
+            c.process()                                              # nothing uploaded
+        assert e.value.status == ERR_STATE
+        cap = oracle.simulate_delayed_fm(3000, 0, 1, 1)
+        c.capture_upload(0, cap)
+        with pytest.raises(tdoa_amd.TdoaError) as e:
+            c.process()                                              # one station: no pair
+        assert e.value.status == ERR_STATE
+        c.capture_upload(2, cap)                                     # station 1 left empty
+        with pytest.raises(tdoa_amd.TdoaError) as e:
+            c.process()
+        assert e.value.status == ERR_STATE
+        c.capture_upload(1, cap)
+        assert c.process().shape == (3, 3)                           # blocks of 1000 samples = one window each
+        for rank, world in ((0, 0), (2, 2), (-1, 1)):
+            with pytest.raises(tdoa_amd.TdoaError) as e:
+                c.process(rank=rank, world=world)
+            assert e.value.status == ERR_INVALID
+        with pytest.raises(tdoa_amd.TdoaError) as e:
+            c.capture_upload(5000, cap)                              # station index out of range
+        assert e.value.status == ERR_INVALID
+        c.capture_clear()
+        c.capture_upload(0, cap[:2 * 5])                             # 5 samples: blocks of 1 sample
+        c.capture_upload(1, cap[:2 * 5])
+        with pytest.raises(tdoa_amd.TdoaError) as e:
+            c.process()
+        assert e.value.status == ERR_UNSUPPORTED
+    L = tdoa_amd.capi.load()
+    assert L.tdoa_strerror(ERR_STATE) and L.tdoa_strerror(12345)      # every code has a message
+    prm = tdoa_amd.capi.Params()
+    L.tdoa_default_params(C.byref(prm))
+    prm.max_lag = 0
+    h = C.c_void_p()
+    assert L.tdoa_create(C.byref(prm), C.byref(h)) == ERR_INVALID and not h.value
+
+
+def test_ragged_captures_use_their_own_thirds(oracle):
+    """processor.go:214 cuts every file into its own thirds; the window grid comes from the shortest capture."""
+    import tdoa_amd
+    wl, ml = 4000, 100
+    lens = [12000, 13500, 12600]                                      # blocks of 4000, 4500, 4200 samples
+    delays = [0, 13, 31]
+    caps = []
+    for s, (n, d) in enumerate(zip(lens, delays)):
+        b = n // 3
+        caps.append(np.concatenate([oracle.simulate_delayed_fm(b, d, 70 + k, 10 * s + k) for k in range(3)]
+                                   + [np.zeros(2 * (n - 3 * b), np.uint8)]))
+    with tdoa_amd.Context(max_lag=ml, window_len=wl) as c:
+        peaks = c.process_u8(caps)
+        assert peaks.shape == (3, 3)                                 # one window per block
+        pairs = [(0, 1), (0, 2), (1, 2)]
+        for k in range(3):
+            pre = [oracle.b_preprocess(cp[2 * k * (n // 3):2 * (k * (n // 3) + wl)])[0] for cp, n in zip(caps, lens)]
+            for p, (i, j) in enumerate(pairs):
+                olag, ocorr = oracle.b_xcorr_peak(pre[i], pre[j], ml)
+                assert peaks[k, p]["lag"] == olag == delays[j] - delays[i]
+                assert abs(peaks[k, p]["corr"] - ocorr) <= REL_TOL * abs(ocorr)
+        q = c.window_quality_all()
+        for k in range(3):
+            for s, (cp, n) in enumerate(zip(caps, lens)):
+                w = cp[2 * k * (n // 3):2 * (k * (n // 3) + wl)]
+                assert q[k, s]["i_avg"] == w[0::2].astype(np.float64).sum() / wl
+
+
+def test_block_shorter_than_window_and_lag_longer_than_window(oracle):
+    import tdoa_amd
+    n = 900                                                          # blocks of 300 samples < window_len
+    a = oracle.simulate_delayed_fm(n, 0, 5, 1)
+    b = oracle.simulate_delayed_fm(n, 4, 5, 2)
+    with tdoa_amd.Context(max_lag=1000, window_len=2_000_000) as c:  # lags far beyond the 300-sample windows
+        peaks = c.process_u8([a, b])
+        assert peaks.shape == (3, 1)
+        for k in range(3):
+            ta, _ = oracle.b_preprocess(a[600 * k:600 * (k + 1)])
+            tb, _ = oracle.b_preprocess(b[600 * k:600 * (k + 1)])
+            olag, ocorr = oracle.b_xcorr_peak(ta, tb, 1000)
+            assert peaks[k, 0]["lag"] == olag
+            assert abs(peaks[k, 0]["corr"] - ocorr) <= REL_TOL * abs(ocorr)
+        lags = c.fm_xcorr_lags(a[:600], b[:600], 1000)
+        want = oracle.b_xcorr_all_lags(*[oracle.b_preprocess(x[:600])[0] for x in (a, b)], 1000)
+        assert np.abs(lags - want).max() <= REL_TOL * np.abs(want).max()
+        assert not want[:1000 - 300].any() and not want[1000 + 300:].any()    # no overlap beyond +-299 samples
+        assert np.abs(lags[:700]).max() <= REL_TOL * np.abs(want).max()        # FFT rounding noise only
+
+
+def test_two_sample_blocks(oracle):
+    """the smallest capture the path accepts: blocks of 2 samples"""
+    import tdoa_amd
+    a = np.array([10, 200, 250, 3, 128, 127, 90, 91, 7, 255, 0, 64], np.uint8)
+    b = a[::-1].copy()
+    with tdoa_amd.Context(max_lag=4, window_len=1000) as c:
+        peaks = c.process_u8([a, b])
+        assert peaks.shape == (3, 1)
+        for k in range(3):
+            ta, _ = oracle.b_preprocess(a[4 * k:4 * k + 4])
+            tb, _ = oracle.b_preprocess(b[4 * k:4 * k + 4])
+            olag, ocorr = oracle.b_xcorr_peak(ta, tb, 4)
+            assert peaks[k, 0]["lag"] == olag
+            assert abs(peaks[k, 0]["corr"] - ocorr) <= REL_TOL * max(abs(ocorr), 1e-30)
