@@ -255,6 +255,7 @@ int main(int argc, char **argv)
                         if (fk.plausible) ok.push_back(fk.delay);
                     }
                     lag_used = median(ok.empty() ? all : ok);
+                    if (ok.empty()) ct.clear();                    // no plausible window: the pair gets weight 0 in the N-station solve
                     std::printf("TGT %s - %s: refined delay=%.3f samples, %zu of %zu windows within +-%.1f samples\n",
                                 caps[i].st.name.c_str(), caps[j].st.name.c_str(), lag_used, ok.size(), all.size(), gate);
                 }
@@ -275,7 +276,7 @@ int main(int argc, char **argv)
     double out[3];
     int iters = 0;
     if (S == 3) rc = tdoa_solve_3station(lle.data(), rd.data(), out, &iters);
-    else rc = tdoa_solve_nstation(lle.data(), S, rd.data(), nullptr, 0, out, &iters);
+    else rc = tdoa_solve_nstation(lle.data(), S, rd.data(), tgt_w.data(), 0, out, &iters);   // weights: median |corr| per pair
     if (rc != TDOA_OK) {                                       // processor.go:919-921
         std::fprintf(stderr, "TDOA solution failed: %s at iteration %d\n", tdoa_strerror(rc), iters);
         tdoa_destroy(ctx);
