@@ -161,7 +161,8 @@ int tdoa_capture_download(tdoa_ctx *ctx, int station, size_t first_sample, size_
 int tdoa_num_windows(const tdoa_ctx *ctx, int *windows_per_block, int *n_windows_total);
 int tdoa_num_pairs(const tdoa_ctx *ctx);
 
-/* Correlate every pair on every window wid with wid % world == rank.
+/* Correlate every pair on every window wid with wid % world == rank (with fewer windows than
+ * ranks: every unit u = wid * n_pairs + pair with u % world == rank, so no rank idles).
  * out_host (may be NULL): [n_windows_total][n_pairs] tdoa_peak, entries of
  *   windows owned by other ranks are zero-filled;
  * out_dev (may be NULL): same array in device memory (for an RCCL all-gather

@@ -826,28 +826,46 @@ static int process_impl(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host,
     ctx->plan = pl;
     ctx->plan_n = n;
 
+    // Sharding: window-major -- rank r owns the windows wid = r (mod world), so a station-window
+    // is transformed once and reused by all its pairs.  With fewer windows than ranks that would leave ranks idle:
+    // then the (window, pair) units u = wid*P + p are dealt u = r (mod world) and a rank transforms only the
+    // stations its pairs need (station spectra are duplicated across ranks).
+    const bool pair_major = W < world;
+    auto owns = [&](int wid, int p) { return pair_major ? ((wid * P + p) % world) == rank : (wid % world) == rank; };
     std::vector<int> mine;
-    for (int w = rank; w < W; w += world) mine.push_back(w);
+    for (int w = 0; w < W; w++) {
+        bool any = false;
+        for (int p = 0; p < P && !any; p++) any = owns(w, p);
+        if (any) mine.push_back(w);
+    }
     // default: every window of this rank in one launch group (launch tails cost more than cache
     // residency gains), bounded by ~24 GiB of workspace
     int per_batch = ctx->prm.windows_per_batch > 0 ? ctx->prm.windows_per_batch : (int)std::max<size_t>(mine.size(), 1);
     const double bytes_per_window = 8.0 * (double)pl.Nc * (S + P) + 2.0 * (double)(wlen + 16) * S;
     per_batch = (int)std::max(1.0, std::min<double>(per_batch, 24.0 * 1073741824.0 / bytes_per_window));
 
-    // all descriptors, uploaded once
-    std::vector<SWDesc> sw(mine.size() * (size_t)S);
-    std::vector<PWDesc> pw(mine.size() * (size_t)P);
+    // all descriptors, uploaded once; window wi of this rank owns sw[sw_off[wi] .. sw_off[wi+1]) and likewise pw
+    std::vector<SWDesc> sw;
+    std::vector<PWDesc> pw;
+    std::vector<size_t> sw_off(mine.size() + 1, 0), pw_off(mine.size() + 1, 0);
     for (size_t wi = 0; wi < mine.size(); wi++) {
-        int wid = mine[wi];
-        int local = (int)(wi % per_batch);
-        for (int s = 0; s < S; s++) {
-            const long long off = (long long)(wid / wpb) * (long long)(ctx->caps[s].n / 3) + (long long)(wid % wpb) * wlen;
-            sw[wi * S + s] = SWDesc{ctx->caps[s].dev + 2 * off, (int32_t)wlen, 0};
-        }
+        const int wid = mine[wi];
+        const size_t batch_base = sw_off[wi - (wi % (size_t)per_batch)];   // PWDesc indices are relative to the batch
+        std::vector<int> slot(S, -1);
         int p = 0;
         for (int i = 0; i < S; i++)
-            for (int j = i + 1; j < S; j++, p++)
-                pw[wi * P + p] = PWDesc{local * S + i, local * S + j, wid * P + p, (int32_t)wlen};
+            for (int j = i + 1; j < S; j++, p++) {
+                if (!owns(wid, p)) continue;
+                for (int s : {i, j})
+                    if (slot[s] < 0) {
+                        const long long off = (long long)(wid / wpb) * (long long)(ctx->caps[s].n / 3) + (long long)(wid % wpb) * wlen;
+                        slot[s] = (int)(sw.size() - batch_base);
+                        sw.push_back(SWDesc{ctx->caps[s].dev + 2 * off, (int32_t)wlen, 0});
+                    }
+                pw.push_back(PWDesc{slot[i], slot[j], wid * P + p, (int32_t)wlen});
+            }
+        sw_off[wi + 1] = sw.size();
+        pw_off[wi + 1] = pw.size();
     }
     const size_t slots = (size_t)W * P;
     hipStream_t st = ctx->stream;
@@ -896,9 +914,10 @@ static int process_impl(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host,
         float *fine_raw = fine_host ? static_cast<float *>(ctx->fine_raw.p) : nullptr;
         for (size_t w0 = 0; w0 < mine.size(); w0 += per_batch) {
             const int nw = (int)std::min<size_t>(per_batch, mine.size() - w0);
-            const int r = run_fm_batch(ctx, d_sw + w0 * S, nw * S, (int)wlen, d_pw + w0 * P, nw * P, d_keys, pl,
+            const int n_sw = (int)(sw_off[w0 + nw] - sw_off[w0]), n_pw = (int)(pw_off[w0 + nw] - pw_off[w0]);
+            const int r = run_fm_batch(ctx, d_sw + sw_off[w0], n_sw, (int)wlen, d_pw + pw_off[w0], n_pw, d_keys, pl,
                                        -(ctx->prm.max_lag - 1), ctx->prm.max_lag - 1, nullptr, 1.0f,
-                                       (double)wlen * nw * S, fine_raw);
+                                       (double)wlen * n_sw, fine_raw);
             if (r) return r;
         }
         if (fine_raw)

@@ -21,6 +21,15 @@ def owner_of(wid, world):
     return wid % world
 
 
+def unit_owner(wid, pair, world, n_windows, n_pairs):
+    """Rank that computes pair `pair` of window `wid` in tdoa_process(rank, world): window-major, or -- with fewer
+    windows than ranks -- (window, pair) units dealt round-robin (SURVEY section 8e fallback; a rank then transforms
+    only the stations its pairs need)."""
+    if n_windows < world:
+        return (wid * n_pairs + pair) % world
+    return wid % world
+
+
 def peaks_as_bytes(peaks):
     """structured peak array -> flat uint8 view (what travels through the collective)."""
     a = np.ascontiguousarray(peaks, dtype=PEAK_DTYPE)
@@ -47,13 +56,13 @@ def all_gather_peaks(local_bytes, dist, group=None):
 
 
 def merge_sharded(gathered, n_windows, n_pairs):
-    """gathered[r] = rank r's [n_windows][n_pairs] peaks with other ranks' windows zero-filled
-    (tdoa_process(rank, world)); returns the complete array, each window taken from its owner."""
+    """gathered[r] = rank r's [n_windows][n_pairs] peaks with other ranks' units zero-filled
+    (tdoa_process(rank, world)); returns the complete array, each unit taken from its owner."""
     world = gathered.shape[0]
     out = np.zeros((n_windows, n_pairs), dtype=PEAK_DTYPE)
-    for r in range(world):
-        part = bytes_as_peaks(np.asarray(gathered[r].cpu() if hasattr(gathered[r], "cpu") else gathered[r]),
-                              n_windows, n_pairs)
-        own = owned_windows(r, world, n_windows)
-        out[own] = part[own]
+    parts = [bytes_as_peaks(np.asarray(gathered[r].cpu() if hasattr(gathered[r], "cpu") else gathered[r]),
+                            n_windows, n_pairs) for r in range(world)]
+    for wid in range(n_windows):
+        for p in range(n_pairs):
+            out[wid, p] = parts[unit_owner(wid, p, world, n_windows, n_pairs)][wid, p]
     return out

@@ -111,3 +111,17 @@ def test_nstation_solver_reduces_to_reference_and_uses_all_pairs(capi, oracle):
     rc, lle, it = capi.solve_nstation(ring, rd, solve_z=False)
     assert rc == 0 and abs(lle[0] - tx[0]) < 2e-3 and abs(lle[1] - tx[1]) < 2e-3
     assert capi.solve_nstation(st[:2], [0.0])[0] != 0       # needs >= 3 stations
+
+
+def test_unit_ownership_window_major_and_pair_major():
+    from tdoa_amd import sharding
+    # enough windows: a window's pairs all live on one rank
+    for world, W, P in ((2, 9, 3), (8, 99, 28), (3, 3, 3)):
+        for wid in range(W):
+            assert {sharding.unit_owner(wid, p, world, W, P) for p in range(P)} == {wid % world}
+    # fewer windows than ranks: units are dealt round-robin and every rank gets work
+    world, W, P = 8, 3, 3
+    owners = [sharding.unit_owner(w, p, world, W, P) for w in range(W) for p in range(P)]
+    assert owners == [u % world for u in range(W * P)]
+    assert set(owners) == set(range(8))
+

@@ -114,3 +114,40 @@ def test_two_sample_blocks(oracle):
             olag, ocorr = oracle.b_xcorr_peak(ta, tb, 4)
             assert peaks[k, 0]["lag"] == olag
             assert abs(peaks[k, 0]["corr"] - ocorr) <= REL_TOL * max(abs(ocorr), 1e-30)
+
+
+def test_pair_major_sharding_when_fewer_windows_than_ranks(oracle):
+    """W < G falls back to dealing (window, pair) units; every unit is computed exactly once and
+    equals the single-rank result."""
+    import tdoa_amd
+    from tdoa_amd import sharding
+    blk, ml = 6000, 120
+    delays = [0, 7, 19, 33]
+    caps = [oracle.simulate_delayed_fm(3 * blk, d, 808, 100 + i) for i, d in enumerate(delays)]
+    with tdoa_amd.Context(max_lag=ml, window_len=blk) as c:
+        for s, cap in enumerate(caps):
+            c.capture_upload(s, cap)
+        full = c.process()
+        W, P = full.shape
+        assert (W, P) == (3, 6)
+        for world in (4, 8, 18, 19):                      # 18 units: world 19 leaves one rank without work
+            parts = [c.process(rank=r, world=world) for r in range(world)]
+            for wid in range(W):
+                for p in range(P):
+                    owner = sharding.unit_owner(wid, p, world, W, P)
+                    for r in range(world):
+                        if r == owner:
+                            assert parts[r][wid, p] == full[wid, p]
+                        else:
+                            assert parts[r][wid, p]["lag"] == 0 and parts[r][wid, p]["corr"] == 0.0
+            merged = sharding.merge_sharded(np.stack([sharding.peaks_as_bytes(x) for x in parts]), W, P)
+            assert np.array_equal(merged, full)
+        _, fine = c.process_fine(60.0)
+        pk, fn = c.process_fine(60.0, rank=5, world=8)
+        for wid in range(W):
+            for p in range(P):
+                if sharding.unit_owner(wid, p, 8, W, P) == 5:
+                    assert fn[wid, p] == fine[wid, p]
+                else:
+                    assert fn[wid, p]["delay"] == 0.0
+
