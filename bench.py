@@ -211,6 +211,8 @@ def main():
                        "fft_n": n_fft, "parallelism": "window-sharded x%d + RCCL all-gather of peaks" % world},
             "pipeline_algorithmic_GBps": round(a_bytes * world / (dt / args.steps) / 1e9, 1),
             "pipeline_frac_of_hbm_peak": round(a_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+            # SURVEY.md 8d secondary figure: pair-samples correlated per second (P*W*L/t), whole job
+            "pair_Msamples_per_s": round(world * n_pairs * n_windows * wlen / (dt / args.steps) / 1e6, 2),
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
