@@ -270,8 +270,19 @@ __global__ __launch_bounds__(512) void k_fwd_colx_c16(const SWDesc *sw, const sh
 // spectrum values, so stage 1 of row a (item t) and of row N2-a (item 255 - t) need no exchange.
 // grid (N2/2 - 1, n_pw) [+ (1, n_pw) for the SELF instance], 256 threads, dynamic LDS 68 KB.
 // ---------------------------------------------------------------------------
-template <bool SELF>
-__global__ __launch_bounds__(256) void k_inv_row_pair4096(const PWDesc *pw, const float2 *Z, float2 *V, FftPlan pl)
+//
+// FK > 0 is the short-lag form (|lag| < 512 FK - 1): only the elements m = n2 N1 + n1 with n2 = 0, n1 < 256 FK
+// and n2 = N2 - 1, n1 >= 4096 - 256 FK can hold a searched lag, and they sit in registers k < FK and k >= 16 - FK
+// of every thread.  Instead of the two V rows (64 KB) the workgroup writes its share of those column sums,
+//   P0[k][j] = V[a][n1] + V[b][n1]                          (n2 = 0,      n1 = j + 256 k)
+//   P1[k][j] = V[a][n1] conj(w_a) + V[b][n1] conj(w_b)      (n2 = N2 - 1, n1 = 4096 - 256 FK + j + 256 k)
+// with w_r = e^{2 pi i r/N2}: part[pw][row pair][P0 | P1][256 FK] float2 (4 FK KB); k_fused_reduce adds the
+// N2/2 shares in a fixed order.  V is never written or read: the inverse side moves 16 N bytes less.
+// (amdgpu_waves_per_eu(2, 2): the 68 KB of dynamic LDS already limit a CU to two workgroups = two waves per
+// SIMD; told so, the scheduler keeps ~20 loads in flight instead of squeezing registers for a third wave it
+// cannot have -- the short-lag instances otherwise dropped to two loads in flight, 1.41 ms against 1.25 ms.)
+template <bool SELF, int FK>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SELF ? 1 : 2, SELF ? 8 : 2))) void k_inv_row_pair4096(const PWDesc *pw, const float2 *Z, float2 *V, FftPlan pl)
 {
     extern __shared__ float2 lds[];   // 2 * kRowLds
     const int N2 = pl.N2;
@@ -381,11 +392,97 @@ __global__ __launch_bounds__(256) void k_inv_row_pair4096(const PWDesc *pw, cons
         const long long f0 = ((long long)j * b) & (pl.Nc - 1), f1 = ((long long)256 * b) & (pl.Nc - 1);
         mul_base_step16(vb, unit_root((float)f0, inv2, true), unit_root((float)f1, inv2, true));
     }
+    if constexpr (FK == 0) {
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        out[(size_t)a * 4096 + j + 256 * k] = va[oreg(k)];
-        out[(size_t)b * 4096 + j + 256 * k] = vb[oreg(k)];
+        for (int k = 0; k < 16; k++) {
+            out[(size_t)a * 4096 + j + 256 * k] = va[oreg(k)];
+            out[(size_t)b * 4096 + j + 256 * k] = vb[oreg(k)];
+        }
+    } else {
+        const float2 ca = unit_root((float)a, 2.0f / (float)N2, false);     // conj(w_a)
+        const float2 cb = unit_root((float)b, 2.0f / (float)N2, false);
+        float2 *part = out + (size_t)a * (2 * 256 * FK);                    // row pair a (0 for the SELF instance)
+#pragma unroll
+        for (int k = 0; k < FK; k++) {
+            part[k * 256 + j] = cadd(va[oreg(k)], vb[oreg(k)]);
+            part[256 * FK + k * 256 + j] = cadd(cmul(va[oreg(16 - FK + k)], ca), cmul(vb[oreg(16 - FK + k)], cb));
+        }
     }
+}
+
+// short-lag form, second half: element sums over the N2/2 row-pair shares in a fixed order (four interleaved
+// partial sums, then ((s0 + s1) + (s2 + s3))), lag filter and K5.
+// part = V + pw_index * Nc: [RP][2][256 FK] float2, followed by the lag array lags[1024 FK] (float),
+// lags[li] = c[li - 512 FK] unscaled, kept for the sub-sample refinement.
+// grid (2 FK, n_pw): blockIdx.x = side * FK + k; 256 threads.
+template <int FK>
+__global__ __launch_bounds__(256) void k_fused_reduce(float2 *V, unsigned long long *keys, const PWDesc *pw, FftPlan pl,
+                                                      int lag_lo, int lag_hi, float *lag_dump, float dump_scale)
+{
+    __shared__ unsigned long long red[4];
+    const int RP = pl.N2 / 2, j = threadIdx.x;
+    const int side = blockIdx.x / FK, k = blockIdx.x % FK;
+    float2 *part = V + (size_t)blockIdx.y * pl.Nc;
+    float *lags = reinterpret_cast<float *>(part + (size_t)RP * 2 * 256 * FK);
+    const float2 *src = part + side * 256 * FK + k * 256 + j;
+    const size_t stride = (size_t)2 * 256 * FK;
+    float2 s4[4] = {make_float2(0.0f, 0.0f), make_float2(0.0f, 0.0f), make_float2(0.0f, 0.0f), make_float2(0.0f, 0.0f)};
+    int rp = 0;
+    for (; rp + 4 <= RP; rp += 4) {
+        float2 x[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) x[u] = src[(size_t)(rp + u) * stride];
+#pragma unroll
+        for (int u = 0; u < 4; u++) s4[u] = cadd(s4[u], x[u]);
+    }
+    for (int u = 0; rp < RP; rp++, u++) s4[u] = cadd(s4[u], src[(size_t)rp * stride]);
+    const float2 acc = cadd(cadd(s4[0], s4[1]), cadd(s4[2], s4[3]));
+    const int m = side == 0 ? 256 * k + j : -256 * FK + 256 * k + j;    // element index, negative side wraps
+    const float vals[2] = {acc.x, acc.y};
+    unsigned long long best = 0;
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const int d = 2 * m + q;
+        lags[d + 512 * FK] = vals[q];
+        if (d >= lag_lo && d <= lag_hi && vals[q] == vals[q]) {
+            const unsigned long long key = peak_key(vals[q], d);
+            best = key > best ? key : best;
+            if (lag_dump) lag_dump[d - lag_lo] = vals[q] * dump_scale;
+        }
+    }
+    best = wave_max_u64(best);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long bb = red[0];
+        for (int w = 1; w < 4; w++) bb = red[w] > bb ? red[w] : bb;
+        if (bb) atomicMax(&keys[pw[blockIdx.y].out_index], bb);
+    }
+}
+
+// refinement neighbours c[lag-1], c[lag], c[lag+1] from the lag array k_fused_reduce left behind
+// (the host only takes the short-lag form when lag_hi + 1 and lag_lo - 1 are inside that array)
+template <int FK>
+__global__ void k_refine_fused(const float2 *V, const unsigned long long *keys, const PWDesc *pw, FftPlan pl, int n_pw,
+                               float *raw)
+{
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;   // one thread per pair-window
+    if (id >= n_pw) return;
+    const int slot = pw[id].out_index;
+    const unsigned long long k = keys[slot];
+    float r[3] = {0.0f, 0.0f, 0.0f};
+    if (k != 0 && (unsigned int)(k >> 32) != 0) {
+        const unsigned int rank = 0x7fffffffu - ((unsigned int)k >> 1);
+        const int lag = rank == 0 ? 0 : ((rank & 1u) ? (int)((rank + 1u) >> 1) : -(int)(rank >> 1));
+        const float *lags = reinterpret_cast<const float *>(V + (size_t)id * pl.Nc + (size_t)(pl.N2 / 2) * 2 * 256 * FK);
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            const int li = lag - 1 + q + 512 * FK;
+            r[q] = li >= 0 && li < 1024 * FK ? lags[li] : 0.0f;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 3; q++) raw[3 * (size_t)slot + q] = r[q];
 }
 
 // ---------------------------------------------------------------------------

@@ -276,6 +276,13 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
         np = lag_hi >= 0 ? (int)((lag_hi / 2) / pl.N1) + 1 : 0;
         nn = lag_lo < 0 ? pl.N2 - (int)(((n_real + lag_lo) / 2) / pl.N1) : 0;
     }
+    // short-lag form: the inverse row kernel emits its shares of the few column sums that can hold a lag and V is
+    // never written (needs lag_lo - 1 .. lag_hi + 1 inside [-512 fk, 512 fk - 1] for the refinement neighbours)
+    int fk = 0;
+    if (row16 && !std::getenv("TDOA_NO_SHORT_LAG")) {
+        const int reach = std::max(lag_hi + 1, -(lag_lo - 1));
+        fk = reach <= 511 ? 1 : reach <= 1023 ? 2 : reach <= 2047 ? 4 : reach <= 4095 ? 8 : 0;
+    }
     const bool pruned = !ctx->force_generic && pl.N1 >= 128 && pl.N2 <= 4096 && np + nn <= kPruneMax && np + nn <= pl.N2 &&
                         lag_hi < pl.Nc && lag_lo > -pl.Nc;
     {
@@ -327,18 +334,43 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
     if (n_pw) {
         {
             ProfScope ps(ctx, TDOA_K_INV_ROW, 3.0 * nc8 * n_pw);
-            if (row16) {
+            if (fk) {
+#define TDOA_FUSED_ROWS(FK)                                                                                          \
+    do {                                                                                                             \
+        if (pl.N2 > 2)                                                                                               \
+            hipLaunchKernelGGL((k_inv_row_pair4096<false, FK>), dim3(pl.N2 / 2 - 1, n_pw), dim3(256), lds_pair16, st,  \
+                               d_pw, tz, v, pl);                                                                     \
+        hipLaunchKernelGGL((k_inv_row_pair4096<true, FK>), dim3(1, n_pw), dim3(256), lds_pair16, st, d_pw, tz, v, pl); \
+    } while (0)
+                if (fk == 1) TDOA_FUSED_ROWS(1);
+                else if (fk == 2) TDOA_FUSED_ROWS(2);
+                else if (fk == 4) TDOA_FUSED_ROWS(4);
+                else TDOA_FUSED_ROWS(8);
+#undef TDOA_FUSED_ROWS
+            } else if (row16) {
                 if (pl.N2 > 2)
-                    hipLaunchKernelGGL(k_inv_row_pair4096<false>, dim3(pl.N2 / 2 - 1, n_pw), dim3(256), lds_pair16, st,
+                    hipLaunchKernelGGL((k_inv_row_pair4096<false, 0>), dim3(pl.N2 / 2 - 1, n_pw), dim3(256), lds_pair16, st,
                                        d_pw, tz, v, pl);
-                hipLaunchKernelGGL(k_inv_row_pair4096<true>, dim3(1, n_pw), dim3(256), lds_pair16, st, d_pw, tz, v, pl);
+                hipLaunchKernelGGL((k_inv_row_pair4096<true, 0>), dim3(1, n_pw), dim3(256), lds_pair16, st, d_pw, tz, v, pl);
             } else {
                 hipLaunchKernelGGL(k_inv_row_pair, dim3(pl.N2 / 2, n_pw), dim3(256), lds_row2, st, d_pw, tz, v, pl);
             }
         }
         {
-            ProfScope ps(ctx, TDOA_K_INV_COL, nc8 * n_pw);
-            if (pruned) {
+            ProfScope ps(ctx, TDOA_K_INV_COL, fk ? 8.0 * 256 * fk * pl.N2 * n_pw : nc8 * n_pw);
+            if (fk == 1)
+                hipLaunchKernelGGL(k_fused_reduce<1>, dim3(2, n_pw), dim3(256), 0, st, v, d_keys, d_pw, pl, lag_lo, lag_hi,
+                                   lag_dump, dump_scale);
+            else if (fk == 2)
+                hipLaunchKernelGGL(k_fused_reduce<2>, dim3(4, n_pw), dim3(256), 0, st, v, d_keys, d_pw, pl, lag_lo, lag_hi,
+                                   lag_dump, dump_scale);
+            else if (fk == 4)
+                hipLaunchKernelGGL(k_fused_reduce<4>, dim3(8, n_pw), dim3(256), 0, st, v, d_keys, d_pw, pl, lag_lo, lag_hi,
+                                   lag_dump, dump_scale);
+            else if (fk == 8)
+                hipLaunchKernelGGL(k_fused_reduce<8>, dim3(16, n_pw), dim3(256), 0, st, v, d_keys, d_pw, pl, lag_lo, lag_hi,
+                                   lag_dump, dump_scale);
+            else if (pruned) {
                 const dim3 grid(pl.N1 / 128, n_pw), blk(256);
                 const size_t lds_wtab = sizeof(float2) * (size_t)pl.N2;
 #define TDOA_PRUNED(NP, NN)                                                                                      \
@@ -359,8 +391,14 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
                                    d_pw, pl, lag_lo, lag_hi, lag_dump, dump_scale);
         }
     }
-    if (n_pw && fine_raw)   // V of this batch is still in place: peak neighbours for the parabola
-        hipLaunchKernelGGL(k_refine_peaks, dim3(n_pw), dim3(64), 0, st, v, d_keys, d_pw, pl, fine_raw);
+    if (n_pw && fine_raw) {   // V (or the short-lag array) of this batch is still in place: peak neighbours for the parabola
+        const dim3 g1((n_pw + 63) / 64), b1(64);
+        if (fk == 1) hipLaunchKernelGGL(k_refine_fused<1>, g1, b1, 0, st, v, d_keys, d_pw, pl, n_pw, fine_raw);
+        else if (fk == 2) hipLaunchKernelGGL(k_refine_fused<2>, g1, b1, 0, st, v, d_keys, d_pw, pl, n_pw, fine_raw);
+        else if (fk == 4) hipLaunchKernelGGL(k_refine_fused<4>, g1, b1, 0, st, v, d_keys, d_pw, pl, n_pw, fine_raw);
+        else if (fk == 8) hipLaunchKernelGGL(k_refine_fused<8>, g1, b1, 0, st, v, d_keys, d_pw, pl, n_pw, fine_raw);
+        else hipLaunchKernelGGL(k_refine_peaks, dim3(n_pw), dim3(64), 0, st, v, d_keys, d_pw, pl, fine_raw);
+    }
     HIPCHK(ctx, hipGetLastError());
     return TDOA_OK;
 }
@@ -379,8 +417,16 @@ int allow_big_lds(tdoa_ctx *ctx)
     if ((rc = set_lds(ctx, k_fwd_col256_c16<true>, all))) return rc;
     if ((rc = set_lds(ctx, k_fwd_colx_c16<2>, all))) return rc;
     if ((rc = set_lds(ctx, k_fwd_colx_c16<4>, all))) return rc;
-    if ((rc = set_lds(ctx, k_inv_row_pair4096<false>, all))) return rc;
-    if ((rc = set_lds(ctx, k_inv_row_pair4096<true>, all))) return rc;
+    if ((rc = set_lds(ctx, k_inv_row_pair4096<false, 0>, all))) return rc;
+    if ((rc = set_lds(ctx, k_inv_row_pair4096<true, 0>, all))) return rc;
+    if ((rc = set_lds(ctx, k_inv_row_pair4096<false, 1>, all))) return rc;
+    if ((rc = set_lds(ctx, k_inv_row_pair4096<true, 1>, all))) return rc;
+    if ((rc = set_lds(ctx, k_inv_row_pair4096<false, 2>, all))) return rc;
+    if ((rc = set_lds(ctx, k_inv_row_pair4096<true, 2>, all))) return rc;
+    if ((rc = set_lds(ctx, k_inv_row_pair4096<false, 4>, all))) return rc;
+    if ((rc = set_lds(ctx, k_inv_row_pair4096<true, 4>, all))) return rc;
+    if ((rc = set_lds(ctx, k_inv_row_pair4096<false, 8>, all))) return rc;
+    if ((rc = set_lds(ctx, k_inv_row_pair4096<true, 8>, all))) return rc;
     return TDOA_OK;
 }
 

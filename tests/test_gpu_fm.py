@@ -266,3 +266,30 @@ def test_attach_device_buffer_from_torch(oracle):
         assert (host["lag"] == np.array([21, 5, -16])).all()
         ref = c.process_u8(caps)                       # same bytes through the upload path
         assert np.array_equal(ref, host)
+
+
+@pytest.mark.parametrize("max_lag,delay", [(128, 57), (128, -127), (511, 300), (512, -511), (1000, 999), (2047, -2046),
+                                           (2048, 1500), (4095, 4094), (4096, -4000)])
+def test_short_lag_form_vs_oracle_and_general_form(oracle, max_lag, delay, monkeypatch):
+    """|lag| ranges below 4095 take the short-lag inverse (no V round trip) on 4096-point rows; 4096 is the first
+    range that takes the general pruned form again.  Both against the f64 oracle, and against each other."""
+    import tdoa_amd
+    n = 300_000                                                   # N = 2^19: 4096 x 64
+    a = oracle.simulate_delayed_fm(n, max(0, -delay), 77, 1)
+    b = oracle.simulate_delayed_fm(n, max(0, delay), 77, 2)
+    ta, _ = oracle.b_preprocess(a)
+    tb, _ = oracle.b_preprocess(b)
+    olag, ocorr, want = oracle.b_xcorr_peak_fft(ta, tb, max_lag)
+    assert olag == delay
+    with tdoa_amd.Context(max_lag=max_lag, window_len=n) as c:
+        lags = c.fm_xcorr_lags(a, b, max_lag)
+        _assert_lags_close(lags, want)
+        (lag, corr), fine = c.fm_xcorr_fine(a, b, max_lag, 1e9)
+        assert lag == olag and abs(corr - ocorr) <= REL_TOL * abs(ocorr)
+        ofine = oracle.b_refine_peak(ta, tb, lag, 1e9)
+        assert np.abs(fine["y"] - ofine["y"]).max() <= REL_TOL * abs(ocorr)
+        assert abs(fine["frac"] - ofine["frac"]) < 1e-4
+        monkeypatch.setenv("TDOA_NO_SHORT_LAG", "1")
+        general = c.fm_xcorr_lags(a, b, max_lag)
+        _assert_lags_close(general, lags)
+        assert c.fm_xcorr(a, b, max_lag)[0] == lag
