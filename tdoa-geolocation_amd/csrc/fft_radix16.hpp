@@ -265,6 +265,57 @@ __global__ __launch_bounds__(512) void k_fwd_colx_c16(const SWDesc *sw, const sh
 }
 
 // ---------------------------------------------------------------------------
+// forward column pass for short columns, N2 = 16 F (F = 1, 2, 4, 8: windows of 0.06 .. 0.5 s at 2 Msps,
+// N = 2^17 .. 2^20).  Decimation in time by F: thread (column c, part p) transforms the 16 rows
+// n2 = p (mod F) in registers, applies W_(16F)^(k p), and after one LDS exchange computes the outputs
+// X[k + 16 q], q = p, as the F-point DFT across the parts.  256/F columns per workgroup:
+// grid (N1 F/256, n_sw), 256 threads, static LDS 32 KB.
+// ---------------------------------------------------------------------------
+template <int F>
+__global__ __launch_bounds__(256) void k_fwd_col16x_c16(const SWDesc *sw, const short *codes, long long code_stride,
+                                                        const FmStats *stats, float2 *T, FftPlan pl)
+{
+    static_assert(F == 1 || F == 2 || F == 4 || F == 8, "N2 = 16, 32, 64 or 128");
+    constexpr int C = 256 / F;
+    __shared__ float2 img[F == 1 ? 1 : F * 16 * C];   // [part][k][column]
+    const int len = sw[blockIdx.y].len;
+    const short *row = codes + (size_t)blockIdx.y * code_stride;
+    const float mean = stats[blockIdx.y].mean, scale = stats[blockIdx.y].scale;
+    const int c = threadIdx.x % C, p = threadIdx.x / C;
+    const int n1 = blockIdx.x * C + c;
+    const int N1 = pl.N1;
+    float2 v[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) v[r] = code_element(row, (long long)(F * r + p) * N1 + n1, len, mean, scale);
+    fft16<false>(v);
+    const int q = p;
+    if constexpr (F > 1) {
+        // Y_p[k] *= W_(16F)^(k p); part 0 needs no factor
+        if (p) mul_base_step16(v, make_float2(1.0f, 0.0f), unit_root((float)p, 2.0f / (16.0f * F), false));
+#pragma unroll
+        for (int k = 0; k < 16; k++) img[(p * 16 + k) * C + c] = v[oreg(k)];
+        __syncthreads();
+        // W_F^m for m = 0 .. F-1 are entries (8/F) m of the eighth roots of unity e^{-2 pi i m/8}
+        constexpr float h = 0.70710678118654752f;
+        const float2 w8[8] = {{1.0f, 0.0f}, {h, -h}, {0.0f, -1.0f}, {-h, -h}, {-1.0f, 0.0f}, {-h, h}, {0.0f, 1.0f}, {h, h}};
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            float2 acc = img[k * C + c];
+#pragma unroll
+            for (int pp = 1; pp < F; pp++) acc = cadd(acc, cmul(img[(pp * 16 + k) * C + c], w8[((q * pp) % F) * (8 / F)]));
+            v[oreg(k)] = acc;
+        }
+    }
+    // X[k2 = k + 16 q] *= W_Nc^(n1 k2) = W^(16 q n1) * (W^(n1))^k
+    float2 *out = T + (size_t)blockIdx.y * pl.Nc;
+    const float inv2 = 2.0f / (float)pl.Nc;
+    const long long e0 = ((long long)n1 * 16 * q) & (pl.Nc - 1);
+    mul_base_step16(v, unit_root((float)e0, inv2, false), unit_root((float)n1, inv2, false));
+#pragma unroll
+    for (int k = 0; k < 16; k++) out[(size_t)(k + 16 * q) * N1 + n1] = v[oreg(k)];
+}
+
+// ---------------------------------------------------------------------------
 // inverse row pass with K3 fused, N1 = 4096: one workgroup owns rows a and N2 - a (a >= 1).
 // Thread t builds Q[a][t + 256 r] and its mirror Q[N2-a][4095 - t - 256 r] from the same four
 // spectrum values, so stage 1 of row a (item t) and of row N2-a (item 255 - t) need no exchange.

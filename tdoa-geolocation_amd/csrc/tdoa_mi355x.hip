@@ -269,6 +269,7 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
     const bool row16 = pl.N1 == 4096 && !ctx->force_generic;
     const bool col16 = row16 && pl.N2 == 256;
     const bool col2pass = row16 && (pl.N2 == 4096 || pl.N2 == 2048);   // 256-point sub-transforms + 16-point finish (two sweeps)
+    const int col16x = row16 && pl.N2 >= 16 && pl.N2 <= 128 ? pl.N2 / 16 : 0;   // short columns: k_fwd_col16x_c16<F>
     const int colx = row16 && (pl.N2 == 512 || pl.N2 == 1024) ? pl.N2 / 256 : 0;   // last radix of k_fwd_colx_c16
     int np = 0, nn = 0;
     {
@@ -314,6 +315,18 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
             else
                 hipLaunchKernelGGL(k_fwd_col_finish<8>, dim3(pl.N1 / 256, 256, n_sw), dim3(256), 0, st, tz, pl);
         }
+        else if (col16x == 1)
+            hipLaunchKernelGGL(k_fwd_col16x_c16<1>, dim3(pl.N1 / 256, n_sw), dim3(256), 0, st, d_sw, codes, code_stride,
+                               stats, tz, pl);
+        else if (col16x == 2)
+            hipLaunchKernelGGL(k_fwd_col16x_c16<2>, dim3(pl.N1 / 128, n_sw), dim3(256), 0, st, d_sw, codes, code_stride,
+                               stats, tz, pl);
+        else if (col16x == 4)
+            hipLaunchKernelGGL(k_fwd_col16x_c16<4>, dim3(pl.N1 / 64, n_sw), dim3(256), 0, st, d_sw, codes, code_stride,
+                               stats, tz, pl);
+        else if (col16x == 8)
+            hipLaunchKernelGGL(k_fwd_col16x_c16<8>, dim3(pl.N1 / 32, n_sw), dim3(256), 0, st, d_sw, codes, code_stride,
+                               stats, tz, pl);
         else if (colx == 2)
             hipLaunchKernelGGL(k_fwd_colx_c16<2>, dim3(pl.N1 / 16, n_sw), dim3(512), lds_col16, st, d_sw, codes,
                                code_stride, stats, tz, pl);

@@ -293,3 +293,22 @@ def test_short_lag_form_vs_oracle_and_general_form(oracle, max_lag, delay, monke
         general = c.fm_xcorr_lags(a, b, max_lag)
         _assert_lags_close(general, lags)
         assert c.fm_xcorr(a, b, max_lag)[0] == lag
+
+
+@pytest.mark.parametrize("n,label", [(70_000, "N = 2^17: 4096 x 16"), (200_000, "N = 2^18: 4096 x 32"),
+                                     (400_000, "N = 2^19: 4096 x 64"), (666_666, "cfg1 block, N = 2^20: 4096 x 128")])
+def test_short_column_kernels(oracle, n, label):
+    """hot forward column pass for N2 = 16 .. 128 against the f64 oracle and the any-size kernels"""
+    import tdoa_amd
+    a = oracle.simulate_delayed_fm(n, 11, 55, 1)
+    b = oracle.simulate_delayed_fm(n - 1234, 0, 55, 2)             # unequal lengths; a is the delayed one
+    ta, _ = oracle.b_preprocess(a)
+    tb, _ = oracle.b_preprocess(b)
+    olag, ocorr, want = oracle.b_xcorr_peak_fft(ta, tb, 20000)
+    assert olag == -11, label
+    with tdoa_amd.Context(window_len=n) as c:
+        hot = c.fm_xcorr_lags(a, b, 20000)
+        _assert_lags_close(hot, want)
+        assert c.fm_xcorr(a, b, 20000)[0] == olag
+        c.force_generic(True)
+        _assert_lags_close(c.fm_xcorr_lags(a, b, 20000), hot)
