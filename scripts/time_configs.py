@@ -30,12 +30,14 @@ def run(name, n_st, fs, wlen, block, steps=3):
         c.process(want_host=False)
     dt = (time.perf_counter() - t0) / steps
     n, n1, n2 = c.plan_info()
+    wlen = min(wlen, block)                                   # a block shorter than window_len is one window
     print(json.dumps({"config": name, "stations": n_st, "pairs": P, "windows": W, "window_len": wlen, "fft": [n, n1, n2],
                       "ms_per_step": round(dt * 1e3, 3), "Msamples_per_s": round(n_st * W * wlen / dt / 1e6, 1)}), flush=True)
     c.close()
 
 
 if __name__ == "__main__":
+    run("cfg1 (3 st, 2 000 000 samples each, one 666 666-sample window per block)", 3, 2e6, 2_000_000, 666_666, steps=20)
     run("cfg2 slice (3 st, 1 s windows)", 3, 2e6, 2_000_000, 8_000_000)
     run("cfg4 slice (8 st, 28 pairs)", 8, 2e6, 2_000_000, 8_000_000)
     run("cfg5 slice (16 st, 4 Msps, 1 s windows)", 16, 4e6, 4_000_000, 8_000_000)
