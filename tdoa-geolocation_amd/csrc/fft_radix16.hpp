@@ -144,8 +144,13 @@ __global__ __launch_bounds__(512) void k_fwd_col256_c16(const SWDesc *sw, const 
     const int N1 = pl.N1;
     float2 v[16];
 #pragma unroll
+    for (int r = 0; r < 16; r++) {     // all 16 loads first (the packed codes are one dword each)
+        const unsigned int w = code_fetch(row, (long long)(a + G * (j + 16 * r)) * N1 + n1, len);
+        v[r].x = __uint_as_float(w);
+    }
+#pragma unroll
     for (int r = 0; r < 16; r++)
-        v[r] = code_element(row, (long long)(a + G * (j + 16 * r)) * N1 + n1, len, mean, scale);
+        v[r] = code_convert(__float_as_uint(v[r].x), (long long)(a + G * (j + 16 * r)) * N1 + n1, len, mean, scale);
     fft16<false>(v);
 #pragma unroll
     for (int k = 0; k < 16; k++) lds[((16 * j + k) << 5) + c] = v[oreg(k)];
@@ -220,8 +225,10 @@ __global__ __launch_bounds__(512) void k_fwd_colx_c16(const SWDesc *sw, const sh
     float2 *img = lds + par * 256 * C;
     float2 v[16];
 #pragma unroll
+    for (int r = 0; r < 16; r++) v[r].x = __uint_as_float(code_fetch(row, (long long)(F * (j + 16 * r) + par) * N1 + n1, len));
+#pragma unroll
     for (int r = 0; r < 16; r++)
-        v[r] = code_element(row, (long long)(F * (j + 16 * r) + par) * N1 + n1, len, mean, scale);
+        v[r] = code_convert(__float_as_uint(v[r].x), (long long)(F * (j + 16 * r) + par) * N1 + n1, len, mean, scale);
     fft16<false>(v);
 #pragma unroll
     for (int k = 0; k < 16; k++) img[(16 * j + k) * C + c] = v[oreg(k)];
@@ -286,7 +293,9 @@ __global__ __launch_bounds__(256) void k_fwd_col16x_c16(const SWDesc *sw, const 
     const int N1 = pl.N1;
     float2 v[16];
 #pragma unroll
-    for (int r = 0; r < 16; r++) v[r] = code_element(row, (long long)(F * r + p) * N1 + n1, len, mean, scale);
+    for (int r = 0; r < 16; r++) v[r].x = __uint_as_float(code_fetch(row, (long long)(F * r + p) * N1 + n1, len));
+#pragma unroll
+    for (int r = 0; r < 16; r++) v[r] = code_convert(__float_as_uint(v[r].x), (long long)(F * r + p) * N1 + n1, len, mean, scale);
     fft16<false>(v);
     const int q = p;
     if constexpr (F > 1) {

@@ -115,6 +115,20 @@ __device__ __forceinline__ float2 code_element(const short *codes, long long m, 
     return make_float2(ok0 ? v0 : 0.0f, ok1 ? v1 : 0.0f);
 }
 
+// the same in two steps, so that a thread can issue all its loads before it converts the first one
+__device__ __forceinline__ unsigned int code_fetch(const short *codes, long long m, int len)
+{
+    return reinterpret_cast<const unsigned int *>(codes)[2 * m < len ? m : 0];
+}
+
+__device__ __forceinline__ float2 code_convert(unsigned int w, long long m, int len, float mean, float scale)
+{
+    const long long i0 = 2 * m;
+    const float v0 = k1_normalise((int)(short)(w & 0xffffu), mean, scale);
+    const float v1 = k1_normalise((int)(short)(w >> 16), mean, scale);
+    return make_float2(i0 < len ? v0 : 0.0f, i0 + 1 < len ? v1 : 0.0f);
+}
+
 // ---------------------------------------------------------------------------
 // forward column pass: phase codes -> normalise -> pack -> length-N2 FFT down C adjacent
 // columns -> twiddle -> T[k2][n1]

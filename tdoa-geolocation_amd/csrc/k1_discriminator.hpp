@@ -91,27 +91,44 @@ struct FmStats {          // mirrors tdoa_fm_stats
 };
 
 constexpr int kDemodThreads = 1024;
-constexpr int kDemodPiece = 1024;    // samples per wave step: 64 lanes x 2 x 8
-constexpr int kDemodRun = 16;        // pieces per work item (one pair of atomics per 16384 samples)
+constexpr int kDemodChunks = 4;      // 8-sample chunks a lane owns per wave step: 4 x 16-byte loads in flight per lane
+constexpr int kDemodPiece = 512 * kDemodChunks;   // samples per wave step
+constexpr int kDemodItem = 32;       // pieces per workgroup item: 2 steps of 16 waves (one pair of atomics per 65536 samples)
 
-// eight consecutive IQ samples p[i0 .. i0+7] with whatever alignment the window start has
-__device__ __forceinline__ void k1_load8(const uint16_t *p, int i0, unsigned int (&s)[9])
+// Capture bytes are read through pointers in the GLOBAL address space: a pointer that comes out of a descriptor in
+// memory is generic to the compiler, and generic (flat) loads are ordered against LDS traffic -- every one of them was
+// followed by s_waitcnt vmcnt(0) lgkmcnt(0), i.e. one load in flight per wave.
+typedef const __attribute__((address_space(1))) uint16_t *gptr16;
+
+__device__ __forceinline__ gptr16 k1_global(const uint8_t *base)
 {
-    const uintptr_t a = reinterpret_cast<uintptr_t>(p + i0);
-    if ((a & 15u) == 0) {
-        const uint4 q = *reinterpret_cast<const uint4 *>(p + i0);
-        s[1] = q.x & 0xffffu; s[2] = q.x >> 16; s[3] = q.y & 0xffffu; s[4] = q.y >> 16;
-        s[5] = q.z & 0xffffu; s[6] = q.z >> 16; s[7] = q.w & 0xffffu; s[8] = q.w >> 16;
-    } else if ((a & 3u) == 0) {
-        const unsigned int *w = reinterpret_cast<const unsigned int *>(p + i0);
-        const unsigned int q0 = w[0], q1 = w[1], q2 = w[2], q3 = w[3];
-        s[1] = q0 & 0xffffu; s[2] = q0 >> 16; s[3] = q1 & 0xffffu; s[4] = q1 >> 16;
-        s[5] = q2 & 0xffffu; s[6] = q2 >> 16; s[7] = q3 & 0xffffu; s[8] = q3 >> 16;
-    } else {
-#pragma unroll
-        for (int k = 0; k < 8; k++) s[k + 1] = p[i0 + k];
-    }
+    return (gptr16)(const uint16_t *)base;
 }
+
+// eight consecutive IQ samples p[i0 .. i0+7] as four dwords, for any 2-byte alignment of the window start:
+// one 16-byte load when the address is 4-byte aligned (global memory needs no more), else eight 2-byte loads
+__device__ __forceinline__ uint4 k1_fetch8(gptr16 p, int i0)
+{
+    const uintptr_t a = (uintptr_t)(p + i0);
+    if ((a & 3u) == 0) {
+        typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+        typedef v4u __attribute__((aligned(4))) v4u_a4;
+        const v4u r = *(const __attribute__((address_space(1))) v4u_a4 *)(p + i0);
+        return make_uint4(r.x, r.y, r.z, r.w);
+    }
+    unsigned int h[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) h[k] = p[i0 + k];
+    return make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+}
+
+__device__ __forceinline__ void k1_unpack8(uint4 q, unsigned int (&s)[9])
+{
+    s[1] = q.x & 0xffffu; s[2] = q.x >> 16; s[3] = q.y & 0xffffu; s[4] = q.y >> 16;
+    s[5] = q.z & 0xffffu; s[6] = q.z >> 16; s[7] = q.w & 0xffffu; s[8] = q.w >> 16;
+}
+
+__device__ __forceinline__ void k1_load8(gptr16 p, int i0, unsigned int (&s)[9]) { k1_unpack8(k1_fetch8(p, i0), s); }
 
 // K1 demodulation pass: persistent 1024-thread workgroups (one per CU) keep the 128 KB angle
 // table in LDS; after loading it the 16 waves of a workgroup run independently, each taking
@@ -130,42 +147,71 @@ __global__ __launch_bounds__(kDemodThreads) void k_fm_demod(const SWDesc *sw, in
         for (int k = threadIdx.x; k < 8192; k += kDemodThreads) dst[k] = src[k];
     }
     __syncthreads();
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wave = blockIdx.x * (kDemodThreads / kWave) + threadIdx.x / kWave;
-    const int n_waves = gridDim.x * (kDemodThreads / kWave);
-    // work item = kDemodRun consecutive pieces of one window; consecutive items belong to DIFFERENT
-    // windows, so the waves that run together add into different accumulators
-    const int runs_per_window = (pieces_per_window + kDemodRun - 1) / kDemodRun;
+    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+    // work item of a WORKGROUP = kDemodItem consecutive pieces of one window; at every step its 16 waves take 16
+    // adjacent pieces, so the workgroup streams 32 KB of contiguous capture bytes per step (one DRAM-friendly run,
+    // like a row of the FFT passes) instead of 16 unrelated 2 KB reads.  Consecutive items belong to DIFFERENT
+    // windows, so workgroups that run together add into different accumulators.
+    __shared__ long long red1[kDemodThreads / kWave];
+    __shared__ unsigned long long red2[kDemodThreads / kWave];
+    const int runs_per_window = (pieces_per_window + kDemodItem - 1) / kDemodItem;
     const int n_items = n_sw * runs_per_window;
-    for (int item = wave; item < n_items; item += n_waves) {
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
         const int w = item % n_sw, run = item / n_sw;
         const SWDesc d = sw[w];
         const int len = d.len;
-        // the pointer comes out of a descriptor in memory: tell the compiler it is global, not flat
-        typedef const __attribute__((address_space(1))) uint16_t *global_u16;
-        const uint16_t *p = (const uint16_t *)(global_u16)(const uint16_t *)d.base;
+        const gptr16 p = k1_global(d.base);
         short *out = codes + (size_t)w * code_stride;
         long long s1 = 0;
         unsigned long long s2 = 0;
-        for (int piece = run * kDemodRun; piece < (run + 1) * kDemodRun; piece++) {
+        for (int piece = run * kDemodItem + wv; piece < (run + 1) * kDemodItem; piece += kDemodThreads / kWave) {
             const int start = piece * kDemodPiece;
             if (start >= len) break;
-            // a lane owns samples [ia, ia+8) and [ib, ib+8); both loads are issued before either is used
-            const int ia = start + lane * 8, ib = ia + 512;
-            const bool fa = ia >= 1 && ia + 8 <= len, fb = ib + 8 <= len;     // interior (fast) pieces
-            unsigned int sa[9], sb[9];
-            if (fa) { k1_load8(p, ia, sa); sa[0] = p[ia - 1]; }
-            if (fb) { k1_load8(p, ib, sb); sb[0] = p[ib - 1]; }
+            // a lane owns samples [i0, i0+8) of each 512-sample chunk; all loads are issued before any is used
+            uint4 qs[kDemodChunks];
+            unsigned int prev[kDemodChunks];
+            bool fastc[kDemodChunks];
+            bool interior = true;
 #pragma unroll
-            for (int half = 0; half < 2; half++) {
-                const int i0 = half ? ib : ia;
-                const bool fast = half ? fb : fa;
+            for (int h = 0; h < kDemodChunks; h++) {
+                const int i0 = start + h * 512 + lane * 8;
+                fastc[h] = i0 >= 1 && i0 + 8 <= len;                              // interior (fast) chunks
+                interior = interior && fastc[h];
+                qs[h] = make_uint4(0, 0, 0, 0);
+                prev[h] = 0;
+            }
+            if (__all(interior)) {
+                // whole piece inside the window: the sample before a lane's chunk is the last sample of the lane to
+                // its left (lane 0: lane 63 of the previous chunk; chunk 0: one broadcast load) -- no 2-byte gathers
+                const unsigned int before = p[start - 1];
+#pragma unroll
+                for (int h = 0; h < kDemodChunks; h++) qs[h] = k1_fetch8(p, start + h * 512 + lane * 8);
+#pragma unroll
+                for (int h = 0; h < kDemodChunks; h++) {
+                    const unsigned int left = __shfl_up(qs[h].w >> 16, 1, kWave);
+                    const unsigned int wrap = h ? __shfl(qs[h ? h - 1 : 0].w >> 16, kWave - 1, kWave) : before;
+                    prev[h] = lane ? left : wrap;
+                }
+            } else {
+#pragma unroll
+                for (int h = 0; h < kDemodChunks; h++) {
+                    const int i0 = start + h * 512 + lane * 8;
+                    if (fastc[h]) { qs[h] = k1_fetch8(p, i0); prev[h] = p[i0 - 1]; }
+                }
+            }
+#pragma unroll
+            for (int half = 0; half < kDemodChunks; half++) {
+                const int i0 = start + half * 512 + lane * 8;
+                const bool fast = fastc[half];
                 if (i0 >= len) continue;
                 int c[8];
                 if (fast) {
+                    unsigned int sm[9];
+                    k1_unpack8(qs[half], sm);
+                    sm[0] = prev[half];
                     int a[9];
 #pragma unroll
-                    for (int k = 0; k < 9; k++) a[k] = lut[k1_slot(half ? sb[k] : sa[k])];
+                    for (int k = 0; k < 9; k++) a[k] = lut[k1_slot(sm[k])];
                     int t1 = 0;
                     unsigned long long t2 = 0;
 #pragma unroll
@@ -208,9 +254,18 @@ __global__ __launch_bounds__(kDemodThreads) void k_fm_demod(const SWDesc *sw, in
             s2 += __shfl_xor(s2, off, kWave);
         }
         if (lane == 0) {
-            atomicAdd(reinterpret_cast<unsigned long long *>(&acc[w].s1), (unsigned long long)s1);   // two's complement
-            atomicAdd(&acc[w].s2, s2);
+            red1[wv] = s1;
+            red2[wv] = s2;
         }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            long long t1 = 0;
+            unsigned long long t2 = 0;
+            for (int k = 0; k < kDemodThreads / kWave; k++) { t1 += red1[k]; t2 += red2[k]; }
+            atomicAdd(reinterpret_cast<unsigned long long *>(&acc[w].s1), (unsigned long long)t1);   // two's complement
+            atomicAdd(&acc[w].s2, t2);
+        }
+        __syncthreads();
     }
 }
 

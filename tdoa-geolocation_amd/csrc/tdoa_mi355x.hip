@@ -290,9 +290,8 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
         // K1: capture bytes -> 16-bit phase codes + exact window statistics
         ProfScope ps(ctx, TDOA_K_STATS, 4.0 * sum_len);
         HIPCHK(ctx, hipMemsetAsync(partials, 0, sizeof(StatsPartial) * (size_t)n_sw, st));
-        const long long items = (long long)pieces * n_sw;
-        const int waves_per_block = kDemodThreads / kWave;
-        const int blocks = (int)std::max<long long>(1, std::min<long long>((items + waves_per_block - 1) / waves_per_block, ctx->n_cu));
+        const long long items = (long long)((pieces + kDemodItem - 1) / kDemodItem) * n_sw;      // workgroup items
+        const int blocks = (int)std::max<long long>(1, std::min<long long>(items, ctx->n_cu));
         hipLaunchKernelGGL(k_fm_demod, dim3(blocks), dim3(kDemodThreads), 65536 * sizeof(short), st, d_sw, n_sw, pieces,
                            static_cast<const short *>(ctx->k1_table.p), codes, code_stride, partials);
         hipLaunchKernelGGL(k_fm_stats_final, dim3((n_sw + 63) / 64), dim3(64), 0, st, d_sw, partials, stats, n_sw);
@@ -1171,7 +1170,7 @@ int tdoa_fm_preprocess_u8(tdoa_ctx *ctx, const uint8_t *iq, size_t n, float *out
     HIPCHK(ctx, hipMemsetAsync(ctx->partials.p, 0, sizeof(StatsPartial), st));
     HIPCHK(ctx, hipStreamSynchronize(st));
     auto *d_sw = static_cast<SWDesc *>(ctx->sw_desc.p);
-    hipLaunchKernelGGL(k_fm_demod, dim3(std::max(1, std::min((pieces + 15) / 16, ctx->n_cu))), dim3(kDemodThreads),
+    hipLaunchKernelGGL(k_fm_demod, dim3(std::max(1, std::min((pieces + kDemodItem - 1) / kDemodItem, ctx->n_cu))), dim3(kDemodThreads),
                        65536 * sizeof(short), st, d_sw, 1, pieces, static_cast<const short *>(ctx->k1_table.p),
                        static_cast<short *>(ctx->codes.p), code_stride, static_cast<StatsPartial *>(ctx->partials.p));
     hipLaunchKernelGGL(k_fm_stats_final, dim3(1), dim3(64), 0, st, d_sw, static_cast<StatsPartial *>(ctx->partials.p),

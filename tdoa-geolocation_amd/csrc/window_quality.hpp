@@ -34,8 +34,7 @@ __global__ __launch_bounds__(256) void k_window_quality(const SWDesc *sw, QualAc
     const int len = d.len;
     const int start = blockIdx.x * kQualChunk;
     if (start >= len) return;
-    typedef const __attribute__((address_space(1))) uint16_t *global_u16;
-    const uint16_t *p = (const uint16_t *)(global_u16)(const uint16_t *)d.base;
+    const gptr16 p = k1_global(d.base);
     unsigned int si = 0, sq = 0, sii = 0, sqq = 0, imin = 255u, imax = 0u, qmin = 255u, qmax = 0u;   // <= 64 samples: no overflow
     for (int trip = 0; trip < kQualChunk / 2048; trip++) {
         const int i0 = start + trip * 2048 + threadIdx.x * 8;
