@@ -249,3 +249,27 @@ def test_simulator_shape_and_determinism(oracle):
     assert 120 <= a.min() and a.max() <= 135
     w = oracle.simulate_weak_station("kf0mtl", 5000, 44)
     assert w.size == 30000 and abs(float(w.mean()) - 127.0) < 1.0
+
+
+def test_k1_codes_agree_with_the_elf_discriminator_definition(oracle):
+    """SURVEY section 8, row K1 (read off the prebuilt binary): x = ((I-127.5)/127.5, (Q-127.5)/127.5),
+    p = x_i conj(x_{i-1}), y_i = atan2(Im p, Re p) unless |p|^2 <= 1e-10, y_0 := y_1.  The 16-bit phase code is that
+    angle in units of pi/32768, up to the two roundings of the angle codes it is the difference of."""
+    rng = np.random.default_rng(2024)
+    iq = rng.integers(0, 256, size=2 * 50000, dtype=np.uint8)
+    iq[:12] = [0, 0, 255, 255, 0, 255, 255, 0, 127, 128, 128, 127]       # corners and the centre
+    code = oracle.b_discriminate(iq).astype(np.float64)
+    x = ((iq[0::2].astype(np.float64) - 127.5) + 1j * (iq[1::2].astype(np.float64) - 127.5)) / 127.5
+    p = x[1:] * np.conj(x[:-1])
+    assert (np.abs(p) ** 2 > 1e-10).all()                                  # the binary's gate can never fire on u8 data
+    y = np.arctan2(p.imag, p.real)
+    y = np.concatenate([[y[0]], y])                                        # y_0 := y_1
+    diff = code * (np.pi / 32768.0) - y
+    diff = (diff + np.pi) % (2 * np.pi) - np.pi                            # the int16 wrap is the phase circle
+    assert np.abs(diff).max() <= 1.01 * (np.pi / 32768.0)                   # two half-step roundings
+    assert code[0] == code[1]
+    # and the single-sample angle itself against atan2, every one of the 65536 byte pairs
+    bi, bq = np.meshgrid(np.arange(256), np.arange(256), indexing="ij")
+    want = np.arctan2(2.0 * bq - 255.0, 2.0 * bi - 255.0)
+    got = np.array([[oracle.b_theta(2 * i - 255, 2 * q - 255) for q in range(256)] for i in range(256)])
+    assert np.abs(got - want).max() < 5e-7
