@@ -49,6 +49,19 @@ def pmc_traffic(kernel):
         return None, None
 
 
+def pipeline_pmc_rate(step_seconds):
+    """sum of the per-launch PMC traffic of every kernel of one step (one launch each in the default run) / step time"""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
+    if not files:
+        return None
+    try:
+        total = sum(v["traffic_bytes_per_launch"] for v in json.load(open(files[-1]))["kernels"].values())
+        return round(total / step_seconds / 1e9, 1)
+    except Exception:
+        return None
+
+
 def cpu_baseline_leg(ctx, peaks, block, wlen, max_lag, budget_s):
     """Times the CPU oracle (restatement of processor.go crossCorrelate) on the host cores on a
     bounded sample of the same bytes, and uses the same oracle to check the GPU peaks of
@@ -211,6 +224,9 @@ def main():
                        "fft_n": n_fft, "parallelism": "window-sharded x%d + RCCL all-gather of peaks" % world},
             "pipeline_algorithmic_GBps": round(a_bytes * world / (dt / args.steps) / 1e9, 1),
             "pipeline_frac_of_hbm_peak": round(a_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+            # HBM-side bytes the whole step really moved (PMC sum over its kernels, committed passes) over the same time
+            "pipeline_pmc_GBps": pipeline_pmc_rate(dt / args.steps) if (world == 1 and (n1, n2) == (4096, 256)
+                                                                         and args.seconds == 100.0) else None,
             # SURVEY.md 8d secondary figure: pair-samples correlated per second (P*W*L/t), whole job
             "pair_Msamples_per_s": round(world * n_pairs * n_windows * wlen / (dt / args.steps) / 1e6, 2),
             "roofline": roof,
