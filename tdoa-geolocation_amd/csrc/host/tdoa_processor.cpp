@@ -223,6 +223,29 @@ int main(int argc, char **argv)
         int wpb = 0, W = 0;
         if ((rc = tdoa_num_windows(ctx, &wpb, &W))) return die("tdoa_num_windows", rc);
         const int P = tdoa_num_pairs(ctx);
+        {
+            // capture QA in the spirit of collector.go:204-248 (validateDataFile), on every window instead of 1000 samples:
+            // mean block power per station, REF blocks consistent within 2x, TGT block different from REF by > 50 %
+            std::vector<tdoa_window_quality> q((size_t)W * S);
+            if ((rc = tdoa_window_quality_all(ctx, 0, 1, q.data()))) return die("tdoa_window_quality_all", rc);
+            std::printf("\n=== CAPTURE QUALITY (mean power of (I-127.5)^2+(Q-127.5)^2 per block) ===\n");
+            for (int s = 0; s < S; s++) {
+                double pw[3] = {0, 0, 0};
+                int clip = 0, overload = 0;
+                for (int w = 0; w < W; w++) {
+                    const tdoa_window_quality &x = q[(size_t)w * S + s];
+                    pw[w / wpb] += x.mean_power / wpb;
+                    clip += x.has_clipping;
+                    overload += x.has_overload;
+                }
+                const double ref_ratio = pw[2] / pw[0];                       // collector.go:231
+                const double tgt_ratio = (pw[1] / pw[0] + pw[1] / pw[2]) / 2.0; // collector.go:240-242
+                std::printf("%s: REF %.2f  TGT %.2f  REF %.2f  | REF blocks %s (%.2fx), TGT/REF %.2fx%s | %d clipped, %d low-level windows of %d\n",
+                            caps[s].st.name.c_str(), pw[0], pw[1], pw[2],
+                            (ref_ratio > 2.0 || ref_ratio < 0.5) ? "INCONSISTENT" : "consistent", ref_ratio, tgt_ratio,
+                            (tgt_ratio > 1.5 || tgt_ratio < 0.67) ? "" : " (very similar)", clip, overload, W);
+            }
+        }
         std::vector<tdoa_peak> peaks((size_t)W * P);
         std::vector<tdoa_fine_peak> fines;
         if (fine) {

@@ -78,6 +78,8 @@ def test_fm_flow_on_golden_captures(cli, csv_path):
     # solve may legitimately fail exactly as the reference would (processor.go:997-999 -> exit 3)
     assert r.returncode in (0, 3), r.stderr
     assert "FM-DISCRIMINATOR CROSS-CORRELATION: 6 windows x 3 pairs" in r.stdout
+    qa = re.findall(r"^(\w+): REF ([\d.]+)  TGT ([\d.]+)  REF ([\d.]+)  \| REF blocks (\w+)", r.stdout, flags=re.M)
+    assert [x[0] for x in qa] == ["kx0u", "n3pay", "kf0mtl"] and all(x[4] == "consistent" for x in qa)   # collector.go:231-237
     assert len(re.findall(r"^TGT .* median lag=-?\d+ samples over 2 windows", r.stdout, flags=re.M)) == 3
     if r.returncode == 0:
         assert "*** CALCULATED TRANSMITTER LOCATION ***" in r.stdout
