@@ -73,6 +73,7 @@ def cpu_baseline_leg(ctx, peaks, block, wlen, max_lag, budget_s):
     os.environ.setdefault("OMP_NUM_THREADS", str(cores))
     # --- parity of the timed GPU path on window 0 (mode B oracle, f64 FFT form)
     w0 = [ctx.capture_download(s, 0, wlen) for s in range(3)]
+    t_fft = time.perf_counter()
     pre = [o.b_preprocess(x)[0] for x in w0]
     parity = True
     for p, (i, j) in enumerate([(0, 1), (0, 2), (1, 2)]):
@@ -80,6 +81,7 @@ def cpu_baseline_leg(ctx, peaks, block, wlen, max_lag, budget_s):
         g = peaks[0, p]
         if int(g["lag"]) != olag or abs(float(g["corr"]) - ocorr) > 1e-5 * abs(ocorr):
             parity = False
+    t_fft = time.perf_counter() - t_fft     # the same algorithm as the GPU path (mode B), float64 FFTs, one window
     # --- CPU baseline: reference call pattern (3 pairs, reference-frequency block) on the
     # first n samples of each station's capture; calibrate n to the time budget
     def run(n):
@@ -98,6 +100,10 @@ def cpu_baseline_leg(ctx, peaks, block, wlen, max_lag, budget_s):
         "sample": "oracle restatement of processor.go crossCorrelate (weak-signal filter chain + "
                   "time-domain correlation), 3 pairs on the first %d samples of each station's "
                   "reference block, same bytes as the GPU run, OpenMP over %d threads, %.1f s" % (n, cores, t),
+        # the same algorithm on the CPU for an apples-to-apples comparison (not the baseline `value`)
+        "same_algorithm_f64_fft": {"value": round(3 * wlen / t_fft / 1e6, 3), "unit": "Msamples/s", "cores": 1,
+                                   "sample": "mode-B oracle (C discriminator + numpy float64 FFT cross-correlation), "
+                                             "3 stations x 1 window x 3 pairs, %.2f s" % t_fft},
     }, parity
 
 
