@@ -312,3 +312,34 @@ def test_short_column_kernels(oracle, n, label):
         assert c.fm_xcorr(a, b, 20000)[0] == olag
         c.force_generic(True)
         _assert_lags_close(c.fm_xcorr_lags(a, b, 20000), hot)
+
+
+@pytest.mark.parametrize("per_batch", [0, 2])
+def test_short_lag_form_in_the_batched_path(oracle, per_batch, monkeypatch):
+    """tdoa_process with 4096-point rows and a 300-lag range: many pair-windows through the short-lag inverse,
+    against the oracle and against the general form."""
+    import tdoa_amd
+    block, wl, ml = 140_000, 70_000, 300
+    delays = [0, 41, -17]
+    caps = [np.concatenate([oracle.simulate_delayed_fm(block, 100 + d, 640 + k, 10 * s + k) for k in range(3)])
+            for s, d in enumerate(delays)]
+    pairs = [(0, 1), (0, 2), (1, 2)]
+    with tdoa_amd.Context(max_lag=ml, window_len=wl, windows_per_batch=per_batch) as c:
+        peaks, fine = None, None
+        for s, cap in enumerate(caps):
+            c.capture_upload(s, cap)
+        peaks, fine = c.process_fine(120.0)
+        assert peaks.shape == (6, 3)
+        for wid in range(6):
+            off = (wid // 2) * block + (wid % 2) * wl
+            pre = [oracle.b_preprocess(cp[2 * off:2 * (off + wl)])[0] for cp in caps]
+            for p, (i, j) in enumerate(pairs):
+                olag, ocorr = oracle.b_xcorr_peak(pre[i], pre[j], ml)
+                assert peaks[wid, p]["lag"] == olag == delays[j] - delays[i]
+                assert abs(peaks[wid, p]["corr"] - ocorr) <= REL_TOL * abs(ocorr)
+                of = oracle.b_refine_peak(pre[i], pre[j], olag, 120.0)
+                assert abs(fine[wid, p]["frac"] - of["frac"]) < 1e-4
+        monkeypatch.setenv("TDOA_NO_SHORT_LAG", "1")
+        general = c.process()
+        assert np.array_equal(general["lag"], peaks["lag"])
+        assert np.abs(general["corr"] - peaks["corr"]).max() <= REL_TOL * np.abs(peaks["corr"]).max()
