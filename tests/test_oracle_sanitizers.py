@@ -27,6 +27,11 @@ o.time_domain_correlation(ref[:5], ref[:7], 20000)
 w = o.simulate_weak_station("n3pay", 2000, 9)
 p, st = o.b_preprocess(w[:2 * 1999])
 o.b_xcorr_peak(p, p[:1500], 64)
+o.b_refine_peak(p, p[:1500], 0, 120.0)
+o.b_refine_peak(p[:3], p[:2], 63, 1.0)
+o.b_xcorr_all_lags(p[:100], p[:90], 64)
+o.block_power(w[:2000])
+o.b_discriminate(w[:2])
 o.simulate_delayed_fm(1000, 17, 1, 2)
 o.solve_tdoa([o.STATIONS[k] for k in o.COLLECTORS], [10.0, -20.0, 0.0])
 print("SANITIZED_OK")
