@@ -1,0 +1,45 @@
+"""Seeded sweep over window lengths, length mismatches and lag ranges: every plan variant the dispatcher can pick
+(short / long column kernels, short-lag and pruned inverse, any-size fallbacks) against the any-size kernels, which the
+small-size tests pin to the time-domain oracle.  A disagreement here is an indexing bug in one of the hot variants."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-5
+
+
+def _cases():
+    rng = np.random.default_rng(20260101)
+    out = []
+    for _ in range(36):
+        logn = rng.integers(16, 21)                       # FFT sizes 2^17 .. 2^21 (4096-point rows) and one below
+        n = int(rng.integers((1 << logn) // 2 + 10, (1 << logn) - 10))
+        cut = int(rng.integers(0, min(5000, n // 4)))     # second window shorter by `cut` samples
+        max_lag = int(rng.choice([3, 64, 127, 511, 512, 1023, 1024, 2047, 2048, 4095, 4096, 9000, 20000]))
+        max_lag = min(max_lag, (1 << logn) - n)           # keep N = nextpow2(n + max_lag) inside the bucket
+        if max_lag >= 2:
+            out.append((n, cut, max_lag, int(rng.integers(0, 2 ** 31))))
+    return out
+
+
+@pytest.mark.parametrize("n,cut,max_lag,seed", _cases())
+def test_hot_variants_agree_with_any_size_kernels(oracle, n, cut, max_lag, seed):
+    import tdoa_amd
+    delay = int(seed % (2 * max_lag - 1)) - (max_lag - 1)
+    a = oracle.simulate_delayed_fm(n, max(0, -delay), seed & 0xffff, 1)
+    b = oracle.simulate_delayed_fm(n, max(0, delay), seed & 0xffff, 2)[:2 * (n - cut)]
+    with tdoa_amd.Context(max_lag=max_lag, window_len=n) as c:
+        hot = c.fm_xcorr_lags(a, b, max_lag)
+        hot_peak = c.fm_xcorr(a, b, max_lag)
+        (_, _), fine = c.fm_xcorr_fine(a, b, max_lag, 1e9)
+        c.force_generic(True)
+        gen = c.fm_xcorr_lags(a, b, max_lag)
+        gen_peak = c.fm_xcorr(a, b, max_lag)
+        (_, _), gfine = c.fm_xcorr_fine(a, b, max_lag, 1e9)
+    peak = np.abs(gen).max()
+    assert peak > 0
+    assert np.abs(hot - gen).max() <= REL_TOL * peak
+    assert hot_peak[0] == gen_peak[0] == delay
+    assert abs(hot_peak[1] - gen_peak[1]) <= REL_TOL * abs(gen_peak[1])
+    assert abs(fine["frac"] - gfine["frac"]) < 1e-4
