@@ -20,6 +20,10 @@ def _cases():
         max_lag = min(max_lag, (1 << logn) - n)           # keep N = nextpow2(n + max_lag) inside the bucket
         if max_lag >= 2:
             out.append((n, cut, max_lag, int(rng.integers(0, 2 ** 31))))
+    for logn in (21, 22, 22, 23, 23, 24):                 # the long-column variants (N2 = 256 .. 2048), fewer cases
+        n = int(rng.integers((1 << logn) // 2 + 10, (1 << logn) - 20010))
+        max_lag = int(rng.choice([300, 4000, 20000]))
+        out.append((n, int(rng.integers(0, 3000)), max_lag, int(rng.integers(0, 2 ** 31))))
     return out
 
 
