@@ -47,3 +47,31 @@ def test_hot_variants_agree_with_any_size_kernels(oracle, n, cut, max_lag, seed)
     assert hot_peak[0] == gen_peak[0] == delay
     assert abs(hot_peak[1] - gen_peak[1]) <= REL_TOL * abs(gen_peak[1])
     assert abs(fine["frac"] - gfine["frac"]) < 1e-4
+
+
+@pytest.mark.parametrize("n_st,block,wlen,per_batch,max_lag,seed", [
+    (2, 70_000, 70_000, 0, 300, 1), (4, 150_000, 70_000, 1, 5000, 2), (5, 33_000, 11_000, 2, 100, 3),
+    (6, 262_144 + 4000, 131_072, 3, 2047, 4), (3, 9_001, 3_000, 0, 50, 5),
+])
+def test_batched_path_equals_pair_calls(oracle, n_st, block, wlen, per_batch, max_lag, seed):
+    """every (window, pair) of tdoa_process is the same arithmetic as one tdoa_fm_xcorr_u8 call on the same bytes:
+    the peak records must be identical bit for bit, whatever the station count, launch grouping or plan"""
+    import tdoa_amd
+    rng = np.random.default_rng(seed)
+    delays = [int(x) for x in rng.integers(0, max_lag // 3 + 1, size=n_st)]
+    caps = [np.concatenate([oracle.simulate_delayed_fm(block, d, 900 + 7 * seed + k, 100 * s + k) for k in range(3)])
+            for s, d in enumerate(delays)]
+    with tdoa_amd.Context(max_lag=max_lag, window_len=wlen, windows_per_batch=per_batch) as c:
+        peaks = c.process_u8(caps)
+        wpb = max(1, block // wlen)
+        wl = min(wlen, block)
+        assert peaks.shape == (3 * wpb, n_st * (n_st - 1) // 2)
+        for wid in range(3 * wpb):
+            off = (wid // wpb) * block + (wid % wpb) * wl
+            p = 0
+            for i in range(n_st):
+                for j in range(i + 1, n_st):
+                    lag, corr = c.fm_xcorr(caps[i][2 * off:2 * (off + wl)], caps[j][2 * off:2 * (off + wl)], max_lag)
+                    assert (int(peaks[wid, p]["lag"]), float(peaks[wid, p]["corr"])) == (lag, corr), (wid, i, j)
+                    assert lag == delays[j] - delays[i]
+                    p += 1
