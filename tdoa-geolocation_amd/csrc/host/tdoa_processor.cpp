@@ -157,9 +157,22 @@ int main(int argc, char **argv)
         for (auto &s : stations)
             if (base.find(s.name) != std::string::npos) { c.st = s; found = true; break; }
         if (!found) { std::fprintf(stderr, "TDOA processing failed: could not identify station from filename: %s\n", pos[i].c_str()); return 1; }
-        if (!read_file(pos[i], &c.raw, &err)) { std::fprintf(stderr, "TDOA processing failed: %s\n", err.c_str()); return 1; }
+        size_t n_samples = 0;
+        if (fm) {
+            // the batched path streams the file straight to the GPU later: only its size is needed here
+            FILE *f = std::fopen(pos[i].c_str(), "rb");
+            if (!f) { std::fprintf(stderr, "TDOA processing failed: failed to open file: %s\n", pos[i].c_str()); return 1; }
+            std::fseek(f, 0, SEEK_END);
+            const long long size = std::ftell(f);
+            std::fclose(f);
+            if (size < 0) { std::fprintf(stderr, "TDOA processing failed: failed to get file size: %s\n", pos[i].c_str()); return 1; }
+            n_samples = (size_t)size / 2;
+        } else {
+            if (!read_file(pos[i], &c.raw, &err)) { std::fprintf(stderr, "TDOA processing failed: %s\n", err.c_str()); return 1; }
+            n_samples = c.raw.size() / 2;
+        }
         std::printf("Loaded collector: %s at %.6f°, %.6f°, %.1fm (%zu samples)\n", c.st.name.c_str(), c.st.lat, c.st.lon,
-                    c.st.elev, c.raw.size() / 2);
+                    c.st.elev, n_samples);
         caps.push_back(std::move(c));
     }
     const int S = (int)caps.size();
@@ -218,7 +231,7 @@ int main(int argc, char **argv)
         }
     } else {
         // ---- north-star path: raw bytes in, one peak per (window, pair) out
-        for (int s = 0; s < S; s++)   // file -> pinned staging -> HBM (the bytes read above are only used for the listing)
+        for (int s = 0; s < S; s++)   // file -> pinned staging -> HBM
             if ((rc = tdoa_capture_upload_file(ctx, s, caps[s].path.c_str(), nullptr))) return die("tdoa_capture_upload_file", rc);
         int wpb = 0, W = 0;
         if ((rc = tdoa_num_windows(ctx, &wpb, &W))) return die("tdoa_num_windows", rc);
