@@ -349,8 +349,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SELF ? 1 : 
     // SELF: the two self-mirrored rows (0, N2/2), grid (1, n_pw); else the mirrored pair (a, N2 - a),
     // a = blockIdx.x + 1, grid (N2/2 - 1, n_pw).  (Two instantiations: the self-mirrored loader needs
     // twice the loads and would cost the paired kernel its occupancy.)
-    // An XCD-aware 1-D remap that puts the station pairs sharing a spectrum row on one XCD (staggered or
-    // not) measured 4-8 % SLOWER than this plain grid on cfg2, so the plain grid stays.
+    // An XCD-aware 1-D remap that puts the station pairs sharing a spectrum row on one XCD measured 4-8 % slower
+    // than this plain grid while the kernel was still latency-bound, and exactly the same (1.257 ms both ways) once
+    // it was bandwidth-bound: the plain grid stays.
     constexpr bool self = SELF;
     const int pw_index = blockIdx.y;
     const int a = self ? 0 : blockIdx.x + 1;
