@@ -125,3 +125,29 @@ def test_unit_ownership_window_major_and_pair_major():
     assert owners == [u % world for u in range(W * P)]
     assert set(owners) == set(range(8))
 
+
+
+def test_nstation_solver_ignores_a_zero_weight_outlier(capi):
+    """the plausibility gate hands a pair weight 0: a wildly wrong range difference on that pair must not move the fix"""
+    rng = np.random.default_rng(12)
+    ring = [(41.25 + 0.10 * np.cos(a), -96.0 + 0.13 * np.sin(a), 300.0 + 50 * rng.random())
+            for a in np.linspace(0.3, 2 * np.pi + 0.3, 6, endpoint=False)]
+    for _ in range(5):
+        tx = (41.25 + 0.04 * (rng.random() - 0.5), -96.0 + 0.05 * (rng.random() - 0.5), 330.0)
+        e = [capi.latlon_to_ecef(*s) for s in ring]
+        te = capi.latlon_to_ecef(*tx)
+        r = [float(np.linalg.norm(x - te)) for x in e]
+        rd = [r[j] - r[i] for i in range(6) for j in range(i + 1, 6)]
+        w = [1.0] * len(rd)
+        rc, clean, _ = capi.solve_nstation(ring, rd, weights=w)
+        assert rc == 0
+        err = np.linalg.norm(capi.latlon_to_ecef(clean[0], clean[1], tx[2]) - te)
+        assert err < 150.0                                     # Z is frozen at the centroid height, as in the reference
+        bad = list(rd)
+        bad[4] += 9000.0                                       # 30 us of error on one pair
+        w[4] = 0.0
+        rc, gated, _ = capi.solve_nstation(ring, bad, weights=w)
+        assert rc == 0 and np.allclose(gated[:2], clean[:2], rtol=0, atol=2e-4)     # ~20 m: one pair fewer, same fix
+        w[4] = 1.0
+        rc, pulled, _ = capi.solve_nstation(ring, bad, weights=w)
+        assert rc == 0 and np.linalg.norm(np.array(pulled[:2]) - np.array(clean[:2])) > 1e-3   # with weight 1 it would
