@@ -151,3 +151,35 @@ def test_pair_major_sharding_when_fewer_windows_than_ranks(oracle):
                 else:
                     assert fn[wid, p]["delay"] == 0.0
 
+
+
+def test_two_contexts_interleaved_and_threads(oracle):
+    """A Go host may hold one context per GPU in one process.  Two contexts on the
+    same device, used alternately and from two threads, must not disturb each other (separate streams, buffers and
+    captured graphs)."""
+    import threading
+    import tdoa_amd
+    blk, wl, ml = 30000, 10000, 200
+    caps_a = [oracle.simulate_delayed_fm(3 * blk, d, 31, 10 + i) for i, d in enumerate((0, 21, 55))]
+    caps_b = [oracle.simulate_delayed_fm(3 * blk, d, 32, 20 + i) for i, d in enumerate((0, 8, 90))]
+    with tdoa_amd.Context(max_lag=ml, window_len=wl) as ca, tdoa_amd.Context(max_lag=ml, window_len=wl) as cb:
+        ra = ca.process_u8(caps_a)
+        rb = cb.process_u8(caps_b)
+        assert (ra[:, 0]["lag"] == 21).all() and (rb[:, 1]["lag"] == 90).all()
+        for _ in range(3):                                   # alternate replays of the two captured graphs
+            assert ca.process().tobytes() == ra.tobytes()
+            assert cb.process().tobytes() == rb.tobytes()
+        out = {}
+
+        def run(name, ctx, want):
+            ok = True
+            for _ in range(10):
+                ok = ok and ctx.process().tobytes() == want.tobytes()
+            out[name] = ok
+
+        ts = [threading.Thread(target=run, args=("a", ca, ra)), threading.Thread(target=run, args=("b", cb, rb))]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        assert out == {"a": True, "b": True}
