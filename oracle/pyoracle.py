@@ -60,8 +60,8 @@ def lib():
         L.o_fast_snr.restype = C.c_double
         L.o_rand_float64.restype = C.c_double
         L.o_rand_float64.argtypes = [C.c_uint64, C.c_uint64]
-        L.ob_theta.restype = C.c_float
-        L.ob_theta.argtypes = [C.c_int, C.c_int]
+        L.ob_octant_angle.restype = C.c_float
+        L.ob_octant_angle.argtypes = [C.c_int, C.c_int]
         L.ob_angle_code.restype = C.c_int
         L.ob_angle_code.argtypes = [C.c_int, C.c_int]
         L.o_lowpass.argtypes = [fp, sz, C.c_int, fp]
@@ -352,8 +352,8 @@ def rand_float64(seed, counter):
 
 # --- mode B ------------------------------------------------------------------------
 
-def b_theta(i, q):
-    return lib().ob_theta(int(i), int(q))
+def b_octant_angle(mn, mx):
+    return lib().ob_octant_angle(int(mn), int(mx))
 
 
 def b_angle_code(i, q):
@@ -361,18 +361,18 @@ def b_angle_code(i, q):
 
 
 def b_discriminate(iq_u8):
-    """u8 IQ -> int16 phase codes (pi == 32768)."""
+    """u8 IQ -> phase codes in units of pi/32768, -32767 .. +32768 (int32)."""
     s = np.ascontiguousarray(iq_u8, dtype=np.uint8)
     n = s.size // 2
-    out = np.empty(n, dtype=np.int16)
-    lib().ob_discriminate_u8(_u8(s), C.c_size_t(n), out.ctypes.data_as(C.POINTER(C.c_int16)))
+    out = np.empty(n, dtype=np.int32)
+    lib().ob_discriminate_u8(_u8(s), C.c_size_t(n), out.ctypes.data_as(C.POINTER(C.c_int32)))
     return out
 
 
 def b_phase_stats(code):
-    p = np.ascontiguousarray(code, dtype=np.int16)
+    p = np.ascontiguousarray(code, dtype=np.int32)
     st = BStats()
-    lib().ob_phase_stats(p.ctypes.data_as(C.POINTER(C.c_int16)), C.c_size_t(p.size), C.byref(st))
+    lib().ob_phase_stats(p.ctypes.data_as(C.POINTER(C.c_int32)), C.c_size_t(p.size), C.byref(st))
     return st
 
 

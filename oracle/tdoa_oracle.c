@@ -950,54 +950,81 @@ void o_simulate_delayed_fm(uint8_t *out, size_t n, int delay, double mod_index, 
 /* mode B oracle (north-star pipeline; definition in DESIGN.md section 3)    */
 /* ------------------------------------------------------------------------ */
 
-/* K1 sample angle: theta = arg(I + iQ) for odd integers I, Q in [-255, 255], as an explicit
- * sequence of correctly rounded f32 operations that the device kernel repeats bit for bit:
- *   t = min(|I|,|Q|) * RCP[max(|I|,|Q|)]      RCP[m] = f32(1/m) (table of correctly rounded reciprocals)
- *   a = t * P(t*t)                              P: degree-7 Horner with fused multiply-adds
- *   octant fix-ups (pi/2 - a, pi - a, -a)
- * max error 1.7e-7 rad over all byte pairs. */
+/* K1 sample angle code.  I = 2 b_I - 255, Q = 2 b_Q - 255 are odd integers proportional to
+ * (b - 127.5)/127.5 of processor.go:198-199, never zero.  The angle code of one sample,
+ *   a(I, Q) = arg(I + iQ) in units of pi/32768, rounded,
+ * is built so that (i) collinear samples share one code and (ii) a(-I, -Q) = a(I, Q) -+ 32768
+ * EXACTLY -- property (ii) is what lets the discriminator below tell an exactly reversed sample:
+ *   1. reduce (|I|, |Q|) by their gcd                      (collinear samples -> one direction)
+ *   2. first-octant angle of the reduced direction as an explicit sequence of correctly rounded
+ *      f32 operations that the device kernel repeats bit for bit:
+ *        t = mn * RCP[mx]     RCP[m] = f32(1/m), mn = min, mx = max of the reduced pair
+ *        a = t * P(t*t)       P: degree-7 Horner with fused multiply-adds (max error 1.7e-7 rad)
+ *        c = rint(a * f32(32768/pi))                        0 < c <= 8192
+ *   3. octant / quadrant placement in INTEGER arithmetic: |Q| > |I| -> 16384 - c; I < 0 -> 32768 - c;
+ *      Q < 0 -> negate.  |a| <= 32768 - 41. */
 static const float K1_C[8] = {
     0x1.fffffcp-1f, -0x1.5551bcp-2f, 0x1.98f84ep-3f, -0x1.1f0f46p-3f,
     0x1.95c0f4p-4f, -0x1.e655d6p-5f, 0x1.8bf058p-6f, -0x1.31f904p-8f,
 };
-#define K1_PI     3.1415927410125732f
-#define K1_PIO2   1.5707963705062866f
+#define K1_CODE_SCALE 10430.3779296875f   /* f32(32768/pi) */
 
-float ob_theta(int I, int Q)
+/* atan(mn/mx) for 0 < mn <= mx <= 255 */
+float ob_octant_angle(int mn, int mx)
 {
-    int ax = I < 0 ? -I : I, ay = Q < 0 ? -Q : Q;
-    int mx = ax > ay ? ax : ay, mn = ax > ay ? ay : ax;
     float r = 1.0f / (float)mx;                  /* == RCP[mx] */
     float t = (float)mn * r;
     float z = t * t;
     float p = K1_C[7];
     for (int k = 6; k >= 0; k--)
         p = fmaf(p, z, K1_C[k]);
-    float a = p * t;
-    if (ay > ax) a = K1_PIO2 - a;
-    if (I < 0) a = K1_PI - a;
-    if (Q < 0) a = -a;
+    return p * t;
+}
+
+static int gcd_int(int a, int b)
+{
+    while (b) { int t = a % b; a = b; b = t; }
     return a;
 }
 
-/* K1: u8 IQ -> phase-difference FM discriminator -> 16-bit phase code.
- * With I = 2b_I - 255, Q = 2b_Q - 255 (exact odd integers proportional to (b-127.5)/127.5 of
- * processor.go:198-199, never zero):
- *   a_i    = rint(arg(x_i) * 32768/pi)                 angle code of one sample, |a_i| < 32768
- *   code_i = int16(a_i - a_{i-1})  (two's-complement wrap = the phase circle)   (i >= 1)
- *          = arg(x_i * conj(x_{i-1})) in units of pi/32768,   code_0 = code_1
- * x_i is never 0 for byte data, so the |p|^2 > 1e-10 gate of the prebuilt binary's
- * convertToInstantaneousFrequency never fires.  The code step (9.6e-5 rad) is far below the
- * phase noise that 8-bit I/Q quantisation itself causes (>= 2e-3 rad at full scale).
- * a_i depends only on the two bytes of sample i: the device keeps it as a 65536-entry table. */
-#define K1_CODE_SCALE 10430.3779296875f   /* f32(32768/pi) */
-
 int ob_angle_code(int I, int Q)
 {
-    return (int)lrintf(ob_theta(I, Q) * K1_CODE_SCALE);
+    int ax = I < 0 ? -I : I, ay = Q < 0 ? -Q : Q;
+    int g = gcd_int(ax, ay);
+    ax /= g;
+    ay /= g;
+    int mx = ax > ay ? ax : ay, mn = ax > ay ? ay : ax;
+    int c = (int)lrintf(ob_octant_angle(mn, mx) * K1_CODE_SCALE);
+    if (ay > ax) c = 16384 - c;
+    if (I < 0) c = 32768 - c;
+    if (Q < 0) c = -c;
+    return c;
 }
 
-void ob_discriminate_u8(const uint8_t *iq, size_t n, int16_t *code)
+/* K1: u8 IQ -> phase-difference FM discriminator -> phase code in units of pi/32768.
+ * The definition being quantised is the discriminator of the prebuilt reference binary (SURVEY.md
+ * section 8, row K1): p = x_i * conj(x_{i-1}), y_i = atan2(Im p, Re p), y_0 := y_1.  x_i is never 0
+ * for byte data, so its |p|^2 > 1e-10 gate never fires.  atan2 returns values in (-pi, +pi]: an
+ * exactly reversed sample (Im p = +0, Re p < 0) is +pi, never -pi.  Hence
+ *   w      = int16 wrap of (a_i - a_{i-1})              (two's-complement wrap = the phase circle)
+ *   code_i = w                                           if w != -32768
+ *          = +32768 if Im p >= 0 else -32767             if the two angle codes are exactly opposite
+ * (Im p has the sign of Q_i I_{i-1} - I_i Q_{i-1}; by property (ii) every exactly reversed pair has
+ * opposite codes).  code_i is within one step of y_i * 32768/pi AS A REAL NUMBER, -32767 <= code_i <= 32768.
+ * The step (9.6e-5 rad) is far below the phase noise 8-bit I/Q quantisation itself causes
+ * (>= 2e-3 rad at full scale).  The device stores -code_i as an int16. */
+static int32_t phase_code(const uint8_t *cur, const uint8_t *prev)
+{
+    int I = 2 * (int)cur[0] - 255, Q = 2 * (int)cur[1] - 255;
+    int Ip = 2 * (int)prev[0] - 255, Qp = 2 * (int)prev[1] - 255;
+    int a1 = ob_angle_code(I, Q), a0 = ob_angle_code(Ip, Qp);
+    int w = (int16_t)(uint16_t)((a1 - a0) & 0xffff);
+    if (w == -32768)
+        return (Q * Ip - I * Qp) >= 0 ? 32768 : -32767;
+    return w;
+}
+
+void ob_discriminate_u8(const uint8_t *iq, size_t n, int32_t *code)
 {
     if (n == 0)
         return;
@@ -1006,16 +1033,13 @@ void ob_discriminate_u8(const uint8_t *iq, size_t n, int16_t *code)
         return;
     }
 #pragma omp parallel for schedule(static)
-    for (long i = 1; i < (long)n; i++) {
-        int a1 = ob_angle_code(2 * (int)iq[2 * i] - 255, 2 * (int)iq[2 * i + 1] - 255);
-        int a0 = ob_angle_code(2 * (int)iq[2 * i - 2] - 255, 2 * (int)iq[2 * i - 1] - 255);
-        code[i] = (int16_t)(uint16_t)((a1 - a0) & 0xffff);
-    }
+    for (long i = 1; i < (long)n; i++)
+        code[i] = phase_code(iq + 2 * i, iq + 2 * i - 2);
     code[0] = code[1];
 }
 
 /* exact, order-independent statistics of the phase codes */
-void ob_phase_stats(const int16_t *code, size_t n, ob_stats *st)
+void ob_phase_stats(const int32_t *code, size_t n, ob_stats *st)
 {
     int64_t s1 = 0;
     uint64_t s2 = 0;
@@ -1043,7 +1067,7 @@ void ob_phase_stats(const int16_t *code, size_t n, ob_stats *st)
 void ob_preprocess_u8(const uint8_t *iq, size_t n, float *out, ob_stats *st_out)
 {
     ob_stats st;
-    int16_t *code = (int16_t *)malloc((n ? n : 1) * sizeof(int16_t));
+    int32_t *code = (int32_t *)malloc((n ? n : 1) * sizeof(int32_t));
     ob_discriminate_u8(iq, n, code);
     ob_phase_stats(code, n, &st);
     for (size_t i = 0; i < n; i++) {

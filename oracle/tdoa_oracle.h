@@ -122,18 +122,19 @@ void   o_simulate_delayed_fm(uint8_t *out, size_t n_samples, int delay_samples,
 double o_rand_float64(uint64_t seed, uint64_t counter);
 
 /* ---- mode B oracle (north-star pipeline) ----------- */
-float  ob_theta(int I, int Q);
-int    ob_angle_code(int I, int Q);
-void   ob_discriminate_u8(const uint8_t *iq, size_t n, int16_t *code);
+float  ob_octant_angle(int mn, int mx);          /* atan(mn/mx), 0 < mn <= mx <= 255, explicit f32 ops */
+int    ob_angle_code(int I, int Q);               /* arg(I + iQ) in units of pi/32768 */
+/* phase codes in units of pi/32768, -32767 <= code <= 32768 (+pi for an exactly reversed sample) */
+void   ob_discriminate_u8(const uint8_t *iq, size_t n, int32_t *code);
 typedef struct {
-    int64_t  s1;        /* sum of the 16-bit phase codes               */
+    int64_t  s1;        /* sum of the phase codes                       */
     uint64_t s2_lo;     /* sum of code^2                                */
     uint64_t s2_hi;     /* always 0 (kept for layout)                   */
     float    mean;      /* f32((double)s1 / n), in code units           */
     float    scale;     /* f32(1/sqrt(var)), 1.0f if var <= 0           */
     double   var;
 } ob_stats;
-void   ob_phase_stats(const int16_t *code, size_t n, ob_stats *st);
+void   ob_phase_stats(const int32_t *code, size_t n, ob_stats *st);
 void   ob_preprocess_u8(const uint8_t *iq, size_t n, float *out, ob_stats *st);
 /* c[d] = sum_i t[i]*s[i+d] (f64, zero outside), lags -(max_lag-1)..max_lag-1,
  * out[d + max_lag - 1]; scaled by 1/sqrt(nt). */

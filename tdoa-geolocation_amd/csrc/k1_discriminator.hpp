@@ -3,12 +3,19 @@
 //
 // Replaces (reference file:line): the u8 -> complex64 conversion of processor.go:195-201 and,
 // for the north-star pipeline, the instantaneous-frequency demodulation that exists only in
-// the prebuilt processor binary:
-//   a_i    = rint(arg(x_i) * 32768/pi)          angle code of one IQ sample (depends on its 2 bytes)
-//   code_i = int16(a_i - a_{i-1})               = arg(x_i * conj(x_{i-1})), wrapped;  code_0 := code_1
-// a_i comes from a 65536-entry int16 table (k_k1_build_table, built once per context with the
-// explicit f32 arithmetic of k1_theta, which the CPU restatement repeats bit for bit).  One
-// streaming pass (k_fm_demod) reads the capture bytes once, looks the angles up in an LDS copy of
+// the prebuilt processor binary: p = x_i conj(x_{i-1}),
+// y_i = atan2(Im p, Re p) in (-pi, +pi], y_0 := y_1.  Quantised to units of pi/32768:
+//   a_i    = angle code of one IQ sample (depends on its 2 bytes only; 65536-entry int16 table)
+//   w      = int16 wrap of (a_i - a_{i-1})        (the two's-complement wrap is the phase circle)
+//   code_i = w, except when the two angle codes are exactly opposite (w = -32768):
+//            +32768 if Im p >= 0 (an exactly reversed sample is +pi, as atan2(+0, negative) is), else -32767
+// so -32767 <= code_i <= 32768 is within one step of y_i as a real number; code_0 := code_1.
+// The table is built (k_k1_build_table, once per context) so that collinear samples share a code and
+// a(-I, -Q) = a(I, Q) -+ 32768 exactly: gcd-reduced direction, first-octant angle by the explicit f32
+// arithmetic of k1_octant_angle (which the CPU restatement repeats bit for bit), octant / quadrant
+// placement in integers.  Every exactly reversed pair therefore has opposite codes.
+// In memory a code is held NEGATED as an int16 (stored = -code in [-32768, 32767]).
+// One streaming pass (k_fm_demod) reads the capture bytes once, looks the angles up in an LDS copy of
 // the table, writes 2 bytes of code per sample and accumulates sum(code), sum(code^2) as exact
 // integers; the FFT pass then reads the codes.
 #pragma once
@@ -18,7 +25,6 @@
 namespace tdoa {
 
 // Reciprocal table RCP[k] = f32(1 / (2k+1)), k < 128, kept in LDS (random per-lane index).
-// Every kernel that evaluates K1 calls k1_init_rcp() once (it contains a barrier).
 __device__ __forceinline__ void k1_init_rcp(float *rcp)
 {
 #pragma clang fp contract(off)
@@ -26,16 +32,11 @@ __device__ __forceinline__ void k1_init_rcp(float *rcp)
     __syncthreads();
 }
 
-// theta = arg(I + iQ), I = 2 b_I - 255, Q = 2 b_Q - 255, for one IQ sample s = b_I | b_Q << 8:
-// t = min * RCP[max], degree-7 Horner in t^2 with fused multiply-adds, octant fix-ups.
-__device__ __forceinline__ float k1_theta(unsigned int s, const float *rcp)
+// atan(mn / mx) for odd 0 < mn <= mx <= 255: t = mn * RCP[mx], degree-7 Horner in t^2 with fused multiply-adds
+__device__ __forceinline__ float k1_octant_angle(int mn, int mx, const float *rcp)
 {
 #pragma clang fp contract(off)
-    const float fi = __builtin_fmaf(2.0f, (float)(s & 0xffu), -255.0f);
-    const float fq = __builtin_fmaf(2.0f, (float)((s >> 8) & 0xffu), -255.0f);
-    const float ax = fabsf(fi), ay = fabsf(fq);
-    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
-    const float t = mn * rcp[(unsigned int)mx >> 1];
+    const float t = (float)mn * rcp[mx >> 1];
     const float z = t * t;
     float p = -0x1.31f904p-8f;
     p = __builtin_fmaf(p, z, 0x1.8bf058p-6f);
@@ -45,17 +46,25 @@ __device__ __forceinline__ float k1_theta(unsigned int s, const float *rcp)
     p = __builtin_fmaf(p, z, 0x1.98f84ep-3f);
     p = __builtin_fmaf(p, z, -0x1.5551bcp-2f);
     p = __builtin_fmaf(p, z, 0x1.fffffcp-1f);
-    float a = p * t;
-    a = ay > ax ? 1.5707963705062866f - a : a;
-    a = (s & 0x80u) ? a : 3.1415927410125732f - a;            // I < 0  <=>  b_I < 128
-    return __uint_as_float(__float_as_uint(a) ^ ((~s & 0x8000u) << 16));   // Q < 0: negate
+    return p * t;
 }
 
-// angle code of one sample: rint(theta * 32768/pi), |code| < 32768
+// angle code of the IQ sample s = b_I | b_Q << 8 (I = 2 b_I - 255, Q = 2 b_Q - 255), |code| <= 32768 - 41
 __device__ __forceinline__ int k1_angle_code(unsigned int s, const float *rcp)
 {
 #pragma clang fp contract(off)
-    return __float2int_rn(k1_theta(s, rcp) * 10430.3779296875f);
+    const int I = 2 * (int)(s & 0xffu) - 255, Q = 2 * (int)((s >> 8) & 0xffu) - 255;
+    int ax = I < 0 ? -I : I, ay = Q < 0 ? -Q : Q;
+    int g = ax, h = ay;
+    while (h) { const int t = g % h; g = h; h = t; }      // gcd of two odd numbers (odd, >= 1)
+    ax /= g;
+    ay /= g;
+    const int mx = ax > ay ? ax : ay, mn = ax > ay ? ay : ax;
+    int c = __float2int_rn(k1_octant_angle(mn, mx, rcp) * 10430.3779296875f);   // f32(32768/pi)
+    if (ay > ax) c = 16384 - c;
+    if (I < 0) c = 32768 - c;
+    if (Q < 0) c = -c;
+    return c;
 }
 
 // Table slot of sample s = b_I | b_Q << 8.  LDS banks are picked by bits 1..5 of a 2-byte index;
@@ -72,10 +81,24 @@ __global__ __launch_bounds__(256) void k_k1_build_table(short *table)
     table[k1_slot(s)] = (short)k1_angle_code(s, rcp);
 }
 
-__device__ __forceinline__ float k1_normalise(int code, float mean, float scale)
+// stored (negated) phase code of sample `cur` after sample `prev` from their angle codes; the rare
+// exactly-opposite case reads the sign of Im p = Q I' - I Q' off the bytes
+__device__ __forceinline__ int k1_stored_code(int a_cur, int a_prev, unsigned int cur, unsigned int prev)
+{
+    int st = (int)(short)(a_prev - a_cur);
+    if (st == -32768) {      // code +32768 unless Im p < 0
+        const int I = 2 * (int)(cur & 0xffu) - 255, Q = 2 * (int)((cur >> 8) & 0xffu) - 255;
+        const int Ip = 2 * (int)(prev & 0xffu) - 255, Qp = 2 * (int)((prev >> 8) & 0xffu) - 255;
+        if (Q * Ip - I * Qp < 0) st = 32767;
+    }
+    return st;
+}
+
+// normalised discriminator sample from a STORED code: (float(code) - mean) * scale with code = -stored
+__device__ __forceinline__ float k1_normalise(int stored, float mean, float scale)
 {
 #pragma clang fp contract(off)
-    float d = (float)code - mean;
+    float d = -(float)stored - mean;
     return d * scale;
 }
 
@@ -214,10 +237,19 @@ __global__ __launch_bounds__(kDemodThreads) void k_fm_demod(const SWDesc *sw, in
                     for (int k = 0; k < 9; k++) a[k] = lut[k1_slot(sm[k])];
                     int t1 = 0;
                     unsigned long long t2 = 0;
+                    bool opposite = false;
 #pragma unroll
                     for (int k = 0; k < 8; k++) {
-                        c[k] = (int)(short)(a[k + 1] - a[k]);
-                        t1 += c[k];
+                        c[k] = (int)(short)(a[k] - a[k + 1]);                  // stored = -code
+                        opposite = opposite || c[k] == -32768;
+                    }
+                    if (__any(opposite)) {   // exactly opposite angle codes: +pi unless Im p < 0 (k1_stored_code)
+#pragma unroll
+                        for (int k = 0; k < 8; k++) c[k] = k1_stored_code(a[k + 1], a[k], sm[k + 1], sm[k]);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        t1 -= c[k];
                         t2 += (unsigned int)(c[k] * c[k]);     // <= 2^30 each
                     }
                     s1 += t1;
@@ -231,11 +263,12 @@ __global__ __launch_bounds__(kDemodThreads) void k_fm_demod(const SWDesc *sw, in
                         int v = 0;
                         if (i < len && len >= 2) {
                             const int ii = i == 0 ? 1 : i;
-                            v = (int)(short)(lut[k1_slot(p[ii])] - lut[k1_slot(p[ii - 1])]);
+                            const unsigned int sc = p[ii], sp = p[ii - 1];
+                            v = k1_stored_code(lut[k1_slot(sc)], lut[k1_slot(sp)], sc, sp);
                         }
                         c[k] = v;
                         if (i < len) {
-                            s1 += v;
+                            s1 -= v;
                             s2 += (unsigned long long)(unsigned int)(v * v);
                         }
                     }

@@ -1,0 +1,100 @@
+"""GPU: the timed mode-B path against its two independent anchors at BASELINE config-2 size
+(L = 2 000 000, max_lag 20000, N = 2^21) -- VERDICT r01 item 1.
+
+(i)  oracle/float_pipeline.py: float64 atan2 discriminator (the prebuilt binary's definition),
+     f64 FFT correlation; no table, no 16-bit code, nothing shared with the kernels or with ob_*.
+(ii) processor.go:646-736 timeDomainCorrelation (o_time_domain_all_lags) on the same normalised signals, unequal
+     lengths so that the lag search is not trivial; the FFT path restricted to [0, maxLag_eff) must pick the same index.
+Measured deviations are printed (quoted in DESIGN.md section 5)."""
+import numpy as np
+import pytest
+
+from oracle import float_pipeline as fp
+
+pytestmark = pytest.mark.gpu
+
+L, ML = 2_000_000, 20000
+
+
+def _inputs(oracle):
+    out = [("delayed_fm", oracle.simulate_delayed_fm(L, 0, 4242, 1), oracle.simulate_delayed_fm(L, 37, 4242, 2))]
+    sim = [oracle.simulate_station(nm, L, oracle.SEED_BASE + i) for i, nm in enumerate(oracle.COLLECTORS)]
+    weak = [oracle.simulate_weak_station(nm, L, oracle.SEED_BASE + i) for i, nm in enumerate(oracle.COLLECTORS)]
+    for tag, caps in (("simulator.go", sim), ("weak_signal_simulator.go", weak)):
+        for kind, off in (("ref", 0), ("tgt", L)):
+            for (i, j) in ((0, 1), (0, 2), (1, 2)):
+                out.append(("%s %s %d-%d" % (tag, kind, i, j), caps[i][2 * off:2 * (off + L)], caps[j][2 * off:2 * (off + L)]))
+    return out
+
+
+def test_gpu_vs_float_definition_full_size(oracle, capsys):
+    """lag identical everywhere; corr within 1e-5 on the real-amplitude FM pair, within 1e-4 on the simulators'
+    +-1..3 LSB captures (the 16-bit phase code: see tests/test_mode_b_anchors.py); constant windows give (0, 0.0)"""
+    import tdoa_amd
+    rows = []
+    with tdoa_amd.Context(max_lag=ML, window_len=L) as c:
+        for name, a, b in _inputs(oracle):
+            lag, corr = c.fm_xcorr(a, b, ML)
+            flag, fcorr, _ = fp.xcorr_peak_u8(a, b, ML)
+            assert lag == flag, (name, lag, flag)
+            if fcorr == 0.0:
+                assert corr == 0.0
+                rows.append((name, lag, corr, 0.0))
+                continue
+            dev = abs(corr - fcorr) / abs(fcorr)
+            rows.append((name, lag, corr, dev))
+            assert dev < (1e-5 if name == "delayed_fm" else 1e-4), (name, dev)
+    with capsys.disabled():
+        print("\n  GPU mode B vs float64 atan2 pipeline, L = %d, max_lag %d" % (L, ML))
+        for r in rows:
+            print("    %-38s lag %6d  corr %13.6f  |dcorr|/|corr| %.2e" % r)
+
+
+@pytest.mark.parametrize("blocks,ns,delay", [(1980, 2_000_000, 4321), (1999, 2_000_000, 0), (500, 600_000, 19999)])
+def test_gpu_fft_path_vs_go_time_domain_correlation(oracle, blocks, ns, delay, capsys):
+    """template of exactly B*1000 samples: the mode-B sum and processor.go:686-720 coincide term by term (the extra
+    sample handed to the Go form is dropped by its block truncation, :691), so the FFT path on lags [0, maxLag_eff)
+    must reproduce timeDomainCorrelation's values and its first-max index."""
+    import tdoa_amd
+    nt = blocks * 1000
+    a = oracle.simulate_delayed_fm(nt, 0, 777, 1)
+    b = oracle.simulate_delayed_fm(ns, delay, 777, 2)
+    eff = max(1, min(ML, ns - (nt + 1)))                                  # processor.go:668-675
+    with tdoa_amd.Context(max_lag=ML, window_len=L) as c:
+        lags = c.fm_xcorr_lags(a, b, ML)[ML - 1:ML - 1 + eff]              # lags 0 .. eff-1
+        vt, _ = c.fm_preprocess(a)                                         # the SAME preprocessed inputs (bit-equal to ob_*)
+        vs, _ = c.fm_preprocess(b)
+    wt, _ = oracle.b_preprocess(a)
+    ws, _ = oracle.b_preprocess(b)
+    assert np.array_equal(vt.view(np.uint32), wt.view(np.uint32)) and np.array_equal(vs.view(np.uint32), ws.view(np.uint32))
+    t64 = np.concatenate([vt, [0.0]]).astype(np.complex64)
+    go = oracle.time_domain_all_lags(t64, vs.astype(np.complex64), ML)
+    assert go.size == eff
+    err = np.abs(go - lags).max() / np.abs(go).max()
+    assert err < 1e-5
+    gd, gc = oracle.time_domain_correlation(t64, vs.astype(np.complex64), ML)
+    assert gd == int(np.argmax(np.abs(lags))) == delay
+    assert abs(gc - lags[gd]) <= 1e-5 * abs(gc)
+    with capsys.disabled():
+        print("\n  FFT path vs timeDomainCorrelation: %d lags, template %d, max |diff| %.2e of the peak, index %d" % (eff, nt, err, gd))
+
+
+def test_k1_exact_reversals_bit_exact(oracle):
+    """exactly reversed samples (+pi), collinear reversals of different magnitude, and non-collinear samples whose
+    angle codes are exactly opposite (sign of Im p decides), in the vector fast path and in the window head / tail"""
+    import tdoa_amd
+    rng = np.random.default_rng(5)
+    iq = rng.integers(0, 256, size=2 * 70000, dtype=np.uint8)
+    special = [129, 129, 126, 126, 128, 126, 127, 129, 128, 128, 126, 126, 129, 129, 127, 127, 254, 253, 0, 1, 234, 229, 0, 6]
+    for off in (0, 2, 4096, 2 * 512 * 40 + 10, 2 * 70000 - len(special)):
+        iq[off:off + len(special)] = special
+    with tdoa_amd.Context(max_lag=100, window_len=70000) as c:
+        for lo, n in ((0, 70000), (2, 69999), (4096, 30001)):
+            got, st = c.fm_preprocess(iq[lo:lo + 2 * n])
+            want, ost = oracle.b_preprocess(iq[lo:lo + 2 * n])
+            assert (st.s1, st.s2_lo) == (ost.s1, ost.s2_lo)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        sim = oracle.simulate_station("n3pay", 50000, 3)[:100000]          # +-1..3 LSB: reversals everywhere
+        got, st = c.fm_preprocess(sim)
+        want, ost = oracle.b_preprocess(sim)
+        assert (st.s1, st.s2_lo) == (ost.s1, ost.s2_lo) and np.array_equal(got.view(np.uint32), want.view(np.uint32))

@@ -1,0 +1,94 @@
+"""CPU: the two independent anchors of the mode-B oracle.
+
+(i)  oracle/float_pipeline.py -- the discriminator as read off the prebuilt reference binary
+     (atan2(Im p, Re p), float64, no table, no 16-bit code) carried end to end
+     through mean / scale / f64 FFT correlation / peak pick -- against the ob_* oracle the device
+     kernels are bit-exact with.
+(ii) timeDomainCorrelation as processor.go:646-736 executes it (o_time_domain_all_lags: 1000-sample
+     blocks, f64 block sums, sqrt(numBlocks*1000) gain, lags [0, maxLag_eff), first strict max) against
+     the mode-B correlation restricted to the same lags, on the SAME normalised real signals.
+
+The GPU versions at BASELINE sizes are in tests/test_gpu_anchors.py."""
+import numpy as np
+import pytest
+
+from oracle import float_pipeline as fp
+
+L, ML = 200_000, 3000
+
+
+def _three_inputs(oracle, n):
+    """(name, template bytes, signal bytes): a true sample delay, simulator.go and weak_signal_simulator.go captures"""
+    out = [("delayed_fm", oracle.simulate_delayed_fm(n, 0, 4242, 1), oracle.simulate_delayed_fm(n, 37, 4242, 2))]
+    sim = [oracle.simulate_station(nm, n, oracle.SEED_BASE + i) for i, nm in enumerate(oracle.COLLECTORS)]
+    weak = [oracle.simulate_weak_station(nm, n, oracle.SEED_BASE + i) for i, nm in enumerate(oracle.COLLECTORS)]
+    for tag, caps in (("simulator.go", sim), ("weak_signal_simulator.go", weak)):
+        for kind, off in (("ref", 0), ("tgt", n)):
+            for (i, j) in ((0, 1), (0, 2), (1, 2)):
+                out.append(("%s %s %d-%d" % (tag, kind, i, j), caps[i][2 * off:2 * (off + n)], caps[j][2 * off:2 * (off + n)]))
+    return out
+
+
+def test_code_pipeline_vs_float_definition(oracle, capsys):
+    """peak lag identical on every input; the 16-bit phase code costs at most 1e-6 of the peak on a real-amplitude FM
+    signal and at most 1e-4 on the simulators' +-1..3 LSB captures (few distinct I/Q values: the code's rounding
+    error is a fixed function of the sample pair and does not average out).  Measured values are printed."""
+    rows = []
+    for name, a, b in _three_inputs(oracle, L):
+        ta, _ = oracle.b_preprocess(a)
+        tb, _ = oracle.b_preprocess(b)
+        olag, ocorr, oc = oracle.b_xcorr_peak_fft(ta, tb, ML)
+        flag, fcorr, fc = fp.xcorr_peak_u8(a, b, ML)
+        assert olag == flag, name
+        if fcorr == 0.0:                       # weak-simulator reference blocks: constant bytes, zero phase
+            assert ocorr == 0.0 and not oc.any()
+            rows.append((name, olag, fcorr, 0.0, 0.0))
+            continue
+        dev = abs(ocorr - fcorr) / abs(fcorr)
+        dev_all = np.abs(oc - fc).max() / abs(fcorr)
+        rows.append((name, olag, fcorr, dev, dev_all))
+        assert dev < (1e-6 if name == "delayed_fm" else 1e-4), (name, dev)
+    with capsys.disabled():
+        print("\n  16-bit-code oracle vs float64 atan2 pipeline, L = %d, max_lag %d" % (L, ML))
+        for r in rows:
+            print("    %-38s lag %6d  corr %12.6f  |dcorr|/|corr| %.2e  max|dc|/|corr| %.2e" % r)
+
+
+def test_float_pipeline_conventions():
+    assert fp.pick_peak(np.array([0.0, -2.0, 1.0, 2.0, 0.0]), 3) == (1, 2.0)        # tie -> positive lag
+    assert fp.pick_peak(np.array([2.0, 0.0, 1.0, 0.0, 2.0]), 3) == (2, 2.0)
+    assert fp.pick_peak(np.array([2.0, 0.0, 2.0, 0.0, -3.0]), 3) == (2, -3.0)
+    assert fp.pick_peak(np.array([np.nan, 0.0, 0.0, 0.0, 0.0]), 3) == (0, 0.0)      # NaN never wins; all-zero -> (0, 0.0)
+    assert fp.pick_peak(np.array([1.0, 1.0, 1.0, 1.0, 1.0]), 3) == (0, 1.0)         # tie -> smaller |lag|
+    y = fp.discriminate(np.array([128, 128, 126, 126, 128, 128], np.uint8))        # (1,1) -> (-3,-3) -> (1,1)
+    assert y[1] == np.pi and y[2] == np.pi and y[0] == y[1]
+    assert fp.discriminate(np.zeros(0, np.uint8)).size == 0 and fp.discriminate(np.array([1, 2], np.uint8))[0] == 0.0
+    v = fp.normalise(np.array([1.0, 2.0, 3.0, 4.0]))
+    assert abs(v.mean()) < 1e-15 and abs((v * v).mean() - 1.0) < 1e-15
+    assert not fp.normalise(np.ones(5)).any()
+    t, s = np.array([1.0, 2.0, 3.0]), np.array([0.0, 1.0, 2.0, 3.0, 0.0])
+    c = fp.xcorr_lags(t, s, 3)                                                        # template found at lag +1
+    assert np.allclose(c * np.sqrt(3.0), [0.0, 3.0, 8.0, 14.0, 8.0], atol=1e-12)         # lags -2 .. +2
+    assert fp.pick_peak(c, 3)[0] == 1
+
+
+@pytest.mark.parametrize("blocks,ns,delay", [(20, 26000, 137), (7, 9500, 0), (33, 40000, 1999)])
+def test_mode_b_correlation_vs_go_time_domain(oracle, blocks, ns, delay):
+    """SURVEY section 7 'hard parts': mode B restricted to [0, maxLag_eff) must pick the index timeDomainCorrelation
+    picks on the same preprocessed inputs.  With a template of exactly B*1000 samples (+1, which the block
+    truncation of processor.go:691 drops) the two definitions coincide term by term:
+    corr[d] = (B*1000)^(-1/2) sum_{i < B*1000} t_i s_{i+d}."""
+    nt = blocks * 1000
+    a = oracle.simulate_delayed_fm(nt, 0, 777, 1)
+    b = oracle.simulate_delayed_fm(ns, delay, 777, 2)
+    vt, _ = oracle.b_preprocess(a)
+    vs, _ = oracle.b_preprocess(b)
+    max_lag = 20000                                                       # processor.go:633
+    eff = max(1, min(max_lag, ns - (nt + 1)))                             # processor.go:668-675
+    go = oracle.time_domain_all_lags(np.concatenate([vt, [0.0]]).astype(np.complex64), vs.astype(np.complex64), max_lag)
+    assert go.size == eff
+    mb = oracle.b_xcorr_all_lags(vt, vs, eff)[eff - 1:]                   # lags 0 .. eff-1
+    assert np.abs(go - mb).max() <= 1e-6 * np.abs(go).max()
+    gd, gc = oracle.time_domain_correlation(np.concatenate([vt, [0.0]]).astype(np.complex64), vs.astype(np.complex64), max_lag)
+    assert gd == int(np.argmax(np.abs(mb))) == delay                     # first strict max == argmax (no exact ties here)
+    assert abs(gc - mb[gd]) <= 1e-6 * abs(gc)

@@ -253,23 +253,48 @@ def test_simulator_shape_and_determinism(oracle):
 
 def test_k1_codes_agree_with_the_elf_discriminator_definition(oracle):
     """SURVEY section 8, row K1 (read off the prebuilt binary): x = ((I-127.5)/127.5, (Q-127.5)/127.5),
-    p = x_i conj(x_{i-1}), y_i = atan2(Im p, Re p) unless |p|^2 <= 1e-10, y_0 := y_1.  The 16-bit phase code is that
-    angle in units of pi/32768, up to the two roundings of the angle codes it is the difference of."""
+    p = x_i conj(x_{i-1}), y_i = atan2(Im p, Re p) unless |p|^2 <= 1e-10, y_0 := y_1.  The phase code is that
+    angle in units of pi/32768 AS A REAL NUMBER in (-pi, +pi] (no modulo 2 pi: an exactly reversed sample is +pi,
+    a near reversal keeps the sign of Im p), up to the two roundings of the angle codes it is the difference of."""
+    from oracle import float_pipeline as fp
     rng = np.random.default_rng(2024)
-    iq = rng.integers(0, 256, size=2 * 50000, dtype=np.uint8)
+    iq = rng.integers(0, 256, size=2 * 200000, dtype=np.uint8)
     iq[:12] = [0, 0, 255, 255, 0, 255, 255, 0, 127, 128, 128, 127]       # corners and the centre
+    # exactly reversed samples: equal magnitude, and collinear with different magnitudes (Im p = 0, Re p < 0)
+    iq[20:28] = [129, 129, 126, 126, 128, 126, 127, 129]                    # (3,3)->(-3,-3), (1,-3)->(-1,3)
+    iq[28:36] = [128, 128, 126, 126, 129, 129, 127, 127]                    # (1,1)->(-3,-3), (3,3)->(-1,-1)
+    # near reversals at full scale whose two angle codes are exactly opposite although the samples are not collinear:
+    # the sign of Im p decides (sample 21: Im p < 0 -> -pi side; sample 23: Im p > 0 -> +pi side)
+    iq[40:48] = [254, 253, 0, 1, 234, 229, 0, 6]
     code = oracle.b_discriminate(iq).astype(np.float64)
-    x = ((iq[0::2].astype(np.float64) - 127.5) + 1j * (iq[1::2].astype(np.float64) - 127.5)) / 127.5
-    p = x[1:] * np.conj(x[:-1])
-    assert (np.abs(p) ** 2 > 1e-10).all()                                  # the binary's gate can never fire on u8 data
-    y = np.arctan2(p.imag, p.real)
-    y = np.concatenate([[y[0]], y])                                        # y_0 := y_1
-    diff = code * (np.pi / 32768.0) - y
-    diff = (diff + np.pi) % (2 * np.pi) - np.pi                            # the int16 wrap is the phase circle
+    assert code.min() >= -32767 and code.max() <= 32768
+    y = fp.discriminate(iq)                                                # exact-product float64 statement
+    diff = code * (np.pi / 32768.0) - y                                    # NOT wrapped
     assert np.abs(diff).max() <= 1.01 * (np.pi / 32768.0)                   # two half-step roundings
     assert code[0] == code[1]
-    # and the single-sample angle itself against atan2, every one of the 65536 byte pairs
+    assert code[11] == 32768 and code[13] == 32768 and code[15] == 32768 and code[17] == 32768
+    assert code[21] == -32767 and -np.pi < y[21] < -3.1415 and code[23] == 32768 and 3.1415 < y[23] < np.pi
+    # a small-amplitude capture (simulator.go: I/Q of +-1, +-3 LSB) is full of exact reversals
+    sim = oracle.simulate_station("kx0u", 20000, 7)
+    cs, ys = oracle.b_discriminate(sim).astype(np.float64), fp.discriminate(sim)
+    assert (ys == np.pi).sum() > 100 and (ys == -np.pi).sum() == 0
+    assert np.abs(cs * (np.pi / 32768.0) - ys).max() <= 1.01 * (np.pi / 32768.0)
+
+
+def test_k1_angle_table_properties(oracle):
+    """every one of the 65536 byte pairs: within half a step (+ the 1.7e-7 rad of the polynomial) of atan2,
+    collinear samples share a code, opposite samples differ by exactly half a turn"""
+    from math import gcd
+    code = np.array([[oracle.b_angle_code(2 * i - 255, 2 * q - 255) for q in range(256)] for i in range(256)])
     bi, bq = np.meshgrid(np.arange(256), np.arange(256), indexing="ij")
-    want = np.arctan2(2.0 * bq - 255.0, 2.0 * bi - 255.0)
-    got = np.array([[oracle.b_theta(2 * i - 255, 2 * q - 255) for q in range(256)] for i in range(256)])
-    assert np.abs(got - want).max() < 5e-7
+    want = np.arctan2(2.0 * bq - 255.0, 2.0 * bi - 255.0) * (32768.0 / np.pi)
+    assert np.abs(code - want).max() <= 0.5 + 0.01
+    assert np.abs(code).max() <= 32768 - 41
+    opp = code[::-1, ::-1]                                                  # (b_I, b_Q) -> (255 - b_I, 255 - b_Q)
+    assert (np.abs(code - opp) == 32768).all()
+    for (i, q, k) in [(1, 1, 3), (1, 3, 5), (3, 5, 7), (7, 1, 9), (5, 11, 21), (1, 1, 255)]:
+        for si in (1, -1):
+            for sq in (1, -1):
+                assert oracle.b_angle_code(si * i, sq * q) == oracle.b_angle_code(si * i * k, sq * q * k)
+    assert gcd(3, 9) == 3 and oracle.b_angle_code(1, 1) == 8192 and oracle.b_angle_code(-1, 1) == 24576
+    assert oracle.b_angle_code(-1, -1) == -24576 and oracle.b_angle_code(1, -1) == -8192
