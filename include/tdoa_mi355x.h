@@ -224,6 +224,16 @@ int tdoa_fm_xcorr_lags_u8(tdoa_ctx *ctx, const uint8_t *iq1, size_t n1, const ui
 
 /* tests only: run the any-size fallback kernels even where a hot-size kernel exists */
 int tdoa_debug_force_generic(tdoa_ctx *ctx, int on);
+/* tests / measurements only: pick kernel variants by hand (a bit set = that specialised form is NOT used).
+ * The same switches can be given once, at tdoa_create time, through the environment (TDOA_NO_SHORT_LAG=1,
+ * TDOA_NO_FUSED_ROWS=1, TDOA_NO_SEGMENT_FORM=1); results are the same to rounding whichever form runs. */
+enum {
+    TDOA_DEBUG_GENERIC_KERNELS = 1,  /* any-size LDS radix-4 kernels instead of the radix-16 register kernels        */
+    TDOA_DEBUG_NO_SHORT_LAG    = 2,  /* general pruned inverse even when the search range is below 4095 lags          */
+    TDOA_DEBUG_NO_FUSED_ROWS   = 4,  /* separate forward row pass even when every station is in at most two pairs     */
+    TDOA_DEBUG_NO_SEGMENT_FORM = 8   /* no LDS-resident overlap-save correlation for search ranges below 1024 lags    */
+};
+int tdoa_debug_flags(tdoa_ctx *ctx, unsigned flags);
 
 /* ---- downstream (processor.go:125-163, 932-1045), host side ---------------- */
 void tdoa_latlon_to_ecef(double lat, double lon, double elev, double xyz[3]);

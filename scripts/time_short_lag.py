@@ -17,11 +17,8 @@ TX = (41.20, -96.00, 400.0)
 for max_lag in (128, 511, 1023, 2047, 4095, 20000):
     row = {"max_lag": max_lag}
     for mode in ("short", "general"):
-        if mode == "general":
-            os.environ["TDOA_NO_SHORT_LAG"] = "1"
-        else:
-            os.environ.pop("TDOA_NO_SHORT_LAG", None)
         with tdoa_amd.Context(max_lag=max_lag) as c:
+            c.debug_flags(no_short_lag=(mode == "general"))
             for s in range(3):
                 c.synth_capture(s, 66_666_666, ST[s], TX, 0x5D0A0000 + s)
             c.process(want_host=False)

@@ -77,6 +77,16 @@ __device__ __forceinline__ void mul_base_step16(float2 (&v)[16], float2 base, fl
 }
 
 __device__ __forceinline__ int pad16(int i) { return i + (i >> 4); }
+
+// A value the compiler must treat as unknown.  The stage twiddles of a row transform are the same for every row a
+// workgroup handles; when a kernel transforms several rows one after the other, common-subexpression elimination
+// would keep all 2 x 15 twiddle powers alive from the first row to the last (60 VGPRs) instead of rebuilding them
+// from one root (~25 complex multiplies).  Laundering the root per call keeps the register file for data.
+__device__ __forceinline__ float2 opaque(float2 w)
+{
+    asm volatile("" : "+v"(w.x), "+v"(w.y));
+    return w;
+}
 constexpr int kRowLds = 4096 + 256;   // padded float2 per 4096-point row
 
 // stages 2 and 3 of a 4096-point row FFT whose stage-1 outputs X[k] (thread j, in v[oreg(k)])
@@ -89,7 +99,7 @@ __device__ __forceinline__ void row4096_finish(float2 (&v)[16], float2 *lds, int
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < 16; r++) v[r] = lds[pad16(j + 256 * r)];
-    mul_powers16(v, unit_root((float)(j & 15), 2.0f / 256.0f, INV));
+    mul_powers16(v, opaque(unit_root((float)(j & 15), 2.0f / 256.0f, INV)));
     fft16<INV>(v);
     __syncthreads();
     {
@@ -100,17 +110,19 @@ __device__ __forceinline__ void row4096_finish(float2 (&v)[16], float2 *lds, int
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < 16; r++) v[r] = lds[pad16(j + 256 * r)];
-    mul_powers16(v, unit_root((float)j, 2.0f / 4096.0f, INV));
+    mul_powers16(v, opaque(unit_root((float)j, 2.0f / 4096.0f, INV)));
     fft16<INV>(v);
 }
 
 // ---------------------------------------------------------------------------
 // forward row pass, N1 = 4096, in place.  grid (N2, n_sw), 256 threads, static LDS 34 KB
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_fwd_row4096(float2 *TZ, FftPlan pl)
+// row_mul: row index = blockIdx.x * row_mul (1: every row, grid.x = N2; N2/2: only the two self-mirrored rows 0 and
+// N2/2, grid.x = 2 -- the rest of the rows are then transformed inside k_pair_rows_fused4096)
+__global__ __launch_bounds__(256) void k_fwd_row4096(float2 *TZ, FftPlan pl, int row_mul)
 {
     __shared__ float2 lds[kRowLds];
-    float2 *row = TZ + (size_t)blockIdx.y * pl.Nc + (size_t)blockIdx.x * 4096;
+    float2 *row = TZ + (size_t)blockIdx.y * pl.Nc + (size_t)blockIdx.x * row_mul * 4096;
     const int j = threadIdx.x;
     float2 v[16];
 #pragma unroll
@@ -325,77 +337,17 @@ __global__ __launch_bounds__(256) void k_fwd_col16x_c16(const SWDesc *sw, const 
 }
 
 // ---------------------------------------------------------------------------
-// inverse row pass with K3 fused, N1 = 4096: one workgroup owns rows a and N2 - a (a >= 1).
-// Thread t builds Q[a][t + 256 r] and its mirror Q[N2-a][4095 - t - 256 r] from the same four
-// spectrum values, so stage 1 of row a (item t) and of row N2-a (item 255 - t) need no exchange.
-// grid (N2/2 - 1, n_pw) [+ (1, n_pw) for the SELF instance], 256 threads, dynamic LDS 68 KB.
+// second half of the inverse row pair kernels: the two rows' Q values are in registers (va: row a as stage-1
+// item t; vb: row b as stage-1 item 255 - t, or t for the self-mirrored pair); three radix-16 stages through two
+// LDS images, the four-step twiddle, then either the two V rows or (FK > 0) the row pair's share of the short-lag
+// column sums.  All threads of the workgroup call it; LDS must be free to overwrite on entry.
 // ---------------------------------------------------------------------------
-//
-// FK > 0 is the short-lag form (|lag| < 512 FK - 1): only the elements m = n2 N1 + n1 with n2 = 0, n1 < 256 FK
-// and n2 = N2 - 1, n1 >= 4096 - 256 FK can hold a searched lag, and they sit in registers k < FK and k >= 16 - FK
-// of every thread.  Instead of the two V rows (64 KB) the workgroup writes its share of those column sums,
-//   P0[k][j] = V[a][n1] + V[b][n1]                          (n2 = 0,      n1 = j + 256 k)
-//   P1[k][j] = V[a][n1] conj(w_a) + V[b][n1] conj(w_b)      (n2 = N2 - 1, n1 = 4096 - 256 FK + j + 256 k)
-// with w_r = e^{2 pi i r/N2}: part[pw][row pair][P0 | P1][256 FK] float2 (4 FK KB); k_fused_reduce adds the
-// N2/2 shares in a fixed order.  V is never written or read: the inverse side moves 16 N bytes less.
-// (amdgpu_waves_per_eu(2, 2): the 68 KB of dynamic LDS already limit a CU to two workgroups = two waves per
-// SIMD; told so, the scheduler keeps ~20 loads in flight instead of squeezing registers for a third wave it
-// cannot have -- the short-lag instances otherwise dropped to two loads in flight, 1.41 ms against 1.25 ms.)
 template <bool SELF, int FK>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SELF ? 1 : 2, SELF ? 8 : 2))) void k_inv_row_pair4096(const PWDesc *pw, const float2 *Z, float2 *V, FftPlan pl)
+__device__ __forceinline__ void inv_row_pair_tail(float2 (&va)[16], float2 (&vb)[16], float2 *lds, const int t, const int a,
+                                                  const int b, const int pw_index, float2 *V, const FftPlan &pl)
 {
-    extern __shared__ float2 lds[];   // 2 * kRowLds
-    const int N2 = pl.N2;
-    // SELF: the two self-mirrored rows (0, N2/2), grid (1, n_pw); else the mirrored pair (a, N2 - a),
-    // a = blockIdx.x + 1, grid (N2/2 - 1, n_pw).  (Two instantiations: the self-mirrored loader needs
-    // twice the loads and would cost the paired kernel its occupancy.)
-    // An XCD-aware 1-D remap that puts the station pairs sharing a spectrum row on one XCD measured 4-8 % slower
-    // than this plain grid while the kernel was still latency-bound, and exactly the same (1.257 ms both ways) once
-    // it was bandwidth-bound: the plain grid stays.
     constexpr bool self = SELF;
-    const int pw_index = blockIdx.y;
-    const int a = self ? 0 : blockIdx.x + 1;
-    const PWDesc d = pw[pw_index];
-    const int b = self ? N2 / 2 : N2 - a;
-    const float2 *ZaA = Z + (size_t)d.sw_a * pl.Nc + (size_t)a * 4096;
-    const float2 *ZaB = Z + (size_t)d.sw_a * pl.Nc + (size_t)b * 4096;
-    const float2 *ZbA = Z + (size_t)d.sw_b * pl.Nc + (size_t)a * 4096;
-    const float2 *ZbB = Z + (size_t)d.sw_b * pl.Nc + (size_t)b * 4096;
-    const int t = threadIdx.x;
-    const float invNc = 1.0f / (float)pl.Nc;
-    float2 va[16], vb[16];
-    if constexpr (self) {
-        // each row mirrors onto itself: row 0 by k1 -> (4096 - k1) mod 4096, row N2/2 by k1 -> 4095 - k1;
-        // every thread builds only its own Q values (the mirror operand is re-read)
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int k1 = t + 256 * r;
-            float2 q, qm;
-            const int m0 = (4096 - k1) & 4095;
-            pair_q(ZaA[k1], ZaA[m0], ZbA[k1], ZbA[m0], unit_root((float)((long long)k1 * N2), invNc, false), q, qm);
-            va[r] = q;
-            const int m1 = 4095 - k1;
-            pair_q(ZaB[k1], ZaB[m1], ZbB[k1], ZbB[m1], unit_root((float)((long long)k1 * N2 + b), invNc, false), q, qm);
-            vb[r] = q;
-        }
-    } else {
-        // w(k) = W_N^k, k = (t + 256 r) N2 + a  =>  w = w0 * W_32^r
-        const long long k0 = (long long)t * N2 + a;
-        const float2 st = make_float2(0.98078528040323043f, -0.19509032201612825f);   // e^{-2 pi i/32}
-        float2 w = unit_root((float)k0, invNc, false);
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int k1 = t + 256 * r;
-            float2 q, qm;
-            pair_q(ZaA[k1], ZaB[4095 - k1], ZbA[k1], ZbB[4095 - k1], w, q, qm);
-            va[r] = q;
-            vb[15 - r] = qm;
-            if ((r & 3) == 3)   // re-anchor every 4 steps to keep the running product short
-                w = unit_root((float)(k0 + (long long)(r + 1) * 256 * N2), invNc, false);
-            else
-                w = cmul(w, st);
-        }
-    }
+    const int N2 = pl.N2;
     const int item_b = self ? t : 255 - t;   // which item of row b this thread's stage-1 butterfly is
     fft16<true>(va);
     fft16<true>(vb);
@@ -469,6 +421,220 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SELF ? 1 : 
             part[256 * FK + k * 256 + j] = cadd(cmul(va[oreg(16 - FK + k)], ca), cmul(vb[oreg(16 - FK + k)], cb));
         }
     }
+}
+
+// one 4096-point forward row transform, registers in (x[r] = row[j + 256 r]) and out (X[j + 256 k] in
+// x[oreg(k)]), through one LDS image that must be free to overwrite on entry
+__device__ __forceinline__ void fwd_row1_4096(float2 (&x)[16], float2 *img, const int j)
+{
+    fft16<false>(x);
+    row4096_finish<false>(x, img, j);
+}
+
+// two 4096-point forward row transforms side by side, registers in (x[r] = row[j + 256 r]) and out
+// (X[j + 256 k] in x[oreg(k)]), each row through its own LDS image.  LDS must be free to overwrite on entry.
+__device__ __forceinline__ void fwd_rows2_4096(float2 (&x)[16], float2 (&y)[16], float2 *la, float2 *lb, const int j)
+{
+    fft16<false>(x);
+    fft16<false>(y);
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        la[pad16(16 * j + k)] = x[oreg(k)];
+        lb[pad16(16 * j + k)] = y[oreg(k)];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        x[r] = la[pad16(j + 256 * r)];
+        y[r] = lb[pad16(j + 256 * r)];
+    }
+    {
+        const float2 w = unit_root((float)(j & 15), 2.0f / 256.0f, false);
+        mul_powers16(x, w);
+        mul_powers16(y, w);
+    }
+    fft16<false>(x);
+    fft16<false>(y);
+    __syncthreads();
+    {
+        const int dd = ((j >> 4) << 8) + (j & 15);
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            la[pad16(dd + 16 * k)] = x[oreg(k)];
+            lb[pad16(dd + 16 * k)] = y[oreg(k)];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        x[r] = la[pad16(j + 256 * r)];
+        y[r] = lb[pad16(j + 256 * r)];
+    }
+    {
+        const float2 w = unit_root((float)j, 2.0f / 4096.0f, false);
+        mul_powers16(x, w);
+        mul_powers16(y, w);
+    }
+    fft16<false>(x);
+    fft16<false>(y);
+}
+
+// ---------------------------------------------------------------------------
+// inverse row pass with K3 fused, N1 = 4096: one workgroup owns rows a and N2 - a (a >= 1).
+// Thread t builds Q[a][t + 256 r] and its mirror Q[N2-a][4095 - t - 256 r] from the same four
+// spectrum values, so stage 1 of row a (item t) and of row N2-a (item 255 - t) need no exchange.
+// grid (N2/2 - 1, n_pw) [+ (1, n_pw) for the SELF instance], 256 threads, dynamic LDS 68 KB.
+// ---------------------------------------------------------------------------
+//
+// FK > 0 is the short-lag form (|lag| < 512 FK - 1): only the elements m = n2 N1 + n1 with n2 = 0, n1 < 256 FK
+// and n2 = N2 - 1, n1 >= 4096 - 256 FK can hold a searched lag, and they sit in registers k < FK and k >= 16 - FK
+// of every thread.  Instead of the two V rows (64 KB) the workgroup writes its share of those column sums,
+//   P0[k][j] = V[a][n1] + V[b][n1]                          (n2 = 0,      n1 = j + 256 k)
+//   P1[k][j] = V[a][n1] conj(w_a) + V[b][n1] conj(w_b)      (n2 = N2 - 1, n1 = 4096 - 256 FK + j + 256 k)
+// with w_r = e^{2 pi i r/N2}: part[pw][row pair][P0 | P1][256 FK] float2 (4 FK KB); k_fused_reduce adds the
+// N2/2 shares in a fixed order.  V is never written or read: the inverse side moves 16 N bytes less.
+// (amdgpu_waves_per_eu(2, 2): the 68 KB of dynamic LDS already limit a CU to two workgroups = two waves per
+// SIMD; told so, the scheduler keeps ~20 loads in flight instead of squeezing registers for a third wave it
+// cannot have -- the short-lag instances otherwise dropped to two loads in flight, 1.41 ms against 1.25 ms.)
+template <bool SELF, int FK>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SELF ? 1 : 2, SELF ? 8 : 2))) void k_inv_row_pair4096(const PWDesc *pw, const float2 *Z, float2 *V, FftPlan pl)
+{
+    extern __shared__ float2 lds[];   // 2 * kRowLds
+    const int N2 = pl.N2;
+    // SELF: the two self-mirrored rows (0, N2/2), grid (1, n_pw); else the mirrored pair (a, N2 - a),
+    // a = blockIdx.x + 1, grid (N2/2 - 1, n_pw).  (Two instantiations: the self-mirrored loader needs
+    // twice the loads and would cost the paired kernel its occupancy.)
+    // An XCD-aware 1-D remap that puts the station pairs sharing a spectrum row on one XCD measured 4-8 % slower
+    // than this plain grid while the kernel was still latency-bound, and exactly the same (1.257 ms both ways) once
+    // it was bandwidth-bound: the plain grid stays.
+    constexpr bool self = SELF;
+    const int pw_index = blockIdx.y;
+    const int a = self ? 0 : blockIdx.x + 1;
+    const PWDesc d = pw[pw_index];
+    const int b = self ? N2 / 2 : N2 - a;
+    const float2 *ZaA = Z + (size_t)d.sw_a * pl.Nc + (size_t)a * 4096;
+    const float2 *ZaB = Z + (size_t)d.sw_a * pl.Nc + (size_t)b * 4096;
+    const float2 *ZbA = Z + (size_t)d.sw_b * pl.Nc + (size_t)a * 4096;
+    const float2 *ZbB = Z + (size_t)d.sw_b * pl.Nc + (size_t)b * 4096;
+    const int t = threadIdx.x;
+    const float invNc = 1.0f / (float)pl.Nc;
+    float2 va[16], vb[16];
+    if constexpr (self) {
+        // each row mirrors onto itself: row 0 by k1 -> (4096 - k1) mod 4096, row N2/2 by k1 -> 4095 - k1;
+        // every thread builds only its own Q values (the mirror operand is re-read)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int k1 = t + 256 * r;
+            float2 q, qm;
+            const int m0 = (4096 - k1) & 4095;
+            pair_q(ZaA[k1], ZaA[m0], ZbA[k1], ZbA[m0], unit_root((float)((long long)k1 * N2), invNc, false), q, qm);
+            va[r] = q;
+            const int m1 = 4095 - k1;
+            pair_q(ZaB[k1], ZaB[m1], ZbB[k1], ZbB[m1], unit_root((float)((long long)k1 * N2 + b), invNc, false), q, qm);
+            vb[r] = q;
+        }
+    } else {
+        // w(k) = W_N^k, k = (t + 256 r) N2 + a  =>  w = w0 * W_32^r
+        const long long k0 = (long long)t * N2 + a;
+        const float2 st = make_float2(0.98078528040323043f, -0.19509032201612825f);   // e^{-2 pi i/32}
+        float2 w = unit_root((float)k0, invNc, false);
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int k1 = t + 256 * r;
+            float2 q, qm;
+            pair_q(ZaA[k1], ZaB[4095 - k1], ZbA[k1], ZbB[4095 - k1], w, q, qm);
+            va[r] = q;
+            vb[15 - r] = qm;
+            if ((r & 3) == 3)   // re-anchor every 4 steps to keep the running product short
+                w = unit_root((float)(k0 + (long long)(r + 1) * 256 * N2), invNc, false);
+            else
+                w = cmul(w, st);
+        }
+    }
+    inv_row_pair_tail<SELF, FK>(va, vb, lds, t, a, b, pw_index, V, pl);
+}
+
+// ---------------------------------------------------------------------------
+// forward row pass FUSED into the inverse row pair kernel (rows a and N2 - a, a >= 1): the workgroup reads the
+// COLUMN-pass output T of both stations (the same 4 x 32 KB the pair kernel reads anyway), runs the four forward
+// row transforms itself, exchanges the two rows b through LDS to get at their mirrored elements, and carries on
+// with K3 + the inverse rows as k_inv_row_pair4096 does.  The separate forward row pass (16 Nc bytes per
+// station-window, read + write) disappears; the price is that a station's row pair is transformed once per pair
+// the station is in.  The host takes this form when n_pw <= n_sw (3 stations / 3 pairs, or a single pair).
+// The self-mirrored rows 0 and N2/2 keep the two-kernel form (k_fwd_row4096 on those two rows only).
+// grid (N2/2 - 1, n_pw), 256 threads, dynamic LDS 68 KB.
+// ---------------------------------------------------------------------------
+template <int FK>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_pair_rows_fused4096(const PWDesc *pw, const float2 *T, float2 *V, FftPlan pl)
+{
+    extern __shared__ float2 lds[];   // 2 * kRowLds
+    const int N2 = pl.N2;
+    const int pw_index = blockIdx.y;
+    const int a = blockIdx.x + 1, b = N2 - a;
+    const PWDesc d = pw[pw_index];
+    const float2 *TaA = T + (size_t)d.sw_a * pl.Nc + (size_t)a * 4096;
+    const float2 *TaB = T + (size_t)d.sw_a * pl.Nc + (size_t)b * 4096;
+    const float2 *TbA = T + (size_t)d.sw_b * pl.Nc + (size_t)a * 4096;
+    const float2 *TbB = T + (size_t)d.sw_b * pl.Nc + (size_t)b * 4096;
+    const int t = threadIdx.x;
+    float2 *la = lds, *lb = lds + kRowLds;
+    // Register plan (256 per lane at two waves per SIMD): one row in the transform at a time (32 + its temporaries),
+    // the next row's 16 loads in flight (32), the finished rows a held (64); the rows b are parked in their LDS image
+    // in natural order, where the pair stage reads their mirrored elements.  The scheduling barriers pin that order:
+    // left alone, the compiler overlaps the phases and spills the held spectra to scratch.
+    float2 xa[16], ya[16];     // x: template station, y: signal station; a / b: the row
+#pragma unroll
+    for (int r = 0; r < 16; r++) xa[r] = TaA[t + 256 * r];
+#pragma unroll
+    for (int r = 0; r < 16; r++) ya[r] = TbA[t + 256 * r];
+    __builtin_amdgcn_sched_barrier(0);
+    fwd_row1_4096(xa, la, t);
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        float2 xb[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) xb[r] = TaB[t + 256 * r];
+        __builtin_amdgcn_sched_barrier(0);
+        fwd_row1_4096(ya, lb, t);
+        __builtin_amdgcn_sched_barrier(0);
+        float2 yb[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) yb[r] = TbB[t + 256 * r];
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        fwd_row1_4096(xb, la, t);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; k++) la[t + 256 * k] = xb[oreg(k)];     // natural order: Z[b][t + 256 k]
+        __builtin_amdgcn_sched_barrier(0);
+        fwd_row1_4096(yb, lb, t);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; k++) lb[t + 256 * k] = yb[oreg(k)];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    float2 va[16], vb[16];
+    {
+        // w(k) = W_N^k, k = (t + 256 r) N2 + a  =>  w = w0 * W_32^r   (as in k_inv_row_pair4096)
+        const float invNc = 1.0f / (float)pl.Nc;
+        const long long k0 = (long long)t * N2 + a;
+        const float2 st = make_float2(0.98078528040323043f, -0.19509032201612825f);   // e^{-2 pi i/32}
+        float2 w = unit_root((float)k0, invNc, false);
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            float2 q, qm;
+            pair_q(xa[oreg(r)], la[4095 - t - 256 * r], ya[oreg(r)], lb[4095 - t - 256 * r], w, q, qm);
+            va[r] = q;
+            vb[15 - r] = qm;
+            if ((r & 3) == 3)
+                w = unit_root((float)(k0 + (long long)(r + 1) * 256 * N2), invNc, false);
+            else
+                w = cmul(w, st);
+        }
+    }
+    __syncthreads();      // every mirrored read is done before the inverse stages overwrite the images
+    inv_row_pair_tail<false, FK>(va, vb, lds, t, a, b, pw_index, V, pl);
 }
 
 // short-lag form, second half: element sums over the N2/2 row-pair shares in a fixed order (four interleaved

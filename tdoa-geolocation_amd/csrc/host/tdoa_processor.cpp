@@ -75,9 +75,9 @@ bool read_file(const std::string &path, std::vector<uint8_t> *out, std::string *
 {
     FILE *f = std::fopen(path.c_str(), "rb");
     if (!f) { *err = "failed to open file: " + path; return false; }
-    std::fseek(f, 0, SEEK_END);
-    long long size = std::ftell(f);
-    std::fseek(f, 0, SEEK_SET);
+    if (std::fseek(f, 0, SEEK_END) != 0) { std::fclose(f); *err = "failed to get file size: " + path; return false; }
+    const long long size = std::ftell(f);                     // -1 on a directory, FIFO or other unseekable path
+    if (size < 0 || std::fseek(f, 0, SEEK_SET) != 0) { std::fclose(f); *err = "failed to get file size: " + path; return false; }
     out->resize((size_t)size);
     size_t got = 0;
     while (got < (size_t)size) {
@@ -251,8 +251,10 @@ int main(int argc, char **argv)
                     clip += x.has_clipping;
                     overload += x.has_overload;
                 }
-                const double ref_ratio = pw[2] / pw[0];                       // collector.go:231
-                const double tgt_ratio = (pw[1] / pw[0] + pw[1] / pw[2]) / 2.0; // collector.go:240-242
+                // an all-127/128 block has power 0.25 at least, but an empty or all-127.5-equivalent one must not print inf/NaN
+                const auto ratio = [](double a, double b) { return b > 0 ? a / b : 0.0; };
+                const double ref_ratio = ratio(pw[2], pw[0]);                       // collector.go:231
+                const double tgt_ratio = (ratio(pw[1], pw[0]) + ratio(pw[1], pw[2])) / 2.0; // collector.go:240-242
                 std::printf("%s: REF %.2f  TGT %.2f  REF %.2f  | REF blocks %s (%.2fx), TGT/REF %.2fx%s | %d clipped, %d low-level windows of %d\n",
                             caps[s].st.name.c_str(), pw[0], pw[1], pw[2],
                             (ref_ratio > 2.0 || ref_ratio < 0.5) ? "INCONSISTENT" : "consistent", ref_ratio, tgt_ratio,
@@ -314,7 +316,11 @@ int main(int argc, char **argv)
     if (S == 3) rc = tdoa_solve_3station(lle.data(), rd.data(), out, &iters);
     else rc = tdoa_solve_nstation(lle.data(), S, rd.data(), tgt_w.data(), 0, out, &iters);   // weights: median |corr| per pair
     if (rc != TDOA_OK) {                                       // processor.go:919-921
-        std::fprintf(stderr, "TDOA solution failed: %s at iteration %d\n", tdoa_strerror(rc), iters);
+        if (rc == TDOA_ERR_INVALID)
+            std::fprintf(stderr, "TDOA solution failed: fewer usable station pairs than unknowns (no target window of the "
+                                 "other pairs passed the +-%.1f-sample plausibility gate, or a weight is not finite)\n", gate);
+        else
+            std::fprintf(stderr, "TDOA solution failed: %s at iteration %d\n", tdoa_strerror(rc), iters);
         tdoa_destroy(ctx);
         return 3;
     }

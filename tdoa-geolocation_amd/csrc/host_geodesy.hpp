@@ -83,7 +83,10 @@ inline int solve_3station(const double st[9], const double *rd, double out[3], i
 // ECEF X,Y (Z frozen at the centroid like the reference, processor.go:1004) or X,Y,Z when
 // solve_z is set.  Same start (centroid), damping (0.5), iteration cap (10) and 1 m stop rule as
 // the reference; with n = 3 and weights {1,1,0} it solves the reference's own 2x2 system.
-// returns 0 ok, -1 singular normal matrix.
+// A pair with weight 0 is skipped; a negative or non-finite weight (or range difference of a used pair) is an
+// error, and so is a weight set that leaves fewer usable pairs than unknowns -- with nothing to fit the
+// iteration would "converge" at the centroid after 0 steps.
+// returns 0 ok, -1 singular normal matrix, -2 unsupported station count, -3 too few usable pairs / bad weights.
 inline int solve_nstation(const double *st_lle, int n, const double *rd, const double *wt, int solve_z,
                           int max_iter, double damping, double tol_m, double out[3], int *iters)
 {
@@ -95,6 +98,18 @@ inline int solve_nstation(const double *st_lle, int n, const double *rd, const d
     }
     latlon_to_ecef(c[0], c[1], c[2], x);
     const int nu = solve_z ? 3 : 2;
+    {
+        int used = 0, p = 0;
+        for (int i = 0; i < n; i++)
+            for (int j = i + 1; j < n; j++, p++) {
+                const double w = wt ? wt[p] : 1.0;
+                if (!(w >= 0) || !std::isfinite(w)) return -3;        // negative or NaN / inf
+                if (w == 0) continue;
+                if (!std::isfinite(rd[p])) return -3;
+                used++;
+            }
+        if (used < nu) return -3;
+    }
     int it = 0;
     for (; it < max_iter; it++) {
         double r[64], u[64][3];

@@ -243,9 +243,22 @@ __global__ __launch_bounds__(kDemodThreads) void k_fm_demod(const SWDesc *sw, in
                         c[k] = (int)(short)(a[k] - a[k + 1]);                  // stored = -code
                         opposite = opposite || c[k] == -32768;
                     }
-                    if (__any(opposite)) {   // exactly opposite angle codes: +pi unless Im p < 0 (k1_stored_code)
+                    if (__any(opposite)) {
+                        // Exactly opposite angle codes mean +pi unless Im p < 0, and Im p < 0 needs two NON-collinear
+                        // samples less than one code step away from a reversal: |x_i||x_{i-1}| > 2 * 32768/pi = 20861
+                        // in units of (2b - 255).  A small-amplitude capture (simulator.go: +-3 LSB) is full of exact
+                        // reversals but can never get there -- if every byte of the lane's nine samples is within
+                        // [96, 159], |x|^2 <= 2 * 63^2 = 7938 -- so the byte-level check is skipped for it.
+                        const uint4 q = qs[half];
+                        const unsigned int y0 = q.x ^ 0x80808080u, y1 = q.y ^ 0x80808080u, y2 = q.z ^ 0x80808080u,
+                                           y3 = q.w ^ 0x80808080u, y4 = (sm[0] | (sm[0] << 16)) ^ 0x80808080u;
+                        // a byte b is in [96, 159] iff the top three bits of b ^ 0x80 are equal
+                        const unsigned int far = ((y0 ^ (y0 << 1)) | (y1 ^ (y1 << 1)) | (y2 ^ (y2 << 1)) | (y3 ^ (y3 << 1)) |
+                                                  (y4 ^ (y4 << 1))) & 0xC0C0C0C0u;
+                        if (__any(opposite && far != 0)) {
 #pragma unroll
-                        for (int k = 0; k < 8; k++) c[k] = k1_stored_code(a[k + 1], a[k], sm[k + 1], sm[k]);
+                            for (int k = 0; k < 8; k++) c[k] = k1_stored_code(a[k + 1], a[k], sm[k + 1], sm[k]);
+                        }
                     }
 #pragma unroll
                     for (int k = 0; k < 8; k++) {

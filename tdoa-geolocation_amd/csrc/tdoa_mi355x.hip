@@ -73,7 +73,10 @@ struct tdoa_ctx {
 
     // whole-step hipGraph of tdoa_process (launch-bound when windows are processed in many groups)
     int n_cu = 256;                         // multiprocessors of this device
-    bool use_graph = true;
+    bool use_graph = true;                  // TDOA_NO_GRAPH=1 at tdoa_create time turns the whole-step hipGraph off
+    bool short_lag = true;                  // TDOA_NO_SHORT_LAG=1 at tdoa_create time forces the general inverse for short searches
+    bool fused_rows = false;                // forward row pass inside the pair kernel when P <= S (TDOA_FUSED_ROWS=1 / tdoa_debug_flags)
+    bool segment_form = true;               // TDOA_NO_SEGMENT_FORM=1: no LDS-resident overlap-save form for short searches
     uint64_t alloc_gen = 0;                 // bumped whenever a workspace buffer moves
     std::vector<uint64_t> graph_key;
     hipGraph_t graph = nullptr;
@@ -280,7 +283,7 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
     // short-lag form: the inverse row kernel emits its shares of the few column sums that can hold a lag and V is
     // never written (needs lag_lo - 1 .. lag_hi + 1 inside [-512 fk, 512 fk - 1] for the refinement neighbours)
     int fk = 0;
-    if (row16 && !std::getenv("TDOA_NO_SHORT_LAG")) {
+    if (row16 && ctx->short_lag) {
         const int reach = std::max(lag_hi + 1, -(lag_lo - 1));
         fk = reach <= 511 ? 1 : reach <= 1023 ? 2 : reach <= 2047 ? 4 : reach <= 4095 ? 8 : 0;
     }
@@ -336,10 +339,15 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
             hipLaunchKernelGGL(k_fwd_col_c16, dim3(pl.N1 / pl.C, n_sw), dim3(256), lds_col, st, d_sw, codes,
                                code_stride, stats, tz, pl);
     }
+    // forward row pass fused into the pair kernel: pays when a station's rows are re-transformed at most as often as
+    // they would be written and read back (no more pair-windows than station-windows: 3 stations, or a single pair)
+    const bool fused_rows = row16 && ctx->fused_rows && n_pw > 0 && n_pw <= n_sw;
     {
-        ProfScope ps(ctx, TDOA_K_FWD_ROW, 2.0 * nc8 * n_sw);
-        if (row16)
-            hipLaunchKernelGGL(k_fwd_row4096, dim3(pl.N2, n_sw), dim3(256), 0, st, tz, pl);
+        ProfScope ps(ctx, TDOA_K_FWD_ROW, fused_rows ? 2.0 * 8.0 * 4096 * 2 * n_sw : 2.0 * nc8 * n_sw);
+        if (fused_rows)    // only the two self-mirrored rows 0 and N2/2 (their pair kernel reads finished spectra)
+            hipLaunchKernelGGL(k_fwd_row4096, dim3(2, n_sw), dim3(256), 0, st, tz, pl, pl.N2 / 2);
+        else if (row16)
+            hipLaunchKernelGGL(k_fwd_row4096, dim3(pl.N2, n_sw), dim3(256), 0, st, tz, pl, 1);
         else
             hipLaunchKernelGGL(k_fwd_row, dim3(pl.N2, n_sw), dim3(256), lds_row, st, tz, pl);
     }
@@ -347,23 +355,23 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
         {
             ProfScope ps(ctx, TDOA_K_INV_ROW, 3.0 * nc8 * n_pw);
             if (fk) {
-#define TDOA_FUSED_ROWS(FK)                                                                                          \
+#define TDOA_PAIR_ROWS(FK)                                                                                           \
     do {                                                                                                             \
-        if (pl.N2 > 2)                                                                                               \
+        if (pl.N2 > 2 && fused_rows)                                                                                 \
+            hipLaunchKernelGGL((k_pair_rows_fused4096<FK>), dim3(pl.N2 / 2 - 1, n_pw), dim3(256), lds_pair16, st,    \
+                               d_pw, tz, v, pl);                                                                     \
+        else if (pl.N2 > 2)                                                                                          \
             hipLaunchKernelGGL((k_inv_row_pair4096<false, FK>), dim3(pl.N2 / 2 - 1, n_pw), dim3(256), lds_pair16, st,  \
                                d_pw, tz, v, pl);                                                                     \
         hipLaunchKernelGGL((k_inv_row_pair4096<true, FK>), dim3(1, n_pw), dim3(256), lds_pair16, st, d_pw, tz, v, pl); \
     } while (0)
-                if (fk == 1) TDOA_FUSED_ROWS(1);
-                else if (fk == 2) TDOA_FUSED_ROWS(2);
-                else if (fk == 4) TDOA_FUSED_ROWS(4);
-                else TDOA_FUSED_ROWS(8);
-#undef TDOA_FUSED_ROWS
+                if (fk == 1) TDOA_PAIR_ROWS(1);
+                else if (fk == 2) TDOA_PAIR_ROWS(2);
+                else if (fk == 4) TDOA_PAIR_ROWS(4);
+                else TDOA_PAIR_ROWS(8);
             } else if (row16) {
-                if (pl.N2 > 2)
-                    hipLaunchKernelGGL((k_inv_row_pair4096<false, 0>), dim3(pl.N2 / 2 - 1, n_pw), dim3(256), lds_pair16, st,
-                                       d_pw, tz, v, pl);
-                hipLaunchKernelGGL((k_inv_row_pair4096<true, 0>), dim3(1, n_pw), dim3(256), lds_pair16, st, d_pw, tz, v, pl);
+                TDOA_PAIR_ROWS(0);
+#undef TDOA_PAIR_ROWS
             } else {
                 hipLaunchKernelGGL(k_inv_row_pair, dim3(pl.N2 / 2, n_pw), dim3(256), lds_row2, st, d_pw, tz, v, pl);
             }
@@ -439,6 +447,11 @@ int allow_big_lds(tdoa_ctx *ctx)
     if ((rc = set_lds(ctx, k_inv_row_pair4096<true, 4>, all))) return rc;
     if ((rc = set_lds(ctx, k_inv_row_pair4096<false, 8>, all))) return rc;
     if ((rc = set_lds(ctx, k_inv_row_pair4096<true, 8>, all))) return rc;
+    if ((rc = set_lds(ctx, k_pair_rows_fused4096<0>, all))) return rc;
+    if ((rc = set_lds(ctx, k_pair_rows_fused4096<1>, all))) return rc;
+    if ((rc = set_lds(ctx, k_pair_rows_fused4096<2>, all))) return rc;
+    if ((rc = set_lds(ctx, k_pair_rows_fused4096<4>, all))) return rc;
+    if ((rc = set_lds(ctx, k_pair_rows_fused4096<8>, all))) return rc;
     return TDOA_OK;
 }
 
@@ -640,7 +653,12 @@ int tdoa_create(const tdoa_params *p, tdoa_ctx **out)
             return TDOA_ERR_HIP;
         }
     }
+    // run-time switches are read ONCE here (a captured graph must not depend on an environment that changes later)
     if (const char *e = std::getenv("TDOA_NO_GRAPH")) ctx->use_graph = !(e[0] == '1');
+    if (const char *e = std::getenv("TDOA_NO_SHORT_LAG")) ctx->short_lag = !(e[0] == '1');
+    if (const char *e = std::getenv("TDOA_FUSED_ROWS")) ctx->fused_rows = e[0] == '1';
+    if (const char *e = std::getenv("TDOA_NO_FUSED_ROWS")) ctx->fused_rows = !(e[0] == '1');
+    if (const char *e = std::getenv("TDOA_NO_SEGMENT_FORM")) ctx->segment_form = !(e[0] == '1');
     *out = ctx;
     return TDOA_OK;
 }
@@ -901,6 +919,9 @@ static int process_impl(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host,
     int per_batch = ctx->prm.windows_per_batch > 0 ? ctx->prm.windows_per_batch : (int)std::max<size_t>(mine.size(), 1);
     const double bytes_per_window = 8.0 * (double)pl.Nc * (S + P) + 2.0 * (double)(wlen + 16) * S;
     per_batch = (int)std::max(1.0, std::min<double>(per_batch, 24.0 * 1073741824.0 / bytes_per_window));
+    // per_batch * S and per_batch * P become gridDim.y of the FFT kernels (HIP limit 65535)
+    if (std::max(S, P) > 65535) return fail(ctx, TDOA_ERR_UNSUPPORTED, "too many station pairs for one launch group");
+    per_batch = std::max(1, std::min(per_batch, 65535 / std::max(S, P)));
 
     // all descriptors, uploaded once; window wi of this rank owns sw[sw_off[wi] .. sw_off[wi+1]) and likewise pw
     std::vector<SWDesc> sw;
@@ -947,7 +968,9 @@ static int process_impl(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host,
 
     // everything the launches depend on: same key => the captured graph can be replayed as is
     std::vector<uint64_t> key = {(uint64_t)S, (uint64_t)rank, (uint64_t)world, (uint64_t)per_batch, (uint64_t)wlen,
-                                 (uint64_t)ctx->prm.max_lag, (uint64_t)block, (uint64_t)ctx->force_generic,
+                                 (uint64_t)ctx->prm.max_lag, (uint64_t)block,
+                                 (uint64_t)ctx->force_generic | ((uint64_t)ctx->short_lag << 1) |
+                                     ((uint64_t)ctx->fused_rows << 2) | ((uint64_t)ctx->segment_form << 3),
                                  ctx->alloc_gen, (uint64_t)(fine_host != nullptr), 0};
     std::memcpy(&key.back(), &gate, sizeof(double));
     for (auto &c : ctx->caps) {
@@ -1195,6 +1218,16 @@ int tdoa_debug_force_generic(tdoa_ctx *ctx, int on)
     return TDOA_OK;
 }
 
+int tdoa_debug_flags(tdoa_ctx *ctx, unsigned flags)
+{
+    if (!ctx) return TDOA_ERR_INVALID;
+    ctx->force_generic = (flags & TDOA_DEBUG_GENERIC_KERNELS) != 0;
+    ctx->short_lag = !(flags & TDOA_DEBUG_NO_SHORT_LAG);
+    ctx->fused_rows = !(flags & TDOA_DEBUG_NO_FUSED_ROWS);
+    ctx->segment_form = !(flags & TDOA_DEBUG_NO_SEGMENT_FORM);
+    return TDOA_OK;
+}
+
 int tdoa_profile_enable(tdoa_ctx *ctx, int on)
 {
     if (!ctx) return TDOA_ERR_INVALID;
@@ -1240,7 +1273,7 @@ int tdoa_solve_nstation(const double *stations_lle, int n_stations, const double
     if (!stations_lle || !range_diff || !out_lle) return TDOA_ERR_INVALID;
     const int rc = geo::solve_nstation(stations_lle, n_stations, range_diff, weights, solve_z, 10, 0.5, 1.0, out_lle,
                                        iterations);
-    return rc == 0 ? TDOA_OK : (rc == -2 ? TDOA_ERR_UNSUPPORTED : TDOA_ERR_SINGULAR);
+    return rc == 0 ? TDOA_OK : (rc == -2 ? TDOA_ERR_UNSUPPORTED : rc == -3 ? TDOA_ERR_INVALID : TDOA_ERR_SINGULAR);
 }
 
 }  // extern "C"

@@ -68,6 +68,7 @@ SYMBOLS = [
     "tdoa_num_windows", "tdoa_num_pairs", "tdoa_process", "tdoa_process_u8",
     "tdoa_process_fine", "tdoa_fm_xcorr_fine_u8", "tdoa_window_quality_all", "tdoa_window_quality_u8",
     "tdoa_fm_xcorr_u8", "tdoa_fm_preprocess_u8", "tdoa_fm_xcorr_lags_u8", "tdoa_debug_force_generic",
+    "tdoa_debug_flags",
     "tdoa_latlon_to_ecef", "tdoa_ecef_to_latlon", "tdoa_solve_3station", "tdoa_solve_nstation",
     "tdoa_profile_enable", "tdoa_profile_reset", "tdoa_profile_get", "tdoa_kernel_name",
     "tdoa_plan_info",
@@ -132,6 +133,7 @@ def load(build_if_missing=True):
     L.tdoa_fm_preprocess_u8.argtypes = [vp, u8p, sz, fp, C.POINTER(FmStats)]
     L.tdoa_fm_xcorr_lags_u8.argtypes = [vp, u8p, sz, u8p, sz, C.c_int, dp]
     L.tdoa_debug_force_generic.argtypes = [vp, C.c_int]
+    L.tdoa_debug_flags.argtypes = [vp, C.c_uint]
     L.tdoa_latlon_to_ecef.argtypes = [C.c_double, C.c_double, C.c_double, dp]
     L.tdoa_latlon_to_ecef.restype = None
     L.tdoa_ecef_to_latlon.argtypes = [C.c_double, C.c_double, C.c_double, dp]
@@ -380,6 +382,11 @@ class Context:
 
     def force_generic(self, on=True):
         self._chk(self._L.tdoa_debug_force_generic(self._h, 1 if on else 0))
+
+    def debug_flags(self, generic=False, no_short_lag=False, no_fused_rows=False, no_segment_form=False):
+        """pick kernel variants by hand (tests / measurements): include/tdoa_mi355x.h TDOA_DEBUG_*"""
+        self._chk(self._L.tdoa_debug_flags(self._h, (1 if generic else 0) | (2 if no_short_lag else 0) |
+                                           (4 if no_fused_rows else 0) | (8 if no_segment_form else 0)))
 
     # ---- measurement -------------------------------------------------------
     def profile_enable(self, on=True):

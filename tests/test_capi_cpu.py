@@ -151,3 +151,20 @@ def test_nstation_solver_ignores_a_zero_weight_outlier(capi):
         w[4] = 1.0
         rc, pulled, _ = capi.solve_nstation(ring, bad, weights=w)
         assert rc == 0 and np.linalg.norm(np.array(pulled[:2]) - np.array(clean[:2])) > 1e-3   # with weight 1 it would
+
+
+def test_nstation_solver_rejects_empty_and_invalid_weight_sets(capi, oracle):
+    """with every pair at weight 0 the iteration used to stop after 0 steps and report the station
+    centroid as the fix; NaN weights produced a NaN position with status 0."""
+    st = [oracle.STATIONS[k] for k in oracle.COLLECTORS]
+    rd = [1500.0, -2500.0, 0.0]
+    assert capi.solve_nstation(st, rd, weights=[0, 0, 0])[0] != 0                 # nothing to fit
+    assert capi.solve_nstation(st, rd, weights=[1, 0, 0])[0] != 0                 # 1 pair < 2 unknowns
+    assert capi.solve_nstation(st, rd, weights=[1, 1, 0], solve_z=True)[0] != 0   # 2 pairs < 3 unknowns
+    assert capi.solve_nstation(st, rd, weights=[1, 1, 0])[0] == 0
+    assert capi.solve_nstation(st, rd, weights=[1, -1, 1])[0] != 0                # negative weight
+    assert capi.solve_nstation(st, rd, weights=[1, float("nan"), 1])[0] != 0
+    assert capi.solve_nstation(st, rd, weights=[1, float("inf"), 1])[0] != 0
+    assert capi.solve_nstation(st, [1500.0, float("nan"), 0.0], weights=[1, 1, 1])[0] != 0
+    rc, lle, _ = capi.solve_nstation(st, [1500.0, float("nan"), 0.0], weights=[1, 0, 1])   # NaN on an unused pair is fine
+    assert rc == 0 and np.isfinite(lle).all()

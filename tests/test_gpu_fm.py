@@ -270,7 +270,7 @@ def test_attach_device_buffer_from_torch(oracle):
 
 @pytest.mark.parametrize("max_lag,delay", [(128, 57), (128, -127), (511, 300), (512, -511), (1000, 999), (2047, -2046),
                                            (2048, 1500), (4095, 4094), (4096, -4000)])
-def test_short_lag_form_vs_oracle_and_general_form(oracle, max_lag, delay, monkeypatch):
+def test_short_lag_form_vs_oracle_and_general_form(oracle, max_lag, delay):
     """|lag| ranges below 4095 take the short-lag inverse (no V round trip) on 4096-point rows; 4096 is the first
     range that takes the general pruned form again.  Both against the f64 oracle, and against each other."""
     import tdoa_amd
@@ -289,7 +289,7 @@ def test_short_lag_form_vs_oracle_and_general_form(oracle, max_lag, delay, monke
         ofine = oracle.b_refine_peak(ta, tb, lag, 1e9)
         assert np.abs(fine["y"] - ofine["y"]).max() <= REL_TOL * abs(ocorr)
         assert abs(fine["frac"] - ofine["frac"]) < 1e-4
-        monkeypatch.setenv("TDOA_NO_SHORT_LAG", "1")
+        c.debug_flags(no_short_lag=True)
         general = c.fm_xcorr_lags(a, b, max_lag)
         _assert_lags_close(general, lags)
         assert c.fm_xcorr(a, b, max_lag)[0] == lag
@@ -315,7 +315,7 @@ def test_short_column_kernels(oracle, n, label):
 
 
 @pytest.mark.parametrize("per_batch", [0, 2])
-def test_short_lag_form_in_the_batched_path(oracle, per_batch, monkeypatch):
+def test_short_lag_form_in_the_batched_path(oracle, per_batch):
     """tdoa_process with 4096-point rows and a 300-lag range: many pair-windows through the short-lag inverse,
     against the oracle and against the general form."""
     import tdoa_amd
@@ -339,7 +339,46 @@ def test_short_lag_form_in_the_batched_path(oracle, per_batch, monkeypatch):
                 assert abs(peaks[wid, p]["corr"] - ocorr) <= REL_TOL * abs(ocorr)
                 of = oracle.b_refine_peak(pre[i], pre[j], olag, 120.0)
                 assert abs(fine[wid, p]["frac"] - of["frac"]) < 1e-4
-        monkeypatch.setenv("TDOA_NO_SHORT_LAG", "1")
+        c.debug_flags(no_short_lag=True)
         general = c.process()
         assert np.array_equal(general["lag"], peaks["lag"])
         assert np.abs(general["corr"] - peaks["corr"]).max() <= REL_TOL * np.abs(peaks["corr"]).max()
+
+
+@pytest.mark.parametrize("n,max_lag", [(70_000, 20000), (300_000, 300), (2_000_000, 20000)])
+def test_fused_forward_rows_vs_separate_pass(oracle, n, max_lag):
+    """with no more pair-windows than station-windows the forward row transform runs inside the pair kernel
+    (k_pair_rows_fused4096); the separate-pass form must give the same lags to rounding, and both match the oracle"""
+    import tdoa_amd
+    a = oracle.simulate_delayed_fm(n, 0, 31, 1)
+    b = oracle.simulate_delayed_fm(n, 41, 31, 2)
+    ta, _ = oracle.b_preprocess(a)
+    tb, _ = oracle.b_preprocess(b)
+    olag, ocorr, want = oracle.b_xcorr_peak_fft(ta, tb, max_lag)
+    with tdoa_amd.Context(max_lag=max_lag, window_len=n) as c:
+        c.debug_flags()                                            # every specialised form on, the fused rows included
+        fused = c.fm_xcorr_lags(a, b, max_lag)
+        lag, corr = c.fm_xcorr(a, b, max_lag)
+        c.debug_flags(no_fused_rows=True)
+        separate = c.fm_xcorr_lags(a, b, max_lag)
+        lag2, corr2 = c.fm_xcorr(a, b, max_lag)
+    _assert_lags_close(fused, want)
+    _assert_lags_close(separate, want)
+    _assert_lags_close(fused, separate, 2e-6)
+    assert lag == lag2 == olag == 41
+    assert abs(corr - ocorr) <= REL_TOL * abs(ocorr) and abs(corr2 - ocorr) <= REL_TOL * abs(ocorr)
+
+
+def test_fused_forward_rows_in_the_batched_path(oracle):
+    """3 stations / 3 pairs (fused) against the same batch with the separate forward row pass, bit-comparable lags"""
+    import tdoa_amd
+    block, wl, ml = 140_000, 70_000, 20000
+    caps = [oracle.simulate_station(nm, block, oracle.SEED_BASE + i, tx_power=200000.0) for i, nm in enumerate(oracle.COLLECTORS)]
+    with tdoa_amd.Context(max_lag=ml, window_len=wl) as c:
+        c.debug_flags()
+        fused = c.process_u8(caps)
+        c.debug_flags(no_fused_rows=True)
+        separate = c.process()
+    assert fused.shape == (6, 3)
+    assert np.array_equal(fused["lag"], separate["lag"])
+    assert np.abs(fused["corr"] - separate["corr"]).max() <= 2e-6 * np.abs(separate["corr"]).max()
