@@ -114,6 +114,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--seconds", type=float, default=100.0, help="capture length per station")
     ap.add_argument("--batch", type=int, default=0, help="windows per launch group (0 = library default)")
+    ap.add_argument("--max-lag", type=int, default=20000, help="search range in samples (reference: 20000, processor.go:633)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     args = ap.parse_args()
@@ -142,7 +143,7 @@ def main():
             dist.init_process_group(backend=backend)
 
     fs = 2_000_000
-    wlen, max_lag = 2_000_000, 20000
+    wlen, max_lag = 2_000_000, args.max_lag
     total = int(args.seconds * fs)
     block = total // 3
     ctx = tdoa_amd.Context(device=device, window_len=wlen, max_lag=max_lag, windows_per_batch=args.batch)

@@ -8,6 +8,6 @@ TAG=${1:-r01}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_${TAG}_$c -- \
-      python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/pmc_${TAG}_$c.log 2>&1
+      python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline $BENCH_ARGS > gpurun_out/pmc_${TAG}_$c.log 2>&1
 done
 python3 scripts/pmc_summary.py gpurun_out/pmc_${TAG}_FETCH_SIZE gpurun_out/pmc_${TAG}_WRITE_SIZE gpurun_out/${TAG}_pmc_traffic.json

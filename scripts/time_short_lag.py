@@ -14,11 +14,11 @@ ST = [(41.18660274289527, -95.96064116595667, 355.69), (41.24669616513154, -96.0
       (41.32916620016985, -96.03513381562004, 373.18)]
 TX = (41.20, -96.00, 400.0)
 
-for max_lag in (128, 511, 1023, 2047, 4095, 20000):
+for max_lag in (128, 512, 1023, 2047, 4095, 20000):
     row = {"max_lag": max_lag}
-    for mode in ("short", "general"):
+    for mode in ("segment", "short", "general"):
         with tdoa_amd.Context(max_lag=max_lag) as c:
-            c.debug_flags(no_short_lag=(mode == "general"))
+            c.debug_flags(no_short_lag=(mode == "general"), no_segment_form=(mode != "segment"), no_fused_rows=True)
             for s in range(3):
                 c.synth_capture(s, 66_666_666, ST[s], TX, 0x5D0A0000 + s)
             c.process(want_host=False)

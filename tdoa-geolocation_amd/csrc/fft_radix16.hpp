@@ -118,7 +118,7 @@ __device__ __forceinline__ void row4096_finish(float2 (&v)[16], float2 *lds, int
 // forward row pass, N1 = 4096, in place.  grid (N2, n_sw), 256 threads, static LDS 34 KB
 // ---------------------------------------------------------------------------
 // row_mul: row index = blockIdx.x * row_mul (1: every row, grid.x = N2; N2/2: only the two self-mirrored rows 0 and
-// N2/2, grid.x = 2 -- the rest of the rows are then transformed inside k_pair_rows_fused4096)
+// N2/2, grid.x = 2 -- the rest of the rows are then transformed inside k_pair_rows_fused_r8, fft_radix8.hpp)
 __global__ __launch_bounds__(256) void k_fwd_row4096(float2 *TZ, FftPlan pl, int row_mul)
 {
     __shared__ float2 lds[kRowLds];
@@ -423,62 +423,6 @@ __device__ __forceinline__ void inv_row_pair_tail(float2 (&va)[16], float2 (&vb)
     }
 }
 
-// one 4096-point forward row transform, registers in (x[r] = row[j + 256 r]) and out (X[j + 256 k] in
-// x[oreg(k)]), through one LDS image that must be free to overwrite on entry
-__device__ __forceinline__ void fwd_row1_4096(float2 (&x)[16], float2 *img, const int j)
-{
-    fft16<false>(x);
-    row4096_finish<false>(x, img, j);
-}
-
-// two 4096-point forward row transforms side by side, registers in (x[r] = row[j + 256 r]) and out
-// (X[j + 256 k] in x[oreg(k)]), each row through its own LDS image.  LDS must be free to overwrite on entry.
-__device__ __forceinline__ void fwd_rows2_4096(float2 (&x)[16], float2 (&y)[16], float2 *la, float2 *lb, const int j)
-{
-    fft16<false>(x);
-    fft16<false>(y);
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        la[pad16(16 * j + k)] = x[oreg(k)];
-        lb[pad16(16 * j + k)] = y[oreg(k)];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-        x[r] = la[pad16(j + 256 * r)];
-        y[r] = lb[pad16(j + 256 * r)];
-    }
-    {
-        const float2 w = unit_root((float)(j & 15), 2.0f / 256.0f, false);
-        mul_powers16(x, w);
-        mul_powers16(y, w);
-    }
-    fft16<false>(x);
-    fft16<false>(y);
-    __syncthreads();
-    {
-        const int dd = ((j >> 4) << 8) + (j & 15);
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            la[pad16(dd + 16 * k)] = x[oreg(k)];
-            lb[pad16(dd + 16 * k)] = y[oreg(k)];
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-        x[r] = la[pad16(j + 256 * r)];
-        y[r] = lb[pad16(j + 256 * r)];
-    }
-    {
-        const float2 w = unit_root((float)j, 2.0f / 4096.0f, false);
-        mul_powers16(x, w);
-        mul_powers16(y, w);
-    }
-    fft16<false>(x);
-    fft16<false>(y);
-}
-
 // ---------------------------------------------------------------------------
 // inverse row pass with K3 fused, N1 = 4096: one workgroup owns rows a and N2 - a (a >= 1).
 // Thread t builds Q[a][t + 256 r] and its mirror Q[N2-a][4095 - t - 256 r] from the same four
@@ -554,89 +498,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SELF ? 1 : 
     inv_row_pair_tail<SELF, FK>(va, vb, lds, t, a, b, pw_index, V, pl);
 }
 
-// ---------------------------------------------------------------------------
-// forward row pass FUSED into the inverse row pair kernel (rows a and N2 - a, a >= 1): the workgroup reads the
-// COLUMN-pass output T of both stations (the same 4 x 32 KB the pair kernel reads anyway), runs the four forward
-// row transforms itself, exchanges the two rows b through LDS to get at their mirrored elements, and carries on
-// with K3 + the inverse rows as k_inv_row_pair4096 does.  The separate forward row pass (16 Nc bytes per
-// station-window, read + write) disappears; the price is that a station's row pair is transformed once per pair
-// the station is in.  The host takes this form when n_pw <= n_sw (3 stations / 3 pairs, or a single pair).
-// The self-mirrored rows 0 and N2/2 keep the two-kernel form (k_fwd_row4096 on those two rows only).
-// grid (N2/2 - 1, n_pw), 256 threads, dynamic LDS 68 KB.
-// ---------------------------------------------------------------------------
-template <int FK>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_pair_rows_fused4096(const PWDesc *pw, const float2 *T, float2 *V, FftPlan pl)
-{
-    extern __shared__ float2 lds[];   // 2 * kRowLds
-    const int N2 = pl.N2;
-    const int pw_index = blockIdx.y;
-    const int a = blockIdx.x + 1, b = N2 - a;
-    const PWDesc d = pw[pw_index];
-    const float2 *TaA = T + (size_t)d.sw_a * pl.Nc + (size_t)a * 4096;
-    const float2 *TaB = T + (size_t)d.sw_a * pl.Nc + (size_t)b * 4096;
-    const float2 *TbA = T + (size_t)d.sw_b * pl.Nc + (size_t)a * 4096;
-    const float2 *TbB = T + (size_t)d.sw_b * pl.Nc + (size_t)b * 4096;
-    const int t = threadIdx.x;
-    float2 *la = lds, *lb = lds + kRowLds;
-    // Register plan (256 per lane at two waves per SIMD): one row in the transform at a time (32 + its temporaries),
-    // the next row's 16 loads in flight (32), the finished rows a held (64); the rows b are parked in their LDS image
-    // in natural order, where the pair stage reads their mirrored elements.  The scheduling barriers pin that order:
-    // left alone, the compiler overlaps the phases and spills the held spectra to scratch.
-    float2 xa[16], ya[16];     // x: template station, y: signal station; a / b: the row
-#pragma unroll
-    for (int r = 0; r < 16; r++) xa[r] = TaA[t + 256 * r];
-#pragma unroll
-    for (int r = 0; r < 16; r++) ya[r] = TbA[t + 256 * r];
-    __builtin_amdgcn_sched_barrier(0);
-    fwd_row1_4096(xa, la, t);
-    __builtin_amdgcn_sched_barrier(0);
-    {
-        float2 xb[16];
-#pragma unroll
-        for (int r = 0; r < 16; r++) xb[r] = TaB[t + 256 * r];
-        __builtin_amdgcn_sched_barrier(0);
-        fwd_row1_4096(ya, lb, t);
-        __builtin_amdgcn_sched_barrier(0);
-        float2 yb[16];
-#pragma unroll
-        for (int r = 0; r < 16; r++) yb[r] = TbB[t + 256 * r];
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
-        fwd_row1_4096(xb, la, t);
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 16; k++) la[t + 256 * k] = xb[oreg(k)];     // natural order: Z[b][t + 256 k]
-        __builtin_amdgcn_sched_barrier(0);
-        fwd_row1_4096(yb, lb, t);
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 16; k++) lb[t + 256 * k] = yb[oreg(k)];
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();
-    float2 va[16], vb[16];
-    {
-        // w(k) = W_N^k, k = (t + 256 r) N2 + a  =>  w = w0 * W_32^r   (as in k_inv_row_pair4096)
-        const float invNc = 1.0f / (float)pl.Nc;
-        const long long k0 = (long long)t * N2 + a;
-        const float2 st = make_float2(0.98078528040323043f, -0.19509032201612825f);   // e^{-2 pi i/32}
-        float2 w = unit_root((float)k0, invNc, false);
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            float2 q, qm;
-            pair_q(xa[oreg(r)], la[4095 - t - 256 * r], ya[oreg(r)], lb[4095 - t - 256 * r], w, q, qm);
-            va[r] = q;
-            vb[15 - r] = qm;
-            if ((r & 3) == 3)
-                w = unit_root((float)(k0 + (long long)(r + 1) * 256 * N2), invNc, false);
-            else
-                w = cmul(w, st);
-        }
-    }
-    __syncthreads();      // every mirrored read is done before the inverse stages overwrite the images
-    inv_row_pair_tail<false, FK>(va, vb, lds, t, a, b, pw_index, V, pl);
-}
-
 // short-lag form, second half: element sums over the N2/2 row-pair shares in a fixed order (four interleaved
 // partial sums, then ((s0 + s1) + (s2 + s3))), lag filter and K5.
 // part = V + pw_index * Nc: [RP][2][256 FK] float2, followed by the lag array lags[1024 FK] (float),
@@ -689,7 +550,8 @@ __global__ __launch_bounds__(256) void k_fused_reduce(float2 *V, unsigned long l
 
 // refinement neighbours c[lag-1], c[lag], c[lag+1] from the lag array k_fused_reduce left behind
 // (the host only takes the short-lag form when lag_hi + 1 and lag_lo - 1 are inside that array)
-template <int FK>
+// W: entries of the lag array (the segment form of fft_radix8.hpp leaves one more, d = +512 FK)
+template <int FK, int W = 1024 * FK>
 __global__ void k_refine_fused(const float2 *V, const unsigned long long *keys, const PWDesc *pw, FftPlan pl, int n_pw,
                                float *raw)
 {
@@ -705,7 +567,7 @@ __global__ void k_refine_fused(const float2 *V, const unsigned long long *keys, 
 #pragma unroll
         for (int q = 0; q < 3; q++) {
             const int li = lag - 1 + q + 512 * FK;
-            r[q] = li >= 0 && li < 1024 * FK ? lags[li] : 0.0f;
+            r[q] = li >= 0 && li < W ? lags[li] : 0.0f;
         }
     }
 #pragma unroll

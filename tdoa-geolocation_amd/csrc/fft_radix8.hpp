@@ -1,0 +1,441 @@
+// fft_radix8.hpp -- 4096-point row transforms on 512 threads: 8 complex values per thread, radix-8 Stockham stages
+// 8 x 8 x 8 x 8 with three LDS exchanges.  Same math and layouts as fft_radix16.hpp; what changes is the register
+// footprint.  A workgroup that has to hold the spectra of several rows at once (the forward row pass fused into the
+// pair kernel, below) needs 4 rows x 16 values x 8 B = 128 VGPRs on 256 threads before the first temporary; the
+// compiler answers with spills or two waves per SIMD, and at two waves per SIMD a VALU-heavy kernel only issues on
+// every other slot (one wave alone gets a vector instruction every 4 cycles, MI355X_MICROARCH.md).  On 512 threads
+// the same rows cost 64 VGPRs, the kernel fits 128 and runs four waves per SIMD.
+//
+// LDS images are 4096 float2 (32 KB) with an XOR swizzle instead of padding: element i lives at
+//   swz(i) = i ^ ((i >> 5) & 7) ^ (((i >> 6) & 3) << 3)
+// which only permutes the 32 elements of an aligned 256-byte line.  Every access pattern of the four stages then
+// touches 32 distinct 8-byte bank pairs per half-wave: consecutive elements (the stage reads, j + 512 r), stride 8
+// (stage-1 writes, 8 j + k), runs of 8 at stride 64 (stage-2 writes) and runs of 64 (stage-3 writes).
+#pragma once
+
+#include "device_common.hpp"
+#include "fft_stockham.hpp"
+#include "fft_radix16.hpp"
+
+namespace tdoa {
+
+__device__ __forceinline__ constexpr int oreg8(int k) { return ((k & 1) << 2) | (k >> 1); }
+
+// 8-point DFT in registers: natural order in, X[k] left in v[oreg8(k)].
+// n = 4 n1 + n2, k = k1 + 2 k2:  radix-2 over n1, twiddle W8^(n2 k1), radix-4 over n2.
+template <bool INV>
+__device__ __forceinline__ void fft8(float2 (&v)[8])
+{
+    constexpr float h = 0.70710678118654752f;
+#pragma unroll
+    for (int n2 = 0; n2 < 4; n2++) {
+        const float2 s = cadd(v[n2], v[n2 + 4]), d = csub(v[n2], v[n2 + 4]);
+        v[n2] = s;
+        v[n2 + 4] = d;
+    }
+    // v[4 + n2] *= W8^n2   (forward e^{-2 pi i n2/8}; inverse: conjugate)
+    {
+        const float2 a = v[5];   // W8^1 = h (1 -+ i)
+        v[5] = INV ? make_float2(h * (a.x - a.y), h * (a.x + a.y)) : make_float2(h * (a.x + a.y), h * (a.y - a.x));
+        const float2 b = v[6];   // W8^2 = -+ i
+        v[6] = INV ? make_float2(-b.y, b.x) : make_float2(b.y, -b.x);
+        const float2 c = v[7];   // W8^3 = h (-1 -+ i)
+        v[7] = INV ? make_float2(-h * (c.x + c.y), h * (c.x - c.y)) : make_float2(h * (c.y - c.x), -h * (c.x + c.y));
+    }
+    bfly4<INV>(v[0], v[1], v[2], v[3]);
+    bfly4<INV>(v[4], v[5], v[6], v[7]);
+}
+
+// v[r] *= w^r, r = 1..7
+__device__ __forceinline__ void mul_powers8(float2 (&v)[8], float2 w)
+{
+    const float2 w2 = cmul(w, w), w3 = cmul(w2, w), w4 = cmul(w2, w2);
+    v[1] = cmul(v[1], w);
+    v[2] = cmul(v[2], w2);
+    v[3] = cmul(v[3], w3);
+    v[4] = cmul(v[4], w4);
+    v[5] = cmul(v[5], cmul(w4, w));
+    v[6] = cmul(v[6], cmul(w4, w2));
+    v[7] = cmul(v[7], cmul(w4, w3));
+}
+
+// X[k] (in v[oreg8(k)]) *= base * step^k
+__device__ __forceinline__ void mul_base_step8(float2 (&v)[8], float2 base, float2 step)
+{
+    const float2 s2 = cmul(step, step), s3 = cmul(s2, step), s4 = cmul(s2, s2);
+    const float2 g = cmul(base, s4);
+    v[oreg8(0)] = cmul(v[oreg8(0)], base);
+    v[oreg8(1)] = cmul(v[oreg8(1)], cmul(base, step));
+    v[oreg8(2)] = cmul(v[oreg8(2)], cmul(base, s2));
+    v[oreg8(3)] = cmul(v[oreg8(3)], cmul(base, s3));
+    v[oreg8(4)] = cmul(v[oreg8(4)], g);
+    v[oreg8(5)] = cmul(v[oreg8(5)], cmul(g, step));
+    v[oreg8(6)] = cmul(v[oreg8(6)], cmul(g, s2));
+    v[oreg8(7)] = cmul(v[oreg8(7)], cmul(g, s3));
+}
+
+__device__ __forceinline__ int swz(int i) { return i ^ ((i >> 5) & 7) ^ (((i >> 6) & 3) << 3); }
+
+// Left alone, the backend pairs the 8-byte LDS accesses of a stage into ds_read2st64_b64 / ds_write2st64_b64, which the
+// LDS serves at half the rate of plain b64 (MI355X_MICROARCH.md, LDS table) and with a banking the swizzle was not
+// built for.  The subtarget feature only exists in the device pass.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TDOA_PLAIN_DS_OPS , target("no-load-store-opt")
+#else
+#define TDOA_PLAIN_DS_OPS
+#endif
+
+constexpr int kRow8Lds = 4096;       // float2 per row image (no padding)
+
+// Stages 2..4 of TWO 4096-point row transforms side by side (row x through image la, row y through lb), whose
+// stage-1 outputs X[k] are still in registers (in v[oreg8(k)]): x belongs to stage-1 item jx, y to item jy (the
+// caller may have run item 511 - t for the mirrored row); from stage 2 on thread j = threadIdx.x owns item j of
+// both rows.  On return thread j holds Y[j + 512 k] of each row in [oreg8(k)].  512 threads; the images must be
+// free to overwrite on entry; they are free again after the caller's next barrier.
+// w2, w3, w4: the stage roots e^{-+2 pi i (j & 7)/64}, e^{-+2 pi i (j & 63)/512}, e^{-+2 pi i j/4096} of thread j
+template <bool INV>
+__device__ __forceinline__ void rows2_r8_finish_w(float2 (&x)[8], float2 (&y)[8], float2 *la, float2 *lb, const int j,
+                                                  const int jx, const int jy, const float2 w2, const float2 w3,
+                                                  const float2 w4)
+{
+    {
+        // element 8 jj + k: (i >> 5) & 7 = (jj >> 2) & 7, (i >> 6) & 3 = (jj >> 3) & 3
+        const int sx = ((jx >> 2) & 7) ^ (((jx >> 3) & 3) << 3), sy = ((jy >> 2) & 7) ^ (((jy >> 3) & 3) << 3);
+        const int bx = (8 * jx) ^ (sx & 0x18), by = (8 * jy) ^ (sy & 0x18);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            la[bx + (k ^ (sx & 7))] = x[oreg8(k)];
+            lb[by + (k ^ (sy & 7))] = y[oreg8(k)];
+        }
+    }
+    __syncthreads();
+    const int rb = swz(j);              // element j + 512 r lives at swz(j) + 512 r
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        x[r] = la[rb + 512 * r];
+        y[r] = lb[rb + 512 * r];
+    }
+    mul_powers8(x, w2);
+    mul_powers8(y, w2);
+    fft8<INV>(x);
+    fft8<INV>(y);
+    __syncthreads();
+    {
+        const int d = ((j >> 3) << 6) + (j & 7);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int p = swz(d + 8 * k);
+            la[p] = x[oreg8(k)];
+            lb[p] = y[oreg8(k)];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        x[r] = la[rb + 512 * r];
+        y[r] = lb[rb + 512 * r];
+    }
+    mul_powers8(x, w3);
+    mul_powers8(y, w3);
+    fft8<INV>(x);
+    fft8<INV>(y);
+    __syncthreads();
+    {
+        const int d = ((j >> 6) << 9) + (j & 63);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int p = swz(d + 64 * k);
+            la[p] = x[oreg8(k)];
+            lb[p] = y[oreg8(k)];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        x[r] = la[rb + 512 * r];
+        y[r] = lb[rb + 512 * r];
+    }
+    mul_powers8(x, w4);
+    mul_powers8(y, w4);
+    fft8<INV>(x);
+    fft8<INV>(y);
+}
+
+// the same with the roots rebuilt on every call (opaque: see fft_radix16.hpp -- a kernel that transforms several row
+// pairs must not keep 3 x 7 twiddle powers alive between the calls)
+template <bool INV>
+__device__ __forceinline__ void rows2_r8_finish(float2 (&x)[8], float2 (&y)[8], float2 *la, float2 *lb, const int j,
+                                                const int jx, const int jy)
+{
+    rows2_r8_finish_w<INV>(x, y, la, lb, j, jx, jy, opaque(unit_root((float)(j & 7), 2.0f / 64.0f, INV)),
+                           opaque(unit_root((float)(j & 63), 2.0f / 512.0f, INV)),
+                           opaque(unit_root((float)j, 2.0f / 4096.0f, INV)));
+}
+
+// ---------------------------------------------------------------------------
+// Forward row pass FUSED into the inverse row pair kernel, rows a and b = N2 - a (a >= 1): the workgroup reads the
+// COLUMN-pass output T of both stations (the same 4 x 32 KB the pair kernel reads anyway), runs the four forward
+// row transforms itself, parks the two rows b in LDS to get at their mirrored elements, forms Q (K3) and runs the two
+// inverse rows.  The separate forward row pass (16 Nc bytes per station-window, read + write) disappears; the price
+// is that a station's row pair is transformed once per pair the station is in, so the host takes this form when a
+// launch group has no more pair-windows than station-windows (3 stations / 3 pairs, or a single pair).
+// The self-mirrored rows 0 and N2/2 keep the two-kernel form (k_fwd_row4096 on those two rows, then
+// k_inv_row_pair4096<true, FK>).
+// FK as in k_inv_row_pair4096: 0 writes the two V rows, FK > 0 the row pair's share of the short-lag column sums.
+// grid (N2/2 - 1, n_pw), 512 threads, dynamic LDS 64 KB (two workgroups per CU, four waves per SIMD).
+// ---------------------------------------------------------------------------
+template <int FK>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_pair_rows_fused_r8(const PWDesc *pw, const float2 *T, float2 *V, FftPlan pl)
+{
+    extern __shared__ float2 lds[];   // 2 * kRow8Lds
+    const int N2 = pl.N2;
+    const int pw_index = blockIdx.y;
+    const int a = blockIdx.x + 1, b = N2 - a;
+    const PWDesc d = pw[pw_index];
+    const float2 *TaA = T + (size_t)d.sw_a * pl.Nc + (size_t)a * 4096;
+    const float2 *TaB = T + (size_t)d.sw_a * pl.Nc + (size_t)b * 4096;
+    const float2 *TbA = T + (size_t)d.sw_b * pl.Nc + (size_t)a * 4096;
+    const float2 *TbB = T + (size_t)d.sw_b * pl.Nc + (size_t)b * 4096;
+    const int t = threadIdx.x;
+    float2 *la = lds, *lb = lds + kRow8Lds;
+    float2 xa[8], ya[8], xb[8], yb[8];     // x: template station, y: signal station; a / b: the row
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        xa[r] = TaA[t + 512 * r];
+        ya[r] = TbA[t + 512 * r];
+    }
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        xb[r] = TaB[t + 512 * r];
+        yb[r] = TbB[t + 512 * r];
+    }
+    fft8<false>(xa);
+    fft8<false>(ya);
+    rows2_r8_finish<false>(xa, ya, la, lb, t, t, t);       // Z[a][t + 512 k] in [oreg8(k)]
+    __syncthreads();
+    fft8<false>(xb);
+    fft8<false>(yb);
+    rows2_r8_finish<false>(xb, yb, la, lb, t, t, t);
+    __syncthreads();
+    // park the rows b in natural order; the pair stage reads their mirrored elements Z[b][4095 - t - 512 r]
+    {
+        const int rb = swz(t);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            la[rb + 512 * k] = xb[oreg8(k)];
+            lb[rb + 512 * k] = yb[oreg8(k)];
+        }
+    }
+    __syncthreads();
+    float2 va[8], vb[8];
+    {
+        // w(k) = W_N^k, k = (t + 512 r) N2 + a  =>  w = w0 * W_16^r, re-anchored half way
+        const float invNc = 1.0f / (float)pl.Nc;
+        const long long k0 = (long long)t * N2 + a;
+        const float2 st = make_float2(0.92387953251128674f, -0.38268343236508977f);   // e^{-2 pi i/16}
+        const int mb = swz(4095 - t);      // element (4095 - t) - 512 r lives at swz(4095 - t) - 512 r
+        float2 w = unit_root((float)k0, invNc, false);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            float2 q, qm;
+            pair_q(xa[oreg8(r)], la[mb - 512 * r], ya[oreg8(r)], lb[mb - 512 * r], w, q, qm);
+            va[r] = q;              // Q[a][t + 512 r]:                 row a, stage-1 item t, input r
+            vb[7 - r] = qm;         // Q[b][(511 - t) + 512 (7 - r)]:   row b, stage-1 item 511 - t, input 7 - r
+            if (r == 3)
+                w = unit_root((float)(k0 + (long long)4 * 512 * N2), invNc, false);
+            else
+                w = cmul(w, st);
+        }
+    }
+    __syncthreads();      // every mirrored read is done before the inverse stages overwrite the images
+    fft8<true>(va);
+    fft8<true>(vb);
+    rows2_r8_finish<true>(va, vb, la, lb, t, t, 511 - t);
+    // V[k2][n1] = y[n1] * W_Nc^(-n1 k2), n1 = t + 512 k
+    float2 *out = V + (size_t)pw_index * pl.Nc;
+    const float inv2 = 2.0f / (float)pl.Nc;
+    {
+        const long long e0 = ((long long)t * a) & (pl.Nc - 1), e1 = ((long long)512 * a) & (pl.Nc - 1);
+        mul_base_step8(va, unit_root((float)e0, inv2, true), unit_root((float)e1, inv2, true));
+        const long long f0 = ((long long)t * b) & (pl.Nc - 1), f1 = ((long long)512 * b) & (pl.Nc - 1);
+        mul_base_step8(vb, unit_root((float)f0, inv2, true), unit_root((float)f1, inv2, true));
+    }
+    if constexpr (FK == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            out[(size_t)a * 4096 + t + 512 * k] = va[oreg8(k)];
+            out[(size_t)b * 4096 + t + 512 * k] = vb[oreg8(k)];
+        }
+    } else {
+        // short-lag form (see k_inv_row_pair4096): P0[n1] = V[a][n1] + V[b][n1] for n1 < 256 FK,
+        // P1[n1 - (4096 - 256 FK)] = V[a][n1] conj(w_a) + V[b][n1] conj(w_b) for n1 >= 4096 - 256 FK
+        const float2 ca = unit_root((float)a, 2.0f / (float)N2, false);
+        const float2 cb = unit_root((float)b, 2.0f / (float)N2, false);
+        float2 *part = out + (size_t)a * (2 * 256 * FK);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int n1 = t + 512 * k;
+            if (512 * k < 256 * FK && n1 < 256 * FK) part[n1] = cadd(va[oreg8(k)], vb[oreg8(k)]);
+            if (512 * (k + 1) > 4096 - 256 * FK && n1 >= 4096 - 256 * FK)
+                part[256 * FK + n1 - (4096 - 256 * FK)] = cadd(cmul(va[oreg8(k)], ca), cmul(vb[oreg8(k)], cb));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Segment form (search ranges up to 1024 lags): the whole correlation stays in LDS and registers.
+// The deployed geometry bounds |TDOA| by 114 samples (PROJECT_NOTES.md:29-32); a caller who searches a few hundred
+// lags instead of the reference's 20 000 (processor.go:633) does not need a 2^21-point transform.  Overlap-save
+// over the template: segment k is t[kH, kH + H), H = 4096 - 2P (P = 512 FK >= max_lag), placed at [P, P + H) of a
+// 4096-point frame next to the signal samples s[kH - P, kH - P + 4096).  One complex transform Z of z = t + i s
+// carries both real frames; with A = |Z[k]|^2 and B = Z[k] Z[-k]
+//   conj(T[k]) S[k] = Im(B[k]) / 2 - i (A[k] - A[-k]) / 4,
+// so a workgroup only ADDS 4 FMAs per bin per segment into 2 x 8 registers and runs one inverse transform at the end.
+// No wrap-around reaches the lags |d| <= P.  HBM traffic: the phase codes of both stations, about 2.7 B per sample
+// and station (frames overlap by 2P), against 31.4 B per sample of the four-step form.
+// grid (n_chunks, n_pw), 512 threads, dynamic LDS 64 KB.  Chunk c of a pair-window takes the segment pairs
+// c, c + n_chunks, ...; its 2P + 1 lag sums (d = -P .. P) go to part[pw][c][1024 FK + 8] (floats, at V + pw * Nc),
+// k_segments_reduce adds the chunks in a fixed order.
+// ---------------------------------------------------------------------------
+template <int FK>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_PLAIN_DS_OPS)) void k_xcorr_segments(const SWDesc *sw, const PWDesc *pw, const short *codes, long long code_stride, const FmStats *stats, float2 *V, FftPlan pl, int n_chunks)
+{
+    constexpr int P = 512 * FK, H = 4096 - 2 * P;
+    extern __shared__ float2 lds[];   // 2 * kRow8Lds
+    float2 *la = lds, *lb = lds + kRow8Lds;
+    const int t = threadIdx.x;
+    const PWDesc d = pw[blockIdx.y];
+    const int len_t = sw[d.sw_a].len, len_s = sw[d.sw_b].len;
+    const short *ct = codes + (size_t)d.sw_a * code_stride, *cs = codes + (size_t)d.sw_b * code_stride;
+    const float mean_t = stats[d.sw_a].mean, scale_t = stats[d.sw_a].scale;
+    const float mean_s = stats[d.sw_b].mean, scale_s = stats[d.sw_b].scale;
+    const int n_seg = (len_t + H - 1) / H, len_min = len_t < len_s ? len_t : len_s;
+    // forward stage roots of this thread, once (6 VGPRs instead of three root evaluations per trip)
+    const float2 w2 = unit_root((float)(t & 7), 2.0f / 64.0f, false), w3 = unit_root((float)(t & 63), 2.0f / 512.0f, false),
+                 w4 = unit_root((float)t, 2.0f / 4096.0f, false);
+    // mirror element (4096 - (t + 512 k)) mod 4096 = ((512 - t) mod 512) + 512 ((7 - k + [t == 0]) mod 8)
+    const int mb = swz((512 - t) & 511), mz = t == 0 ? 1 : 0, rb = swz(t);
+    float accA[8], accB[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) accA[k] = accB[k] = 0.0f;
+
+    for (int s0 = 2 * blockIdx.x; s0 < n_seg; s0 += 2 * n_chunks) {
+        float2 x[8], y[8];          // two frames per trip (they share the stage twiddles)
+        // sample index of frame position n: i = seg * H + n - P (32-bit: windows are shorter than 2^31 samples);
+        // the row pointers are uniform, so every load is base (SGPR) + 32-bit lane offset
+        const int i0 = s0 * H - P + t, i1 = i0 + H;
+        if (s0 * H - P >= 0 && (s0 + 1) * H - P + 4096 <= len_min) {
+            // both frames lie inside both windows (all but the first and last trips): no bounds checks; the template
+            // part of a frame is the positions [P, P + H) = the values r = FK .. 7 - FK of every thread
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const bool tpos = r >= FK && r < 8 - FK;
+                const int a0 = tpos ? (int)ct[i0 + 512 * r] : 0, b0 = cs[i0 + 512 * r];
+                const int a1 = tpos ? (int)ct[i1 + 512 * r] : 0, b1 = cs[i1 + 512 * r];
+                x[r] = make_float2(tpos ? k1_normalise(a0, mean_t, scale_t) : 0.0f, k1_normalise(b0, mean_s, scale_s));
+                y[r] = make_float2(tpos ? k1_normalise(a1, mean_t, scale_t) : 0.0f, k1_normalise(b1, mean_s, scale_s));
+            }
+        } else {
+            const bool odd_ok = s0 + 1 < n_seg;     // the odd segment of the last pair may not exist: then BOTH its
+                                                    // parts are zero (a signal-only frame adds nothing to the result,
+                                                    // but |S|^2 would go through the accumulators and cancel only to
+                                                    // rounding)
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const bool tpos = r >= FK && r < 8 - FK;
+                {
+                    const int i = i0 + 512 * r;
+                    const bool in_t = tpos && i < len_t, in_s = i >= 0 && i < len_s;
+                    const int qt = in_t ? (int)ct[i] : 0, qs = in_s ? (int)cs[i] : 0;
+                    x[r] = make_float2(in_t ? k1_normalise(qt, mean_t, scale_t) : 0.0f, in_s ? k1_normalise(qs, mean_s, scale_s) : 0.0f);
+                }
+                {
+                    const int i = i1 + 512 * r;
+                    const bool in_t = tpos && i < len_t, in_s = odd_ok && i >= 0 && i < len_s;
+                    const int qt = in_t ? (int)ct[i] : 0, qs = in_s ? (int)cs[i] : 0;
+                    y[r] = make_float2(in_t ? k1_normalise(qt, mean_t, scale_t) : 0.0f, in_s ? k1_normalise(qs, mean_s, scale_s) : 0.0f);
+                }
+            }
+        }
+        fft8<false>(x);
+        fft8<false>(y);
+        // (opaque: keep the three roots, rebuild the 3 x 7 powers -- hoisted out of the loop they would be spilled)
+        rows2_r8_finish_w<false>(x, y, la, lb, t, t, t, opaque(w2), opaque(w3), opaque(w4));      // Z[t + 512 k] in [oreg8(k)]
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            la[rb + 512 * k] = x[oreg8(k)];
+            lb[rb + 512 * k] = y[oreg8(k)];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int o = 512 * ((7 - k + mz) & 7);
+            const float2 zx = x[oreg8(k)], zy = y[oreg8(k)], mx = la[mb + o], my = lb[mb + o];
+            accA[k] += zx.x * zx.x + zx.y * zx.y + zy.x * zy.x + zy.y * zy.y;
+            accB[k] += zx.x * mx.y + zx.y * mx.x + zy.x * my.y + zy.y * my.x;
+        }
+        __syncthreads();
+    }
+    // C[k] = Im B / 2 - i (A[k] - A[-k]) / 4, then one inverse transform: M r[d] = sum_k C[k] e^{+2 pi i k d / M}
+    float2 c[8], zero[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) la[rb + 512 * k] = make_float2(accA[k], 0.0f);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const float am = la[mb + 512 * ((7 - k + mz) & 7)].x;
+        c[k] = make_float2(0.5f * accB[k], -0.25f * (accA[k] - am));      // input k of stage-1 item t
+        zero[k] = make_float2(0.0f, 0.0f);
+    }
+    __syncthreads();
+    fft8<true>(c);
+    rows2_r8_finish<true>(c, zero, la, lb, t, t, t);
+    // lags d = n for n <= P and d = n - 4096 for n >= 4096 - P, n = t + 512 k; part index d + P (2P + 1 lags, row
+    // pitch kSegPitch<FK>)
+    float *part = reinterpret_cast<float *>(V + (size_t)blockIdx.y * pl.Nc) + (size_t)blockIdx.x * (2 * P + 8);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int n = t + 512 * k;
+        if (512 * k <= P && n <= P) part[P + n] = c[oreg8(k)].x;
+        if (512 * (k + 1) > 4096 - P && n >= 4096 - P) part[n - (4096 - P)] = c[oreg8(k)].x;
+    }
+}
+
+// chunk sums in a fixed order -> lag array (kept for the sub-sample refinement, same place and layout as
+// k_fused_reduce leaves it: lags[li] = c[li - 512 FK], unscaled like the keys), lag filter, K5.
+// mul = 4 N / 4096 brings the sums to the scale of the four-step form (decode multiplies by 1 / (4 N sqrt(len))).
+// grid (4 FK + 1, n_pw), 256 threads.
+template <int FK>
+__global__ __launch_bounds__(256) void k_segments_reduce(float2 *V, unsigned long long *keys, const PWDesc *pw, FftPlan pl,
+                                                        int n_chunks, float mul, int lag_lo, int lag_hi, float *lag_dump,
+                                                        float dump_scale)
+{
+    constexpr int P = 512 * FK;
+    __shared__ unsigned long long red[4];
+    float *base = reinterpret_cast<float *>(V + (size_t)blockIdx.y * pl.Nc);
+    float *lags = reinterpret_cast<float *>(V + (size_t)blockIdx.y * pl.Nc + (size_t)(pl.N2 / 2) * 2 * 256 * FK);
+    const int li = blockIdx.x * 256 + threadIdx.x;            // lag index d + P, valid up to 2 P
+    const bool live = li <= 2 * P;
+    float s = 0.0f;
+    if (live)
+        for (int ch = 0; ch < n_chunks; ch++) s += base[(size_t)ch * (2 * P + 8) + li];
+    const float v = s * mul;
+    const int dlag = li - P;
+    if (live) lags[li] = v;
+    unsigned long long best = 0;
+    if (live && dlag >= lag_lo && dlag <= lag_hi && v == v) {
+        best = peak_key(v, dlag);
+        if (lag_dump) lag_dump[dlag - lag_lo] = v * dump_scale;
+    }
+    best = wave_max_u64(best);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long bb = red[0];
+        for (int w = 1; w < 4; w++) bb = red[w] > bb ? red[w] : bb;
+        if (bb) atomicMax(&keys[pw[blockIdx.y].out_index], bb);
+    }
+}
+
+}  // namespace tdoa

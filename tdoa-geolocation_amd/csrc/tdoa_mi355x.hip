@@ -20,6 +20,7 @@
 #include "k1_discriminator.hpp"
 #include "fft_stockham.hpp"
 #include "fft_radix16.hpp"
+#include "fft_radix8.hpp"
 #include "exact_reference.hpp"
 #include "synth_capture.hpp"
 #include "window_quality.hpp"
@@ -289,6 +290,22 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
     }
     const bool pruned = !ctx->force_generic && pl.N1 >= 128 && pl.N2 <= 4096 && np + nn <= kPruneMax && np + nn <= pl.N2 &&
                         lag_hi < pl.Nc && lag_lo > -pl.Nc;
+    // segment form (search ranges up to 1024 lags): overlap-save over 4096-point frames entirely in LDS; neither the
+    // column pass nor TZ nor V rows are touched.  Its chunk sums and lag array live where the short-lag form keeps its
+    // shares (inside this pair-window's V row), which bounds the chunk count by N2 / 2.
+    int seg_chunks = 0, seg_fk = 0;
+    {
+        // lags lag_lo - 1 .. lag_hi + 1 (refinement neighbours included) must lie in [-P, P], P = 512 seg_fk
+        const int reach = std::max(lag_hi + 1, -(lag_lo - 1));
+        seg_fk = reach <= 512 ? 1 : reach <= 1024 ? 2 : 0;
+    }
+    if (seg_fk && row16 && ctx->short_lag && ctx->segment_form && n_pw > 0 && pl.N2 >= 8) {
+        fk = seg_fk;
+        const int hop = 4096 - 1024 * fk;
+        const int pairs = ((maxlen + hop - 1) / hop + 1) / 2;
+        seg_chunks = std::max(1, std::min({pairs / 8, pl.N2 / 2 - 1, (4096 + n_pw - 1) / n_pw}));
+        if (const char *e = std::getenv("TDOA_SEG_CHUNKS")) seg_chunks = std::max(1, std::min({std::atoi(e), pairs, pl.N2 / 2 - 1}));
+    }
     {
         // K1: capture bytes -> 16-bit phase codes + exact window statistics
         ProfScope ps(ctx, TDOA_K_STATS, 4.0 * sum_len);
@@ -304,7 +321,7 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
     const size_t lds_row2 = sizeof(float2) * 4 * (size_t)pl.N1;
     const size_t lds_col16 = sizeof(float2) * 256 * 32;
     const size_t lds_pair16 = sizeof(float2) * 2 * kRowLds;
-    {
+    if (!seg_chunks) {
         ProfScope ps(ctx, TDOA_K_FWD_COL, 2.0 * sum_len + nc8 * n_sw);
         if (col16)
             hipLaunchKernelGGL(k_fwd_col256_c16<false>, dim3(pl.N1 / 32, n_sw), dim3(512), lds_col16, st, d_sw, codes,
@@ -342,7 +359,7 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
     // forward row pass fused into the pair kernel: pays when a station's rows are re-transformed at most as often as
     // they would be written and read back (no more pair-windows than station-windows: 3 stations, or a single pair)
     const bool fused_rows = row16 && ctx->fused_rows && n_pw > 0 && n_pw <= n_sw;
-    {
+    if (!seg_chunks) {
         ProfScope ps(ctx, TDOA_K_FWD_ROW, fused_rows ? 2.0 * 8.0 * 4096 * 2 * n_sw : 2.0 * nc8 * n_sw);
         if (fused_rows)    // only the two self-mirrored rows 0 and N2/2 (their pair kernel reads finished spectra)
             hipLaunchKernelGGL(k_fwd_row4096, dim3(2, n_sw), dim3(256), 0, st, tz, pl, pl.N2 / 2);
@@ -351,15 +368,37 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
         else
             hipLaunchKernelGGL(k_fwd_row, dim3(pl.N2, n_sw), dim3(256), lds_row, st, tz, pl);
     }
-    if (n_pw) {
+    if (n_pw && seg_chunks) {
+        const int hop = 4096 - 1024 * fk;
+        const double frames = (double)((maxlen + hop - 1) / hop);
+        const float mul = (float)(4.0 * 2.0 * (double)pl.Nc / 4096.0);          // 4 N / M
+        {
+            ProfScope ps(ctx, TDOA_K_INV_ROW, 2.0 * 2.0 * 4096.0 * frames * n_pw);   // two frames of 2-byte codes per segment
+            if (fk == 1)
+                hipLaunchKernelGGL(k_xcorr_segments<1>, dim3(seg_chunks, n_pw), dim3(512), sizeof(float2) * 2 * kRow8Lds, st,
+                                   d_sw, d_pw, codes, code_stride, stats, v, pl, seg_chunks);
+            else
+                hipLaunchKernelGGL(k_xcorr_segments<2>, dim3(seg_chunks, n_pw), dim3(512), sizeof(float2) * 2 * kRow8Lds, st,
+                                   d_sw, d_pw, codes, code_stride, stats, v, pl, seg_chunks);
+        }
+        {
+            ProfScope ps(ctx, TDOA_K_INV_COL, 4.0 * 1024.0 * fk * (seg_chunks + 1) * n_pw);
+            if (fk == 1)
+                hipLaunchKernelGGL(k_segments_reduce<1>, dim3(5, n_pw), dim3(256), 0, st, v, d_keys, d_pw, pl, seg_chunks, mul,
+                                   lag_lo, lag_hi, lag_dump, dump_scale);
+            else
+                hipLaunchKernelGGL(k_segments_reduce<2>, dim3(9, n_pw), dim3(256), 0, st, v, d_keys, d_pw, pl, seg_chunks, mul,
+                                   lag_lo, lag_hi, lag_dump, dump_scale);
+        }
+    } else if (n_pw) {
         {
             ProfScope ps(ctx, TDOA_K_INV_ROW, 3.0 * nc8 * n_pw);
             if (fk) {
 #define TDOA_PAIR_ROWS(FK)                                                                                           \
     do {                                                                                                             \
         if (pl.N2 > 2 && fused_rows)                                                                                 \
-            hipLaunchKernelGGL((k_pair_rows_fused4096<FK>), dim3(pl.N2 / 2 - 1, n_pw), dim3(256), lds_pair16, st,    \
-                               d_pw, tz, v, pl);                                                                     \
+            hipLaunchKernelGGL((k_pair_rows_fused_r8<FK>), dim3(pl.N2 / 2 - 1, n_pw), dim3(512),                     \
+                               sizeof(float2) * 2 * kRow8Lds, st, d_pw, tz, v, pl);                                  \
         else if (pl.N2 > 2)                                                                                          \
             hipLaunchKernelGGL((k_inv_row_pair4096<false, FK>), dim3(pl.N2 / 2 - 1, n_pw), dim3(256), lds_pair16, st,  \
                                d_pw, tz, v, pl);                                                                     \
@@ -413,7 +452,9 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
     }
     if (n_pw && fine_raw) {   // V (or the short-lag array) of this batch is still in place: peak neighbours for the parabola
         const dim3 g1((n_pw + 63) / 64), b1(64);
-        if (fk == 1) hipLaunchKernelGGL(k_refine_fused<1>, g1, b1, 0, st, v, d_keys, d_pw, pl, n_pw, fine_raw);
+        if (seg_chunks && fk == 1) hipLaunchKernelGGL((k_refine_fused<1, 1025>), g1, b1, 0, st, v, d_keys, d_pw, pl, n_pw, fine_raw);
+        else if (seg_chunks) hipLaunchKernelGGL((k_refine_fused<2, 2049>), g1, b1, 0, st, v, d_keys, d_pw, pl, n_pw, fine_raw);
+        else if (fk == 1) hipLaunchKernelGGL(k_refine_fused<1>, g1, b1, 0, st, v, d_keys, d_pw, pl, n_pw, fine_raw);
         else if (fk == 2) hipLaunchKernelGGL(k_refine_fused<2>, g1, b1, 0, st, v, d_keys, d_pw, pl, n_pw, fine_raw);
         else if (fk == 4) hipLaunchKernelGGL(k_refine_fused<4>, g1, b1, 0, st, v, d_keys, d_pw, pl, n_pw, fine_raw);
         else if (fk == 8) hipLaunchKernelGGL(k_refine_fused<8>, g1, b1, 0, st, v, d_keys, d_pw, pl, n_pw, fine_raw);
@@ -447,11 +488,13 @@ int allow_big_lds(tdoa_ctx *ctx)
     if ((rc = set_lds(ctx, k_inv_row_pair4096<true, 4>, all))) return rc;
     if ((rc = set_lds(ctx, k_inv_row_pair4096<false, 8>, all))) return rc;
     if ((rc = set_lds(ctx, k_inv_row_pair4096<true, 8>, all))) return rc;
-    if ((rc = set_lds(ctx, k_pair_rows_fused4096<0>, all))) return rc;
-    if ((rc = set_lds(ctx, k_pair_rows_fused4096<1>, all))) return rc;
-    if ((rc = set_lds(ctx, k_pair_rows_fused4096<2>, all))) return rc;
-    if ((rc = set_lds(ctx, k_pair_rows_fused4096<4>, all))) return rc;
-    if ((rc = set_lds(ctx, k_pair_rows_fused4096<8>, all))) return rc;
+    if ((rc = set_lds(ctx, k_pair_rows_fused_r8<0>, all))) return rc;
+    if ((rc = set_lds(ctx, k_pair_rows_fused_r8<1>, all))) return rc;
+    if ((rc = set_lds(ctx, k_pair_rows_fused_r8<2>, all))) return rc;
+    if ((rc = set_lds(ctx, k_pair_rows_fused_r8<4>, all))) return rc;
+    if ((rc = set_lds(ctx, k_pair_rows_fused_r8<8>, all))) return rc;
+    if ((rc = set_lds(ctx, k_xcorr_segments<1>, all))) return rc;
+    if ((rc = set_lds(ctx, k_xcorr_segments<2>, all))) return rc;
     return TDOA_OK;
 }
 

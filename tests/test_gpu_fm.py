@@ -271,8 +271,9 @@ def test_attach_device_buffer_from_torch(oracle):
 @pytest.mark.parametrize("max_lag,delay", [(128, 57), (128, -127), (511, 300), (512, -511), (1000, 999), (2047, -2046),
                                            (2048, 1500), (4095, 4094), (4096, -4000)])
 def test_short_lag_form_vs_oracle_and_general_form(oracle, max_lag, delay):
-    """|lag| ranges below 4095 take the short-lag inverse (no V round trip) on 4096-point rows; 4096 is the first
-    range that takes the general pruned form again.  Both against the f64 oracle, and against each other."""
+    """|lag| ranges below 1024 take the segment form (overlap-save in LDS, no four-step transform at all), ranges below
+    4095 the short-lag inverse (no V round trip) on 4096-point rows; 4096 is the first range that takes the general
+    pruned form again.  All against the f64 oracle, and against each other."""
     import tdoa_amd
     n = 300_000                                                   # N = 2^19: 4096 x 64
     a = oracle.simulate_delayed_fm(n, max(0, -delay), 77, 1)
@@ -289,6 +290,12 @@ def test_short_lag_form_vs_oracle_and_general_form(oracle, max_lag, delay):
         ofine = oracle.b_refine_peak(ta, tb, lag, 1e9)
         assert np.abs(fine["y"] - ofine["y"]).max() <= REL_TOL * abs(ocorr)
         assert abs(fine["frac"] - ofine["frac"]) < 1e-4
+        c.debug_flags(no_segment_form=True)                        # short-lag shares of the four-step form
+        shares = c.fm_xcorr_lags(a, b, max_lag)
+        _assert_lags_close(shares, want)
+        _assert_lags_close(shares, lags)
+        (lag_s, corr_s), fine_s = c.fm_xcorr_fine(a, b, max_lag, 1e9)
+        assert lag_s == olag and abs(corr_s - ocorr) <= REL_TOL * abs(ocorr) and abs(fine_s["frac"] - ofine["frac"]) < 1e-4
         c.debug_flags(no_short_lag=True)
         general = c.fm_xcorr_lags(a, b, max_lag)
         _assert_lags_close(general, lags)
@@ -339,6 +346,10 @@ def test_short_lag_form_in_the_batched_path(oracle, per_batch):
                 assert abs(peaks[wid, p]["corr"] - ocorr) <= REL_TOL * abs(ocorr)
                 of = oracle.b_refine_peak(pre[i], pre[j], olag, 120.0)
                 assert abs(fine[wid, p]["frac"] - of["frac"]) < 1e-4
+        c.debug_flags(no_segment_form=True)
+        shares = c.process()
+        assert np.array_equal(shares["lag"], peaks["lag"])
+        assert np.abs(shares["corr"] - peaks["corr"]).max() <= REL_TOL * np.abs(peaks["corr"]).max()
         c.debug_flags(no_short_lag=True)
         general = c.process()
         assert np.array_equal(general["lag"], peaks["lag"])
@@ -382,3 +393,21 @@ def test_fused_forward_rows_in_the_batched_path(oracle):
     assert fused.shape == (6, 3)
     assert np.array_equal(fused["lag"], separate["lag"])
     assert np.abs(fused["corr"] - separate["corr"]).max() <= 2e-6 * np.abs(separate["corr"]).max()
+
+
+@pytest.mark.parametrize("n1,n2,max_lag,delay", [(300_000, 300_000, 512, 77), (123_457, 99_991, 200, -150),
+                                                 (50_001, 50_000, 1023, 1000), (2_000_000, 2_000_000, 512, -333)])
+def test_segment_form_ragged_and_full_size(oracle, n1, n2, max_lag, delay):
+    """segment form on unequal / odd lengths (frames that run off either window) and at the BASELINE window length"""
+    import tdoa_amd
+    a = oracle.simulate_delayed_fm(n1, max(0, -delay), 88, 1)
+    b = oracle.simulate_delayed_fm(n2, max(0, delay), 88, 2)
+    ta, _ = oracle.b_preprocess(a)
+    tb, _ = oracle.b_preprocess(b)
+    olag, ocorr, want = oracle.b_xcorr_peak_fft(ta, tb, max_lag)
+    assert olag == delay
+    with tdoa_amd.Context(max_lag=max_lag, window_len=max(n1, n2)) as c:
+        lags = c.fm_xcorr_lags(a, b, max_lag)
+        lag, corr = c.fm_xcorr(a, b, max_lag)
+    _assert_lags_close(lags, want)
+    assert lag == olag and abs(corr - ocorr) <= REL_TOL * abs(ocorr)
