@@ -143,6 +143,11 @@ int tdoa_fast_analyze_capture_u8(tdoa_ctx *ctx, const uint8_t *raw, size_t n_byt
  * hipMemcpy); a station's previous buffer is reused when the new capture fits, so repeated
  * uploads of equal-sized captures keep their device addresses (TDOA_UPLOAD_THREADS overrides 4). */
 int tdoa_capture_upload(tdoa_ctx *ctx, int station, const uint8_t *iq, size_t n_samples);
+/* sharded ingest: upload only samples [first_sample, first_sample + n_samples) of a capture of total_samples -- a rank
+ * of a multi-GPU job calls it once per run of windows it owns (tdoa_process(rank, world) reads nothing else), so the
+ * host-to-device traffic of a G-rank job is 1/G of the capture per rank instead of all of it */
+int tdoa_capture_upload_range(tdoa_ctx *ctx, int station, size_t total_samples, size_t first_sample, const uint8_t *iq,
+                              size_t n_samples);
 /* the same from a .dat file (collector.go:61 naming, raw u8 I,Q; any size, > 1 GiB safe): the threads
  * pread their chunks straight into the pinned buffers;
  * *n_samples (may be NULL) receives size/2 like processor.go:182 */
@@ -155,6 +160,11 @@ int tdoa_capture_clear(tdoa_ctx *ctx);
 int tdoa_synth_capture(tdoa_ctx *ctx, int station, size_t block_samples, double ref_freq, double tgt_freq,
                        double noise_level, const double station_lle[3], const double tx_lle[3],
                        double tx_power, uint64_t seed);
+/* the same for weak_signal_simulator.go (BASELINE config 3; weak_signal_simulator.go:89-257): weak reference blocks
+ * (Gaussian noise 0.8 A, impulses p = 1e-3 at 5 A, phase drift 0.05 rad/s, DC 0.1 A), strong target block */
+int tdoa_synth_weak_capture(tdoa_ctx *ctx, int station, size_t block_samples, double ref_freq, double tgt_freq,
+                            const double station_lle[3], const double tx_lle[3], double ref_power, double tgt_power,
+                            uint64_t seed);
 /* read back part of a capture that lives in HBM */
 int tdoa_capture_download(tdoa_ctx *ctx, int station, size_t first_sample, size_t n_samples, uint8_t *out);
 

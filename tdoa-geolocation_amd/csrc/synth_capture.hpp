@@ -56,4 +56,59 @@ __global__ void k_synth_tone_block(uint8_t *out, long long n, SynthBlock b)
     reinterpret_cast<uint16_t *>(out)[i] = (uint16_t)(synth_quantise(re) | (synth_quantise(im) << 8));
 }
 
+// ---- weak_signal_simulator.go (BASELINE config 3: weak reference, strong target) ----------------------------
+// standard normal: Box-Muller on two counter-based uniforms (the reference calls rand.NormFloat64, time-seeded:
+// only the distribution is reproducible); same counters as the CPU restatement in oracle/tdoa_oracle.c
+__device__ __forceinline__ double synth_normal(unsigned long long seed, unsigned long long counter)
+{
+    double u1 = synth_uniform(seed, 2 * counter);
+    const double u2 = synth_uniform(seed, 2 * counter + 1);
+    u1 = u1 < 1e-300 ? 1e-300 : u1;
+    return sqrt(-2.0 * log(u1)) * cos(6.283185307179586476925286766559 * u2);
+}
+
+struct SynthWeakBlock {
+    double omega_over_fs;   // 2*pi*f / fs
+    double phase;
+    double amp;
+    double gaussian;        // sigma of the Gaussian noise (weak block: 0.8 amp; strong block: 0.001 absolute)
+    double impulse_p;       // weak block only: probability, level, phase drift per sample, DC offset
+    double impulse_level;
+    double drift_per_sample;
+    double dc;
+    unsigned long long seed;
+    unsigned long long block_id;
+    int weak;               // 1: generateWeakSignal (weak_signal_simulator.go:89-126), 0: generateStrongSignal (:129-148)
+};
+
+// one block of `n` samples; each thread writes one IQ pair.  Phase drift in closed form ((i + 1) drift / fs instead of
+// the reference's running sum) so that samples are independent, as in the CPU restatement.
+__global__ void k_synth_weak_block(uint8_t *out, long long n, SynthWeakBlock b)
+{
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double arg = b.omega_over_fs * (double)i + b.phase;
+    if (b.weak) arg += (double)(i + 1) * b.drift_per_sample;
+    double s, c;
+    sincos(arg, &s, &c);
+    double re = b.amp * c, im = b.amp * s;
+    const unsigned long long ctr = ((b.block_id << 40) + (unsigned long long)i) * 8;
+    if (b.weak) {
+        re += b.dc;
+        im += b.dc;
+        if (b.gaussian > 0) {
+            re += b.gaussian * synth_normal(b.seed, ctr);
+            im += b.gaussian * synth_normal(b.seed, ctr + 1);
+        }
+        if (synth_uniform(b.seed, 2 * (ctr + 2)) < b.impulse_p) {
+            re += b.impulse_level * (2.0 * synth_uniform(b.seed, 2 * (ctr + 3)) - 1.0);
+            im += b.impulse_level * (2.0 * synth_uniform(b.seed, 2 * (ctr + 4)) - 1.0);
+        }
+    } else {
+        re += b.gaussian * synth_normal(b.seed, ctr);
+        im += b.gaussian * synth_normal(b.seed, ctr + 1);
+    }
+    reinterpret_cast<uint16_t *>(out)[i] = (uint16_t)(synth_quantise((float)re) | (synth_quantise((float)im) << 8));
+}
+
 }  // namespace tdoa

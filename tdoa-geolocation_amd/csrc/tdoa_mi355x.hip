@@ -544,6 +544,8 @@ int fm_pair(tdoa_ctx *ctx, const uint8_t *iq1, size_t n1, const uint8_t *iq2, si
     long long n = std::max<long long>(next_pow2((long long)std::max(n1, n2) + max_lag), 64);
     FftPlan pl;
     if ((rc = make_plan(n, true, &pl))) return fail(ctx, rc, "FFT size unsupported");
+    ctx->plan = pl;            // tdoa_plan_info reports the plan of the last call, pair calls included
+    ctx->plan_n = n;
     SWDesc *d_sw;
     PWDesc *d_pw;
     if ((rc = stage_pair_u8(ctx, iq1, n1, iq2, n2, &d_sw, &d_pw))) return rc;
@@ -787,6 +789,27 @@ int tdoa_capture_upload(tdoa_ctx *ctx, int station, const uint8_t *iq, size_t n_
     return TDOA_OK;
 }
 
+// Sharded ingest: a rank of a multi-GPU job only reads the windows it owns (tdoa_process(rank, world)), so it only
+// needs those bytes in its HBM.  The station's buffer has the full capture's size (window offsets stay what they are);
+// the samples outside the uploaded ranges are never read by that rank.
+int tdoa_capture_upload_range(tdoa_ctx *ctx, int station, size_t total_samples, size_t first_sample, const uint8_t *iq,
+                              size_t n_samples)
+{
+    int rc;
+    if ((rc = check_ctx(ctx))) return rc;
+    if (station < 0 || station > 1023 || (!iq && n_samples) || first_sample > total_samples ||
+        n_samples > total_samples - first_sample)
+        return fail(ctx, TDOA_ERR_INVALID, "bad station/iq/range");
+    uint8_t *d = nullptr;
+    if ((rc = capture_buffer(ctx, station, 2 * total_samples, &d))) return rc;
+    const size_t had = ctx->caps[station].n;
+    ctx->caps[station].n = 0;                                  // not valid until the copy has finished
+    if ((rc = staged_upload(ctx, d + 2 * first_sample, iq, -1, 2 * n_samples))) return rc;
+    (void)had;
+    ctx->caps[station].n = total_samples;
+    return TDOA_OK;
+}
+
 int tdoa_capture_upload_file(tdoa_ctx *ctx, int station, const char *path, size_t *n_samples)
 {
     int rc;
@@ -854,6 +877,42 @@ int tdoa_synth_capture(tdoa_ctx *ctx, int station, size_t block_samples, double 
     for (int k = 0; k < 3; k++)
         hipLaunchKernelGGL(k_synth_tone_block, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
                            d + 2 * n * k, n, blk[k]);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->caps[station].n = 3 * block_samples;
+    return TDOA_OK;
+}
+
+int tdoa_synth_weak_capture(tdoa_ctx *ctx, int station, size_t block_samples, double ref_freq, double tgt_freq,
+                            const double station_lle[3], const double tx_lle[3], double ref_power, double tgt_power,
+                            uint64_t seed)
+{
+    int rc;
+    if ((rc = check_ctx(ctx))) return rc;
+    if (station < 0 || station > 1023 || block_samples < 2 || !station_lle || !tx_lle)
+        return fail(ctx, TDOA_ERR_INVALID, "bad argument");
+    uint8_t *d = nullptr;
+    if ((rc = capture_buffer(ctx, station, 6 * block_samples, &d))) return rc;
+    ctx->caps[station].n = 0;
+    // weak_signal_simulator.go:155-173: distance -> travel time -> carrier phases; amplitudes power/d*0.1
+    double a[3], b[3];
+    geo::latlon_to_ecef(station_lle[0], station_lle[1], station_lle[2], a);
+    geo::latlon_to_ecef(tx_lle[0], tx_lle[1], tx_lle[2], b);
+    const double dist = geo::range(a, b);
+    const double travel = dist / geo::kC;
+    const double fs = ctx->prm.sample_rate;
+    const double ref_amp = ref_power / dist * 0.1, tgt_amp = tgt_power / dist * 0.1;
+    // weak profile, weak_signal_simulator.go:180-186; the strong block adds 0.001 sigma of noise only (:141-143)
+    SynthWeakBlock weak = {2 * geo::kPi * ref_freq / fs, 2 * geo::kPi * ref_freq * travel, ref_amp, ref_amp * 0.8, 0.001,
+                           ref_amp * 5.0, 0.05 / fs, ref_amp * 0.1, seed, 1, 1};
+    SynthWeakBlock strong = {2 * geo::kPi * tgt_freq / fs, 2 * geo::kPi * tgt_freq * travel, tgt_amp, 0.001, 0.0, 0.0, 0.0,
+                             0.0, seed, 2, 0};
+    const long long n = (long long)block_samples;
+    const dim3 grid((unsigned)((n + 255) / 256)), blk(256);
+    hipLaunchKernelGGL(k_synth_weak_block, grid, blk, 0, ctx->stream, d, n, weak);                    // block 1: weak reference
+    hipLaunchKernelGGL(k_synth_weak_block, grid, blk, 0, ctx->stream, d + 2 * n, n, strong);          // block 2: strong target
+    weak.block_id = 3;
+    hipLaunchKernelGGL(k_synth_weak_block, grid, blk, 0, ctx->stream, d + 4 * n, n, weak);            // block 3: weak reference
+    HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->caps[station].n = 3 * block_samples;
     return TDOA_OK;

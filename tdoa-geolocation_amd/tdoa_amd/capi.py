@@ -64,7 +64,7 @@ SYMBOLS = [
     "tdoa_cross_correlate_c64", "tdoa_simple_correlate_c64", "tdoa_fast_snr_u8",
     "tdoa_fast_analyze_u8", "tdoa_fast_analyze_capture_u8",
     "tdoa_capture_upload", "tdoa_capture_upload_file", "tdoa_capture_attach_device", "tdoa_capture_clear",
-    "tdoa_synth_capture", "tdoa_capture_download",
+    "tdoa_synth_capture", "tdoa_synth_weak_capture", "tdoa_capture_download", "tdoa_capture_upload_range",
     "tdoa_num_windows", "tdoa_num_pairs", "tdoa_process", "tdoa_process_u8",
     "tdoa_process_fine", "tdoa_fm_xcorr_fine_u8", "tdoa_window_quality_all", "tdoa_window_quality_u8",
     "tdoa_fm_xcorr_u8", "tdoa_fm_preprocess_u8", "tdoa_fm_xcorr_lags_u8", "tdoa_debug_force_generic",
@@ -119,6 +119,9 @@ def load(build_if_missing=True):
     L.tdoa_capture_clear.argtypes = [vp]
     L.tdoa_synth_capture.argtypes = [vp, C.c_int, sz, C.c_double, C.c_double, C.c_double, dp, dp, C.c_double,
                                      C.c_uint64]
+    L.tdoa_synth_weak_capture.argtypes = [vp, C.c_int, sz, C.c_double, C.c_double, dp, dp, C.c_double, C.c_double,
+                                          C.c_uint64]
+    L.tdoa_capture_upload_range.argtypes = [vp, C.c_int, sz, sz, u8p, sz]
     L.tdoa_capture_download.argtypes = [vp, C.c_int, sz, sz, u8p]
     L.tdoa_num_windows.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.tdoa_num_pairs.argtypes = [vp]
@@ -271,6 +274,22 @@ class Context:
         s = np.ascontiguousarray(iq_u8, dtype=np.uint8)
         self._chk(self._L.tdoa_capture_upload(self._h, int(station), _u8(s), s.size // 2))
 
+    def capture_upload_range(self, station, total_samples, first_sample, iq_u8):
+        """upload only samples [first_sample, first_sample + len) of a capture of total_samples (sharded ingest)"""
+        s = np.ascontiguousarray(iq_u8, dtype=np.uint8)
+        self._chk(self._L.tdoa_capture_upload_range(self._h, int(station), int(total_samples), int(first_sample),
+                                                    _u8(s), s.size // 2))
+
+    def capture_upload_owned(self, station, iq_u8, rank, world, window_len):
+        """upload the sample runs of `iq_u8` that tdoa_process(rank, world) reads; returns the bytes sent"""
+        from . import sharding
+        s = np.ascontiguousarray(iq_u8, dtype=np.uint8)
+        sent = 0
+        for first, count in sharding.owned_sample_runs(rank, world, s.size // 2, window_len):
+            self.capture_upload_range(station, s.size // 2, first, s[2 * first:2 * (first + count)])
+            sent += 2 * count
+        return sent
+
     def capture_upload_file(self, station, path):
         n = C.c_size_t()
         self._chk(self._L.tdoa_capture_upload_file(self._h, int(station), os.fsencode(path), C.byref(n)))
@@ -285,6 +304,14 @@ class Context:
         tx = np.ascontiguousarray(tx_lle, dtype=np.float64)
         self._chk(self._L.tdoa_synth_capture(self._h, int(station), int(block_samples), ref_freq, tgt_freq, noise,
                                              _d(st), _d(tx), tx_power, int(seed)))
+
+    def synth_weak_capture(self, station, block_samples, station_lle, tx_lle, seed, ref_freq=162.4e6,
+                           tgt_freq=92.3e6, ref_power=10.0, tgt_power=1000.0):
+        """weak_signal_simulator.go capture (weak reference blocks, strong target block) generated in HBM"""
+        st = np.ascontiguousarray(station_lle, dtype=np.float64)
+        tx = np.ascontiguousarray(tx_lle, dtype=np.float64)
+        self._chk(self._L.tdoa_synth_weak_capture(self._h, int(station), int(block_samples), ref_freq, tgt_freq,
+                                                  _d(st), _d(tx), ref_power, tgt_power, int(seed)))
 
     def capture_download(self, station, first_sample, n_samples):
         out = np.empty(2 * int(n_samples), dtype=np.uint8)

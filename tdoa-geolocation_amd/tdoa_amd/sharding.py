@@ -30,6 +30,34 @@ def unit_owner(wid, pair, world, n_windows, n_pairs):
     return wid % world
 
 
+def window_grid(n_samples, window_len):
+    """(block, window length, windows per block) of a capture of n_samples: own thirds per file (processor.go:214),
+    windows of window_len inside each block (processor.go:772-780 generalised) -- the library's window_geometry"""
+    block = n_samples // 3
+    wlen = min(window_len, block)
+    return block, wlen, max(1, block // wlen) if wlen else 0
+
+
+def owned_sample_runs(rank, world, n_samples, window_len, n_min=None):
+    """[(first_sample, n_samples)] runs of a capture that tdoa_process(rank, world) reads under window-major sharding
+    (adjacent owned windows merged).  With fewer windows than ranks the pair-major fallback may touch any window:
+    then the whole capture is one run.  n_min: length of the shortest capture of the job when they differ (the
+    window grid comes from it, the block offsets from the capture's own thirds)."""
+    block = n_samples // 3
+    _, wlen, wpb = window_grid(n_samples if n_min is None else n_min, window_len)
+    n_windows = 3 * wpb
+    if n_windows < world:
+        return [(0, n_samples)]
+    runs = []
+    for wid in owned_windows(rank, world, n_windows):
+        first = (wid // wpb) * block + (wid % wpb) * wlen
+        if runs and runs[-1][0] + runs[-1][1] == first:
+            runs[-1] = (runs[-1][0], runs[-1][1] + wlen)
+        else:
+            runs.append((first, wlen))
+    return runs
+
+
 def peaks_as_bytes(peaks):
     """structured peak array -> flat uint8 view (what travels through the collective)."""
     a = np.ascontiguousarray(peaks, dtype=PEAK_DTYPE)
