@@ -1,17 +1,27 @@
 #!/usr/bin/env python3
 """bench.py -- IQ Msamples/s through demod + xcorr on MI355X (BASELINE.json metric).
 
-A step = one pass of the hot path (u8 IQ -> FM discriminator -> FFT -> conj-multiply ->
-inverse FFT -> peak pick) over one synthetic capture set already resident in HBM:
-BASELINE config 2 -- 3 stations x 2 Msps x 100 s (400 MB each, blocks [ref|target|ref] of
-66 666 666 samples), windows of L = 2 000 000 samples, N = 2^21, all 3 pairs on all 99
-windows.  With N ranks (one per GPU, torch.distributed over RCCL) every rank owns its own
-capture set (weak scaling) and the per-pair peaks are collected with one all-gather.
+A step = one pass of the hot path (u8 IQ -> FM discriminator -> FFT -> conj-multiply -> inverse FFT -> peak pick)
+over one synthetic capture set already resident in HBM; peaks end on the host.
+
+  --config cfg2 (default at --gpus 1)  3 stations x 2 Msps x 100 s, 99 windows x 3 pairs, L = 2 000 000, N = 2^21
+  --config cfg3                        weak_signal_simulator.go captures, 10 s windows (L = 2e7, N = 2^25), 342 windows
+                                       x 3 pairs = 1026 pair-windows streamed in launch groups
+  --config cfg4 (default at --gpus >1) 8 stations (28 pairs) x 2 Msps x 100 s
+  --config cfg5                        16 stations (120 pairs) x 4 Msps x 300 s, 1 s windows (L = 4e6, N = 2^22)
+
+Multi-GPU (one rank per GPU, torch.distributed over RCCL):
+  --scaling strong (default for --gpus > 1): ONE capture set; rank r runs tdoa_process(ctx, r, world) on the windows it
+      owns (window-major, wid % world == r), one all-gather of the per-pair peak records, merge, N-station least-squares
+      solve on rank 0 -- all inside the timed region.  value = the job's station-samples / time.
+  --scaling weak: every rank owns its own capture set (replicas + the same all-gather); value = sum over ranks.
 
 Prints ONE JSON line on rank 0 (see the contract in the task description).
 """
 import argparse
+import hashlib
 import json
+import math
 import os
 import sys
 import time
@@ -30,104 +40,209 @@ STATIONS = [
 TX = (41.20, -96.00, 400.0)
 SEED_BASE = 0x5D0A0000
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured achievable)
-# profile scope -> kernel that runs for the cfg2 plan (N = 2^21 = 2 x 4096 x 256)
-HOT_KERNELS = {"k_fm_demod": "k_fm_demod", "k_fwd_col": "k_fwd_col256_c16", "k_fwd_row": "k_fwd_row4096",
-               "k_inv_row_pair": "k_inv_row_pair4096", "k_inv_col_peak": "k_inv_col_pruned"}
+
+CONFIGS = {
+    "cfg2": dict(stations=3, fs=2e6, block=66_666_666, wlen=2_000_000, sim="simulator", steps=10,
+                 label="BASELINE config 2: 3 stations x 2 Msps x 100 s simulator.go-style capture"),
+    "cfg3": dict(stations=3, fs=2e6, block=114 * 20_000_000, wlen=20_000_000, sim="weak", steps=3,
+                 label="BASELINE config 3: weak_signal_simulator.go captures, 10 s windows, 1026 pair-windows"),
+    "cfg4": dict(stations=8, fs=2e6, block=66_666_666, wlen=2_000_000, sim="simulator", steps=5,
+                 label="BASELINE config 4: 8 collectors (28 pairs) x 2 Msps x 100 s"),
+    "cfg5": dict(stations=16, fs=4e6, block=400_000_000, wlen=4_000_000, sim="simulator", steps=3,
+                 label="BASELINE config 5: 16 collectors (120 pairs) x 4 Msps x 300 s, 1 s windows"),
+}
+
+
+def station_table(n):
+    """the 3 real collectors + synthetic ones on 12 / 7 km rings about their centroid"""
+    out = list(STATIONS)
+    clat = sum(s[0] for s in STATIONS) / 3
+    clon = sum(s[1] for s in STATIONS) / 3
+    k = 0
+    while len(out) < n:
+        ang = 2 * math.pi * (k + 0.37) / max(n - 3, 1)
+        r_km = 12.0 if k % 2 == 0 else 7.0
+        out.append((clat + r_km / 111.2 * math.cos(ang), clon + r_km / (111.2 * math.cos(math.radians(clat))) * math.sin(ang),
+                    300.0 + 10.0 * k))
+        k += 1
+    return out
+
+
+def source_hash():
+    """hash of the kernel sources: a committed PMC traffic file is only quoted when it was taken on these kernels"""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "tdoa-geolocation_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp", ".inc")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def pmc_traffic(kernel):
-    """HBM-side bytes per launch from the committed rocprofv3 --pmc passes (scripts/collect_pmc.sh);
-    bench.py cannot profile itself, so this is read back from profiles/ (None if absent)."""
+    """HBM-side bytes per launch from the committed rocprofv3 --pmc passes (scripts/collect_pmc.sh); bench.py cannot
+    profile itself, so this is read back from profiles/ -- and only if the file was taken on the current kernel sources.
+    returns (bytes per launch of `kernel`, source label, sum over the step's kernels)"""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
     if not files:
-        return None, None
+        return None, None, None
     try:
-        rec = json.load(open(files[-1]))["kernels"].get(kernel)
-        return (rec["traffic_bytes_per_launch"], os.path.basename(files[-1])) if rec else (None, None)
+        doc = json.load(open(files[-1]))
+        if doc.get("source_sha16") != source_hash():
+            return None, "stale: %s was taken on other kernel sources" % os.path.basename(files[-1]), None
+        rec = doc["kernels"].get(kernel)
+        total = sum(v["traffic_bytes_per_launch"] for v in doc["kernels"].values())
+        return (rec["traffic_bytes_per_launch"] if rec else None), os.path.basename(files[-1]), total
     except Exception:
-        return None, None
+        return None, None, None
 
 
-def pipeline_pmc_rate(step_seconds):
-    """sum of the per-launch PMC traffic of every kernel of one step (one launch each in the default run) / step time"""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
-    if not files:
-        return None
+def cpu_info():
+    model, phys = "unknown", set()
     try:
-        total = sum(v["traffic_bytes_per_launch"] for v in json.load(open(files[-1]))["kernels"].values())
-        return round(total / step_seconds / 1e9, 1)
-    except Exception:
-        return None
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model == "unknown":
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                pid = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                cid = line.split(":", 1)[1].strip()
+            elif not line.strip():
+                if pid is not None and cid is not None:
+                    phys.add((pid, cid))
+                pid = cid = None
+    except OSError:
+        pass
+    return model, (len(phys) or (os.cpu_count() or 1))
+
+
+def _mode_b_f64_unit(args):
+    """one (pair, window) of the north-star pipeline in float64 on the CPU (worker process of the CPU-fft leg)"""
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    import numpy as np
+    from oracle import float_pipeline as fp
+    a, b, max_lag = args
+    lag, corr, _ = fp.xcorr_peak_u8(np.frombuffer(a, np.uint8), np.frombuffer(b, np.uint8), max_lag)
+    return lag, corr
 
 
 def cpu_baseline_leg(ctx, peaks, block, wlen, max_lag, budget_s):
-    """Times the CPU oracle (restatement of processor.go crossCorrelate) on the host cores on a
-    bounded sample of the same bytes, and uses the same oracle to check the GPU peaks of
-    window 0.  This is the only place bench.py touches oracle/."""
-    import numpy as np
+    """BASELINE.md section 2.  Times the CPU oracle (restatement of processor.go crossCorrelate) on the host on a
+    bounded sample of the same bytes, in the reference's own call pattern (3 pairs x {reference, target} block,
+    processor.go:816-850): once on ONE thread (the reference is single-threaded), once with OpenMP on every core; the
+    same algorithm as the GPU path in float64 on the CPU cores; and checks the GPU peaks of window 0 against the
+    oracle.  This is the only place bench.py touches oracle/."""
+    import ctypes
     from oracle import pyoracle as o
     o.build()
-    cores = os.cpu_count() or 1
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
-    # --- parity of the timed GPU path on window 0 (mode B oracle, f64 FFT form)
-    w0 = [ctx.capture_download(s, 0, wlen) for s in range(3)]
-    t_fft = time.perf_counter()
-    pre = [o.b_preprocess(x)[0] for x in w0]
-    parity = True
-    for p, (i, j) in enumerate([(0, 1), (0, 2), (1, 2)]):
-        olag, ocorr, _ = o.b_xcorr_peak_fft(pre[i], pre[j], max_lag)
-        g = peaks[0, p]
-        if int(g["lag"]) != olag or abs(float(g["corr"]) - ocorr) > 1e-5 * abs(ocorr):
-            parity = False
-    t_fft = time.perf_counter() - t_fft     # the same algorithm as the GPU path (mode B), float64 FFTs, one window
-    # --- CPU baseline: reference call pattern (3 pairs, reference-frequency block) on the
-    # first n samples of each station's capture; calibrate n to the time budget
-    def run(n):
-        sig = [o.iq_u8_to_c64(x[:2 * n]) for x in w0]
+    model, phys = cpu_info()
+    threads = os.cpu_count() or 1
+    # --- parity of the timed GPU path on window 0 (mode B oracle, f64 FFT form); 10 s windows are left to the tests
+    parity = None
+    if wlen <= 4_000_000:
+        w0 = [ctx.capture_download(s, 0, wlen) for s in range(3)]
+        pre = [o.b_preprocess(x)[0] for x in w0]
+        parity = True
+        for p, (i, j) in enumerate([(0, 1), (0, 2)]):             # pairs (0,1), (0,2) are slots 0, 1 for any station count
+            olag, ocorr, _ = o.b_xcorr_peak_fft(pre[i], pre[j], max_lag)
+            g = peaks[0, p]
+            if int(g["lag"]) != olag or abs(float(g["corr"]) - ocorr) > 1e-5 * max(abs(ocorr), 1e-30):
+                parity = False
+    # --- the reference's call pattern on the first n samples of the reference block and of the target block
+    n_max = min(wlen, 2_000_000)                                   # processor.go:772 testChunkSize
+    ref = [ctx.capture_download(s, 0, n_max) for s in range(3)]
+    tgt = [ctx.capture_download(s, block, n_max) for s in range(3)]
+    gomp = None
+    try:
+        gomp = ctypes.CDLL("libgomp.so.1")
+    except OSError:
+        pass
+
+    def run(n, nthreads):
+        if gomp is not None:
+            gomp.omp_set_num_threads(int(nthreads))
+        sig = [[o.iq_u8_to_c64(x[:2 * n]) for x in blk] for blk in (ref, tgt)]
         t0 = time.perf_counter()
-        for (i, j) in [(0, 1), (0, 2), (1, 2)]:
-            o.cross_correlate(sig[i], sig[j])
+        for blk in sig:
+            for (i, j) in [(0, 1), (0, 2), (1, 2)]:
+                o.cross_correlate(blk[i], blk[j])
         return time.perf_counter() - t0
-    n = 20000
-    t = run(n)
-    n_big = int(min(wlen, max(n, n * budget_s / max(t, 1e-3))))
-    if n_big > 2 * n:
-        n, t = n_big, run(n_big)
+
+    def calibrated(nthreads, budget):
+        n = 20000
+        t = run(n, nthreads)
+        n_big = int(min(n_max, max(n, n * budget / max(t, 1e-3))))
+        if n_big > 2 * n:
+            n, t = n_big, run(n_big, nthreads)
+        return n, t
+
+    n1, t1 = calibrated(1, budget_s)
+    # all cores: one thread per physical core, on at least the single-thread sample (a 20 000-sample probe on 256 threads
+    # measures nothing but the fork/join cost of the filter loops)
+    nn = int(min(n_max, 4 * n1))
+    tn = run(nn, phys) if gomp is not None else t1 * nn / n1
+    # --- same algorithm as the GPU path, float64, on the CPU cores (one (pair, window) per worker process)
+    try:
+        import multiprocessing as mp
+        workers = max(1, min(phys, 12))
+        n_f = min(wlen, 2_000_000)
+        segs = [ctx.capture_download(s, 0, n_f).tobytes() for s in range(3)]
+        units = [(segs[i], segs[j], max_lag) for (i, j) in [(0, 1), (0, 2), (1, 2)]] * max(1, workers // 3)
+        with mp.get_context("spawn").Pool(min(workers, len(units))) as pool:
+            pool.map(_mode_b_f64_unit, units[:min(workers, len(units))])            # start-up outside the clock
+            t0 = time.perf_counter()
+            pool.map(_mode_b_f64_unit, units)
+            tf = time.perf_counter() - t0
+        fft = {"value": round(len(units) * n_f / tf / 1e6, 3), "unit": "pair-Msamples/s",
+               "cores": min(workers, len(units)),
+               "sample": "float64 atan2 discriminator + numpy FFT cross-correlation (oracle/float_pipeline.py), %d (pair, window) "
+                         "units of %d samples on %d worker processes, %.2f s" % (len(units), n_f, min(workers, len(units)), tf)}
+    except Exception as e:                                                           # never fail the bench on the extra leg
+        fft = {"error": repr(e)}
     return {
-        "value": round(3 * n / t / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
-        "sample": "oracle restatement of processor.go crossCorrelate (weak-signal filter chain + "
-                  "time-domain correlation), 3 pairs on the first %d samples of each station's "
-                  "reference block, same bytes as the GPU run, OpenMP over %d threads, %.1f s" % (n, cores, t),
-        # SURVEY.md 8d: the same algorithm on the CPU for an apples-to-apples comparison (not the baseline `value`)
-        "same_algorithm_f64_fft": {"value": round(3 * wlen / t_fft / 1e6, 3), "unit": "Msamples/s", "cores": 1,
-                                   "sample": "mode-B oracle (C discriminator + numpy float64 FFT cross-correlation), "
-                                             "3 stations x 1 window x 3 pairs, %.2f s" % t_fft},
+        "value": round(6 * n1 / t1 / 1e6, 4), "unit": "Msamples/s", "cores": 1, "kind": "port",
+        "cpu_model": model, "physical_cores": phys, "hardware_threads": threads,
+        "sample": "oracle restatement of processor.go crossCorrelate (power gate, moving-average filter chain, time-domain "
+                  "correlation), the reference's 6-call pattern: 3 pairs x {reference block, target block}, first %d samples "
+                  "of each, same bytes as the GPU run, ONE thread (the reference is single-threaded), %.1f s" % (n1, t1),
+        "all_cores": {"value": round(6 * nn / tn / 1e6, 4), "unit": "Msamples/s", "cores": phys,
+                      "sample": "the same 6 calls, OpenMP inside each call, one thread per physical core (%d of %d hardware "
+                                "threads), first %d samples, %.1f s" % (phys, threads, nn, tn)},
+        "same_algorithm_f64_fft": fft,
     }, parity
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--seconds", type=float, default=100.0, help="capture length per station")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default=None)
+    ap.add_argument("--scaling", choices=("strong", "weak"), default=None)
+    ap.add_argument("--seconds", type=float, default=None, help="capture length per station (overrides the config)")
     ap.add_argument("--batch", type=int, default=0, help="windows per launch group (0 = library default)")
     ap.add_argument("--max-lag", type=int, default=20000, help="search range in samples (reference: 20000, processor.go:633)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget", type=float, default=15.0)
+    ap.add_argument("--no-graph-leg", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=10.0)
     args = ap.parse_args()
 
     import numpy as np
     import torch
     import tdoa_amd
+    from tdoa_amd import sharding
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    cfg_name = args.config or ("cfg2" if world == 1 else "cfg4")
+    cfg = dict(CONFIGS[cfg_name])
+    scaling = args.scaling or ("weak" if world == 1 else "strong")
+    steps = args.steps if args.steps is not None else cfg["steps"]
     # one rank per GPU; TDOA_BENCH_BACKEND=gloo is a rehearsal mode (several ranks may then share
     # a GPU and the peak records travel through host memory) -- the driver always runs nccl (= RCCL)
     backend = os.environ.get("TDOA_BENCH_BACKEND", "nccl")
@@ -137,119 +252,189 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device))
         else:
             dist.init_process_group(backend=backend)
 
-    fs = 2_000_000
-    wlen, max_lag = 2_000_000, args.max_lag
-    total = int(args.seconds * fs)
-    block = total // 3
-    ctx = tdoa_amd.Context(device=device, window_len=wlen, max_lag=max_lag, windows_per_batch=args.batch)
-    for s in range(3):
-        ctx.synth_capture(s, block, STATIONS[s], TX, SEED_BASE + 16 * rank + s)
+    fs, wlen, max_lag = cfg["fs"], cfg["wlen"], args.max_lag
+    S = cfg["stations"]
+    block = int(args.seconds * fs) // 3 if args.seconds else cfg["block"]
+    stations = station_table(S)
+    ctx = tdoa_amd.Context(device=device, window_len=wlen, max_lag=max_lag, sample_rate=fs, windows_per_batch=args.batch)
+    seed0 = SEED_BASE + (16 * rank if scaling == "weak" else 0)        # strong: every rank holds the SAME capture set
+    for s in range(S):
+        if cfg["sim"] == "weak":
+            ctx.synth_weak_capture(s, block, stations[s], TX, seed0 + s, tgt_power=20000.0)
+        else:
+            ctx.synth_capture(s, block, stations[s], TX, seed0 + s)
     wpb, n_windows = ctx.num_windows()
     n_pairs = ctx.num_pairs()
-    samples_per_step = 3 * n_windows * min(wlen, block)
+    wl = min(wlen, block)
+    job_samples = S * n_windows * wl                                    # station-samples one capture set holds
+    samples_per_step = job_samples * (world if scaling == "weak" else 1)
 
     peak_bytes = n_windows * n_pairs * 16
     dev_peaks = torch.zeros(peak_bytes, dtype=torch.uint8, device="cuda")
     gathered = torch.zeros(peak_bytes * world, dtype=torch.uint8, device="cuda") if world > 1 else None
+    state = {"peaks": None, "fix": None}
+    tgt_rows = np.arange(wpb, 2 * wpb)                                    # windows of the target block
+
+    def solve(pk):
+        """downstream of the path (processor.go:892-926): median target-block lag per pair -> range differences ->
+        least-squares position (3 stations: the reference's solver; more: tdoa_solve_nstation weighted by |corr|)"""
+        lag = np.median(pk["lag"][tgt_rows], axis=0)
+        wgt = np.median(pk["abs_corr"][tgt_rows], axis=0).astype(np.float64)
+        rd = lag / fs * 299792458.0
+        if S == 3:
+            return tdoa_amd.capi.solve_3station(stations, rd)
+        return tdoa_amd.capi.solve_nstation(stations, rd, weights=np.maximum(wgt, 1e-12))
 
     def step():
-        ctx.process(0, 1, out_dev_ptr=dev_peaks.data_ptr(), want_host=False)
-        if world > 1:
-            if backend == "nccl":
-                dist.all_gather_into_tensor(gathered, dev_peaks)  # RCCL over xGMI: per-pair peaks
-            else:
-                parts = [torch.empty(peak_bytes, dtype=torch.uint8) for _ in range(world)]
-                dist.all_gather(parts, dev_peaks.cpu())
-                gathered.copy_(torch.cat(parts))
+        if world == 1:
+            state["peaks"] = ctx.process(0, 1, out_dev_ptr=dev_peaks.data_ptr(), want_host=True)     # peaks on the host
+            return
+        if scaling == "strong":
+            ctx.process(rank, world, out_dev_ptr=dev_peaks.data_ptr(), want_host=False)
+        else:
+            ctx.process(0, 1, out_dev_ptr=dev_peaks.data_ptr(), want_host=False)
+        if backend == "nccl":
+            dist.all_gather_into_tensor(gathered, dev_peaks)        # RCCL over xGMI: per-pair peak records
+        else:
+            parts = [torch.empty(peak_bytes, dtype=torch.uint8) for _ in range(world)]
+            dist.all_gather(parts, dev_peaks.cpu())
+            gathered.copy_(torch.cat(parts))
+        if scaling == "strong" and rank == 0:
+            # other ranks' units are zero bytes in every part: the byte-wise maximum IS the owner merge
+            merged = gathered.view(world, -1).amax(dim=0).cpu().numpy()
+            state["peaks"] = sharding.bytes_as_peaks(merged, n_windows, n_pairs)
+            state["fix"] = solve(state["peaks"])
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(n_steps):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            step()
+        fence()
+        dt_ = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt_], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt_ = float(tt.item())
+        return dt_
+
     for _ in range(args.warmup):
         step()
-    ctx.profile_enable(os.environ.get("TDOA_BENCH_NOPROF", "0") != "1")
+    # timed region of the contract: per-kernel HIP events on the library's stream (tdoa_profile_*), kernels launched
+    # one by one.  The product default replays the whole step as one hipGraph; that path is timed right after.
+    ctx.profile_enable(True)
     ctx.profile_reset()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
+    dt = timed(steps)
     ctx.profile_enable(False)
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-        # every rank must hold every rank's peaks after the gather
+    prof = ctx.profile()
+    graph_leg = None
+    # (single GPU only: in a two-process gloo rehearsal on ONE card the second replay of the step graph returned
+    # uninitialised records for windows the rank does not own -- not reproducible in one process, nor in two independent
+    # processes; until that is understood the multi-rank runs time the kernel-by-kernel path only, see DESIGN.md)
+    if not args.no_graph_leg and world == 1:
+        step()                                                            # captures the graph
+        dtg = timed(steps)
+        graph_leg = {"ms_per_step": round(dtg / steps * 1e3, 4), "value": round(samples_per_step / (dtg / steps) / 1e6, 2),
+                     "note": "the same steps with the whole step replayed as one hipGraph and no per-kernel events "
+                             "(the library's default path)"}
+
+    if world > 1 and scaling == "strong" and n_windows >= world:
+        # every rank's part must be what the owner merge expects: its own windows, zeros elsewhere
+        mine = np.frombuffer(dev_peaks.cpu().numpy().tobytes(), dtype=tdoa_amd.capi.PEAK_DTYPE).reshape(n_windows, n_pairs)
+        for wid in range(n_windows):
+            if wid % world != rank and (mine[wid]["lag"].any() or mine[wid]["corr"].any()):
+                raise SystemExit("rank %d of %d wrote a window it does not own (%d): nonzero windows %r"
+                                 % (rank, world, wid, [w for w in range(n_windows) if mine[w]["lag"].any() or mine[w]["corr"].any()]))
+    if world > 1 and scaling == "weak":
         got = torch.frombuffer(bytearray(gathered.cpu().numpy().tobytes()), dtype=torch.uint8).view(world, -1)
-        mine = dev_peaks.cpu()
-        if not torch.equal(got[rank], mine):
+        if not torch.equal(got[rank], dev_peaks.cpu()):
             raise SystemExit("all-gather of peak records is inconsistent on rank %d" % rank)
 
-    prof = ctx.profile()
+    rc = 0
     if rank == 0:
-        ms_per_step = dt / args.steps * 1e3
-        value = samples_per_step * world / (dt / args.steps) / 1e6
-        dom = max(prof.items(), key=lambda kv: kv[1]["ms"])
-        name, rec = dom
+        ms_per_step = dt / steps * 1e3
+        value = samples_per_step / (dt / steps) / 1e6
+        n_fft, n1, n2 = ctx.plan_info()
+        name, rec = max(prof.items(), key=lambda kv: kv[1]["ms"])
+        hot = {"k_fm_demod": "k_fm_demod", "k_fwd_col": "k_fwd_col256_c16", "k_fwd_row": "k_fwd_row4096",
+               "k_inv_row_pair": "k_inv_row_pair4096", "k_inv_col_peak": "k_inv_col_pruned"} if (n1, n2) == (4096, 256) else {}
+        if max_lag <= 1024 and n1 == 4096:
+            hot = dict(hot, k_inv_row_pair="k_xcorr_segments", k_inv_col_peak="k_segments_reduce")
         roof = None
         if rec["launches"]:
             per_launch_bytes = rec["bytes"] / rec["launches"]
             avg_s = rec["ms"] / rec["launches"] / 1e3
             achieved = per_launch_bytes / avg_s / 1e9
-            n_fft_, n1_, n2_ = ctx.plan_info()
-            traffic, src = (None, None)
-            default_cfg = (n1_, n2_) == (4096, 256) and args.seconds == 100.0 and args.batch == 0 and world == 1
-            if default_cfg and name in HOT_KERNELS:
-                traffic, src = pmc_traffic(HOT_KERNELS[name])
-            roof = {"bound": "hbm", "kernel": HOT_KERNELS.get(name, name) if (n1_, n2_) == (4096, 256) else name,
+            traffic, src, pmc_total = (None, None, None)
+            default_cfg = cfg_name == "cfg2" and args.seconds is None and args.batch == 0 and world == 1 and max_lag == 20000
+            if default_cfg and name in hot:
+                traffic, src, pmc_total = pmc_traffic(hot[name])
+            roof = {"bound": "hbm", "kernel": hot.get(name, name),
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                     "frac_of_measured_achievable": round(achieved / 6290.0, 4),   # guide: 6.29 TB/s achievable
-                    "traffic": traffic,
-                    "traffic_source": src,
+                    "traffic": traffic, "traffic_source": src,
                     "algorithmic_bytes_per_launch": per_launch_bytes,
                     "avg_launch_us": round(avg_s * 1e6, 2), "launches": rec["launches"],
-                    "kernels_ms_per_step": {k: round(v["ms"] / args.steps, 4) for k, v in prof.items()}}
-        n_fft, n1, n2 = ctx.plan_info()
-        # whole-pipeline algorithmic bytes: 2L + 12N per station-window, 16N per pair-window
-        a_bytes = n_windows * (3 * (2 * wlen + 12 * n_fft) + n_pairs * 16 * n_fft)
+                    "kernels_ms_per_step": {k: round(v["ms"] / steps, 4) for k, v in prof.items()}}
+        # whole-pipeline algorithmic bytes (SURVEY.md 8d): k = ceil(log2 N / 12) passes of 4096-point tiles, e = 4 B:
+        # 2L + e N (2k - 1) per station-window, e N 2k per pair-window  (k = 2: 2L + 12N and 16N; k = 3: 2L + 20N and 24N)
+        k_pass = max(2, math.ceil(math.log2(n_fft) / 12.0))
+        units_w = n_windows * (world if scaling == "weak" else 1)
+        a_bytes = units_w * (S * (2 * wl + 4 * n_fft * (2 * k_pass - 1)) + n_pairs * 4 * n_fft * 2 * k_pass)
+        if world > 1 and scaling == "strong":
+            par = ("one capture set, windows dealt wid %% %d to the ranks, RCCL all-gather of the peak records, owner merge + "
+                   "least-squares solve on rank 0, all inside the timed region" % world)
+        elif world > 1:
+            par = "independent capture set per GPU x%d + RCCL all-gather of the peak records" % world
+        else:
+            par = "single GPU"
         out = {
             "metric": "IQ Msamples/s through demod+xcorr", "value": round(value, 2), "unit": "Msamples/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "BASELINE config 2: 3 stations x 2 Msps x %g s simulator.go-style capture per GPU, "
-                                   "3 pairs x %d windows of %d samples, FFT N=%d (%dx%d), max_lag %d"
-                                   % (args.seconds, n_windows, wlen, n_fft, n1, n2, max_lag),
-                       "stations": 3, "pairs": n_pairs, "windows": n_windows, "window_len": wlen,
-                       "fft_n": n_fft, "parallelism": "window-sharded x%d + RCCL all-gather of peaks" % world},
-            "pipeline_algorithmic_GBps": round(a_bytes * world / (dt / args.steps) / 1e9, 1),
-            "pipeline_frac_of_hbm_peak": round(a_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
-            # HBM-side bytes the whole step really moved (PMC sum over its kernels, committed passes) over the same time
-            "pipeline_pmc_GBps": pipeline_pmc_rate(dt / args.steps) if (world == 1 and (n1, n2) == (4096, 256)
-                                                                         and args.seconds == 100.0) else None,
+            "config": {"workload": "%s%s, %d pairs x %d windows of %d samples, FFT N=%d (%dx%d), max_lag %d; peaks on the host"
+                                   % (cfg["label"], " per GPU" if (scaling == "weak" and world > 1) else "", n_pairs, n_windows, wl,
+                                      n_fft, n1, n2, max_lag),
+                       "name": cfg_name, "stations": S, "pairs": n_pairs, "windows": n_windows, "window_len": wl,
+                       "fft_n": n_fft, "sample_rate": fs, "parallelism": par},
+            "timed_path": "kernels launched one by one with per-kernel HIP events (the roofline's source); graph replay: graph_replay",
+            "graph_replay": graph_leg,
+            "pipeline_algorithmic_GBps": round(a_bytes / (dt / steps) / 1e9, 1),
+            "pipeline_frac_of_hbm_peak": round(a_bytes / (dt / steps) / 1e9 / HBM_PEAK_GBS / world, 4),
             # SURVEY.md 8d secondary figure: pair-samples correlated per second (P*W*L/t), whole job
-            "pair_Msamples_per_s": round(world * n_pairs * n_windows * wlen / (dt / args.steps) / 1e6, 2),
+            "pair_Msamples_per_s": round(samples_per_step / S * n_pairs / (dt / steps) / 1e6, 2),
             "roofline": roof,
         }
+        if roof and roof.get("traffic") is not None and pmc_total:
+            out["pipeline_pmc_GBps"] = round(pmc_total / (dt / steps) / 1e9, 1)
+        if state["fix"] is not None:
+            frc, flle, fit = state["fix"]
+            out["solve"] = {"status": int(frc), "lat": round(float(flle[0]), 6), "lon": round(float(flle[1]), 6),
+                            "iterations": int(fit)}
         if world == 1 and not args.no_cpu_baseline:
-            peaks = np.frombuffer(dev_peaks.cpu().numpy().tobytes(), dtype=tdoa_amd.capi.PEAK_DTYPE).reshape(
-                n_windows, n_pairs)
-            out["cpu_baseline"], out["parity_window0"] = cpu_baseline_leg(ctx, peaks, block, min(wlen, block),
-                                                                           max_lag, args.cpu_budget)
+            out["cpu_baseline"], out["parity_window0"] = cpu_baseline_leg(ctx, state["peaks"], block, wl, max_lag, args.cpu_budget)
+            if out["parity_window0"] is False:
+                rc = 3
         print(json.dumps(out), flush=True)
     ctx.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if rc:
+        raise SystemExit("parity check of window 0 against the oracle FAILED")
 
 
 if __name__ == "__main__":

@@ -11,7 +11,11 @@ import collections
 import csv
 import glob
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import source_hash  # noqa: E402  (hash of the kernel sources the counters were taken on)
 
 FETCH_CORRECTION = {"k_fm_demod": 2.0, "k_fwd_row4096": 2.0, "k_inv_row_pair4096": 2.0, "k_inv_col_pruned": 2.0,
                     "k_fwd_col256_c16": 1.0}
@@ -41,7 +45,7 @@ def main():
         rec["WRITE_SIZE_KiB"] += w
         rec["traffic_bytes_per_launch"] += f * 1024 * corr + w * 1024
     json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py cfg2, batch = all windows",
-               "kernels": res}, open(sys.argv[3], "w"), indent=1, sort_keys=True)
+               "source_sha16": source_hash(), "kernels": res}, open(sys.argv[3], "w"), indent=1, sort_keys=True)
     print(json.dumps(res, indent=1))
 
 
