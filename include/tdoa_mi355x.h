@@ -100,6 +100,11 @@ int tdoa_time_domain_correlation_c64(tdoa_ctx *ctx, const float *s1, size_t n1,
 int tdoa_cross_correlate_c64(tdoa_ctx *ctx, const float *s1, size_t n1,
                              const float *s2, size_t n2,
                              int32_t *delay, double *corr);
+/* the reference's pair loop (processor.go:816-830, :836-850) in one call: every signal goes through
+ * preprocessSignal ONCE (crossCorrelate re-does it for every pair a station is in, :629-630), then each pair
+ * i < j is correlated; delay[p], corr[p] in the reference's pair order, bit-identical to per-pair calls */
+int tdoa_cross_correlate_batch_c64(tdoa_ctx *ctx, const float *const *signals, const size_t *n_samples, int n_signals,
+                                   int32_t *delay, double *corr);
 
 /* simple_corr.go:83-160 simpleCorrelate -> (delay, float32 corr) */
 int tdoa_simple_correlate_c64(tdoa_ctx *ctx, const float *s1, size_t n1,

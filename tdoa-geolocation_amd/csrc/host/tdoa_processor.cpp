@@ -217,12 +217,20 @@ int main(int argc, char **argv)
         for (int kind = 0; kind < 2; kind++) {
             std::printf(kind == 0 ? "\n=== REFERENCE SIGNAL CORRELATION TEST ===\n" : "\n=== TARGET SIGNAL CORRELATION TEST ===\n");
             auto &sig = kind == 0 ? refs : tgts;
+            // one call for all pairs: every station's signal goes through preprocessSignal once instead of once per pair
+            // (processor.go:629-630); the numbers are the per-pair crossCorrelate's, bit for bit
+            std::vector<const float *> ptr(S);
+            std::vector<size_t> len(S);
+            for (int s = 0; s < S; s++) { ptr[s] = sig[s].data(); len[s] = sig[s].size() / 2; }
+            std::vector<int32_t> delays((size_t)S * (S - 1) / 2);
+            std::vector<double> corrs(delays.size());
+            if ((rc = tdoa_cross_correlate_batch_c64(ctx, ptr.data(), len.data(), S, delays.data(), corrs.data())))
+                return die("tdoa_cross_correlate_batch_c64", rc);
+            int pidx = 0;
             for (int i = 0; i < S; i++)
-                for (int j = i + 1; j < S; j++) {
-                    int32_t delay = 0;
-                    double corr = 0;
-                    if ((rc = tdoa_cross_correlate_c64(ctx, sig[i].data(), sig[i].size() / 2, sig[j].data(), sig[j].size() / 2, &delay, &corr)))
-                        return die("tdoa_cross_correlate_c64", rc);
+                for (int j = i + 1; j < S; j++, pidx++) {
+                    const int32_t delay = delays[pidx];
+                    const double corr = corrs[pidx];
                     const double dt = (double)delay / prm.sample_rate;       // processor.go:821-822
                     std::printf("%s %s - %s: delay=%d samples (%.3f μs), correlation=%.17g\n", kind == 0 ? "REF" : "TGT",
                                 caps[i].st.name.c_str(), caps[j].st.name.c_str(), delay, dt * 1e6, corr);

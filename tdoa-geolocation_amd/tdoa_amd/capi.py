@@ -68,7 +68,7 @@ SYMBOLS = [
     "tdoa_num_windows", "tdoa_num_pairs", "tdoa_process", "tdoa_process_u8",
     "tdoa_process_fine", "tdoa_fm_xcorr_fine_u8", "tdoa_window_quality_all", "tdoa_window_quality_u8",
     "tdoa_fm_xcorr_u8", "tdoa_fm_preprocess_u8", "tdoa_fm_xcorr_lags_u8", "tdoa_debug_force_generic",
-    "tdoa_debug_flags",
+    "tdoa_debug_flags", "tdoa_cross_correlate_batch_c64",
     "tdoa_latlon_to_ecef", "tdoa_ecef_to_latlon", "tdoa_solve_3station", "tdoa_solve_nstation",
     "tdoa_profile_enable", "tdoa_profile_reset", "tdoa_profile_get", "tdoa_kernel_name",
     "tdoa_plan_info",
@@ -109,6 +109,7 @@ def load(build_if_missing=True):
     L.tdoa_preprocess_c64.argtypes = [vp, fp, sz, fp, C.POINTER(C.c_int)]
     L.tdoa_time_domain_correlation_c64.argtypes = [vp, fp, sz, fp, sz, C.c_int, i32p, dp]
     L.tdoa_cross_correlate_c64.argtypes = [vp, fp, sz, fp, sz, i32p, dp]
+    L.tdoa_cross_correlate_batch_c64.argtypes = [vp, C.POINTER(fp), C.POINTER(sz), C.c_int, i32p, dp]
     L.tdoa_simple_correlate_c64.argtypes = [vp, fp, sz, fp, sz, i32p, fp]
     L.tdoa_fast_snr_u8.argtypes = [vp, u8p, C.c_int, dp]
     L.tdoa_fast_analyze_u8.argtypes = [vp, u8p, C.c_int, C.POINTER(FastAnalysis)]
@@ -242,6 +243,18 @@ class Context:
         d, c = C.c_int32(), C.c_double()
         self._chk(self._L.tdoa_cross_correlate_c64(self._h, _f(va), a.size, _f(vb), b.size, C.byref(d), C.byref(c)))
         return d.value, c.value
+
+    def cross_correlate_batch(self, signals):
+        """every signal preprocessed once, every pair i < j correlated (processor.go:816-850): [(delay, corr)] in pair order"""
+        arrs = [_c64(x) for x in signals]
+        k = len(arrs)
+        ptrs = (C.POINTER(C.c_float) * k)(*[_f(v) for _, v in arrs])
+        sizes = (C.c_size_t * k)(*[a.size for a, _ in arrs])
+        npair = k * (k - 1) // 2
+        d = (C.c_int32 * npair)()
+        c = (C.c_double * npair)()
+        self._chk(self._L.tdoa_cross_correlate_batch_c64(self._h, ptrs, sizes, k, d, c))
+        return [(d[p], c[p]) for p in range(npair)]
 
     def simple_correlate(self, s1, s2):
         a, va = _c64(s1)

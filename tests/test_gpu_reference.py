@@ -199,3 +199,24 @@ def test_reference_call_size_two_million_samples(oracle):
         od, ocorr = oracle.cross_correlate(sig[0], sig[1])
         assert d == od == 0
         assert abs(corr - ocorr) <= 1e-12 * abs(ocorr)
+
+
+def test_cross_correlate_batch_equals_pair_calls(ctx, oracle):
+    """tdoa_cross_correlate_batch_c64: every signal preprocessed once (the reference re-does it per pair,
+    processor.go:629-630), every pair i < j correlated -- bit-identical to the per-pair calls and to the oracle's delay"""
+    raw = [oracle.simulate_station(nm, 20000, oracle.SEED_BASE + i) for i, nm in enumerate(oracle.COLLECTORS)]
+    sigs = [oracle.extract_target(oracle.iq_u8_to_c64(r)) for r in raw]
+    sigs.append(sigs[0][:12000])                                  # a shorter one: real lag searches against the others
+    got = ctx.cross_correlate_batch(sigs)
+    assert len(got) == 6
+    p = 0
+    for i in range(4):
+        for j in range(i + 1, 4):
+            d, c = ctx.cross_correlate(sigs[i], sigs[j])
+            assert got[p] == (d, c), (i, j)
+            od, oc = oracle.cross_correlate(sigs[i], sigs[j])
+            assert d == od and abs(c - oc) <= 1e-9 * max(abs(oc), 1e-300)
+            p += 1
+    # empty members give (0, 0.0) for their pairs, like processor.go:622-625
+    got = ctx.cross_correlate_batch([sigs[0], np.zeros(0, np.complex64), sigs[1]])
+    assert got[0] == (0, 0.0) and got[2] == (0, 0.0) and got[1] == ctx.cross_correlate(sigs[0], sigs[1])
