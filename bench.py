@@ -68,13 +68,17 @@ def station_table(n):
     return out
 
 
+HOT_SOURCES = ("device_common.hpp", "k1_discriminator.hpp", "fft_stockham.hpp", "fft_radix16.hpp", "fft_radix8.hpp",
+               "tdoa_mi355x.hip")
+
+
 def source_hash():
-    """hash of the kernel sources: a committed PMC traffic file is only quoted when it was taken on these kernels"""
+    """hash of the sources of the timed path's kernels and their launch code: a committed PMC traffic file is only
+    quoted when it was taken on these kernels"""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "tdoa-geolocation_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".hpp", ".inc")):
-            h.update(open(os.path.join(d, f), "rb").read())
+    for f in HOT_SOURCES:
+        h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
 
@@ -338,6 +342,7 @@ def main():
     dt = timed(steps)
     ctx.profile_enable(False)
     prof = ctx.profile()
+    timed_peaks = None if state["peaks"] is None else state["peaks"].copy()     # what the contract's timed region produced
     graph_leg = None
     # (single GPU only: in a two-process gloo rehearsal on ONE card the second replay of the step graph returned
     # uninitialised records for windows the rank does not own -- not reproducible in one process, nor in two independent
@@ -346,6 +351,7 @@ def main():
         step()                                                            # captures the graph
         dtg = timed(steps)
         graph_leg = {"ms_per_step": round(dtg / steps * 1e3, 4), "value": round(samples_per_step / (dtg / steps) / 1e6, 2),
+                     "identical_to_timed_path": bool(timed_peaks is not None and np.array_equal(timed_peaks, state["peaks"])),
                      "note": "the same steps with the whole step replayed as one hipGraph and no per-kernel events "
                              "(the library's default path)"}
 
@@ -425,7 +431,7 @@ def main():
             out["solve"] = {"status": int(frc), "lat": round(float(flle[0]), 6), "lon": round(float(flle[1]), 6),
                             "iterations": int(fit)}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"], out["parity_window0"] = cpu_baseline_leg(ctx, state["peaks"], block, wl, max_lag, args.cpu_budget)
+            out["cpu_baseline"], out["parity_window0"] = cpu_baseline_leg(ctx, timed_peaks, block, wl, max_lag, args.cpu_budget)
             if out["parity_window0"] is False:
                 rc = 3
         print(json.dumps(out), flush=True)

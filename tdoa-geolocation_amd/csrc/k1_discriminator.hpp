@@ -203,18 +203,33 @@ __global__ __launch_bounds__(kDemodThreads) void k_fm_demod(const SWDesc *sw, in
                 qs[h] = make_uint4(0, 0, 0, 0);
                 prev[h] = 0;
             }
+            // Exactly opposite angle codes mean +pi unless Im p < 0, and Im p < 0 needs two NON-collinear samples less
+            // than one code step away from a reversal: |x_i||x_{i-1}| > 2 * 32768/pi = 20861 in units of (2b - 255).
+            // A small-amplitude capture (simulator.go: +-3 LSB) is full of exact reversals but can never get there: if
+            // every byte of the piece is within [96, 159], |x|^2 <= 2 * 63^2 = 7938.  One wave-uniform test per piece
+            // (2048 samples) then switches the per-sample sign check off altogether.
+            bool check_sign = true;
             if (__all(interior)) {
                 // whole piece inside the window: the sample before a lane's chunk is the last sample of the lane to
                 // its left (lane 0: lane 63 of the previous chunk; chunk 0: one broadcast load) -- no 2-byte gathers
                 const unsigned int before = p[start - 1];
 #pragma unroll
                 for (int h = 0; h < kDemodChunks; h++) qs[h] = k1_fetch8(p, start + h * 512 + lane * 8);
+                unsigned int far = 0;            // a byte b is in [96, 159] iff the top three bits of b ^ 0x80 are equal
 #pragma unroll
                 for (int h = 0; h < kDemodChunks; h++) {
                     const unsigned int left = __shfl_up(qs[h].w >> 16, 1, kWave);
                     const unsigned int wrap = h ? __shfl(qs[h ? h - 1 : 0].w >> 16, kWave - 1, kWave) : before;
                     prev[h] = lane ? left : wrap;
+                    const unsigned int y0 = qs[h].x ^ 0x80808080u, y1 = qs[h].y ^ 0x80808080u, y2 = qs[h].z ^ 0x80808080u,
+                                       y3 = qs[h].w ^ 0x80808080u;
+                    far |= (y0 ^ (y0 << 1)) | (y1 ^ (y1 << 1)) | (y2 ^ (y2 << 1)) | (y3 ^ (y3 << 1));
                 }
+                {
+                    const unsigned int yb = (before | (before << 16)) ^ 0x80808080u;
+                    far |= yb ^ (yb << 1);
+                }
+                check_sign = __any((far & 0xC0C0C0C0u) != 0);
             } else {
 #pragma unroll
                 for (int h = 0; h < kDemodChunks; h++) {
@@ -237,25 +252,13 @@ __global__ __launch_bounds__(kDemodThreads) void k_fm_demod(const SWDesc *sw, in
                     for (int k = 0; k < 9; k++) a[k] = lut[k1_slot(sm[k])];
                     int t1 = 0;
                     unsigned long long t2 = 0;
-                    bool opposite = false;
 #pragma unroll
-                    for (int k = 0; k < 8; k++) {
-                        c[k] = (int)(short)(a[k] - a[k + 1]);                  // stored = -code
-                        opposite = opposite || c[k] == -32768;
-                    }
-                    if (__any(opposite)) {
-                        // Exactly opposite angle codes mean +pi unless Im p < 0, and Im p < 0 needs two NON-collinear
-                        // samples less than one code step away from a reversal: |x_i||x_{i-1}| > 2 * 32768/pi = 20861
-                        // in units of (2b - 255).  A small-amplitude capture (simulator.go: +-3 LSB) is full of exact
-                        // reversals but can never get there -- if every byte of the lane's nine samples is within
-                        // [96, 159], |x|^2 <= 2 * 63^2 = 7938 -- so the byte-level check is skipped for it.
-                        const uint4 q = qs[half];
-                        const unsigned int y0 = q.x ^ 0x80808080u, y1 = q.y ^ 0x80808080u, y2 = q.z ^ 0x80808080u,
-                                           y3 = q.w ^ 0x80808080u, y4 = (sm[0] | (sm[0] << 16)) ^ 0x80808080u;
-                        // a byte b is in [96, 159] iff the top three bits of b ^ 0x80 are equal
-                        const unsigned int far = ((y0 ^ (y0 << 1)) | (y1 ^ (y1 << 1)) | (y2 ^ (y2 << 1)) | (y3 ^ (y3 << 1)) |
-                                                  (y4 ^ (y4 << 1))) & 0xC0C0C0C0u;
-                        if (__any(opposite && far != 0)) {
+                    for (int k = 0; k < 8; k++) c[k] = (int)(short)(a[k] - a[k + 1]);      // stored = -code
+                    if (check_sign) {            // wave-uniform: some byte of the piece is far from the centre
+                        bool opposite = false;
+#pragma unroll
+                        for (int k = 0; k < 8; k++) opposite = opposite || c[k] == -32768;
+                        if (__any(opposite)) {
 #pragma unroll
                             for (int k = 0; k < 8; k++) c[k] = k1_stored_code(a[k + 1], a[k], sm[k + 1], sm[k]);
                         }
