@@ -246,7 +246,9 @@ enum {
     TDOA_DEBUG_GENERIC_KERNELS = 1,  /* any-size LDS radix-4 kernels instead of the radix-16 register kernels        */
     TDOA_DEBUG_NO_SHORT_LAG    = 2,  /* general pruned inverse even when the search range is below 4095 lags          */
     TDOA_DEBUG_NO_FUSED_ROWS   = 4,  /* separate forward row pass even when every station is in at most two pairs     */
-    TDOA_DEBUG_NO_SEGMENT_FORM = 8   /* no LDS-resident overlap-save correlation for search ranges below 1024 lags    */
+    TDOA_DEBUG_NO_SEGMENT_FORM = 8,  /* no LDS-resident overlap-save correlation for search ranges up to 1024 lags    */
+    TDOA_DEBUG_NO_XCD_ROWS     = 16, /* plain 2-D grid of the pair kernel even with more pairs than stations          */
+    TDOA_DEBUG_PAIR_R8         = 32  /* (bit set = form USED) 512-thread / 8-value pair kernel instead of 256 / 16      */
 };
 int tdoa_debug_flags(tdoa_ctx *ctx, unsigned flags);
 

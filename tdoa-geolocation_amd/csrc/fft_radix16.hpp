@@ -441,7 +441,7 @@ __device__ __forceinline__ void inv_row_pair_tail(float2 (&va)[16], float2 (&vb)
 // SIMD; told so, the scheduler keeps ~20 loads in flight instead of squeezing registers for a third wave it
 // cannot have -- the short-lag instances otherwise dropped to two loads in flight, 1.41 ms against 1.25 ms.)
 template <bool SELF, int FK>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SELF ? 1 : 2, SELF ? 8 : 2))) void k_inv_row_pair4096(const PWDesc *pw, const float2 *Z, float2 *V, FftPlan pl)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SELF ? 1 : 2, SELF ? 8 : 2))) void k_inv_row_pair4096(const PWDesc *pw, const float2 *Z, float2 *V, FftPlan pl, int group_pairs, int n_pw)
 {
     extern __shared__ float2 lds[];   // 2 * kRowLds
     const int N2 = pl.N2;
@@ -451,9 +451,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SELF ? 1 : 
     // An XCD-aware 1-D remap that puts the station pairs sharing a spectrum row on one XCD measured 4-8 % slower
     // than this plain grid while the kernel was still latency-bound, and exactly the same (1.257 ms both ways) once
     // it was bandwidth-bound: the plain grid stays.
+    // group_pairs > 0 (many pairs per window: 8 stations -> 28, 16 -> 120): 1-D grid, XCD-aware.  The group_pairs
+    // pair-windows of one window all read the same S station rows a and N2 - a; workgroups are dealt round-robin over
+    // the 8 XCDs (b and b + 8 share an L2), so the workgroups of one (window, row pair) group are given consecutive
+    // slots of ONE XCD: a station row then comes from HBM once and from that XCD's L2 for its other S - 2 pairs.
+    // (With 3 stations a row has two readers and the remap measured neutral: the plain 2-D grid stays for P <= S.)
     constexpr bool self = SELF;
-    const int pw_index = blockIdx.y;
-    const int a = self ? 0 : blockIdx.x + 1;
+    int pw_index = blockIdx.y, a = self ? 0 : blockIdx.x + 1;
+    if (!self && group_pairs > 0) {
+        const int RP = N2 / 2 - 1;
+        const unsigned int L = blockIdx.x, xcd = L & 7u, slot = L >> 3;
+        const unsigned int g = slot / (unsigned int)group_pairs, p = slot % (unsigned int)group_pairs;
+        const unsigned int G = g * 8u + xcd;                       // (window, row pair) group
+        const unsigned int w = G / (unsigned int)RP;
+        if (w * (unsigned int)group_pairs >= (unsigned int)n_pw) return;      // padding of the last round of 8 groups
+        a = (int)(G % (unsigned int)RP) + 1;
+        pw_index = (int)(w * (unsigned int)group_pairs + p);
+    }
     const PWDesc d = pw[pw_index];
     const int b = self ? N2 / 2 : N2 - a;
     const float2 *ZaA = Z + (size_t)d.sw_a * pl.Nc + (size_t)a * 4096;

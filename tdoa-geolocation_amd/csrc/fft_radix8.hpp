@@ -172,6 +172,111 @@ __device__ __forceinline__ void rows2_r8_finish(float2 (&x)[8], float2 (&y)[8], 
                            opaque(unit_root((float)j, 2.0f / 4096.0f, INV)));
 }
 
+// second half of the radix-8 pair kernels: Q of rows a (va: stage-1 item t, inputs in natural order) and b (vb: stage-1
+// item 511 - t) -> two inverse row transforms -> four-step twiddle -> the two V rows (FK = 0) or the row pair's share of
+// the short-lag column sums (FK > 0).  All 512 threads; the LDS images must be free to overwrite on entry.
+template <int FK>
+__device__ __forceinline__ void inv_row_pair_tail_r8(float2 (&va)[8], float2 (&vb)[8], float2 *la, float2 *lb, const int t,
+                                                     const int a, const int b, const int pw_index, float2 *V,
+                                                     const FftPlan &pl)
+{
+    const int N2 = pl.N2;
+    fft8<true>(va);
+    fft8<true>(vb);
+    rows2_r8_finish<true>(va, vb, la, lb, t, t, 511 - t);
+    // V[k2][n1] = y[n1] * W_Nc^(-n1 k2), n1 = t + 512 k
+    float2 *out = V + (size_t)pw_index * pl.Nc;
+    const float inv2 = 2.0f / (float)pl.Nc;
+    {
+        const long long e0 = ((long long)t * a) & (pl.Nc - 1), e1 = ((long long)512 * a) & (pl.Nc - 1);
+        mul_base_step8(va, unit_root((float)e0, inv2, true), unit_root((float)e1, inv2, true));
+        const long long f0 = ((long long)t * b) & (pl.Nc - 1), f1 = ((long long)512 * b) & (pl.Nc - 1);
+        mul_base_step8(vb, unit_root((float)f0, inv2, true), unit_root((float)f1, inv2, true));
+    }
+    if constexpr (FK == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            out[(size_t)a * 4096 + t + 512 * k] = va[oreg8(k)];
+            out[(size_t)b * 4096 + t + 512 * k] = vb[oreg8(k)];
+        }
+    } else {
+        // short-lag form (see k_inv_row_pair4096): P0[n1] = V[a][n1] + V[b][n1] for n1 < 256 FK,
+        // P1[n1 - (4096 - 256 FK)] = V[a][n1] conj(w_a) + V[b][n1] conj(w_b) for n1 >= 4096 - 256 FK
+        const float2 ca = unit_root((float)a, 2.0f / (float)N2, false);
+        const float2 cb = unit_root((float)b, 2.0f / (float)N2, false);
+        float2 *part = out + (size_t)a * (2 * 256 * FK);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int n1 = t + 512 * k;
+            if (512 * k < 256 * FK && n1 < 256 * FK) part[n1] = cadd(va[oreg8(k)], vb[oreg8(k)]);
+            if (512 * (k + 1) > 4096 - 256 * FK && n1 >= 4096 - 256 * FK)
+                part[256 * FK + n1 - (4096 - 256 * FK)] = cadd(cmul(va[oreg8(k)], ca), cmul(vb[oreg8(k)], cb));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Inverse row pair kernel on 512 threads (rows a and b = N2 - a, a >= 1): the same work as k_inv_row_pair4096<false, FK>
+// -- K3 on finished spectra, two inverse row transforms, twiddle, V rows or short-lag shares -- with 8 values per thread,
+// 128 VGPRs and four waves per SIMD instead of 16 values, ~230 VGPRs and two.  The pair kernel issues vector
+// instructions for 0.74 of its 1.19 ms (cfg2); at two waves per SIMD a wave that waits leaves every other issue slot
+// empty.  Grid as k_inv_row_pair4096 (2-D, or the XCD-aware 1-D form with group_pairs > 0), dynamic LDS 64 KB.
+// ---------------------------------------------------------------------------
+template <int FK>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_PLAIN_DS_OPS)) void k_inv_row_pair_r8(const PWDesc *pw, const float2 *Z, float2 *V, FftPlan pl, int group_pairs, int n_pw)
+{
+    extern __shared__ float2 lds[];   // 2 * kRow8Lds
+    const int N2 = pl.N2;
+    int pw_index = blockIdx.y, a = blockIdx.x + 1;
+    if (group_pairs > 0) {            // XCD-aware 1-D grid: see k_inv_row_pair4096
+        const int RP = N2 / 2 - 1;
+        const unsigned int L = blockIdx.x, xcd = L & 7u, slot = L >> 3;
+        const unsigned int g = slot / (unsigned int)group_pairs, p = slot % (unsigned int)group_pairs;
+        const unsigned int G = g * 8u + xcd;
+        const unsigned int w = G / (unsigned int)RP;
+        if (w * (unsigned int)group_pairs >= (unsigned int)n_pw) return;
+        a = (int)(G % (unsigned int)RP) + 1;
+        pw_index = (int)(w * (unsigned int)group_pairs + p);
+    }
+    const int b = N2 - a;
+    const PWDesc d = pw[pw_index];
+    const float2 *ZaA = Z + (size_t)d.sw_a * pl.Nc + (size_t)a * 4096;
+    const float2 *ZaB = Z + (size_t)d.sw_a * pl.Nc + (size_t)b * 4096;
+    const float2 *ZbA = Z + (size_t)d.sw_b * pl.Nc + (size_t)a * 4096;
+    const float2 *ZbB = Z + (size_t)d.sw_b * pl.Nc + (size_t)b * 4096;
+    const int t = threadIdx.x;
+    float2 *la = lds, *lb = lds + kRow8Lds;
+    float2 va[8], vb[8];
+    {
+        float2 za[8], zam[8], zb[8], zbm[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int k1 = t + 512 * r;
+            za[r] = ZaA[k1];
+            zam[r] = ZaB[4095 - k1];
+            zb[r] = ZbA[k1];
+            zbm[r] = ZbB[4095 - k1];
+        }
+        // w(k) = W_N^k, k = (t + 512 r) N2 + a  =>  w = w0 * W_16^r, re-anchored half way
+        const float invNc = 1.0f / (float)pl.Nc;
+        const long long k0 = (long long)t * N2 + a;
+        const float2 st = make_float2(0.92387953251128674f, -0.38268343236508977f);   // e^{-2 pi i/16}
+        float2 w = unit_root((float)k0, invNc, false);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            float2 q, qm;
+            pair_q(za[r], zam[r], zb[r], zbm[r], w, q, qm);
+            va[r] = q;              // Q[a][t + 512 r]:                 row a, stage-1 item t, input r
+            vb[7 - r] = qm;         // Q[b][(511 - t) + 512 (7 - r)]:   row b, stage-1 item 511 - t, input 7 - r
+            if (r == 3)
+                w = unit_root((float)(k0 + (long long)4 * 512 * N2), invNc, false);
+            else
+                w = cmul(w, st);
+        }
+    }
+    inv_row_pair_tail_r8<FK>(va, vb, la, lb, t, a, b, pw_index, V, pl);
+}
+
 // ---------------------------------------------------------------------------
 // Forward row pass FUSED into the inverse row pair kernel, rows a and b = N2 - a (a >= 1): the workgroup reads the
 // COLUMN-pass output T of both stations (the same 4 x 32 KB the pair kernel reads anyway), runs the four forward
@@ -185,7 +290,7 @@ __device__ __forceinline__ void rows2_r8_finish(float2 (&x)[8], float2 (&y)[8], 
 // grid (N2/2 - 1, n_pw), 512 threads, dynamic LDS 64 KB (two workgroups per CU, four waves per SIMD).
 // ---------------------------------------------------------------------------
 template <int FK>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_pair_rows_fused_r8(const PWDesc *pw, const float2 *T, float2 *V, FftPlan pl)
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_PLAIN_DS_OPS)) void k_pair_rows_fused_r8(const PWDesc *pw, const float2 *T, float2 *V, FftPlan pl)
 {
     extern __shared__ float2 lds[];   // 2 * kRow8Lds
     const int N2 = pl.N2;
@@ -248,38 +353,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         }
     }
     __syncthreads();      // every mirrored read is done before the inverse stages overwrite the images
-    fft8<true>(va);
-    fft8<true>(vb);
-    rows2_r8_finish<true>(va, vb, la, lb, t, t, 511 - t);
-    // V[k2][n1] = y[n1] * W_Nc^(-n1 k2), n1 = t + 512 k
-    float2 *out = V + (size_t)pw_index * pl.Nc;
-    const float inv2 = 2.0f / (float)pl.Nc;
-    {
-        const long long e0 = ((long long)t * a) & (pl.Nc - 1), e1 = ((long long)512 * a) & (pl.Nc - 1);
-        mul_base_step8(va, unit_root((float)e0, inv2, true), unit_root((float)e1, inv2, true));
-        const long long f0 = ((long long)t * b) & (pl.Nc - 1), f1 = ((long long)512 * b) & (pl.Nc - 1);
-        mul_base_step8(vb, unit_root((float)f0, inv2, true), unit_root((float)f1, inv2, true));
-    }
-    if constexpr (FK == 0) {
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            out[(size_t)a * 4096 + t + 512 * k] = va[oreg8(k)];
-            out[(size_t)b * 4096 + t + 512 * k] = vb[oreg8(k)];
-        }
-    } else {
-        // short-lag form (see k_inv_row_pair4096): P0[n1] = V[a][n1] + V[b][n1] for n1 < 256 FK,
-        // P1[n1 - (4096 - 256 FK)] = V[a][n1] conj(w_a) + V[b][n1] conj(w_b) for n1 >= 4096 - 256 FK
-        const float2 ca = unit_root((float)a, 2.0f / (float)N2, false);
-        const float2 cb = unit_root((float)b, 2.0f / (float)N2, false);
-        float2 *part = out + (size_t)a * (2 * 256 * FK);
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const int n1 = t + 512 * k;
-            if (512 * k < 256 * FK && n1 < 256 * FK) part[n1] = cadd(va[oreg8(k)], vb[oreg8(k)]);
-            if (512 * (k + 1) > 4096 - 256 * FK && n1 >= 4096 - 256 * FK)
-                part[256 * FK + n1 - (4096 - 256 * FK)] = cadd(cmul(va[oreg8(k)], ca), cmul(vb[oreg8(k)], cb));
-        }
-    }
+    inv_row_pair_tail_r8<FK>(va, vb, la, lb, t, a, b, pw_index, V, pl);
 }
 
 // ---------------------------------------------------------------------------

@@ -78,6 +78,8 @@ struct tdoa_ctx {
     bool short_lag = true;                  // TDOA_NO_SHORT_LAG=1 at tdoa_create time forces the general inverse for short searches
     bool fused_rows = false;                // forward row pass inside the pair kernel when P <= S (TDOA_FUSED_ROWS=1 / tdoa_debug_flags)
     bool segment_form = true;               // TDOA_NO_SEGMENT_FORM=1: no LDS-resident overlap-save form for short searches
+    bool xcd_rows = true;                   // TDOA_NO_XCD_ROWS=1: plain 2-D grid of the pair kernel even with more pairs than stations
+    bool pair_r8 = false;                   // TDOA_PAIR_R8=1: the 512-thread / 8-value pair kernel (measured equal on cfg2, 5 % slower on cfg4)
     uint64_t alloc_gen = 0;                 // bumped whenever a workspace buffer moves
     std::vector<uint64_t> graph_key;
     hipGraph_t graph = nullptr;
@@ -250,7 +252,7 @@ int reserve_fm_batch(tdoa_ctx *ctx, int n_sw, int maxlen, int n_pw, const FftPla
 // sw/pw descriptors are already in device memory; maxlen = longest window.
 int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const PWDesc *d_pw, int n_pw,
                  unsigned long long *d_keys, const FftPlan &pl, int lag_lo, int lag_hi, float *lag_dump,
-                 float dump_scale, double sum_len, float *fine_raw = nullptr)
+                 float dump_scale, double sum_len, float *fine_raw = nullptr, int pairs_per_window = 0)
 {
     int rc;
     const int pieces = std::max(1, (maxlen + kDemodPiece - 1) / kDemodPiece);
@@ -359,6 +361,16 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
     // forward row pass fused into the pair kernel: pays when a station's rows are re-transformed at most as often as
     // they would be written and read back (no more pair-windows than station-windows: 3 stations, or a single pair)
     const bool fused_rows = row16 && ctx->fused_rows && n_pw > 0 && n_pw <= n_sw;
+    // XCD-aware 1-D grid of the pair kernel when every window of the group carries the same `pairs_per_window` > S pairs
+    // (window-major sharding with more pairs than stations): see k_inv_row_pair4096
+    int xcd_pairs = 0;
+    unsigned int xcd_grid = 0;
+    if (row16 && ctx->xcd_rows && pairs_per_window > 0 && n_pw % pairs_per_window == 0 && n_sw > 0 &&
+        pairs_per_window > n_sw / (n_pw / pairs_per_window) && pl.N2 > 2) {
+        const long long groups = (long long)(n_pw / pairs_per_window) * (pl.N2 / 2 - 1);
+        const long long blocks = (groups + 7) / 8 * 8 * pairs_per_window;
+        if (blocks < (1ll << 31)) { xcd_pairs = pairs_per_window; xcd_grid = (unsigned int)blocks; }
+    }
     if (!seg_chunks) {
         ProfScope ps(ctx, TDOA_K_FWD_ROW, fused_rows ? 2.0 * 8.0 * 4096 * 2 * n_sw : 2.0 * nc8 * n_sw);
         if (fused_rows)    // only the two self-mirrored rows 0 and N2/2 (their pair kernel reads finished spectra)
@@ -399,10 +411,14 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
         if (pl.N2 > 2 && fused_rows)                                                                                 \
             hipLaunchKernelGGL((k_pair_rows_fused_r8<FK>), dim3(pl.N2 / 2 - 1, n_pw), dim3(512),                     \
                                sizeof(float2) * 2 * kRow8Lds, st, d_pw, tz, v, pl);                                  \
+        else if (pl.N2 > 2 && ctx->pair_r8)                                                                          \
+            hipLaunchKernelGGL((k_inv_row_pair_r8<FK>), xcd_pairs ? dim3(xcd_grid) : dim3(pl.N2 / 2 - 1, n_pw),      \
+                               dim3(512), sizeof(float2) * 2 * kRow8Lds, st, d_pw, tz, v, pl, xcd_pairs, n_pw);      \
         else if (pl.N2 > 2)                                                                                          \
-            hipLaunchKernelGGL((k_inv_row_pair4096<false, FK>), dim3(pl.N2 / 2 - 1, n_pw), dim3(256), lds_pair16, st,  \
-                               d_pw, tz, v, pl);                                                                     \
-        hipLaunchKernelGGL((k_inv_row_pair4096<true, FK>), dim3(1, n_pw), dim3(256), lds_pair16, st, d_pw, tz, v, pl); \
+            hipLaunchKernelGGL((k_inv_row_pair4096<false, FK>), xcd_pairs ? dim3(xcd_grid) : dim3(pl.N2 / 2 - 1, n_pw), \
+                               dim3(256), lds_pair16, st, d_pw, tz, v, pl, xcd_pairs, n_pw);                         \
+        hipLaunchKernelGGL((k_inv_row_pair4096<true, FK>), dim3(1, n_pw), dim3(256), lds_pair16, st, d_pw, tz, v, pl, \
+                           0, n_pw);                                                                                 \
     } while (0)
                 if (fk == 1) TDOA_PAIR_ROWS(1);
                 else if (fk == 2) TDOA_PAIR_ROWS(2);
@@ -493,6 +509,11 @@ int allow_big_lds(tdoa_ctx *ctx)
     if ((rc = set_lds(ctx, k_pair_rows_fused_r8<2>, all))) return rc;
     if ((rc = set_lds(ctx, k_pair_rows_fused_r8<4>, all))) return rc;
     if ((rc = set_lds(ctx, k_pair_rows_fused_r8<8>, all))) return rc;
+    if ((rc = set_lds(ctx, k_inv_row_pair_r8<0>, all))) return rc;
+    if ((rc = set_lds(ctx, k_inv_row_pair_r8<1>, all))) return rc;
+    if ((rc = set_lds(ctx, k_inv_row_pair_r8<2>, all))) return rc;
+    if ((rc = set_lds(ctx, k_inv_row_pair_r8<4>, all))) return rc;
+    if ((rc = set_lds(ctx, k_inv_row_pair_r8<8>, all))) return rc;
     if ((rc = set_lds(ctx, k_xcorr_segments<1>, all))) return rc;
     if ((rc = set_lds(ctx, k_xcorr_segments<2>, all))) return rc;
     return TDOA_OK;
@@ -704,6 +725,8 @@ int tdoa_create(const tdoa_params *p, tdoa_ctx **out)
     if (const char *e = std::getenv("TDOA_FUSED_ROWS")) ctx->fused_rows = e[0] == '1';
     if (const char *e = std::getenv("TDOA_NO_FUSED_ROWS")) ctx->fused_rows = !(e[0] == '1');
     if (const char *e = std::getenv("TDOA_NO_SEGMENT_FORM")) ctx->segment_form = !(e[0] == '1');
+    if (const char *e = std::getenv("TDOA_NO_XCD_ROWS")) ctx->xcd_rows = !(e[0] == '1');
+    if (const char *e = std::getenv("TDOA_PAIR_R8")) ctx->pair_r8 = e[0] == '1';
     *out = ctx;
     return TDOA_OK;
 }
@@ -1072,7 +1095,8 @@ static int process_impl(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host,
     std::vector<uint64_t> key = {(uint64_t)S, (uint64_t)rank, (uint64_t)world, (uint64_t)per_batch, (uint64_t)wlen,
                                  (uint64_t)ctx->prm.max_lag, (uint64_t)block,
                                  (uint64_t)ctx->force_generic | ((uint64_t)ctx->short_lag << 1) |
-                                     ((uint64_t)ctx->fused_rows << 2) | ((uint64_t)ctx->segment_form << 3),
+                                     ((uint64_t)ctx->fused_rows << 2) | ((uint64_t)ctx->segment_form << 3) |
+                                     ((uint64_t)ctx->xcd_rows << 4) | ((uint64_t)ctx->pair_r8 << 5),
                                  ctx->alloc_gen, (uint64_t)(fine_host != nullptr), 0};
     std::memcpy(&key.back(), &gate, sizeof(double));
     for (auto &c : ctx->caps) {
@@ -1100,7 +1124,7 @@ static int process_impl(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host,
             const int n_sw = (int)(sw_off[w0 + nw] - sw_off[w0]), n_pw = (int)(pw_off[w0 + nw] - pw_off[w0]);
             const int r = run_fm_batch(ctx, d_sw + sw_off[w0], n_sw, (int)wlen, d_pw + pw_off[w0], n_pw, d_keys, pl,
                                        -(ctx->prm.max_lag - 1), ctx->prm.max_lag - 1, nullptr, 1.0f,
-                                       (double)wlen * n_sw, fine_raw);
+                                       (double)wlen * n_sw, fine_raw, pair_major ? 0 : P);
             if (r) return r;
         }
         if (fine_raw)
@@ -1327,6 +1351,8 @@ int tdoa_debug_flags(tdoa_ctx *ctx, unsigned flags)
     ctx->short_lag = !(flags & TDOA_DEBUG_NO_SHORT_LAG);
     ctx->fused_rows = !(flags & TDOA_DEBUG_NO_FUSED_ROWS);
     ctx->segment_form = !(flags & TDOA_DEBUG_NO_SEGMENT_FORM);
+    ctx->xcd_rows = !(flags & TDOA_DEBUG_NO_XCD_ROWS);
+    ctx->pair_r8 = (flags & TDOA_DEBUG_PAIR_R8) != 0;
     return TDOA_OK;
 }
 

@@ -411,3 +411,25 @@ def test_segment_form_ragged_and_full_size(oracle, n1, n2, max_lag, delay):
         lag, corr = c.fm_xcorr(a, b, max_lag)
     _assert_lags_close(lags, want)
     assert lag == olag and abs(corr - ocorr) <= REL_TOL * abs(ocorr)
+
+
+@pytest.mark.parametrize("max_lag", [20000, 700, 3000])
+def test_radix8_pair_kernel_vs_radix16(oracle, max_lag):
+    """k_inv_row_pair_r8 (512 threads x 8 values, opt-in) against the default 256 x 16 pair kernel and the oracle,
+    in the general form, and in the short-lag shares (segment form off)"""
+    import tdoa_amd
+    n = 300_000
+    a = oracle.simulate_delayed_fm(n, 0, 61, 1)
+    b = oracle.simulate_delayed_fm(n, 123, 61, 2)
+    ta, _ = oracle.b_preprocess(a)
+    tb, _ = oracle.b_preprocess(b)
+    olag, ocorr, want = oracle.b_xcorr_peak_fft(ta, tb, max_lag)
+    with tdoa_amd.Context(max_lag=max_lag, window_len=n) as c:
+        c.debug_flags(no_segment_form=True, no_fused_rows=True)
+        r16 = c.fm_xcorr_lags(a, b, max_lag)
+        c.debug_flags(no_segment_form=True, no_fused_rows=True, pair_r8=True)
+        r8 = c.fm_xcorr_lags(a, b, max_lag)
+        lag, corr = c.fm_xcorr(a, b, max_lag)
+    _assert_lags_close(r8, want)
+    _assert_lags_close(r8, r16, 2e-6)
+    assert lag == olag == 123 and abs(corr - ocorr) <= REL_TOL * abs(ocorr)
