@@ -344,14 +344,11 @@ def main():
     prof = ctx.profile()
     timed_peaks = None if state["peaks"] is None else state["peaks"].copy()     # what the contract's timed region produced
     graph_leg = None
-    # (single GPU only: in a two-process gloo rehearsal on ONE card the second replay of the step graph returned
-    # uninitialised records for windows the rank does not own -- not reproducible in one process, nor in two independent
-    # processes; until that is understood the multi-rank runs time the kernel-by-kernel path only)
-    if not args.no_graph_leg and world == 1:
+    if not args.no_graph_leg:
         step()                                                            # captures the graph
         dtg = timed(steps)
         graph_leg = {"ms_per_step": round(dtg / steps * 1e3, 4), "value": round(samples_per_step / (dtg / steps) / 1e6, 2),
-                     "identical_to_timed_path": bool(timed_peaks is not None and np.array_equal(timed_peaks, state["peaks"])),
+                     "identical_to_timed_path": None if timed_peaks is None else bool(np.array_equal(timed_peaks, state["peaks"])),
                      "note": "the same steps with the whole step replayed as one hipGraph and no per-kernel events "
                              "(the library's default path)"}
 

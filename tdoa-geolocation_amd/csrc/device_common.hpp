@@ -78,6 +78,14 @@ __device__ __forceinline__ unsigned long long peak_key(float v, int lag)
     return ((unsigned long long)mag << 32) | low;
 }
 
+// Zero `n` 64-bit words.  Used instead of hipMemsetAsync inside the captured step: a kernel node like every other node
+// of the graph.
+__global__ void k_zero_u64(unsigned long long *p, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0ull;
+}
+
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k)
 {
 #pragma unroll

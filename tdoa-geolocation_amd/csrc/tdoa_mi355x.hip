@@ -311,7 +311,9 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
     {
         // K1: capture bytes -> 16-bit phase codes + exact window statistics
         ProfScope ps(ctx, TDOA_K_STATS, 4.0 * sum_len);
-        HIPCHK(ctx, hipMemsetAsync(partials, 0, sizeof(StatsPartial) * (size_t)n_sw, st));
+        static_assert(sizeof(StatsPartial) == 16, "two 64-bit words per station-window");
+        hipLaunchKernelGGL(k_zero_u64, dim3((unsigned)((2 * (size_t)n_sw + 255) / 256)), dim3(256), 0, st,
+                           reinterpret_cast<unsigned long long *>(partials), 2 * (size_t)n_sw);
         const long long items = (long long)((pieces + kDemodItem - 1) / kDemodItem) * n_sw;      // workgroup items
         const int blocks = (int)std::max<long long>(1, std::min<long long>(items, ctx->n_cu));
         hipLaunchKernelGGL(k_fm_demod, dim3(blocks), dim3(kDemodThreads), 65536 * sizeof(short), st, d_sw, n_sw, pieces,
@@ -1117,7 +1119,7 @@ static int process_impl(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host,
     }
 
     auto enqueue = [&]() -> int {
-        HIPCHK(ctx, hipMemsetAsync(d_keys, 0, sizeof(unsigned long long) * slots, st));
+        hipLaunchKernelGGL(k_zero_u64, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, st, d_keys, slots);
         float *fine_raw = fine_host ? static_cast<float *>(ctx->fine_raw.p) : nullptr;
         for (size_t w0 = 0; w0 < mine.size(); w0 += per_batch) {
             const int nw = (int)std::min<size_t>(per_batch, mine.size() - w0);
