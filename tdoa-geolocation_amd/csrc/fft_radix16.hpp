@@ -564,8 +564,7 @@ __global__ __launch_bounds__(256) void k_fused_reduce(float2 *V, unsigned long l
 
 // refinement neighbours c[lag-1], c[lag], c[lag+1] from the lag array k_fused_reduce left behind
 // (the host only takes the short-lag form when lag_hi + 1 and lag_lo - 1 are inside that array)
-// W: entries of the lag array (the segment form of fft_radix8.hpp leaves one more, d = +512 FK)
-template <int FK, int W = 1024 * FK>
+template <int FK>
 __global__ void k_refine_fused(const float2 *V, const unsigned long long *keys, const PWDesc *pw, FftPlan pl, int n_pw,
                                float *raw)
 {
@@ -581,7 +580,7 @@ __global__ void k_refine_fused(const float2 *V, const unsigned long long *keys, 
 #pragma unroll
         for (int q = 0; q < 3; q++) {
             const int li = lag - 1 + q + 512 * FK;
-            r[q] = li >= 0 && li < W ? lags[li] : 0.0f;
+            r[q] = li >= 0 && li < 1024 * FK ? lags[li] : 0.0f;
         }
     }
 #pragma unroll

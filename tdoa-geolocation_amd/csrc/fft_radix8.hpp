@@ -360,7 +360,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_
 // Segment form (search ranges up to 1024 lags): the whole correlation stays in LDS and registers.
 // The deployed geometry bounds |TDOA| by 114 samples (PROJECT_NOTES.md:29-32); a caller who searches a few hundred
 // lags instead of the reference's 20 000 (processor.go:633) does not need a 2^21-point transform.  Overlap-save
-// over the template: segment k is t[kH, kH + H), H = 4096 - 2P (P = 512 FK >= max_lag), placed at [P, P + H) of a
+// over the template: segment k is t[kH, kH + H), H = 4096 - 2P (P = 256 PQ >= max_lag, PQ = 1, 2, 4), placed at [P, P + H) of a
 // 4096-point frame next to the signal samples s[kH - P, kH - P + 4096).  One complex transform Z of z = t + i s
 // carries both real frames; with A = |Z[k]|^2 and B = Z[k] Z[-k]
 //   conj(T[k]) S[k] = Im(B[k]) / 2 - i (A[k] - A[-k]) / 4,
@@ -368,13 +368,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_
 // No wrap-around reaches the lags |d| <= P.  HBM traffic: the phase codes of both stations, about 2.7 B per sample
 // and station (frames overlap by 2P), against 31.4 B per sample of the four-step form.
 // grid (n_chunks, n_pw), 512 threads, dynamic LDS 64 KB.  Chunk c of a pair-window takes the segment pairs
-// c, c + n_chunks, ...; its 2P + 1 lag sums (d = -P .. P) go to part[pw][c][1024 FK + 8] (floats, at V + pw * Nc),
+// c, c + n_chunks, ...; its 2P + 1 lag sums (d = -P .. P) go to part[pw][c][2P + 8] (floats, at V + pw * Nc),
 // k_segments_reduce adds the chunks in a fixed order.
 // ---------------------------------------------------------------------------
-template <int FK>
+template <int PQ>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_PLAIN_DS_OPS)) void k_xcorr_segments(const SWDesc *sw, const PWDesc *pw, const short *codes, long long code_stride, const FmStats *stats, float2 *V, FftPlan pl, int n_chunks)
 {
-    constexpr int P = 512 * FK, H = 4096 - 2 * P;
+    constexpr int P = 256 * PQ, H = 4096 - 2 * P;
     extern __shared__ float2 lds[];   // 2 * kRow8Lds
     float2 *la = lds, *lb = lds + kRow8Lds;
     const int t = threadIdx.x;
@@ -400,10 +400,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_
         const int i0 = s0 * H - P + t, i1 = i0 + H;
         if (s0 * H - P >= 0 && (s0 + 1) * H - P + 4096 <= len_min) {
             // both frames lie inside both windows (all but the first and last trips): no bounds checks; the template
-            // part of a frame is the positions [P, P + H) = the values r = FK .. 7 - FK of every thread
+            // part of a frame is the positions [P, P + H): whole values r of every thread, except that with P = 256
+            // the band starts and ends in the middle of r = 0 and r = 7
 #pragma unroll
             for (int r = 0; r < 8; r++) {
-                const bool tpos = r >= FK && r < 8 - FK;
+                const bool tpos = t + 512 * r >= P && t + 512 * r < P + H;
                 const int a0 = tpos ? (int)ct[i0 + 512 * r] : 0, b0 = cs[i0 + 512 * r];
                 const int a1 = tpos ? (int)ct[i1 + 512 * r] : 0, b1 = cs[i1 + 512 * r];
                 x[r] = make_float2(tpos ? k1_normalise(a0, mean_t, scale_t) : 0.0f, k1_normalise(b0, mean_s, scale_s));
@@ -416,7 +417,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_
                                                     // rounding)
 #pragma unroll
             for (int r = 0; r < 8; r++) {
-                const bool tpos = r >= FK && r < 8 - FK;
+                const bool tpos = t + 512 * r >= P && t + 512 * r < P + H;
                 {
                     const int i = i0 + 512 * r;
                     const bool in_t = tpos && i < len_t, in_s = i >= 0 && i < len_s;
@@ -466,7 +467,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_
     fft8<true>(c);
     rows2_r8_finish<true>(c, zero, la, lb, t, t, t);
     // lags d = n for n <= P and d = n - 4096 for n >= 4096 - P, n = t + 512 k; part index d + P (2P + 1 lags, row
-    // pitch kSegPitch<FK>)
+    // pitch 2P + 8)
     float *part = reinterpret_cast<float *>(V + (size_t)blockIdx.y * pl.Nc) + (size_t)blockIdx.x * (2 * P + 8);
 #pragma unroll
     for (int k = 0; k < 8; k++) {
@@ -476,19 +477,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_
     }
 }
 
-// chunk sums in a fixed order -> lag array (kept for the sub-sample refinement, same place and layout as
-// k_fused_reduce leaves it: lags[li] = c[li - 512 FK], unscaled like the keys), lag filter, K5.
+// chunk sums in a fixed order -> lag array (kept for the sub-sample refinement: lags[li] = c[li - P], unscaled like the
+// keys, at float offset N2 * P of the pair-window's V row -- behind every chunk sum), lag filter, K5.
 // mul = 4 N / 4096 brings the sums to the scale of the four-step form (decode multiplies by 1 / (4 N sqrt(len))).
-// grid (4 FK + 1, n_pw), 256 threads.
-template <int FK>
+// grid (2 PQ + 1, n_pw), 256 threads.
+template <int PQ>
 __global__ __launch_bounds__(256) void k_segments_reduce(float2 *V, unsigned long long *keys, const PWDesc *pw, FftPlan pl,
                                                         int n_chunks, float mul, int lag_lo, int lag_hi, float *lag_dump,
                                                         float dump_scale)
 {
-    constexpr int P = 512 * FK;
+    constexpr int P = 256 * PQ;
     __shared__ unsigned long long red[4];
     float *base = reinterpret_cast<float *>(V + (size_t)blockIdx.y * pl.Nc);
-    float *lags = reinterpret_cast<float *>(V + (size_t)blockIdx.y * pl.Nc + (size_t)(pl.N2 / 2) * 2 * 256 * FK);
+    float *lags = reinterpret_cast<float *>(V + (size_t)blockIdx.y * pl.Nc) + (size_t)pl.N2 * P;
     const int li = blockIdx.x * 256 + threadIdx.x;            // lag index d + P, valid up to 2 P
     const bool live = li <= 2 * P;
     float s = 0.0f;
@@ -510,6 +511,31 @@ __global__ __launch_bounds__(256) void k_segments_reduce(float2 *V, unsigned lon
         for (int w = 1; w < 4; w++) bb = red[w] > bb ? red[w] : bb;
         if (bb) atomicMax(&keys[pw[blockIdx.y].out_index], bb);
     }
+}
+
+// refinement neighbours c[lag-1], c[lag], c[lag+1] from the lag array k_segments_reduce left behind (2P + 1 entries)
+template <int PQ>
+__global__ void k_refine_segments(const float2 *V, const unsigned long long *keys, const PWDesc *pw, FftPlan pl, int n_pw,
+                                  float *raw)
+{
+    constexpr int P = 256 * PQ;
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;   // one thread per pair-window
+    if (id >= n_pw) return;
+    const int slot = pw[id].out_index;
+    const unsigned long long k = keys[slot];
+    float r[3] = {0.0f, 0.0f, 0.0f};
+    if (k != 0 && (unsigned int)(k >> 32) != 0) {
+        const unsigned int rank = 0x7fffffffu - ((unsigned int)k >> 1);
+        const int lag = rank == 0 ? 0 : ((rank & 1u) ? (int)((rank + 1u) >> 1) : -(int)(rank >> 1));
+        const float *lags = reinterpret_cast<const float *>(V + (size_t)id * pl.Nc) + (size_t)pl.N2 * P;
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            const int li = lag - 1 + q + P;
+            r[q] = li >= 0 && li <= 2 * P ? lags[li] : 0.0f;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 3; q++) raw[3 * (size_t)slot + q] = r[q];
 }
 
 }  // namespace tdoa

@@ -295,15 +295,14 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
     // segment form (search ranges up to 1024 lags): overlap-save over 4096-point frames entirely in LDS; neither the
     // column pass nor TZ nor V rows are touched.  Its chunk sums and lag array live where the short-lag form keeps its
     // shares (inside this pair-window's V row), which bounds the chunk count by N2 / 2.
-    int seg_chunks = 0, seg_fk = 0;
+    int seg_chunks = 0, seg_pq = 0;
     {
-        // lags lag_lo - 1 .. lag_hi + 1 (refinement neighbours included) must lie in [-P, P], P = 512 seg_fk
+        // lags lag_lo - 1 .. lag_hi + 1 (refinement neighbours included) must lie in [-P, P], P = 256 seg_pq
         const int reach = std::max(lag_hi + 1, -(lag_lo - 1));
-        seg_fk = reach <= 512 ? 1 : reach <= 1024 ? 2 : 0;
+        seg_pq = reach <= 256 ? 1 : reach <= 512 ? 2 : reach <= 1024 ? 4 : 0;
     }
-    if (seg_fk && row16 && ctx->short_lag && ctx->segment_form && n_pw > 0 && pl.N2 >= 8) {
-        fk = seg_fk;
-        const int hop = 4096 - 1024 * fk;
+    if (seg_pq && row16 && ctx->short_lag && ctx->segment_form && n_pw > 0 && pl.N2 >= 8) {
+        const int hop = 4096 - 512 * seg_pq;
         const int pairs = ((maxlen + hop - 1) / hop + 1) / 2;
         seg_chunks = std::max(1, std::min({pairs / 8, pl.N2 / 2 - 1, (4096 + n_pw - 1) / n_pw}));
         if (const char *e = std::getenv("TDOA_SEG_CHUNKS")) seg_chunks = std::max(1, std::min({std::atoi(e), pairs, pl.N2 / 2 - 1}));
@@ -383,27 +382,30 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
             hipLaunchKernelGGL(k_fwd_row, dim3(pl.N2, n_sw), dim3(256), lds_row, st, tz, pl);
     }
     if (n_pw && seg_chunks) {
-        const int hop = 4096 - 1024 * fk;
+        const int hop = 4096 - 512 * seg_pq;
         const double frames = (double)((maxlen + hop - 1) / hop);
         const float mul = (float)(4.0 * 2.0 * (double)pl.Nc / 4096.0);          // 4 N / M
-        {
-            ProfScope ps(ctx, TDOA_K_INV_ROW, 2.0 * 2.0 * 4096.0 * frames * n_pw);   // two frames of 2-byte codes per segment
-            if (fk == 1)
-                hipLaunchKernelGGL(k_xcorr_segments<1>, dim3(seg_chunks, n_pw), dim3(512), sizeof(float2) * 2 * kRow8Lds, st,
-                                   d_sw, d_pw, codes, code_stride, stats, v, pl, seg_chunks);
-            else
-                hipLaunchKernelGGL(k_xcorr_segments<2>, dim3(seg_chunks, n_pw), dim3(512), sizeof(float2) * 2 * kRow8Lds, st,
-                                   d_sw, d_pw, codes, code_stride, stats, v, pl, seg_chunks);
-        }
-        {
-            ProfScope ps(ctx, TDOA_K_INV_COL, 4.0 * 1024.0 * fk * (seg_chunks + 1) * n_pw);
-            if (fk == 1)
-                hipLaunchKernelGGL(k_segments_reduce<1>, dim3(5, n_pw), dim3(256), 0, st, v, d_keys, d_pw, pl, seg_chunks, mul,
-                                   lag_lo, lag_hi, lag_dump, dump_scale);
-            else
-                hipLaunchKernelGGL(k_segments_reduce<2>, dim3(9, n_pw), dim3(256), 0, st, v, d_keys, d_pw, pl, seg_chunks, mul,
-                                   lag_lo, lag_hi, lag_dump, dump_scale);
-        }
+        const size_t lds_seg = sizeof(float2) * 2 * kRow8Lds;
+#define TDOA_SEGMENTS(PQ)                                                                                            \
+    do {                                                                                                             \
+        {                                                                                                            \
+            ProfScope ps(ctx, TDOA_K_INV_ROW, 2.0 * 2.0 * 4096.0 * frames * n_pw);   /* two frames of 2-byte codes */  \
+            hipLaunchKernelGGL(k_xcorr_segments<PQ>, dim3(seg_chunks, n_pw), dim3(512), lds_seg, st, d_sw, d_pw, codes, \
+                               code_stride, stats, v, pl, seg_chunks);                                               \
+        }                                                                                                            \
+        {                                                                                                            \
+            ProfScope ps(ctx, TDOA_K_INV_COL, 4.0 * 512.0 * PQ * (seg_chunks + 1) * n_pw);                            \
+            hipLaunchKernelGGL(k_segments_reduce<PQ>, dim3(2 * PQ + 1, n_pw), dim3(256), 0, st, v, d_keys, d_pw, pl,  \
+                               seg_chunks, mul, lag_lo, lag_hi, lag_dump, dump_scale);                               \
+        }                                                                                                            \
+        if (fine_raw)                                                                                                \
+            hipLaunchKernelGGL(k_refine_segments<PQ>, dim3((n_pw + 63) / 64), dim3(64), 0, st, v, d_keys, d_pw, pl,   \
+                               n_pw, fine_raw);                                                                      \
+    } while (0)
+        if (seg_pq == 1) TDOA_SEGMENTS(1);
+        else if (seg_pq == 2) TDOA_SEGMENTS(2);
+        else TDOA_SEGMENTS(4);
+#undef TDOA_SEGMENTS
     } else if (n_pw) {
         {
             ProfScope ps(ctx, TDOA_K_INV_ROW, 3.0 * nc8 * n_pw);
@@ -470,8 +472,7 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
     }
     if (n_pw && fine_raw) {   // V (or the short-lag array) of this batch is still in place: peak neighbours for the parabola
         const dim3 g1((n_pw + 63) / 64), b1(64);
-        if (seg_chunks && fk == 1) hipLaunchKernelGGL((k_refine_fused<1, 1025>), g1, b1, 0, st, v, d_keys, d_pw, pl, n_pw, fine_raw);
-        else if (seg_chunks) hipLaunchKernelGGL((k_refine_fused<2, 2049>), g1, b1, 0, st, v, d_keys, d_pw, pl, n_pw, fine_raw);
+        if (seg_chunks) { /* done above: k_refine_segments */ }
         else if (fk == 1) hipLaunchKernelGGL(k_refine_fused<1>, g1, b1, 0, st, v, d_keys, d_pw, pl, n_pw, fine_raw);
         else if (fk == 2) hipLaunchKernelGGL(k_refine_fused<2>, g1, b1, 0, st, v, d_keys, d_pw, pl, n_pw, fine_raw);
         else if (fk == 4) hipLaunchKernelGGL(k_refine_fused<4>, g1, b1, 0, st, v, d_keys, d_pw, pl, n_pw, fine_raw);
@@ -518,6 +519,7 @@ int allow_big_lds(tdoa_ctx *ctx)
     if ((rc = set_lds(ctx, k_inv_row_pair_r8<8>, all))) return rc;
     if ((rc = set_lds(ctx, k_xcorr_segments<1>, all))) return rc;
     if ((rc = set_lds(ctx, k_xcorr_segments<2>, all))) return rc;
+    if ((rc = set_lds(ctx, k_xcorr_segments<4>, all))) return rc;
     return TDOA_OK;
 }
 
