@@ -370,8 +370,12 @@ def main():
         value = samples_per_step / (dt / steps) / 1e6
         n_fft, n1, n2 = ctx.plan_info()
         name, rec = max(prof.items(), key=lambda kv: kv[1]["ms"])
-        hot = {"k_fm_demod": "k_fm_demod", "k_fwd_col": "k_fwd_col256_c16", "k_fwd_row": "k_fwd_row4096",
-               "k_inv_row_pair": "k_inv_row_pair4096", "k_inv_col_peak": "k_inv_col_pruned"} if (n1, n2) == (4096, 256) else {}
+        hot = {}
+        if n1 == 4096:          # the radix-16 register kernels (fft_radix16.hpp); the column pass depends on N2
+            col = ("k_fwd_col16x_c16" if n2 <= 128 else "k_fwd_col256_c16" if n2 == 256 else "k_fwd_colx_c16" if n2 <= 1024
+                   else "k_fwd_col256_c16<true> + k_fwd_col_finish")
+            hot = {"k_fm_demod": "k_fm_demod", "k_fwd_col": col, "k_fwd_row": "k_fwd_row4096",
+                   "k_inv_row_pair": "k_inv_row_pair4096", "k_inv_col_peak": "k_inv_col_pruned"}
         if max_lag <= 1024 and n1 == 4096:
             hot = dict(hot, k_inv_row_pair="k_xcorr_segments", k_inv_col_peak="k_segments_reduce")
         roof = None

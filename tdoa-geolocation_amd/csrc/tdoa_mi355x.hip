@@ -325,7 +325,8 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
     const size_t lds_col16 = sizeof(float2) * 256 * 32;
     const size_t lds_pair16 = sizeof(float2) * 2 * kRowLds;
     if (!seg_chunks) {
-        ProfScope ps(ctx, TDOA_K_FWD_COL, 2.0 * sum_len + nc8 * n_sw);
+        // two-sweep column pass (N2 = 2048, 4096): 8 Nc written, read and written again -- SURVEY's third pass
+        ProfScope ps(ctx, TDOA_K_FWD_COL, 2.0 * sum_len + (col2pass ? 3.0 : 1.0) * nc8 * n_sw);
         if (col16)
             hipLaunchKernelGGL(k_fwd_col256_c16<false>, dim3(pl.N1 / 32, n_sw), dim3(512), lds_col16, st, d_sw, codes,
                                code_stride, stats, tz, pl);
