@@ -409,7 +409,7 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
 #undef TDOA_SEGMENTS
     } else if (n_pw) {
         {
-            ProfScope ps(ctx, TDOA_K_INV_ROW, 3.0 * nc8 * n_pw);
+            ProfScope ps(ctx, TDOA_K_INV_ROW, 3.0 * nc8 * n_pw);     // SURVEY's model: two spectra read, V written, per pair
             if (fk) {
 #define TDOA_PAIR_ROWS(FK)                                                                                           \
     do {                                                                                                             \
