@@ -45,6 +45,25 @@ __global__ __launch_bounds__(256) void read_f4(const float4 *in, float *out)
     if (acc == 12345.678f) out[0] = acc;
 }
 
+// write only, and the pair kernel's mix (two rows read per row written), same row shape
+__global__ __launch_bounds__(256) void write_f2(float2 *out, float seed)
+{
+    float2 *w = out + (size_t)blockIdx.x * 4096;
+#pragma unroll
+    for (int k = 0; k < 16; k++) w[threadIdx.x + 256 * k] = make_float2(seed + k, seed - threadIdx.x);
+}
+
+__global__ __launch_bounds__(256) void read2_write1_f2(const float2 *in, float2 *out, size_t half_rows)
+{
+    const float2 *r0 = in + (size_t)blockIdx.x * 4096, *r1 = in + ((size_t)blockIdx.x + half_rows) * 4096;
+    float2 *w = out + (size_t)blockIdx.x * 4096;
+    float2 v[16], u[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) { v[k] = r0[threadIdx.x + 256 * k]; u[k] = r1[threadIdx.x + 256 * k]; }
+#pragma unroll
+    for (int k = 0; k < 16; k++) w[threadIdx.x + 256 * k] = make_float2(v[k].x + u[k].y, v[k].y - u[k].x);
+}
+
 int main()
 {
     const size_t rows = 76032;                    // 297 station-windows x 256 rows
@@ -65,5 +84,8 @@ int main()
     time("copy f4", [&] { copy_f4<<<rows, 256>>>((float4 *)a, (float4 *)b); }, 2.0 * bytes);
     time("read f2", [&] { read_f2<<<rows, 256>>>((float2 *)a, (float *)b); }, 1.0 * bytes);
     time("read f4", [&] { read_f4<<<rows, 256>>>((float4 *)a, (float *)b); }, 1.0 * bytes);
+    time("write f2", [&] { write_f2<<<rows, 256>>>((float2 *)b, 1.0f); }, 1.0 * bytes);
+    // 2 reads : 1 write over half the rows each (the pair kernel's mix): 1.5 x bytes moved in all
+    time("2R:1W f2", [&] { read2_write1_f2<<<rows / 2, 256>>>((float2 *)a, (float2 *)b, rows / 2); }, 1.5 * bytes);
     return 0;
 }
