@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TDOA_ABI_VERSION 2
+#define TDOA_ABI_VERSION 3
 
 typedef struct tdoa_ctx tdoa_ctx;
 
@@ -53,6 +53,11 @@ typedef struct {
     int64_t window_len;      /* 2000000 processor.go:772 (testChunkSize)        */
     int32_t device;          /* HIP device ordinal                              */
     int32_t windows_per_batch; /* station-windows processed per launch group; 0 = auto */
+    int32_t k1_smooth;       /* 0 (default): none.  W > 1: centred moving average of W samples (half-window W/2, edges
+                                truncated: applyLowPassFilter, processor.go:270-296) on the discriminator output before
+                                it is normalised -- the prebuilt reference binary's strong-signal chain is discriminator
+                                -> removeDCBias -> applyLowPassFilter(10) -> normalizeSignal */
+    int32_t reserved;
 } tdoa_params;
 
 /* One correlation peak.  lag > 0: the second station of the pair lags the first. */

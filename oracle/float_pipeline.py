@@ -58,8 +58,31 @@ def normalise(y):
     return (y - m) * (1.0 / np.sqrt(var) if var > 0 else 1.0)
 
 
-def preprocess(iq_u8):
-    return normalise(discriminate(iq_u8))
+def lowpass(y, window):
+    """applyLowPassFilter (processor.go:270-296): centred moving average, half-window window // 2, taps outside the
+    signal dropped (the divisor is the number of taps that are inside)"""
+    y = np.asarray(y, dtype=np.float64)
+    h = int(window) // 2
+    if window <= 1 or y.size == 0:
+        return y
+    c = np.concatenate([[0.0], np.cumsum(y)])
+    i = np.arange(y.size)
+    lo, hi = np.maximum(i - h, 0), np.minimum(i + h, y.size - 1)
+    return (c[hi + 1] - c[lo]) / (hi - lo + 1)
+
+
+def preprocess(iq_u8, smooth=0):
+    """smooth = 0: discriminator -> zero mean -> unit variance.  smooth = W: the prebuilt binary's strong-signal chain in
+    ITS order: discriminator -> removeDCBias -> applyLowPassFilter(W) -> normalizeSignal (scale to
+    unit mean power, no second mean removal)"""
+    y = discriminate(iq_u8)
+    if smooth <= 1:
+        return normalise(y)
+    if y.size == 0:
+        return y
+    v = lowpass(y - y.mean(), smooth)
+    p = (v * v).mean()
+    return v * (1.0 / np.sqrt(p) if p > 0 else 1.0)
 
 
 def xcorr_lags(t, s, max_lag):
@@ -93,8 +116,8 @@ def pick_peak(c, max_lag):
     return lag, float(c[lag + max_lag - 1])
 
 
-def xcorr_peak_u8(iq_t, iq_s, max_lag):
+def xcorr_peak_u8(iq_t, iq_s, max_lag, smooth=0):
     """u8 IQ of the template and the signal -> (lag, corr, all lags)"""
-    c = xcorr_lags(preprocess(iq_t), preprocess(iq_s), max_lag)
+    c = xcorr_lags(preprocess(iq_t, smooth), preprocess(iq_s, smooth), max_lag)
     lag, corr = pick_peak(c, max_lag)
     return lag, corr, c

@@ -385,6 +385,16 @@ def b_preprocess(iq_u8):
     return out, st
 
 
+def b_preprocess_smooth(iq_u8, window):
+    """mode B preprocessing with the optional moving average on the phase codes (tdoa_params.k1_smooth)"""
+    s = np.ascontiguousarray(iq_u8, dtype=np.uint8)
+    n = s.size // 2
+    out = np.empty(n, dtype=np.float32)
+    st = BStats()
+    lib().ob_preprocess_smooth_u8(_u8(s), C.c_size_t(n), C.c_int(int(window)), _f(out), C.byref(st))
+    return out, st
+
+
 def b_xcorr_all_lags(t, s, max_lag):
     t = np.ascontiguousarray(t, dtype=np.float32)
     s = np.ascontiguousarray(s, dtype=np.float32)

@@ -1063,6 +1063,42 @@ void ob_phase_stats(const int32_t *code, size_t n, ob_stats *st)
     st->scale = (var > 0) ? (float)(1.0 / sqrt(var)) : 1.0f;
 }
 
+/* Optional smoothing of the discriminator output (tdoa_params.k1_smooth): the centred, edge-truncated moving average
+ * of processor.go:270-296 (half-window window / 2) on the phase codes, in exact integer arithmetic, round half up:
+ * lp_i = floor((2 S + c) / (2 c)), S = sum of the c in-range codes.  The prebuilt reference binary runs
+ * applyLowPassFilter(10) between removeDCBias and normalizeSignal on its discriminator output. */
+void ob_smooth_codes(const int32_t *code, size_t n, int window, int32_t *out)
+{
+    long h = window / 2;
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < (long)n; i++) {
+        long lo = i - h < 0 ? 0 : i - h, hi = i + h >= (long)n ? (long)n - 1 : i + h;
+        long sum = 0;
+        for (long j = lo; j <= hi; j++) sum += code[j];
+        long cnt = hi - lo + 1;
+        long num = 2 * sum + cnt, den = 2 * cnt;
+        out[i] = (int32_t)(num >= 0 ? num / den : -((-num + den - 1) / den));
+    }
+}
+
+void ob_preprocess_smooth_u8(const uint8_t *iq, size_t n, int window, float *out, ob_stats *st_out)
+{
+    ob_stats st;
+    int32_t *code = (int32_t *)malloc((n ? n : 1) * sizeof(int32_t));
+    int32_t *lp = (int32_t *)malloc((n ? n : 1) * sizeof(int32_t));
+    ob_discriminate_u8(iq, n, code);
+    if (window > 1) ob_smooth_codes(code, n, window, lp);
+    else memcpy(lp, code, n * sizeof(int32_t));
+    ob_phase_stats(lp, n, &st);
+    for (size_t i = 0; i < n; i++) {
+        float d = (float)lp[i] - st.mean;
+        out[i] = d * st.scale;
+    }
+    free(code);
+    free(lp);
+    if (st_out) *st_out = st;
+}
+
 /* mode B preprocessing: code -> (float(code) - mean) * scale, f32 sub then f32 mul */
 void ob_preprocess_u8(const uint8_t *iq, size_t n, float *out, ob_stats *st_out)
 {

@@ -136,6 +136,9 @@ typedef struct {
 } ob_stats;
 void   ob_phase_stats(const int32_t *code, size_t n, ob_stats *st);
 void   ob_preprocess_u8(const uint8_t *iq, size_t n, float *out, ob_stats *st);
+/* optional smoothing of the codes (tdoa_params.k1_smooth; applyLowPassFilter, processor.go:270-296, in integers) */
+void   ob_smooth_codes(const int32_t *code, size_t n, int window, int32_t *out);
+void   ob_preprocess_smooth_u8(const uint8_t *iq, size_t n, int window, float *out, ob_stats *st);
 /* c[d] = sum_i t[i]*s[i+d] (f64, zero outside), lags -(max_lag-1)..max_lag-1,
  * out[d + max_lag - 1]; scaled by 1/sqrt(nt). */
 void   ob_xcorr_all_lags(const float *t, size_t nt, const float *s, size_t ns,

@@ -318,6 +318,71 @@ __global__ __launch_bounds__(kDemodThreads) void k_fm_demod(const SWDesc *sw, in
     }
 }
 
+// Optional smoothing of the discriminator output (tdoa_params.k1_smooth = W; the prebuilt reference binary runs
+// applyLowPassFilter(10) between removeDCBias and normalizeSignal): centred moving average with half-window h = W / 2,
+// taps outside the window dropped (processor.go:270-296), in exact integer arithmetic on the phase codes:
+//   lp_i = floor((2 S + c) / (2 c)),  S = sum of the c in-range codes code_{i-h} .. code_{i+h}     (round half up)
+// The average of a constant is that constant, so LP(y - mean) = LP(y) - mean: smoothing the codes and normalising them
+// afterwards with THEIR mean and variance is the binary's order up to the edge samples' share of the mean (O(h / L)).
+// A thread makes 8 consecutive outputs; the window sums of the smoothed codes go to `acc` like k_fm_demod's.
+// grid (ceil(maxlen / 2048), n_sw), 256 threads.
+__global__ __launch_bounds__(256) void k_k1_smooth(const SWDesc *sw, const short *in, short *out, long long code_stride, int h,
+                                                   StatsPartial *acc)
+{
+    __shared__ long long red1[4];
+    __shared__ unsigned long long red2[4];
+    const int len = sw[blockIdx.y].len;
+    const short *src = in + (size_t)blockIdx.y * code_stride;
+    short *dst = out + (size_t)blockIdx.y * code_stride;
+    const int i0 = ((int)blockIdx.x * 256 + (int)threadIdx.x) * 8;
+    long long s1 = 0;
+    unsigned long long s2 = 0;
+    if (i0 < len) {
+        int c[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int i = i0 + k;
+            int v = 0;
+            if (i < len) {
+                const int lo = i - h < 0 ? 0 : i - h, hi = i + h >= len ? len - 1 : i + h;
+                int sum = 0;
+                for (int j = lo; j <= hi; j++) sum -= (int)src[j];            // stored = -code
+                const int cnt = hi - lo + 1;
+                const int num = 2 * sum + cnt, den = 2 * cnt;                 // floor division, den > 0
+                const int lp = num >= 0 ? num / den : -((-num + den - 1) / den);
+                v = -lp;
+                s1 += lp;
+                s2 += (unsigned long long)((long long)lp * lp);
+            }
+            c[k] = v;
+        }
+        uint4 wv;
+        wv.x = (unsigned int)(c[0] & 0xffff) | ((unsigned int)c[1] << 16);
+        wv.y = (unsigned int)(c[2] & 0xffff) | ((unsigned int)c[3] << 16);
+        wv.z = (unsigned int)(c[4] & 0xffff) | ((unsigned int)c[5] << 16);
+        wv.w = (unsigned int)(c[6] & 0xffff) | ((unsigned int)c[7] << 16);
+        *reinterpret_cast<uint4 *>(dst + i0) = wv;        // rows are 16-byte aligned and padded to a multiple of 8
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        s1 += __shfl_xor(s1, off, kWave);
+        s2 += __shfl_xor(s2, off, kWave);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red1[threadIdx.x >> 6] = s1;
+        red2[threadIdx.x >> 6] = s2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const long long t1 = red1[0] + red1[1] + red1[2] + red1[3];
+        const unsigned long long t2 = red2[0] + red2[1] + red2[2] + red2[3];
+        if (t1 | (long long)t2) {
+            atomicAdd(reinterpret_cast<unsigned long long *>(&acc[blockIdx.y].s1), (unsigned long long)t1);
+            atomicAdd(&acc[blockIdx.y].s2, t2);
+        }
+    }
+}
+
 // mean and scale of every station-window from its exact sums, in f64
 __global__ void k_fm_stats_final(const SWDesc *sw, const StatsPartial *acc, FmStats *stats, int n_sw)
 {

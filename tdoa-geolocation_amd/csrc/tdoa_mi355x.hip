@@ -59,7 +59,7 @@ struct tdoa_ctx {
     std::vector<Capture> caps;
 
     DevBuf k1_table;                        // 65536 int16 angle codes (k_k1_build_table)
-    DevBuf sw_desc, pw_desc, partials, stats, codes, tz, v, keys, scales, peaks, scratch_a, scratch_b, lagdump;
+    DevBuf sw_desc, pw_desc, partials, stats, codes, codes_lp, tz, v, keys, scales, peaks, scratch_a, scratch_b, lagdump;
     DevBuf ex_a, ex_b, ex_c, ex_d, ex_part;
 
     bool profiling = false;
@@ -241,6 +241,7 @@ int reserve_fm_batch(tdoa_ctx *ctx, int n_sw, int maxlen, int n_pw, const FftPla
     if ((rc = ensure(ctx, ctx->partials, sizeof(StatsPartial) * (size_t)n_sw))) return rc;
     if ((rc = ensure(ctx, ctx->stats, sizeof(FmStats) * (size_t)n_sw))) return rc;
     if ((rc = ensure(ctx, ctx->codes, sizeof(short) * (size_t)code_stride * n_sw))) return rc;
+    if (ctx->prm.k1_smooth > 1 && (rc = ensure(ctx, ctx->codes_lp, sizeof(short) * (size_t)code_stride * n_sw))) return rc;
     if ((rc = ensure(ctx, ctx->tz, sizeof(float2) * (size_t)pl.Nc * n_sw))) return rc;
     (void)lag_lo;
     (void)lag_hi;
@@ -317,6 +318,15 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
         const int blocks = (int)std::max<long long>(1, std::min<long long>(items, ctx->n_cu));
         hipLaunchKernelGGL(k_fm_demod, dim3(blocks), dim3(kDemodThreads), 65536 * sizeof(short), st, d_sw, n_sw, pieces,
                            static_cast<const short *>(ctx->k1_table.p), codes, code_stride, partials);
+        if (ctx->prm.k1_smooth > 1) {
+            // optional: the prebuilt binary's moving average on the discriminator output; statistics of the smoothed codes
+            auto *lp = static_cast<short *>(ctx->codes_lp.p);
+            hipLaunchKernelGGL(k_zero_u64, dim3((unsigned)((2 * (size_t)n_sw + 255) / 256)), dim3(256), 0, st,
+                               reinterpret_cast<unsigned long long *>(partials), 2 * (size_t)n_sw);
+            hipLaunchKernelGGL(k_k1_smooth, dim3((unsigned)((maxlen + 2047) / 2048), n_sw), dim3(256), 0, st, d_sw, codes, lp,
+                               code_stride, ctx->prm.k1_smooth / 2, partials);
+            codes = lp;
+        }
         hipLaunchKernelGGL(k_fm_stats_final, dim3((n_sw + 63) / 64), dim3(64), 0, st, d_sw, partials, stats, n_sw);
     }
     const size_t lds_col = sizeof(float2) * 2 * (size_t)pl.N2 * pl.C;
@@ -639,6 +649,8 @@ void tdoa_default_params(tdoa_params *p)
     p->window_len = 2000000;      // processor.go:772
     p->device = 0;
     p->windows_per_batch = 0;
+    p->k1_smooth = 0;
+    p->reserved = 0;
 }
 
 int tdoa_abi_version(void) { return TDOA_ABI_VERSION; }
@@ -686,7 +698,8 @@ int tdoa_create(const tdoa_params *p, tdoa_ctx **out)
         prm = *p;
     else
         tdoa_default_params(&prm);
-    if (prm.max_lag < 1 || prm.corr_block < 1 || prm.window_len < 2 || !(prm.sample_rate > 0))
+    if (prm.max_lag < 1 || prm.corr_block < 1 || prm.window_len < 2 || !(prm.sample_rate > 0) || prm.k1_smooth < 0 ||
+        prm.k1_smooth > 2001)
         return TDOA_ERR_INVALID;
     int ndev = tdoa_device_count();
     if (ndev <= 0 || prm.device < 0 || prm.device >= ndev) return TDOA_ERR_NO_DEVICE;
@@ -745,7 +758,7 @@ void tdoa_destroy(tdoa_ctx *ctx)
     if (ctx->graph_exec) (void)hipGraphExecDestroy(ctx->graph_exec);
     if (ctx->graph) (void)hipGraphDestroy(ctx->graph);
     tdoa_capture_clear(ctx);
-    DevBuf *bufs[] = {&ctx->k1_table, &ctx->sw_desc, &ctx->pw_desc, &ctx->partials, &ctx->stats, &ctx->codes, &ctx->tz, &ctx->v, &ctx->keys,
+    DevBuf *bufs[] = {&ctx->k1_table, &ctx->sw_desc, &ctx->pw_desc, &ctx->partials, &ctx->stats, &ctx->codes, &ctx->codes_lp, &ctx->tz, &ctx->v, &ctx->keys,
                       &ctx->scales, &ctx->peaks, &ctx->scratch_a, &ctx->scratch_b, &ctx->lagdump,
                       &ctx->ex_a, &ctx->ex_b, &ctx->ex_c, &ctx->ex_d, &ctx->ex_part,
                       &ctx->g_sw_desc, &ctx->g_pw_desc, &ctx->g_scales, &ctx->g_keys, &ctx->fine_raw, &ctx->fine, &ctx->qual};
@@ -1098,7 +1111,7 @@ static int process_impl(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host,
 
     // everything the launches depend on: same key => the captured graph can be replayed as is
     std::vector<uint64_t> key = {(uint64_t)S, (uint64_t)rank, (uint64_t)world, (uint64_t)per_batch, (uint64_t)wlen,
-                                 (uint64_t)ctx->prm.max_lag, (uint64_t)block,
+                                 (uint64_t)ctx->prm.max_lag | ((uint64_t)ctx->prm.k1_smooth << 32), (uint64_t)block,
                                  (uint64_t)ctx->force_generic | ((uint64_t)ctx->short_lag << 1) |
                                      ((uint64_t)ctx->fused_rows << 2) | ((uint64_t)ctx->segment_form << 3) |
                                      ((uint64_t)ctx->xcd_rows << 4) | ((uint64_t)ctx->pair_r8 << 5),
@@ -1327,10 +1340,19 @@ int tdoa_fm_preprocess_u8(tdoa_ctx *ctx, const uint8_t *iq, size_t n, float *out
     hipLaunchKernelGGL(k_fm_demod, dim3(std::max(1, std::min((pieces + kDemodItem - 1) / kDemodItem, ctx->n_cu))), dim3(kDemodThreads),
                        65536 * sizeof(short), st, d_sw, 1, pieces, static_cast<const short *>(ctx->k1_table.p),
                        static_cast<short *>(ctx->codes.p), code_stride, static_cast<StatsPartial *>(ctx->partials.p));
+    short *codes_used = static_cast<short *>(ctx->codes.p);
+    if (ctx->prm.k1_smooth > 1) {
+        if ((rc = ensure(ctx, ctx->codes_lp, sizeof(short) * (size_t)code_stride))) return rc;
+        HIPCHK(ctx, hipMemsetAsync(ctx->partials.p, 0, sizeof(StatsPartial), st));
+        hipLaunchKernelGGL(k_k1_smooth, dim3((unsigned)((n + 2047) / 2048), 1), dim3(256), 0, st, d_sw, codes_used,
+                           static_cast<short *>(ctx->codes_lp.p), code_stride, ctx->prm.k1_smooth / 2,
+                           static_cast<StatsPartial *>(ctx->partials.p));
+        codes_used = static_cast<short *>(ctx->codes_lp.p);
+    }
     hipLaunchKernelGGL(k_fm_stats_final, dim3(1), dim3(64), 0, st, d_sw, static_cast<StatsPartial *>(ctx->partials.p),
                        static_cast<FmStats *>(ctx->stats.p), 1);
     hipLaunchKernelGGL(k_fm_dump, dim3((unsigned)((n + 255) / 256), 1), dim3(256), 0, st, d_sw,
-                       static_cast<short *>(ctx->codes.p), static_cast<FmStats *>(ctx->stats.p),
+                       codes_used, static_cast<FmStats *>(ctx->stats.p),
                        static_cast<float *>(ctx->scratch_b.p));
     HIPCHK(ctx, hipGetLastError());
     if (out_f32) HIPCHK(ctx, hipMemcpyAsync(out_f32, ctx->scratch_b.p, sizeof(float) * n, hipMemcpyDeviceToHost, st));

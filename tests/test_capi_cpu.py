@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol(capi):
     missing = [f for f in declared if not hasattr(L, f)]
     assert not missing, missing
     assert sorted(capi.SYMBOLS) == declared          # the ctypes binding covers the whole header
-    assert L.tdoa_abi_version() == 2
+    assert L.tdoa_abi_version() == 3          # 3: tdoa_params grew k1_smooth (round 2)
 
 
 def test_default_params_are_the_reference_constants(capi):

@@ -98,3 +98,34 @@ def test_k1_exact_reversals_bit_exact(oracle):
         got, st = c.fm_preprocess(sim)
         want, ost = oracle.b_preprocess(sim)
         assert (st.s1, st.s2_lo) == (ost.s1, ost.s2_lo) and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_optional_k1_smoothing_on_the_gpu(oracle):
+    """tdoa_params.k1_smooth = 10 (the prebuilt binary's applyLowPassFilter(10) on the discriminator output): smoothed,
+    normalised samples and statistics bit-equal to ob_smooth_codes; end to end against the float64 chain in the binary's
+    order; default contexts are untouched"""
+    import tdoa_amd
+    n, ml = 300_000, 2000
+    a = oracle.simulate_delayed_fm(n, 0, 4242, 1)
+    b = oracle.simulate_delayed_fm(n - 1001, 37, 4242, 2)                 # ragged: the tail chunk of k_k1_smooth
+    with tdoa_amd.Context(max_lag=ml, window_len=n, k1_smooth=10) as c:
+        for x in (a, b, a[:2 * 4099], a[:2 * 7]):
+            got, st = c.fm_preprocess(x)
+            want, ost = oracle.b_preprocess_smooth(x, 10)
+            assert (st.s1, st.s2_lo) == (ost.s1, ost.s2_lo)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        lag, corr = c.fm_xcorr(a, b, ml)
+        lags = c.fm_xcorr_lags(a, b, ml)
+        c.debug_flags(no_short_lag=True)
+        lag_g, corr_g = c.fm_xcorr(a, b, ml)
+    ta, _ = oracle.b_preprocess_smooth(a, 10)
+    tb, _ = oracle.b_preprocess_smooth(b, 10)
+    olag, ocorr, want = oracle.b_xcorr_peak_fft(ta, tb, ml)
+    assert lag == lag_g == olag == 37
+    assert abs(corr - ocorr) <= 1e-5 * abs(ocorr) and abs(corr_g - ocorr) <= 1e-5 * abs(ocorr)
+    assert np.abs(lags - want).max() <= 1e-5 * np.abs(want).max()
+    flag, fcorr, _ = fp.xcorr_peak_u8(a, b, ml, smooth=10)
+    assert lag == flag and abs(corr - fcorr) <= 1e-4 * abs(fcorr)
+    with tdoa_amd.Context(max_lag=ml, window_len=n) as c:                  # k1_smooth = 0: the unsmoothed pipeline
+        lag0, corr0 = c.fm_xcorr(a, b, ml)
+    assert lag0 == 37 and abs(corr0) < abs(corr)                           # the message is low-pass: smoothing removes noise

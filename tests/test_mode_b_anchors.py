@@ -92,3 +92,35 @@ def test_mode_b_correlation_vs_go_time_domain(oracle, blocks, ns, delay):
     gd, gc = oracle.time_domain_correlation(np.concatenate([vt, [0.0]]).astype(np.complex64), vs.astype(np.complex64), max_lag)
     assert gd == int(np.argmax(np.abs(mb))) == delay                     # first strict max == argmax (no exact ties here)
     assert abs(gc - mb[gd]) <= 1e-6 * abs(gc)
+
+
+def test_optional_k1_smoothing_vs_the_binarys_chain(oracle, capsys):
+    """tdoa_params.k1_smooth = 10: discriminator -> removeDCBias -> applyLowPassFilter(10) -> normalizeSignal is the prebuilt
+    binary's strong-signal chain.  The integer smoothing of the phase codes (ob_smooth_codes, what the
+    device runs) against that chain in ITS order in float64: same peak lag, corr within 1e-4 (code rounding + the edge
+    samples' share of the mean)."""
+    n, ml = 200_000, 3000
+    # the integer filter itself: exact average, rounded half up, edges truncated
+    code = oracle.b_discriminate(oracle.simulate_delayed_fm(5000, 0, 9, 1)).astype(np.int64)
+    want = np.array([np.floor((2 * code[max(i - 5, 0):i + 6].sum() + len(code[max(i - 5, 0):i + 6])) /
+                              (2 * len(code[max(i - 5, 0):i + 6]))) for i in range(code.size)])
+    pre, st = oracle.b_preprocess_smooth(oracle.simulate_delayed_fm(5000, 0, 9, 1), 10)
+    lp = np.rint(pre.astype(np.float64) / st.scale + st.mean)
+    assert np.array_equal(lp, want)
+    assert np.abs(fp.lowpass(code.astype(np.float64), 10) - want).max() <= 0.5 + 1e-9
+    rows = []
+    for name, a, b in _three_inputs(oracle, n)[:7]:
+        ta, _ = oracle.b_preprocess_smooth(a, 10)
+        tb, _ = oracle.b_preprocess_smooth(b, 10)
+        olag, ocorr, _ = oracle.b_xcorr_peak_fft(ta, tb, ml)
+        flag, fcorr, _ = fp.xcorr_peak_u8(a, b, ml, smooth=10)
+        assert olag == flag, name
+        dev = abs(ocorr - fcorr) / abs(fcorr)
+        rows.append((name, olag, fcorr, dev))
+        assert dev < 1e-4, (name, dev)
+    # smoothing is a low-pass: it must not move the true delay, and it raises the peak of a low-pass message
+    assert rows[0][1] == 37
+    with capsys.disabled():
+        print("\n  k1_smooth = 10: integer-smoothed codes vs float64 chain in the binary's order")
+        for r in rows:
+            print("    %-38s lag %6d  corr %12.6f  |dcorr|/|corr| %.2e" % r)
