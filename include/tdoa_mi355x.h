@@ -253,9 +253,16 @@ enum {
     TDOA_DEBUG_NO_FUSED_ROWS   = 4,  /* separate forward row pass even when every station is in at most two pairs     */
     TDOA_DEBUG_NO_SEGMENT_FORM = 8,  /* no LDS-resident overlap-save correlation for search ranges up to 1024 lags    */
     TDOA_DEBUG_NO_XCD_ROWS     = 16, /* plain 2-D grid of the pair kernel even with more pairs than stations          */
-    TDOA_DEBUG_PAIR_R8         = 32  /* (bit set = form USED) 512-thread / 8-value pair kernel instead of 256 / 16      */
+    TDOA_DEBUG_PAIR_R8         = 32, /* (bit set = form USED) 512-thread / 8-value pair kernel instead of 256 / 16      */
+    TDOA_DEBUG_NO_SEGMENT_QUADS = 64 /* segment form one pair-window at a time: no station transforms shared by pairs  */
 };
 int tdoa_debug_flags(tdoa_ctx *ctx, unsigned flags);
+/* tests only (host, no GPU): the cover of a window's station pairs by "quads" -- two template stations x two signal
+ * stations whose two packed transforms per segment serve up to four pairs in the segment form.
+ * pairs[2 i], pairs[2 i + 1] = template, signal station of pair i; quads_out gets 8 ints per quad: stations a, b, c, d
+ * (-1 = empty slot) and the pair index of (a,c), (a,d), (b,c), (b,d) (-1 = not wanted).  Returns the number of quads
+ * (at most n_pairs), or a negative TDOA_ERR_* value. */
+int tdoa_debug_segment_quads(int n_stations, const int32_t *pairs, int n_pairs, int32_t *quads_out, int max_quads);
 
 /* ---- downstream (processor.go:125-163, 932-1045), host side ---------------- */
 void tdoa_latlon_to_ecef(double lat, double lon, double elev, double xyz[3]);

@@ -22,6 +22,12 @@ struct PWDesc {            // one (pair, window) unit
     int32_t len_a;         // template length (normalisation 1/sqrt(len_a))
 };
 
+struct QuadDesc {          // segment form: two template station-windows x two signal station-windows of one window
+    int32_t sw_ta, sw_tb;  // templates (batch-relative station-window index; sw_tb = -1: none)
+    int32_t sw_sc, sw_sd;  // signals (sw_sd = -1: none)
+    int32_t pw[4];         // batch-relative pair-window of (ta,sc), (ta,sd), (tb,sc), (tb,sd); -1 = not wanted
+};
+
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 __device__ __forceinline__ float2 cmul(float2 a, float2 b)

@@ -85,6 +85,18 @@ __device__ __forceinline__ int swz(int i) { return i ^ ((i >> 5) & 7) ^ (((i >> 
 #define TDOA_PLAIN_DS_OPS
 #endif
 
+// phase code at a 32-bit unsigned byte offset from a uniform row pointer (global_load_sshort v, v_off, s[base])
+__device__ __forceinline__ int code_at(const short *row, unsigned byte_off)
+{
+    return *reinterpret_cast<const short *>(reinterpret_cast<const char *>(row) + byte_off);
+}
+
+__device__ __forceinline__ int opaque_i(int v)
+{
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
 constexpr int kRow8Lds = 4096;       // float2 per row image (no padding)
 
 // Stages 2..4 of TWO 4096-point row transforms side by side (row x through image la, row y through lb), whose
@@ -101,11 +113,14 @@ __device__ __forceinline__ void rows2_r8_finish_w(float2 (&x)[8], float2 (&y)[8]
     {
         // element 8 jj + k: (i >> 5) & 7 = (jj >> 2) & 7, (i >> 6) & 3 = (jj >> 3) & 3
         const int sx = ((jx >> 2) & 7) ^ (((jx >> 3) & 3) << 3), sy = ((jy >> 2) & 7) ^ (((jy >> 3) & 3) << 3);
-        const int bx = (8 * jx) ^ (sx & 0x18), by = (8 * jy) ^ (sy & 0x18);
+        // every store address of a stage is one base XOR a compile-time constant.  The bases are laundered so that the
+        // eight addresses are rebuilt where they are used (one v_xor each): hoisted out of a caller's loop as 3 x 8
+        // invariants they would be spilled and reloaded from scratch on every trip.
+        const int bx = opaque_i(((8 * jx) ^ (sx & 0x18)) | (sx & 7)), by = opaque_i(((8 * jy) ^ (sy & 0x18)) | (sy & 7));
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            la[bx + (k ^ (sx & 7))] = x[oreg8(k)];
-            lb[by + (k ^ (sy & 7))] = y[oreg8(k)];
+            la[bx ^ k] = x[oreg8(k)];
+            lb[by ^ k] = y[oreg8(k)];
         }
     }
     __syncthreads();
@@ -121,10 +136,11 @@ __device__ __forceinline__ void rows2_r8_finish_w(float2 (&x)[8], float2 (&y)[8]
     fft8<INV>(y);
     __syncthreads();
     {
-        const int d = ((j >> 3) << 6) + (j & 7);
+        // swz(d + 8 k) = swz(d) ^ (k << 3) ^ (k >> 2) for d = 64 (j >> 3) + (j & 7)
+        const int d = opaque_i(swz(((j >> 3) << 6) + (j & 7)));
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            const int p = swz(d + 8 * k);
+            const int p = d ^ ((k << 3) ^ (k >> 2));
             la[p] = x[oreg8(k)];
             lb[p] = y[oreg8(k)];
         }
@@ -141,10 +157,11 @@ __device__ __forceinline__ void rows2_r8_finish_w(float2 (&x)[8], float2 (&y)[8]
     fft8<INV>(y);
     __syncthreads();
     {
-        const int d = ((j >> 6) << 9) + (j & 63);
+        // swz(d + 64 k) = swz(d) ^ (k << 6) ^ ((k & 3) << 1) ^ ((k & 3) << 3) for d = 512 (j >> 6) + (j & 63)
+        const int d = opaque_i(swz(((j >> 6) << 9) + (j & 63)));
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            const int p = swz(d + 64 * k);
+            const int p = d ^ ((k << 6) ^ ((k & 3) << 1) ^ ((k & 3) << 3));
             la[p] = x[oreg8(k)];
             lb[p] = y[oreg8(k)];
         }
@@ -474,6 +491,115 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_
         const int n = t + 512 * k;
         if (512 * k <= P && n <= P) part[P + n] = c[oreg8(k)].x;
         if (512 * (k + 1) > 4096 - P && n >= 4096 - P) part[n - (4096 - P)] = c[oreg8(k)].x;
+    }
+}
+
+// The same for up to four pair-windows of one window at a time: templates (a, b) against signals (c, d).
+// Z1 = FFT(t_a + i t_b) (both masked to [P, P + H)) and Z2 = FFT(s_c + i s_d) (full frames) per segment; with
+// p = Z1[k] + conj(Z1[-k]) = 2 T_a[k] and m = Z1[k] - conj(Z1[-k]) = 2 i T_b[k]
+//   conj(T_a) Z2 = conj(p) Z2 / 2      -> inverse transform = c_ac + i c_ad
+//   conj(T_b) Z2 = i conj(m) Z2 / 2    -> inverse transform = c_bc + i c_bd
+// i.e. two forward transforms per segment serve four pair-windows (three for the reference's three stations: a = 0,
+// b = c = 1, d = 2, the (1, 1) output is not wanted), against one transform per pair-window above.  Nothing is
+// subtracted between accumulators (the pair form's A[k] - A[-k] is gone).
+// grid (n_chunks, n_quads), 512 threads, dynamic LDS 64 KB; chunk c takes the segments c, c + n_chunks, ...; output
+// layout as above, one part row per wanted pair-window.
+template <int PQ>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_PLAIN_DS_OPS)) void k_xcorr_segments_quad(const SWDesc *sw, const QuadDesc *quads, const short *codes, long long code_stride, const FmStats *stats, float2 *V, FftPlan pl, int n_chunks)
+{
+    constexpr int P = 256 * PQ, H = 4096 - 2 * P;
+    extern __shared__ float2 lds[];   // 2 * kRow8Lds
+    float2 *la = lds, *lb = lds + kRow8Lds;
+    const int t = threadIdx.x;
+    const QuadDesc q = quads[blockIdx.y];
+    const bool has_b = q.sw_tb >= 0, has_d = q.sw_sd >= 0;
+    const int ia = q.sw_ta, ib = has_b ? q.sw_tb : q.sw_ta, ic = q.sw_sc, id = has_d ? q.sw_sd : q.sw_sc;
+    const int len_a = sw[ia].len, len_b = has_b ? sw[ib].len : 0, len_c = sw[ic].len, len_d = has_d ? sw[id].len : 0;
+    const short *ca = codes + (size_t)ia * code_stride, *cb = codes + (size_t)ib * code_stride;
+    const short *cc = codes + (size_t)ic * code_stride, *cd = codes + (size_t)id * code_stride;
+    const float mean_a = stats[ia].mean, scale_a = stats[ia].scale, mean_b = stats[ib].mean, scale_b = stats[ib].scale;
+    const float mean_c = stats[ic].mean, scale_c = stats[ic].scale, mean_d = stats[id].mean, scale_d = stats[id].scale;
+    const int len_t = len_a > len_b ? len_a : len_b, n_seg = (len_t + H - 1) / H;
+    int len_min = len_a < len_c ? len_a : len_c;
+    len_min = len_min < len_b ? len_min : len_b;
+    len_min = len_min < len_d ? len_min : len_d;       // 0 when a slot is empty: every trip takes the checked path
+    const float2 w2 = unit_root((float)(t & 7), 2.0f / 64.0f, false), w3 = unit_root((float)(t & 63), 2.0f / 512.0f, false),
+                 w4 = unit_root((float)t, 2.0f / 4096.0f, false);
+    const int mq = swz(512 - t), rb = swz(t);
+    float2 accX[8], accY[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) accX[k] = accY[k] = make_float2(0.0f, 0.0f);
+
+    for (int s0 = blockIdx.x; s0 < n_seg; s0 += n_chunks) {
+        float2 x[8], y[8];          // x: the two template frames, y: the two signal frames
+        const int i0 = s0 * H - P + t;
+        if (s0 * H - P >= 0 && s0 * H - P + 4096 <= len_min) {
+            // uniform row pointer (SGPR pair) + unsigned 32-bit byte offset of the lane: one offset register serves all
+            // four streams, where signed sample indices would cost a 64-bit address pair per stream and position
+            const unsigned bo = 2u * (unsigned)i0;
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const bool tpos = t + 512 * r >= P && t + 512 * r < P + H;
+                const int a0 = tpos ? code_at(ca, bo + 1024u * r) : 0, b0 = tpos ? code_at(cb, bo + 1024u * r) : 0;
+                const int c0 = code_at(cc, bo + 1024u * r), d0 = code_at(cd, bo + 1024u * r);
+                x[r] = make_float2(tpos ? k1_normalise(a0, mean_a, scale_a) : 0.0f, tpos ? k1_normalise(b0, mean_b, scale_b) : 0.0f);
+                y[r] = make_float2(k1_normalise(c0, mean_c, scale_c), k1_normalise(d0, mean_d, scale_d));
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const bool tpos = t + 512 * r >= P && t + 512 * r < P + H;
+                const int i = i0 + 512 * r;
+                const bool in_a = tpos && i < len_a, in_b = tpos && i < len_b;
+                const bool in_c = i >= 0 && i < len_c, in_d = i >= 0 && i < len_d;
+                const int qa = in_a ? (int)ca[i] : 0, qb = in_b ? (int)cb[i] : 0, qc = in_c ? (int)cc[i] : 0, qd = in_d ? (int)cd[i] : 0;
+                x[r] = make_float2(in_a ? k1_normalise(qa, mean_a, scale_a) : 0.0f, in_b ? k1_normalise(qb, mean_b, scale_b) : 0.0f);
+                y[r] = make_float2(in_c ? k1_normalise(qc, mean_c, scale_c) : 0.0f, in_d ? k1_normalise(qd, mean_d, scale_d) : 0.0f);
+            }
+        }
+        fft8<false>(x);
+        fft8<false>(y);
+        rows2_r8_finish_w<false>(x, y, la, lb, t, t, t, opaque(w2), opaque(w3), opaque(w4));      // Z[t + 512 k] in [oreg8(k)]
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 8; k++) la[rb + 512 * k] = x[oreg8(k)];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            // mirror of bin t + 512 k: element (512 - t) + 512 (7 - k) -- one base + immediates; thread 0 (whose mirror
+            // of bin 0 is bin 0 itself) reads one element past the image for k = 0 (lb[0], in bounds) and ignores it
+            const float2 z = x[oreg8(k)], w = y[oreg8(k)], zl = la[mq + 512 * (7 - k)];
+            const float2 zm = (k == 0 && t == 0) ? z : zl;
+            const float2 p = make_float2(z.x + zm.x, z.y - zm.y), m = make_float2(z.x - zm.x, z.y + zm.y);
+            accX[k].x += p.x * w.x + p.y * w.y;
+            accX[k].y += p.x * w.y - p.y * w.x;
+            accY[k].x += m.x * w.x + m.y * w.y;
+            accY[k].y += m.x * w.y - m.y * w.x;
+        }
+        __syncthreads();
+    }
+    float2 cx[8], cy[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        cx[k] = make_float2(0.5f * accX[k].x, 0.5f * accX[k].y);          // input k of stage-1 item t
+        cy[k] = make_float2(-0.5f * accY[k].y, 0.5f * accY[k].x);
+    }
+    fft8<true>(cx);
+    fft8<true>(cy);
+    rows2_r8_finish<true>(cx, cy, la, lb, t, t, t);
+    const size_t pitch = 2 * P + 8;
+#pragma unroll
+    for (int o = 0; o < 4; o++) {
+        if (q.pw[o] < 0) continue;
+        float *part = reinterpret_cast<float *>(V + (size_t)q.pw[o] * pl.Nc) + (size_t)blockIdx.x * pitch;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int n = t + 512 * k;
+            const float2 c2 = o < 2 ? cx[oreg8(k)] : cy[oreg8(k)];
+            const float c = (o & 1) ? c2.y : c2.x;
+            if (512 * k <= P && n <= P) part[P + n] = c;
+            if (512 * (k + 1) > 4096 - P && n >= 4096 - P) part[n - (4096 - P)] = c;
+        }
     }
 }
 

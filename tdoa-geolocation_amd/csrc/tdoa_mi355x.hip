@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <new>
 #include <string>
 #include <vector>
@@ -26,6 +27,7 @@
 #include "window_quality.hpp"
 #include "host_geodesy.hpp"
 #include "host_upload.hpp"
+#include "segment_quads.hpp"
 
 using namespace tdoa;
 
@@ -78,13 +80,15 @@ struct tdoa_ctx {
     bool short_lag = true;                  // TDOA_NO_SHORT_LAG=1 at tdoa_create time forces the general inverse for short searches
     bool fused_rows = false;                // forward row pass inside the pair kernel when P <= S (TDOA_FUSED_ROWS=1 / tdoa_debug_flags)
     bool segment_form = true;               // TDOA_NO_SEGMENT_FORM=1: no LDS-resident overlap-save form for short searches
+    bool segment_quads = true;              // TDOA_NO_SEGMENT_QUADS=1: segment form one pair-window at a time (no shared station transforms)
     bool xcd_rows = true;                   // TDOA_NO_XCD_ROWS=1: plain 2-D grid of the pair kernel even with more pairs than stations
     bool pair_r8 = false;                   // TDOA_PAIR_R8=1: the 512-thread / 8-value pair kernel (measured equal on cfg2, 5 % slower on cfg4)
     uint64_t alloc_gen = 0;                 // bumped whenever a workspace buffer moves
     std::vector<uint64_t> graph_key;
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
-    DevBuf g_sw_desc, g_pw_desc, g_scales, g_keys;
+    DevBuf g_sw_desc, g_pw_desc, g_quad_desc, g_scales, g_keys;
+    std::map<std::vector<int>, std::vector<StationQuad>> quad_cache;   // owned pair ids of a window -> its quad cover
     DevBuf qual;                            // QualAcc per (window, station)
     StagedUploader uploader;                // pinned staging buffers + copy streams, created on first use
     DevBuf fine_raw, fine;                  // (f)-4 refinement: 3 raw neighbours and tdoa_fine_peak per slot
@@ -253,7 +257,8 @@ int reserve_fm_batch(tdoa_ctx *ctx, int n_sw, int maxlen, int n_pw, const FftPla
 // sw/pw descriptors are already in device memory; maxlen = longest window.
 int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const PWDesc *d_pw, int n_pw,
                  unsigned long long *d_keys, const FftPlan &pl, int lag_lo, int lag_hi, float *lag_dump,
-                 float dump_scale, double sum_len, float *fine_raw = nullptr, int pairs_per_window = 0)
+                 float dump_scale, double sum_len, float *fine_raw = nullptr, int pairs_per_window = 0,
+                 const QuadDesc *d_quads = nullptr, int n_quads = 0)
 {
     int rc;
     const int pieces = std::max(1, (maxlen + kDemodPiece - 1) / kDemodPiece);
@@ -302,11 +307,24 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
         const int reach = std::max(lag_hi + 1, -(lag_lo - 1));
         seg_pq = reach <= 256 ? 1 : reach <= 512 ? 2 : reach <= 1024 ? 4 : 0;
     }
+    // quads (two station transforms per segment serve up to four pair-windows) when that is fewer transforms than one
+    // per pair-window
+    const bool seg_quads = ctx->segment_quads && d_quads && n_quads > 0 && 2 * n_quads < n_pw;
     if (seg_pq && row16 && ctx->short_lag && ctx->segment_form && n_pw > 0 && pl.N2 >= 8) {
         const int hop = 4096 - 512 * seg_pq;
-        const int pairs = ((maxlen + hop - 1) / hop + 1) / 2;
-        seg_chunks = std::max(1, std::min({pairs / 8, pl.N2 / 2 - 1, (4096 + n_pw - 1) / n_pw}));
-        if (const char *e = std::getenv("TDOA_SEG_CHUNKS")) seg_chunks = std::max(1, std::min({std::atoi(e), pairs, pl.N2 / 2 - 1}));
+        const int frames = (maxlen + hop - 1) / hop;
+        const int trips = seg_quads ? frames : (frames + 1) / 2;        // the pair kernel takes two frames per trip
+        const int units = seg_quads ? n_quads : n_pw;
+        // chunks per unit: the grid runs in rounds of 2 workgroups per CU (64 KB LDS, 128 VGPRs x 512 threads); cost
+        // model = rounds x (trips of the longest chunk + 2 for the prologue and the final inverse transform)
+        const int c_max = std::max(1, std::min({trips / 8, pl.N2 / 2 - 1, (8192 + units - 1) / units}));
+        const long long slots = 2ll * ctx->n_cu;
+        double best = 0.0;
+        for (int c = 1; c <= c_max; c++) {
+            const double cost = (double)(((long long)c * units + slots - 1) / slots) * ((trips + c - 1) / c + 2);
+            if (!seg_chunks || cost < best) { seg_chunks = c; best = cost; }
+        }
+        if (const char *e = std::getenv("TDOA_SEG_CHUNKS")) seg_chunks = std::max(1, std::min({std::atoi(e), trips, pl.N2 / 2 - 1}));
     }
     {
         // K1: capture bytes -> 16-bit phase codes + exact window statistics
@@ -399,7 +417,11 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
         const size_t lds_seg = sizeof(float2) * 2 * kRow8Lds;
 #define TDOA_SEGMENTS(PQ)                                                                                            \
     do {                                                                                                             \
-        {                                                                                                            \
+        if (seg_quads) {                                                                                             \
+            ProfScope ps(ctx, TDOA_K_INV_ROW, 4.0 * 2.0 * 4096.0 * frames * n_quads);  /* four frames of 2-byte codes */ \
+            hipLaunchKernelGGL(k_xcorr_segments_quad<PQ>, dim3(seg_chunks, n_quads), dim3(512), lds_seg, st, d_sw,    \
+                               d_quads, codes, code_stride, stats, v, pl, seg_chunks);                               \
+        } else {                                                                                                     \
             ProfScope ps(ctx, TDOA_K_INV_ROW, 2.0 * 2.0 * 4096.0 * frames * n_pw);   /* two frames of 2-byte codes */  \
             hipLaunchKernelGGL(k_xcorr_segments<PQ>, dim3(seg_chunks, n_pw), dim3(512), lds_seg, st, d_sw, d_pw, codes, \
                                code_stride, stats, v, pl, seg_chunks);                                               \
@@ -743,6 +765,7 @@ int tdoa_create(const tdoa_params *p, tdoa_ctx **out)
     if (const char *e = std::getenv("TDOA_FUSED_ROWS")) ctx->fused_rows = e[0] == '1';
     if (const char *e = std::getenv("TDOA_NO_FUSED_ROWS")) ctx->fused_rows = !(e[0] == '1');
     if (const char *e = std::getenv("TDOA_NO_SEGMENT_FORM")) ctx->segment_form = !(e[0] == '1');
+    if (const char *e = std::getenv("TDOA_NO_SEGMENT_QUADS")) ctx->segment_quads = !(e[0] == '1');
     if (const char *e = std::getenv("TDOA_NO_XCD_ROWS")) ctx->xcd_rows = !(e[0] == '1');
     if (const char *e = std::getenv("TDOA_PAIR_R8")) ctx->pair_r8 = e[0] == '1';
     *out = ctx;
@@ -761,7 +784,7 @@ void tdoa_destroy(tdoa_ctx *ctx)
     DevBuf *bufs[] = {&ctx->k1_table, &ctx->sw_desc, &ctx->pw_desc, &ctx->partials, &ctx->stats, &ctx->codes, &ctx->codes_lp, &ctx->tz, &ctx->v, &ctx->keys,
                       &ctx->scales, &ctx->peaks, &ctx->scratch_a, &ctx->scratch_b, &ctx->lagdump,
                       &ctx->ex_a, &ctx->ex_b, &ctx->ex_c, &ctx->ex_d, &ctx->ex_part,
-                      &ctx->g_sw_desc, &ctx->g_pw_desc, &ctx->g_scales, &ctx->g_keys, &ctx->fine_raw, &ctx->fine, &ctx->qual};
+                      &ctx->g_sw_desc, &ctx->g_pw_desc, &ctx->g_quad_desc, &ctx->g_scales, &ctx->g_keys, &ctx->fine_raw, &ctx->fine, &ctx->qual};
     for (DevBuf *b : bufs) release(*b);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -1069,7 +1092,8 @@ static int process_impl(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host,
     // all descriptors, uploaded once; window wi of this rank owns sw[sw_off[wi] .. sw_off[wi+1]) and likewise pw
     std::vector<SWDesc> sw;
     std::vector<PWDesc> pw;
-    std::vector<size_t> sw_off(mine.size() + 1, 0), pw_off(mine.size() + 1, 0);
+    std::vector<QuadDesc> quads;
+    std::vector<size_t> sw_off(mine.size() + 1, 0), pw_off(mine.size() + 1, 0), q_off(mine.size() + 1, 0);
     for (size_t wi = 0; wi < mine.size(); wi++) {
         const int wid = mine[wi];
         const size_t batch_base = sw_off[wi - (wi % (size_t)per_batch)];   // PWDesc indices are relative to the batch
@@ -1088,6 +1112,26 @@ static int process_impl(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host,
             }
         sw_off[wi + 1] = sw.size();
         pw_off[wi + 1] = pw.size();
+        // segment form: the quad cover of this window's pairs (the same for every window under window-major sharding).
+        // Every pair-window of the rank is in exactly one quad; run_fm_batch takes the quads of a batch or none of them.
+        if (pw_off[wi + 1] > pw_off[wi]) {
+            std::vector<int> owned;
+            std::vector<std::pair<int, int>> st_pairs;
+            p = 0;
+            for (int i = 0; i < S; i++)
+                for (int j = i + 1; j < S; j++, p++)
+                    if (owns(wid, p)) { owned.push_back(p); st_pairs.emplace_back(i, j); }
+            auto it = ctx->quad_cache.find(owned);
+            if (it == ctx->quad_cache.end()) it = ctx->quad_cache.emplace(owned, build_segment_quads(S, st_pairs)).first;
+            const int pw_base = (int)(pw_off[wi] - pw_off[wi - (wi % (size_t)per_batch)]);    // batch-relative pair-window index
+            for (const StationQuad &q : it->second) {
+                QuadDesc d{slot[q.a], q.b >= 0 ? slot[q.b] : -1, slot[q.c], q.d >= 0 ? slot[q.d] : -1, {-1, -1, -1, -1}};
+                for (int o = 0; o < 4; o++)
+                    if (q.pair[o] >= 0) d.pw[o] = pw_base + q.pair[o];
+                quads.push_back(d);
+            }
+        }
+        q_off[wi + 1] = quads.size();
     }
     const size_t slots = (size_t)W * P;
     hipStream_t st = ctx->stream;
@@ -1097,6 +1141,7 @@ static int process_impl(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host,
     if ((rc = ensure(ctx, ctx->g_scales, sizeof(double) * slots))) return rc;
     if ((rc = ensure(ctx, ctx->g_sw_desc, sizeof(SWDesc) * std::max<size_t>(sw.size(), 1)))) return rc;
     if ((rc = ensure(ctx, ctx->g_pw_desc, sizeof(PWDesc) * std::max<size_t>(pw.size(), 1)))) return rc;
+    if ((rc = ensure(ctx, ctx->g_quad_desc, sizeof(QuadDesc) * std::max<size_t>(quads.size(), 1)))) return rc;
     if (fine_host) {
         if ((rc = ensure(ctx, ctx->fine_raw, 3 * sizeof(float) * slots))) return rc;
         if ((rc = ensure(ctx, ctx->fine, sizeof(FineOut) * slots))) return rc;
@@ -1106,6 +1151,7 @@ static int process_impl(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host,
         return rc;
     auto *d_sw = static_cast<SWDesc *>(ctx->g_sw_desc.p);
     auto *d_pw = static_cast<PWDesc *>(ctx->g_pw_desc.p);
+    auto *d_quads = static_cast<QuadDesc *>(ctx->g_quad_desc.p);
     auto *d_keys = static_cast<unsigned long long *>(ctx->g_keys.p);
     auto *d_scales = static_cast<double *>(ctx->g_scales.p);
 
@@ -1114,7 +1160,8 @@ static int process_impl(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host,
                                  (uint64_t)ctx->prm.max_lag | ((uint64_t)ctx->prm.k1_smooth << 32), (uint64_t)block,
                                  (uint64_t)ctx->force_generic | ((uint64_t)ctx->short_lag << 1) |
                                      ((uint64_t)ctx->fused_rows << 2) | ((uint64_t)ctx->segment_form << 3) |
-                                     ((uint64_t)ctx->xcd_rows << 4) | ((uint64_t)ctx->pair_r8 << 5),
+                                     ((uint64_t)ctx->xcd_rows << 4) | ((uint64_t)ctx->pair_r8 << 5) |
+                                     ((uint64_t)ctx->segment_quads << 6),
                                  ctx->alloc_gen, (uint64_t)(fine_host != nullptr), 0};
     std::memcpy(&key.back(), &gate, sizeof(double));
     for (auto &c : ctx->caps) {
@@ -1131,6 +1178,8 @@ static int process_impl(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host,
             HIPCHK(ctx, hipMemcpyAsync(d_sw, sw.data(), sizeof(SWDesc) * sw.size(), hipMemcpyHostToDevice, st));
             HIPCHK(ctx, hipMemcpyAsync(d_pw, pw.data(), sizeof(PWDesc) * pw.size(), hipMemcpyHostToDevice, st));
         }
+        if (!quads.empty())
+            HIPCHK(ctx, hipMemcpyAsync(d_quads, quads.data(), sizeof(QuadDesc) * quads.size(), hipMemcpyHostToDevice, st));
         HIPCHK(ctx, hipStreamSynchronize(st));   // host vectors go out of scope below
     }
 
@@ -1142,7 +1191,8 @@ static int process_impl(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host,
             const int n_sw = (int)(sw_off[w0 + nw] - sw_off[w0]), n_pw = (int)(pw_off[w0 + nw] - pw_off[w0]);
             const int r = run_fm_batch(ctx, d_sw + sw_off[w0], n_sw, (int)wlen, d_pw + pw_off[w0], n_pw, d_keys, pl,
                                        -(ctx->prm.max_lag - 1), ctx->prm.max_lag - 1, nullptr, 1.0f,
-                                       (double)wlen * n_sw, fine_raw, pair_major ? 0 : P);
+                                       (double)wlen * n_sw, fine_raw, pair_major ? 0 : P, d_quads + q_off[w0],
+                                       (int)(q_off[w0 + nw] - q_off[w0]));
             if (r) return r;
         }
         if (fine_raw)
@@ -1371,6 +1421,26 @@ int tdoa_debug_force_generic(tdoa_ctx *ctx, int on)
     return TDOA_OK;
 }
 
+int tdoa_debug_segment_quads(int n_stations, const int32_t *pairs, int n_pairs, int32_t *quads_out, int max_quads)
+{
+    if (n_stations < 2 || n_stations > 1023 || n_pairs < 0 || (n_pairs && !pairs) || max_quads < 0 || (max_quads && !quads_out))
+        return -TDOA_ERR_INVALID;
+    std::vector<std::pair<int, int>> pr;
+    for (int i = 0; i < n_pairs; i++) {
+        const int a = pairs[2 * i], c = pairs[2 * i + 1];
+        if (a < 0 || c < 0 || a >= n_stations || c >= n_stations || a == c) return -TDOA_ERR_INVALID;
+        pr.emplace_back(a, c);
+    }
+    const std::vector<StationQuad> q = build_segment_quads(n_stations, pr);
+    if ((int)q.size() > max_quads) return -TDOA_ERR_INVALID;
+    for (size_t i = 0; i < q.size(); i++) {
+        int32_t *o = quads_out + 8 * i;
+        o[0] = q[i].a; o[1] = q[i].b; o[2] = q[i].c; o[3] = q[i].d;
+        for (int k = 0; k < 4; k++) o[4 + k] = q[i].pair[k];
+    }
+    return (int)q.size();
+}
+
 int tdoa_debug_flags(tdoa_ctx *ctx, unsigned flags)
 {
     if (!ctx) return TDOA_ERR_INVALID;
@@ -1379,6 +1449,7 @@ int tdoa_debug_flags(tdoa_ctx *ctx, unsigned flags)
     ctx->fused_rows = !(flags & TDOA_DEBUG_NO_FUSED_ROWS);
     ctx->segment_form = !(flags & TDOA_DEBUG_NO_SEGMENT_FORM);
     ctx->xcd_rows = !(flags & TDOA_DEBUG_NO_XCD_ROWS);
+    ctx->segment_quads = !(flags & TDOA_DEBUG_NO_SEGMENT_QUADS);
     ctx->pair_r8 = (flags & TDOA_DEBUG_PAIR_R8) != 0;
     return TDOA_OK;
 }

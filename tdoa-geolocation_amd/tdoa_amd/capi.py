@@ -69,7 +69,7 @@ SYMBOLS = [
     "tdoa_num_windows", "tdoa_num_pairs", "tdoa_process", "tdoa_process_u8",
     "tdoa_process_fine", "tdoa_fm_xcorr_fine_u8", "tdoa_window_quality_all", "tdoa_window_quality_u8",
     "tdoa_fm_xcorr_u8", "tdoa_fm_preprocess_u8", "tdoa_fm_xcorr_lags_u8", "tdoa_debug_force_generic",
-    "tdoa_debug_flags", "tdoa_cross_correlate_batch_c64",
+    "tdoa_debug_flags", "tdoa_debug_segment_quads", "tdoa_cross_correlate_batch_c64",
     "tdoa_latlon_to_ecef", "tdoa_ecef_to_latlon", "tdoa_solve_3station", "tdoa_solve_nstation",
     "tdoa_profile_enable", "tdoa_profile_reset", "tdoa_profile_get", "tdoa_kernel_name",
     "tdoa_plan_info",
@@ -139,6 +139,7 @@ def load(build_if_missing=True):
     L.tdoa_fm_xcorr_lags_u8.argtypes = [vp, u8p, sz, u8p, sz, C.c_int, dp]
     L.tdoa_debug_force_generic.argtypes = [vp, C.c_int]
     L.tdoa_debug_flags.argtypes = [vp, C.c_uint]
+    L.tdoa_debug_segment_quads.argtypes = [C.c_int, C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_int32), C.c_int]
     L.tdoa_latlon_to_ecef.argtypes = [C.c_double, C.c_double, C.c_double, dp]
     L.tdoa_latlon_to_ecef.restype = None
     L.tdoa_ecef_to_latlon.argtypes = [C.c_double, C.c_double, C.c_double, dp]
@@ -425,11 +426,12 @@ class Context:
         self._chk(self._L.tdoa_debug_force_generic(self._h, 1 if on else 0))
 
     def debug_flags(self, generic=False, no_short_lag=False, no_fused_rows=False, no_segment_form=False, no_xcd_rows=False,
-                    pair_r8=False):
+                    pair_r8=False, no_segment_quads=False):
         """pick kernel variants by hand (tests / measurements): include/tdoa_mi355x.h TDOA_DEBUG_*"""
         self._chk(self._L.tdoa_debug_flags(self._h, (1 if generic else 0) | (2 if no_short_lag else 0) |
                                            (4 if no_fused_rows else 0) | (8 if no_segment_form else 0) |
-                                           (16 if no_xcd_rows else 0) | (32 if pair_r8 else 0)))
+                                           (16 if no_xcd_rows else 0) | (32 if pair_r8 else 0) |
+                                           (64 if no_segment_quads else 0)))
 
     # ---- measurement -------------------------------------------------------
     def profile_enable(self, on=True):
@@ -471,6 +473,18 @@ def solve_3station(stations_lle, range_diff):
     it = C.c_int()
     rc = load().tdoa_solve_3station(_d(st), _d(rd), _d(out), C.byref(it))
     return rc, out, it.value
+
+
+def segment_quads(n_stations, pairs):
+    """host only: the quad cover the segment form uses for a window's (template, signal) station pairs;
+    returns rows [a, b, c, d, pair(a,c), pair(a,d), pair(b,c), pair(b,d)] (-1 = empty / not wanted)"""
+    pr = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
+    out = np.full((max(len(pr), 1), 8), -2, dtype=np.int32)
+    n = load().tdoa_debug_segment_quads(int(n_stations), pr.ctypes.data_as(C.POINTER(C.c_int32)), len(pr),
+                                        out.ctypes.data_as(C.POINTER(C.c_int32)), len(out))
+    if n < 0:
+        raise ValueError("tdoa_debug_segment_quads: error %d" % -n)
+    return out[:n]
 
 
 def solve_nstation(stations_lle, range_diff, weights=None, solve_z=False):

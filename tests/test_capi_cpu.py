@@ -190,3 +190,34 @@ def test_cgo_shim_only_uses_declared_entry_points():
     body = src[src.index("package main"):]
     assert body in open(os.path.join(root, "INTEGRATION.md")).read()
     assert "len(b) < 2" in body                                      # the empty-slice guard
+
+
+@pytest.mark.parametrize("n_stations", [2, 3, 4, 5, 8, 16, 24])
+def test_segment_quads_cover_every_pair_once(capi, n_stations):
+    """the quad cover of the segment form (two packed station transforms per segment serve up to four pairs): every
+    pair exactly once, in the caller's orientation, in the slot its stations say; about P/2 quads for all pairs"""
+    rng = np.random.default_rng(n_stations)
+    all_pairs = [(i, j) for i in range(n_stations) for j in range(i + 1, n_stations)]
+    subset = [p for p in all_pairs if rng.random() < 0.4] or all_pairs[:1]
+    flipped = [(j, i) if rng.random() < 0.5 else (i, j) for i, j in all_pairs]      # any orientation is the caller's
+    for pairs in (all_pairs, subset, flipped, all_pairs[:1]):
+        quads = capi.segment_quads(n_stations, pairs)
+        seen = []
+        for a, b, c, d, *slots in quads:
+            assert a >= 0 and c >= 0
+            for (t, s), idx in zip(((a, c), (a, d), (b, c), (b, d)), slots):
+                if idx >= 0:
+                    assert tuple(pairs[idx]) == (t, s)
+                    seen.append(idx)
+            assert slots[0] >= 0 or slots[1] >= 0 or slots[2] >= 0 or slots[3] >= 0
+            assert (b >= 0) == (slots[2] >= 0 or slots[3] >= 0) and (d >= 0) == (slots[1] >= 0 or slots[3] >= 0)
+        assert sorted(seen) == list(range(len(pairs)))
+        assert len(quads) <= max(1, (len(pairs) + 1) // 2 + n_stations // 2)
+    if n_stations == 3:
+        assert capi.segment_quads(3, all_pairs).tolist() == [[0, 1, 1, 2, 0, 1, -1, 2]]
+    if n_stations >= 8:
+        assert 2 * len(capi.segment_quads(n_stations, all_pairs)) <= 0.6 * len(all_pairs)
+    with pytest.raises(ValueError):
+        capi.segment_quads(3, [(0, 3)])
+    with pytest.raises(ValueError):
+        capi.segment_quads(3, [(1, 1)])

@@ -433,3 +433,49 @@ def test_radix8_pair_kernel_vs_radix16(oracle, max_lag):
     _assert_lags_close(r8, want)
     _assert_lags_close(r8, r16, 2e-6)
     assert lag == olag == 123 and abs(corr - ocorr) <= REL_TOL * abs(ocorr)
+
+
+@pytest.mark.parametrize("n_st,ml,per_batch", [(3, 512, 0), (3, 100, 2), (4, 200, 0), (5, 1000, 0), (8, 120, 4)])
+def test_segment_quads_vs_one_pair_at_a_time(oracle, n_st, ml, per_batch):
+    """segment form with station transforms shared by the pairs of a window (k_xcorr_segments_quad: two packed
+    transforms per segment serve up to four pair-windows) against the same batch one pair-window at a time
+    (k_xcorr_segments), against the general four-step form, and against the f64 oracle"""
+    import tdoa_amd
+    blk, wl = 140_000, 70_000                                      # N = 2^17: 4096 x 16; 23-35 frames per window
+    delays = [0, 41, -17, 5, 50, -40, 23, 9][:n_st]
+    caps = [np.concatenate([oracle.simulate_delayed_fm(blk, 100 + d, 910 + k, 10 * s + k) for k in range(3)])
+            for s, d in enumerate(delays)]
+    pairs = [(i, j) for i in range(n_st) for j in range(i + 1, n_st)]
+    with tdoa_amd.Context(max_lag=ml, window_len=wl, windows_per_batch=per_batch) as c:
+        for s, cap in enumerate(caps):
+            c.capture_upload(s, cap)
+        quads, fine_q = c.process_fine(120.0)
+        assert quads.shape == (6, len(pairs))
+        c.debug_flags(no_segment_quads=True)
+        single, fine_s = c.process_fine(120.0)
+        c.debug_flags(no_segment_form=True, no_short_lag=True)
+        general = c.process()
+        # sharded: window-major (2 ranks) and pair-major (more ranks than windows: odd pair subsets per rank)
+        c.debug_flags()
+        for world in (2, 7):
+            merged = np.zeros_like(quads)
+            for r in range(world):
+                part = c.process(rank=r, world=world)
+                own = part["corr"] != 0
+                assert not (own & (merged["corr"] != 0)).any()
+                merged[own] = part[own]
+            # (the chunking of a window's segments follows the size of the rank's batch: same lags, sums to rounding)
+            assert np.array_equal(merged["lag"], quads["lag"]), world
+            assert np.abs(merged["corr"] - quads["corr"]).max() <= 2e-6 * np.abs(quads["corr"]).max(), world
+    scale = np.abs(quads["corr"]).max()
+    for other in (single, general):
+        assert np.array_equal(other["lag"], quads["lag"])
+        assert np.abs(other["corr"] - quads["corr"]).max() <= 2e-6 * scale
+    assert np.abs(fine_q["frac"] - fine_s["frac"]).max() < 1e-4
+    for wid in (0, 5):
+        off = (wid // 2) * blk + (wid % 2) * wl
+        pre = [oracle.b_preprocess(cp[2 * off:2 * (off + wl)])[0] for cp in caps]
+        for p, (i, j) in enumerate(pairs):
+            olag, ocorr = oracle.b_xcorr_peak(pre[i], pre[j], ml)
+            assert quads[wid, p]["lag"] == olag == delays[j] - delays[i], (wid, i, j)
+            assert abs(quads[wid, p]["corr"] - ocorr) <= REL_TOL * abs(ocorr)
