@@ -1,0 +1,12 @@
+#!/bin/bash
+# the default bench line next to the opt-in kernel variants (one JSON summary line each -> gpurun_out/variants.jsonl)
+out=gpurun_out/variants.jsonl
+: > $out
+run() {
+  env "$@" python bench.py --no-cpu-baseline --steps 30 $BENCH_ARGS 2>/dev/null | tail -1 | \
+    python -c "import sys,json; d=json.loads(sys.stdin.read()); print(json.dumps({'variant': '$*', 'ms': d['ms_per_step'], 'graph_ms': (d.get('graph_replay') or {}).get('ms_per_step'), 'kernels': d['roofline']['kernels_ms_per_step']}))" >> $out
+}
+run TDOA_DEFAULT=1 || exit 1
+run TDOA_PAIR_R8=1 || exit 1
+run TDOA_FUSED_ROWS=1 || exit 1
+cat $out

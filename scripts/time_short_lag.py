@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """cfg2 (3 stations x 100 s, 99 windows, 3 pairs) with search ranges shorter than the reference's 20000 lags:
-the short-lag inverse (|lag| < 4095, no V round trip) against the general pruned form (TDOA_NO_SHORT_LAG=1)."""
+the segment form (ranges up to 1024 lags; with and without station transforms shared by the pairs of a window) and the
+short-lag inverse (|lag| < 4095, no V round trip) against the general pruned form (TDOA_NO_SHORT_LAG=1); graph replay."""
 import json
 import os
 import sys
@@ -16,9 +17,10 @@ TX = (41.20, -96.00, 400.0)
 
 for max_lag in (128, 512, 1023, 2047, 4095, 20000):
     row = {"max_lag": max_lag}
-    for mode in ("segment", "short", "general"):
+    for mode in ("segment", "segment_pairwise", "short", "general"):
         with tdoa_amd.Context(max_lag=max_lag) as c:
-            c.debug_flags(no_short_lag=(mode == "general"), no_segment_form=(mode != "segment"), no_fused_rows=True)
+            c.debug_flags(no_short_lag=(mode == "general"), no_segment_form=not mode.startswith("segment"),
+                          no_segment_quads=(mode == "segment_pairwise"), no_fused_rows=True)
             for s in range(3):
                 c.synth_capture(s, 66_666_666, ST[s], TX, 0x5D0A0000 + s)
             c.process(want_host=False)

@@ -316,14 +316,16 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
         const int trips = seg_quads ? frames : (frames + 1) / 2;        // the pair kernel takes two frames per trip
         const int units = seg_quads ? n_quads : n_pw;
         // chunks per unit: the grid runs in rounds of 2 workgroups per CU (64 KB LDS, 128 VGPRs x 512 threads); cost
-        // model = rounds x (trips of the longest chunk + 2 for the prologue and the final inverse transform)
+        // model = rounds x (trips of the longest chunk + 1 for the prologue and the final inverse transform).  The model
+        // is flat over a wide range (measured: 10 ... 36 chunks within 2 % on cfg2); among the near-ties take the most
+        // chunks -- more, shorter workgroups balance better than one round of long ones (5 chunks: 4 % slower).
         const int c_max = std::max(1, std::min({trips / 8, pl.N2 / 2 - 1, (8192 + units - 1) / units}));
         const long long slots = 2ll * ctx->n_cu;
-        double best = 0.0;
-        for (int c = 1; c <= c_max; c++) {
-            const double cost = (double)(((long long)c * units + slots - 1) / slots) * ((trips + c - 1) / c + 2);
-            if (!seg_chunks || cost < best) { seg_chunks = c; best = cost; }
-        }
+        auto cost = [&](int c) { return (double)(((long long)c * units + slots - 1) / slots) * ((trips + c - 1) / c + 1); };
+        double best = cost(1);
+        for (int c = 2; c <= c_max; c++) best = std::min(best, cost(c));
+        for (int c = 1; c <= c_max; c++)
+            if (cost(c) <= 1.03 * best) seg_chunks = c;
         if (const char *e = std::getenv("TDOA_SEG_CHUNKS")) seg_chunks = std::max(1, std::min({std::atoi(e), trips, pl.N2 / 2 - 1}));
     }
     {
