@@ -57,7 +57,13 @@ typedef struct {
                                 truncated: applyLowPassFilter, processor.go:270-296) on the discriminator output before
                                 it is normalised -- the prebuilt reference binary's strong-signal chain is discriminator
                                 -> removeDCBias -> applyLowPassFilter(10) -> normalizeSignal */
-    int32_t reserved;
+    int32_t k1_gate;         /* 0 (default): every window through the discriminator (the north-star pipeline).
+                                1: the prebuilt reference binary's power gate (preprocessSignal):
+                                a station-window whose mean power, mean |(b - 127.5)/127.5|^2, is <= 0.01 takes
+                                envelope |x| -> removeDCBias -> normalizeSignal instead of the discriminator chain (and is
+                                not smoothed).  The binary's third branch (<= 0.001: band-passed complex samples) has no
+                                mode-B counterpart; such windows take the envelope too -- tdoa_window_quality_all
+                                reports every window's mean power */
 } tdoa_params;
 
 /* One correlation peak.  lag > 0: the second station of the pair lags the first. */
@@ -254,7 +260,8 @@ enum {
     TDOA_DEBUG_NO_SEGMENT_FORM = 8,  /* no LDS-resident overlap-save correlation for search ranges up to 1024 lags    */
     TDOA_DEBUG_NO_XCD_ROWS     = 16, /* plain 2-D grid of the pair kernel even with more pairs than stations          */
     TDOA_DEBUG_PAIR_R8         = 32, /* (bit set = form USED) 512-thread / 8-value pair kernel instead of 256 / 16      */
-    TDOA_DEBUG_NO_SEGMENT_QUADS = 64 /* segment form one pair-window at a time: no station transforms shared by pairs  */
+    TDOA_DEBUG_NO_SEGMENT_QUADS = 64, /* segment form one pair-window at a time: no station transforms shared by pairs */
+    TDOA_DEBUG_TRI_ROWS        = 128 /* (bit set = form USED) three stations / three pairs: k_rows_tri_fused, all row transforms of a window's row pair in one kernel */
 };
 int tdoa_debug_flags(tdoa_ctx *ctx, unsigned flags);
 /* tests only (host, no GPU): the cover of a window's station pairs by "quads" -- two template stations x two signal

@@ -71,10 +71,27 @@ def lowpass(y, window):
     return (c[hi + 1] - c[lo]) / (hi - lo + 1)
 
 
-def preprocess(iq_u8, smooth=0):
+def mean_power(iq_u8):
+    """mean |x|^2 of x = (b - 127.5) / 127.5 -- the quantity the prebuilt binary's preprocessSignal gates on"""
+    b = np.asarray(iq_u8, dtype=np.float64).reshape(-1, 2)
+    x = (b - 127.5) / 127.5
+    return float((x * x).sum(axis=1).mean()) if len(x) else 0.0
+
+
+def envelope(iq_u8):
+    """the binary's convertToEnvelope: sqrt(re^2 + im^2) of x = (b - 127.5) / 127.5"""
+    b = np.asarray(iq_u8, dtype=np.float64).reshape(-1, 2)
+    x = (b - 127.5) / 127.5
+    return np.sqrt((x * x).sum(axis=1))
+
+
+def preprocess(iq_u8, smooth=0, gate=False):
     """smooth = 0: discriminator -> zero mean -> unit variance.  smooth = W: the prebuilt binary's strong-signal chain in
     ITS order: discriminator -> removeDCBias -> applyLowPassFilter(W) -> normalizeSignal (scale to
-    unit mean power, no second mean removal)"""
+    unit mean power, no second mean removal).  gate: the binary's power gate -- mean power <= 0.01 takes
+    envelope -> removeDCBias -> normalizeSignal instead (its third branch, <= 0.001, is not restated: DESIGN.md 3)"""
+    if gate and mean_power(iq_u8) <= 0.01:
+        return normalise(envelope(iq_u8))
     y = discriminate(iq_u8)
     if smooth <= 1:
         return normalise(y)
@@ -116,8 +133,24 @@ def pick_peak(c, max_lag):
     return lag, float(c[lag + max_lag - 1])
 
 
-def xcorr_peak_u8(iq_t, iq_s, max_lag, smooth=0):
+# ---- a test signal for the envelope branch of the optional power gate ----
+def am_capture(n, delay, amp, seed, station):
+    """amplitude-modulated carrier of mean power ~amp^2 (a moderate-signal capture for the binary's envelope branch):
+    a common low-pass random message delayed by `delay` samples, independent phase walk and noise per station"""
+    rng = np.random.default_rng(seed)
+    msg = np.convolve(rng.standard_normal(n + 4096 + 64), np.ones(32) / np.sqrt(32.0), mode="same")
+    own = np.random.default_rng(1000 * seed + station)
+    m = msg[2048 - delay:2048 - delay + n]
+    phase = np.cumsum(own.standard_normal(n) * 0.2)
+    x = amp * (1.0 + 0.5 * np.tanh(m)) * np.exp(1j * phase) + (own.standard_normal(n) + 1j * own.standard_normal(n)) * amp * 0.05
+    iq = np.empty(2 * n, dtype=np.uint8)
+    iq[0::2] = np.clip(np.trunc(x.real * 127.5 + 127.5), 0, 255).astype(np.uint8)
+    iq[1::2] = np.clip(np.trunc(x.imag * 127.5 + 127.5), 0, 255).astype(np.uint8)
+    return iq
+
+
+def xcorr_peak_u8(iq_t, iq_s, max_lag, smooth=0, gate=False):
     """u8 IQ of the template and the signal -> (lag, corr, all lags)"""
-    c = xcorr_lags(preprocess(iq_t, smooth), preprocess(iq_s, smooth), max_lag)
+    c = xcorr_lags(preprocess(iq_t, smooth, gate), preprocess(iq_s, smooth, gate), max_lag)
     lag, corr = pick_peak(c, max_lag)
     return lag, corr, c

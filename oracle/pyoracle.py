@@ -395,6 +395,25 @@ def b_preprocess_smooth(iq_u8, window):
     return out, st
 
 
+def b_preprocess_gate(iq_u8, window=0, gate=1):
+    """mode B preprocessing with the prebuilt binary's power gate (tdoa_params.k1_gate): returns (signal, stats, cls),
+    cls = 1 when the window took the envelope branch (mean power <= 0.01)"""
+    s = np.ascontiguousarray(iq_u8, dtype=np.uint8)
+    n = s.size // 2
+    out = np.empty(n, dtype=np.float32)
+    st = BStats()
+    cls = C.c_int()
+    lib().ob_preprocess_gate_u8(_u8(s), C.c_size_t(n), C.c_int(int(window)), C.c_int(int(gate)), _f(out), C.byref(st),
+                                C.byref(cls))
+    return out, st, cls.value
+
+
+def b_envelope_code(i, q):
+    f = lib().ob_envelope_code
+    f.restype = C.c_int32
+    return f(C.c_uint(int(i)), C.c_uint(int(q)))
+
+
 def b_xcorr_all_lags(t, s, max_lag):
     t = np.ascontiguousarray(t, dtype=np.float32)
     s = np.ascontiguousarray(s, dtype=np.float32)

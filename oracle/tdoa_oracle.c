@@ -1099,6 +1099,56 @@ void ob_preprocess_smooth_u8(const uint8_t *iq, size_t n, int window, float *out
     if (st_out) *st_out = st;
 }
 
+/* Optional power gate (tdoa_params.k1_gate), as read off the prebuilt reference binary (SURVEY.md section 8, K1:
+ * preprocessSignal @0x49ce6b/0x49ce7d, convertToEnvelope): mean power p = mean |x|^2, x = (b - 127.5)/127.5;
+ * p > 0.01: discriminator chain; p <= 0.01: envelope |x| -> removeDCBias -> normalizeSignal.  (Below 0.001 the binary
+ * band-passes the complex samples instead; mode B has no complex path and keeps the envelope there -- DESIGN.md 3.)
+ * Integers: M = sum (2I-255)^2 + (2Q-255)^2, p = M / (65025 n), so p <= 0.01  <=>  100 M <= 65025 n.
+ * Envelope code = round-half-up(90 sqrt(m)) = (isqrt(32400 m) + 1) >> 1 with m = (2I-255)^2 + (2Q-255)^2 <= 130050
+ * (|x| = sqrt(m)/255; 32400 m < 2^32; code <= 32456): an int16 like the phase codes, same statistics and normalisation. */
+uint64_t ob_power_sum_u8(const uint8_t *iq, size_t n)
+{
+    uint64_t m = 0;
+    for (size_t i = 0; i < n; i++) {
+        int64_t a = 2 * (int64_t)iq[2 * i] - 255, b = 2 * (int64_t)iq[2 * i + 1] - 255;
+        m += (uint64_t)(a * a + b * b);
+    }
+    return m;
+}
+
+int ob_envelope_class(uint64_t power_sum, size_t n) { return 100u * power_sum <= 65025u * (uint64_t)n; }
+
+int32_t ob_envelope_code(unsigned I, unsigned Q)
+{
+    int64_t a = 2 * (int64_t)I - 255, b = 2 * (int64_t)Q - 255;
+    uint64_t x = 32400u * (uint64_t)(a * a + b * b);
+    uint64_t r = (uint64_t)sqrt((double)x);
+    while (r * r > x) r--;
+    while ((r + 1) * (r + 1) <= x) r++;
+    return (int32_t)((r + 1) >> 1);
+}
+
+/* gate != 0: envelope branch for windows with p <= 0.01 (no smoothing there, as in the binary); *cls = 1 for those */
+void ob_preprocess_gate_u8(const uint8_t *iq, size_t n, int window, int gate, float *out, ob_stats *st_out, int *cls)
+{
+    int env = gate && ob_envelope_class(ob_power_sum_u8(iq, n), n);
+    if (cls) *cls = env;
+    if (!env) {
+        ob_preprocess_smooth_u8(iq, n, window, out, st_out);
+        return;
+    }
+    ob_stats st;
+    int32_t *code = (int32_t *)malloc((n ? n : 1) * sizeof(int32_t));
+    for (size_t i = 0; i < n; i++) code[i] = ob_envelope_code(iq[2 * i], iq[2 * i + 1]);
+    ob_phase_stats(code, n, &st);
+    for (size_t i = 0; i < n; i++) {
+        float d = (float)code[i] - st.mean;
+        out[i] = d * st.scale;
+    }
+    free(code);
+    if (st_out) *st_out = st;
+}
+
 /* mode B preprocessing: code -> (float(code) - mean) * scale, f32 sub then f32 mul */
 void ob_preprocess_u8(const uint8_t *iq, size_t n, float *out, ob_stats *st_out)
 {

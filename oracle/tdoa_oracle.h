@@ -139,6 +139,11 @@ void   ob_preprocess_u8(const uint8_t *iq, size_t n, float *out, ob_stats *st);
 /* optional smoothing of the codes (tdoa_params.k1_smooth; applyLowPassFilter, processor.go:270-296, in integers) */
 void   ob_smooth_codes(const int32_t *code, size_t n, int window, int32_t *out);
 void   ob_preprocess_smooth_u8(const uint8_t *iq, size_t n, int window, float *out, ob_stats *st);
+/* optional power gate of the prebuilt binary (tdoa_params.k1_gate): envelope branch for mean power <= 0.01 */
+uint64_t ob_power_sum_u8(const uint8_t *iq, size_t n);
+int    ob_envelope_class(uint64_t power_sum, size_t n);
+int32_t ob_envelope_code(unsigned I, unsigned Q);
+void   ob_preprocess_gate_u8(const uint8_t *iq, size_t n, int window, int gate, float *out, ob_stats *st, int *cls);
 /* c[d] = sum_i t[i]*s[i+d] (f64, zero outside), lags -(max_lag-1)..max_lag-1,
  * out[d + max_lag - 1]; scaled by 1/sqrt(nt). */
 void   ob_xcorr_all_lags(const float *t, size_t nt, const float *s, size_t ns,

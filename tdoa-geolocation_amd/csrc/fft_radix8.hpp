@@ -374,6 +374,148 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_
 }
 
 // ---------------------------------------------------------------------------
+// Three stations, three pairs (the reference's deployment): forward row pass AND pair step in one kernel, every station
+// row transformed ONCE.  k_pair_rows_fused_r8 above transforms a station's row pair once per pair the station is in
+// (9 two-row transforms per window and row pair for 3 pairs) and loses to its own VALU issue time; here a workgroup
+// takes the row pair (a, b = N2 - a) of all three stations of a window: 3 forward + 3 inverse two-row transforms, the
+// same arithmetic as k_fwd_row4096 + k_inv_row_pair4096 together, but T is read once (3 x 64 KB) and only V is written
+// (3 x 64 KB): 48 Nc bytes per window against 120 Nc for the two kernels.
+// Six rows of spectra do not fit two 512-thread workgroups per CU, so ONE workgroup of 1024 threads = two teams of 512
+// (team = wave-uniform), four LDS images (128 KB), 128 VGPRs:
+//   F1  team 0: forward rows of station 0        | team 1: forward rows of station 1
+//   Q1  team 0: loads the rows of station 2      | team 1: K3 for the pair (0, 1) (station 0 through team 0's images)
+//   F2  team 0: forward rows of station 2        | team 1: inverse rows of (0, 1) -> V
+//   Q2  team 0: K3 for (0, 2)                    | team 1: K3 for (1, 2)
+//   F3  team 0: inverse rows of (0, 2) -> V      | team 1: inverse rows of (1, 2) -> V
+// Every transform is the same forward code for both teams (one s_barrier stream): an inverse transform is run as
+// conj(forward(conj(.))) in F2, where the two teams go opposite ways.
+// quads[blockIdx.y] must have the three-station pattern (sw_tb == sw_sc, pw[2] < 0, the other three wanted); the host
+// checks.  grid (N2/2 - 1, n_quads), 1024 threads, dynamic LDS 128 KB.  Rows 0 and N2/2 keep the two-kernel form.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void inv_rows_twiddle_store(float2 (&va)[8], float2 (&vb)[8], const int t, const int a, const int b,
+                                                       float2 *out, const FftPlan &pl)
+{
+    // V[k2][n1] = y[n1] * W_Nc^(-n1 k2), n1 = t + 512 k
+    const float inv2 = 2.0f / (float)pl.Nc;
+    const long long e0 = ((long long)t * a) & (pl.Nc - 1), e1 = ((long long)512 * a) & (pl.Nc - 1);
+    mul_base_step8(va, unit_root((float)e0, inv2, true), unit_root((float)e1, inv2, true));
+    const long long f0 = ((long long)t * b) & (pl.Nc - 1), f1 = ((long long)512 * b) & (pl.Nc - 1);
+    mul_base_step8(vb, unit_root((float)f0, inv2, true), unit_root((float)f1, inv2, true));
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        out[(size_t)a * 4096 + t + 512 * k] = va[oreg8(k)];
+        out[(size_t)b * 4096 + t + 512 * k] = vb[oreg8(k)];
+    }
+}
+
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_PLAIN_DS_OPS)) void k_rows_tri_fused(const QuadDesc *quads, const float2 *T, float2 *V, FftPlan pl)
+{
+    extern __shared__ float2 lds[];   // 4 * kRow8Lds
+    const int N2 = pl.N2;
+    const int team = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 9));
+    const int t = threadIdx.x & 511;
+    const int a = blockIdx.x + 1, b = N2 - a;
+    const QuadDesc qd = quads[blockIdx.y];
+    float2 *la = lds + (size_t)team * 2 * kRow8Lds, *lb = la + kRow8Lds;            // this team's images
+    float2 *oa = lds + (size_t)(1 - team) * 2 * kRow8Lds;                           // the other team's first image
+    const int rb = swz(t), mb = swz(4095 - t);
+    const float2 w2 = unit_root((float)(t & 7), 2.0f / 64.0f, false), w3 = unit_root((float)(t & 63), 2.0f / 512.0f, false),
+                 w4 = unit_root((float)t, 2.0f / 4096.0f, false);
+    const float invNc = 1.0f / (float)pl.Nc;
+    const long long k0 = (long long)t * N2 + a;                                     // w(k) = W_N^k, k = (t + 512 r) N2 + a
+    const float2 st = make_float2(0.92387953251128674f, -0.38268343236508977f);     // e^{-2 pi i/16}
+
+    // F1: forward rows of station 0 (team 0) / station 1 (team 1)
+    float2 xa[8], xb[8];
+    {
+        const float2 *Ts = T + (size_t)(team ? qd.sw_tb : qd.sw_ta) * pl.Nc;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            xa[r] = Ts[(size_t)a * 4096 + t + 512 * r];
+            xb[r] = Ts[(size_t)b * 4096 + t + 512 * r];
+        }
+    }
+    fft8<false>(xa);
+    fft8<false>(xb);
+    rows2_r8_finish_w<false>(xa, xb, la, lb, t, t, t, opaque(w2), opaque(w3), opaque(w4));   // Z[a][t + 512 k] in xa[oreg8(k)], Z[b][.] in xb
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; k++) {          // both rows in natural order: team 1 needs row a of station 0 and the mirrored rows b
+        la[rb + 512 * k] = xa[oreg8(k)];
+        lb[rb + 512 * k] = xb[oreg8(k)];
+    }
+    __syncthreads();
+    // Q1: team 1 forms conj(Q) of the pair (0, 1); team 0 fetches station 2
+    float2 va[8], vb[8];
+    if (team) {
+        float2 w = unit_root((float)k0, invNc, false);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            float2 q, qm;
+            pair_q(oa[rb + 512 * r], oa[kRow8Lds + mb - 512 * r], xa[oreg8(r)], lb[mb - 512 * r], w, q, qm);
+            va[r] = cconj(q);              // Q[a][t + 512 r]:                 row a, stage-1 item t, input r
+            vb[7 - r] = cconj(qm);         // Q[b][(511 - t) + 512 (7 - r)]:   row b, stage-1 item 511 - t, input 7 - r
+            w = r == 3 ? unit_root((float)(k0 + (long long)4 * 512 * N2), invNc, false) : cmul(w, st);
+        }
+    } else {
+        const float2 *Ts = T + (size_t)qd.sw_sd * pl.Nc;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            va[r] = Ts[(size_t)a * 4096 + t + 512 * r];
+            vb[r] = Ts[(size_t)b * 4096 + t + 512 * r];
+        }
+    }
+    __syncthreads();      // team 1 has read team 0's images
+    // F2: the same forward code: station 2 (team 0), conj(Q01) (team 1: conj(forward(conj Q)) = inverse(Q))
+    fft8<false>(va);
+    fft8<false>(vb);
+    rows2_r8_finish_w<false>(va, vb, la, lb, t, t, team ? 511 - t : t, opaque(w2), opaque(w3), opaque(w4));
+    if (team) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            va[k] = cconj(va[k]);
+            vb[k] = cconj(vb[k]);
+        }
+        inv_rows_twiddle_store(va, vb, t, a, b, V + (size_t)qd.pw[0] * pl.Nc, pl);
+    }
+    __syncthreads();      // the images are free again
+    // S2: lb0 = Z0[b], la0 = Z2[b], la1 = Z2[a] (team 0 writes all three), lb1 = Z1[b]
+    if (team) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) lb[rb + 512 * k] = xb[oreg8(k)];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            lb[rb + 512 * k] = xb[oreg8(k)];
+            la[rb + 512 * k] = vb[oreg8(k)];
+            oa[rb + 512 * k] = va[oreg8(k)];
+        }
+    }
+    __syncthreads();
+    // Q2: team 0 the pair (0, 2), team 1 the pair (1, 2); the signal is station 2 for both
+    float2 qa[8], qb[8];
+    {
+        const float2 *z2b = team ? oa : la;        // Z2[b] lives in la0
+        float2 w = unit_root((float)k0, invNc, false);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const float2 z2a = team ? la[rb + 512 * r] : va[oreg8(r)];
+            float2 q, qm;
+            pair_q(xa[oreg8(r)], lb[mb - 512 * r], z2a, z2b[mb - 512 * r], w, q, qm);
+            qa[r] = q;
+            qb[7 - r] = qm;
+            w = r == 3 ? unit_root((float)(k0 + (long long)4 * 512 * N2), invNc, false) : cmul(w, st);
+        }
+    }
+    __syncthreads();
+    // F3: two inverse rows per team
+    fft8<true>(qa);
+    fft8<true>(qb);
+    rows2_r8_finish<true>(qa, qb, la, lb, t, t, 511 - t);
+    inv_rows_twiddle_store(qa, qb, t, a, b, V + (size_t)qd.pw[team ? 3 : 1] * pl.Nc, pl);
+}
+
+// ---------------------------------------------------------------------------
 // Segment form (search ranges up to 1024 lags): the whole correlation stays in LDS and registers.
 // The deployed geometry bounds |TDOA| by 114 samples (PROJECT_NOTES.md:29-32); a caller who searches a few hundred
 // lags instead of the reference's 20 000 (processor.go:633) does not need a 2^21-point transform.  Overlap-save

@@ -92,7 +92,7 @@ bool read_file(const std::string &path, std::vector<uint8_t> *out, std::string *
 
 void usage(const char *argv0)
 {
-    std::printf("Usage: %s [--fm] [--fine] [--gate SAMPLES] [--device N] [--window SAMPLES] [--max-lag SAMPLES] [--k1-smooth SAMPLES] "
+    std::printf("Usage: %s [--fm] [--fine] [--gate SAMPLES] [--device N] [--window SAMPLES] [--max-lag SAMPLES] [--k1-smooth SAMPLES] [--k1-gate] "
                 "<ref_freq_hz> <target_freq_hz> <csv_file> <dat_file1> [dat_file2] [dat_file3] ...\n", argv0);
     std::printf("Example: %s 162400000 101700000 lat-lon-table.csv kx0u-data.dat n3pay-data.dat kf0mtl-data.dat\n", argv0);
 }
@@ -122,6 +122,7 @@ int main(int argc, char **argv)
         else if (a == "--window" && i + 1 < argc) prm.window_len = std::atoll(argv[++i]);
         else if (a == "--max-lag" && i + 1 < argc) prm.max_lag = std::atoi(argv[++i]);
         else if (a == "--k1-smooth" && i + 1 < argc) prm.k1_smooth = std::atoi(argv[++i]);   // the prebuilt binary's chain uses 10
+        else if (a == "--k1-gate") prm.k1_gate = 1;                                          // its power gate (envelope branch)
         else pos.push_back(a);
     }
     if (pos.size() < 4) {                                     // processor.go:1048-1052

@@ -153,15 +153,118 @@ __device__ __forceinline__ void k1_unpack8(uint4 q, unsigned int (&s)[9])
 
 __device__ __forceinline__ void k1_load8(gptr16 p, int i0, unsigned int (&s)[9]) { k1_unpack8(k1_fetch8(p, i0), s); }
 
+// ---- optional power gate (tdoa_params.k1_gate; the prebuilt binary's preprocessSignal) -----
+// mean power p = mean |x|^2 of x = (b - 127.5)/127.5 is M / (65025 len) with the exact integer
+// M = sum (2I-255)^2 + (2Q-255)^2; windows with p <= 0.01 take the envelope |x| instead of the discriminator.
+// Envelope code = round-half-up(90 sqrt(m)) = (isqrt(32400 m) + 1) >> 1, m <= 130050 (32400 m < 2^32, code <= 32456):
+// an int16 like the phase codes, held negated like them, same statistics and normalisation downstream.
+__device__ __forceinline__ bool k1_envelope_class(unsigned long long power_sum, int len)
+{
+    return 100ull * power_sum <= 65025ull * (unsigned long long)len;
+}
+
+__device__ __forceinline__ unsigned int k1_sample_power(unsigned int s)     // s = I | Q << 8
+{
+    const int a = 2 * (int)(s & 0xffu) - 255, b = 2 * (int)(s >> 8) - 255;
+    return (unsigned int)(a * a + b * b);
+}
+
+__device__ __forceinline__ int k1_envelope_code(unsigned int s)
+{
+    const unsigned int x = 32400u * k1_sample_power(s);
+    unsigned int r = (unsigned int)__builtin_sqrtf((float)x);                 // within a few units of isqrt(x)
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+        if ((unsigned long long)r * r > x) r--;
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+        if ((unsigned long long)(r + 1) * (r + 1) <= x) r++;
+    return (int)((r + 1) >> 1);
+}
+
+// M of every station-window.  grid (ceil(maxlen / 2048), n_sw), 256 threads; power zeroed before the launch.
+__global__ __launch_bounds__(256) void k_k1_power(const SWDesc *sw, unsigned long long *power)
+{
+    __shared__ unsigned long long red[4];
+    const SWDesc d = sw[blockIdx.y];
+    const gptr16 p = k1_global(d.base);
+    const int i0 = ((int)blockIdx.x * 256 + (int)threadIdx.x) * 8;
+    unsigned long long m = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+        if (i0 + k < d.len) m += k1_sample_power(p[i0 + k]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m += __shfl_xor(m, off, kWave);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long t = red[0] + red[1] + red[2] + red[3];
+        if (t) atomicAdd(&power[blockIdx.y], t);
+    }
+}
+
+// envelope codes + window sums of the windows in the envelope class (k_fm_demod skips those).  Same grid.
+__global__ __launch_bounds__(256) void k_k1_envelope(const SWDesc *sw, const unsigned long long *power, short *codes,
+                                                     long long code_stride, StatsPartial *acc)
+{
+    __shared__ long long red1[4];
+    __shared__ unsigned long long red2[4];
+    const SWDesc d = sw[blockIdx.y];
+    if (!k1_envelope_class(power[blockIdx.y], d.len)) return;
+    const gptr16 p = k1_global(d.base);
+    short *dst = codes + (size_t)blockIdx.y * code_stride;
+    const int i0 = ((int)blockIdx.x * 256 + (int)threadIdx.x) * 8;
+    long long s1 = 0;
+    unsigned long long s2 = 0;
+    if (i0 < d.len) {
+        int c[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            int e = 0;
+            if (i0 + k < d.len) {
+                e = k1_envelope_code(p[i0 + k]);
+                s1 += e;
+                s2 += (unsigned long long)((long long)e * e);
+            }
+            c[k] = -e;                                                   // stored = -code
+        }
+        uint4 wv;
+        wv.x = (unsigned int)(c[0] & 0xffff) | ((unsigned int)c[1] << 16);
+        wv.y = (unsigned int)(c[2] & 0xffff) | ((unsigned int)c[3] << 16);
+        wv.z = (unsigned int)(c[4] & 0xffff) | ((unsigned int)c[5] << 16);
+        wv.w = (unsigned int)(c[6] & 0xffff) | ((unsigned int)c[7] << 16);
+        *reinterpret_cast<uint4 *>(dst + i0) = wv;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        s1 += __shfl_xor(s1, off, kWave);
+        s2 += __shfl_xor(s2, off, kWave);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red1[threadIdx.x >> 6] = s1;
+        red2[threadIdx.x >> 6] = s2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const long long t1 = red1[0] + red1[1] + red1[2] + red1[3];
+        const unsigned long long t2 = red2[0] + red2[1] + red2[2] + red2[3];
+        if (t1 | (long long)t2) {
+            atomicAdd(reinterpret_cast<unsigned long long *>(&acc[blockIdx.y].s1), (unsigned long long)t1);
+            atomicAdd(&acc[blockIdx.y].s2, t2);
+        }
+    }
+}
+
 // K1 demodulation pass: persistent 1024-thread workgroups (one per CU) keep the 128 KB angle
 // table in LDS; after loading it the 16 waves of a workgroup run independently, each taking
 // (station-window, 1024-sample piece) work items round-robin.  Window sums go straight into
 // per-window integer accumulators with atomic adds: exact, hence independent of arrival order.
 // codes: [n_sw][code_stride] int16, code_stride a multiple of 8 (rows 16-byte aligned);
-// acc: [n_sw] {s1, s2}, zeroed before the launch.
+// acc: [n_sw] {s1, s2}, zeroed before the launch.  power: nullptr, or the windows' power sums (optional gate: windows
+// in the envelope class are skipped here).
 __global__ __launch_bounds__(kDemodThreads) void k_fm_demod(const SWDesc *sw, int n_sw, int pieces_per_window,
                                                             const short *table, short *codes, long long code_stride,
-                                                            StatsPartial *acc)
+                                                            StatsPartial *acc, const unsigned long long *power)
 {
     extern __shared__ short lut[];               // 65536 angle codes
     {
@@ -183,6 +286,7 @@ __global__ __launch_bounds__(kDemodThreads) void k_fm_demod(const SWDesc *sw, in
         const int w = item % n_sw, run = item / n_sw;
         const SWDesc d = sw[w];
         const int len = d.len;
+        if (power && k1_envelope_class(power[w], len)) continue;      // power gate on: k_k1_envelope has this window
         const gptr16 p = k1_global(d.base);
         short *out = codes + (size_t)w * code_stride;
         long long s1 = 0;
@@ -326,12 +430,14 @@ __global__ __launch_bounds__(kDemodThreads) void k_fm_demod(const SWDesc *sw, in
 // afterwards with THEIR mean and variance is the binary's order up to the edge samples' share of the mean (O(h / L)).
 // A thread makes 8 consecutive outputs; the window sums of the smoothed codes go to `acc` like k_fm_demod's.
 // grid (ceil(maxlen / 2048), n_sw), 256 threads.
-__global__ __launch_bounds__(256) void k_k1_smooth(const SWDesc *sw, const short *in, short *out, long long code_stride, int h,
-                                                   StatsPartial *acc)
+__global__ __launch_bounds__(256) void k_k1_smooth(const SWDesc *sw, const short *in, short *out, long long code_stride, int h0,
+                                                   StatsPartial *acc, const unsigned long long *power)
 {
     __shared__ long long red1[4];
     __shared__ unsigned long long red2[4];
     const int len = sw[blockIdx.y].len;
+    // power gate on: the binary smooths its discriminator output only; an envelope window is copied (h = 0)
+    const int h = power && k1_envelope_class(power[blockIdx.y], len) ? 0 : h0;
     const short *src = in + (size_t)blockIdx.y * code_stride;
     short *dst = out + (size_t)blockIdx.y * code_stride;
     const int i0 = ((int)blockIdx.x * 256 + (int)threadIdx.x) * 8;

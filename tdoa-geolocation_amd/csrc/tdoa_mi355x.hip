@@ -61,7 +61,7 @@ struct tdoa_ctx {
     std::vector<Capture> caps;
 
     DevBuf k1_table;                        // 65536 int16 angle codes (k_k1_build_table)
-    DevBuf sw_desc, pw_desc, partials, stats, codes, codes_lp, tz, v, keys, scales, peaks, scratch_a, scratch_b, lagdump;
+    DevBuf sw_desc, pw_desc, partials, stats, codes, codes_lp, k1_power, tz, v, keys, scales, peaks, scratch_a, scratch_b, lagdump;
     DevBuf ex_a, ex_b, ex_c, ex_d, ex_part;
 
     bool profiling = false;
@@ -81,6 +81,7 @@ struct tdoa_ctx {
     bool fused_rows = false;                // forward row pass inside the pair kernel when P <= S (TDOA_FUSED_ROWS=1 / tdoa_debug_flags)
     bool segment_form = true;               // TDOA_NO_SEGMENT_FORM=1: no LDS-resident overlap-save form for short searches
     bool segment_quads = true;              // TDOA_NO_SEGMENT_QUADS=1: segment form one pair-window at a time (no shared station transforms)
+    bool tri_rows = false;                  // TDOA_TRI_ROWS=1: three stations / three pairs through k_rows_tri_fused (measured slower: 2.59 vs 2.16 ms)
     bool xcd_rows = true;                   // TDOA_NO_XCD_ROWS=1: plain 2-D grid of the pair kernel even with more pairs than stations
     bool pair_r8 = false;                   // TDOA_PAIR_R8=1: the 512-thread / 8-value pair kernel (measured equal on cfg2, 5 % slower on cfg4)
     uint64_t alloc_gen = 0;                 // bumped whenever a workspace buffer moves
@@ -236,6 +237,43 @@ void prof_collect(tdoa_ctx *ctx)
     ctx->recs.clear();
 }
 
+// K1 for n_sw station-windows: capture bytes -> 16-bit codes + exact window statistics; every buffer must have been
+// reserved (no allocation here: the caller may be capturing a graph).  Returns the code array downstream reads.
+// Optional steps (tdoa_params): k1_gate -- the prebuilt binary's power gate (windows of mean power <= 0.01 get envelope
+// codes instead of phase codes); k1_smooth -- its moving average on the discriminator output.
+short *launch_k1(tdoa_ctx *ctx, hipStream_t st, const SWDesc *d_sw, int n_sw, int maxlen, int pieces, long long code_stride)
+{
+    auto *partials = static_cast<StatsPartial *>(ctx->partials.p);
+    auto *stats = static_cast<FmStats *>(ctx->stats.p);
+    auto *codes = static_cast<short *>(ctx->codes.p);
+    static_assert(sizeof(StatsPartial) == 16, "two 64-bit words per station-window");
+    const dim3 per_chunk((unsigned)((maxlen + 2047) / 2048), n_sw);
+    unsigned long long *power = nullptr;
+    if (ctx->prm.k1_gate) {
+        power = static_cast<unsigned long long *>(ctx->k1_power.p);
+        hipLaunchKernelGGL(k_zero_u64, dim3((unsigned)(((size_t)n_sw + 255) / 256)), dim3(256), 0, st, power, (size_t)n_sw);
+        hipLaunchKernelGGL(k_k1_power, per_chunk, dim3(256), 0, st, d_sw, power);
+    }
+    hipLaunchKernelGGL(k_zero_u64, dim3((unsigned)((2 * (size_t)n_sw + 255) / 256)), dim3(256), 0, st,
+                       reinterpret_cast<unsigned long long *>(partials), 2 * (size_t)n_sw);
+    const long long items = (long long)((pieces + kDemodItem - 1) / kDemodItem) * n_sw;      // workgroup items
+    const int blocks = (int)std::max<long long>(1, std::min<long long>(items, ctx->n_cu));
+    hipLaunchKernelGGL(k_fm_demod, dim3(blocks), dim3(kDemodThreads), 65536 * sizeof(short), st, d_sw, n_sw, pieces,
+                       static_cast<const short *>(ctx->k1_table.p), codes, code_stride, partials, power);
+    if (power) hipLaunchKernelGGL(k_k1_envelope, per_chunk, dim3(256), 0, st, d_sw, power, codes, code_stride, partials);
+    if (ctx->prm.k1_smooth > 1) {
+        // statistics of the smoothed codes replace those of the raw ones
+        auto *lp = static_cast<short *>(ctx->codes_lp.p);
+        hipLaunchKernelGGL(k_zero_u64, dim3((unsigned)((2 * (size_t)n_sw + 255) / 256)), dim3(256), 0, st,
+                           reinterpret_cast<unsigned long long *>(partials), 2 * (size_t)n_sw);
+        hipLaunchKernelGGL(k_k1_smooth, per_chunk, dim3(256), 0, st, d_sw, codes, lp, code_stride, ctx->prm.k1_smooth / 2,
+                           partials, power);
+        codes = lp;
+    }
+    hipLaunchKernelGGL(k_fm_stats_final, dim3((n_sw + 63) / 64), dim3(64), 0, st, d_sw, partials, stats, n_sw);
+    return codes;
+}
+
 // make every workspace buffer of run_fm_batch large enough (no allocation may happen while a
 // stream capture is open)
 int reserve_fm_batch(tdoa_ctx *ctx, int n_sw, int maxlen, int n_pw, const FftPlan &pl, int lag_lo, int lag_hi)
@@ -246,6 +284,7 @@ int reserve_fm_batch(tdoa_ctx *ctx, int n_sw, int maxlen, int n_pw, const FftPla
     if ((rc = ensure(ctx, ctx->stats, sizeof(FmStats) * (size_t)n_sw))) return rc;
     if ((rc = ensure(ctx, ctx->codes, sizeof(short) * (size_t)code_stride * n_sw))) return rc;
     if (ctx->prm.k1_smooth > 1 && (rc = ensure(ctx, ctx->codes_lp, sizeof(short) * (size_t)code_stride * n_sw))) return rc;
+    if (ctx->prm.k1_gate && (rc = ensure(ctx, ctx->k1_power, sizeof(unsigned long long) * (size_t)n_sw))) return rc;
     if ((rc = ensure(ctx, ctx->tz, sizeof(float2) * (size_t)pl.Nc * n_sw))) return rc;
     (void)lag_lo;
     (void)lag_hi;
@@ -258,7 +297,7 @@ int reserve_fm_batch(tdoa_ctx *ctx, int n_sw, int maxlen, int n_pw, const FftPla
 int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const PWDesc *d_pw, int n_pw,
                  unsigned long long *d_keys, const FftPlan &pl, int lag_lo, int lag_hi, float *lag_dump,
                  float dump_scale, double sum_len, float *fine_raw = nullptr, int pairs_per_window = 0,
-                 const QuadDesc *d_quads = nullptr, int n_quads = 0)
+                 const QuadDesc *d_quads = nullptr, int n_quads = 0, bool tri_quads = false)
 {
     int rc;
     const int pieces = std::max(1, (maxlen + kDemodPiece - 1) / kDemodPiece);
@@ -268,7 +307,6 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
     if ((rc = ensure(ctx, ctx->codes, sizeof(short) * (size_t)code_stride * n_sw))) return rc;
     if ((rc = ensure(ctx, ctx->tz, sizeof(float2) * (size_t)pl.Nc * n_sw))) return rc;
     if ((rc = reserve_fm_batch(ctx, n_sw, maxlen, n_pw, pl, lag_lo, lag_hi))) return rc;
-    auto *partials = static_cast<StatsPartial *>(ctx->partials.p);
     auto *stats = static_cast<FmStats *>(ctx->stats.p);
     auto *codes = static_cast<short *>(ctx->codes.p);
     auto *tz = static_cast<float2 *>(ctx->tz.p);
@@ -331,23 +369,7 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
     {
         // K1: capture bytes -> 16-bit phase codes + exact window statistics
         ProfScope ps(ctx, TDOA_K_STATS, 4.0 * sum_len);
-        static_assert(sizeof(StatsPartial) == 16, "two 64-bit words per station-window");
-        hipLaunchKernelGGL(k_zero_u64, dim3((unsigned)((2 * (size_t)n_sw + 255) / 256)), dim3(256), 0, st,
-                           reinterpret_cast<unsigned long long *>(partials), 2 * (size_t)n_sw);
-        const long long items = (long long)((pieces + kDemodItem - 1) / kDemodItem) * n_sw;      // workgroup items
-        const int blocks = (int)std::max<long long>(1, std::min<long long>(items, ctx->n_cu));
-        hipLaunchKernelGGL(k_fm_demod, dim3(blocks), dim3(kDemodThreads), 65536 * sizeof(short), st, d_sw, n_sw, pieces,
-                           static_cast<const short *>(ctx->k1_table.p), codes, code_stride, partials);
-        if (ctx->prm.k1_smooth > 1) {
-            // optional: the prebuilt binary's moving average on the discriminator output; statistics of the smoothed codes
-            auto *lp = static_cast<short *>(ctx->codes_lp.p);
-            hipLaunchKernelGGL(k_zero_u64, dim3((unsigned)((2 * (size_t)n_sw + 255) / 256)), dim3(256), 0, st,
-                               reinterpret_cast<unsigned long long *>(partials), 2 * (size_t)n_sw);
-            hipLaunchKernelGGL(k_k1_smooth, dim3((unsigned)((maxlen + 2047) / 2048), n_sw), dim3(256), 0, st, d_sw, codes, lp,
-                               code_stride, ctx->prm.k1_smooth / 2, partials);
-            codes = lp;
-        }
-        hipLaunchKernelGGL(k_fm_stats_final, dim3((n_sw + 63) / 64), dim3(64), 0, st, d_sw, partials, stats, n_sw);
+        codes = launch_k1(ctx, st, d_sw, n_sw, maxlen, pieces, code_stride);
     }
     const size_t lds_col = sizeof(float2) * 2 * (size_t)pl.N2 * pl.C;
     const size_t lds_row = sizeof(float2) * 2 * (size_t)pl.N1;
@@ -392,7 +414,11 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
     }
     // forward row pass fused into the pair kernel: pays when a station's rows are re-transformed at most as often as
     // they would be written and read back (no more pair-windows than station-windows: 3 stations, or a single pair)
-    const bool fused_rows = row16 && ctx->fused_rows && n_pw > 0 && n_pw <= n_sw;
+    // three stations / three pairs per window (every quad of the batch has that pattern): all six row transforms of a
+    // window's row pair in one kernel, k_rows_tri_fused (general form only)
+    const bool tri_rows = row16 && ctx->tri_rows && tri_quads && d_quads && n_quads > 0 && 3 * n_quads == n_pw && !seg_chunks &&
+                          fk == 0 && pl.N2 > 2;
+    const bool fused_rows = tri_rows || (row16 && ctx->fused_rows && n_pw > 0 && n_pw <= n_sw);
     // XCD-aware 1-D grid of the pair kernel when every window of the group carries the same `pairs_per_window` > S pairs
     // (window-major sharding with more pairs than stations): see k_inv_row_pair4096
     int xcd_pairs = 0;
@@ -447,7 +473,10 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
             if (fk) {
 #define TDOA_PAIR_ROWS(FK)                                                                                           \
     do {                                                                                                             \
-        if (pl.N2 > 2 && fused_rows)                                                                                 \
+        if (tri_rows)                                                                                                \
+            hipLaunchKernelGGL(k_rows_tri_fused, dim3(pl.N2 / 2 - 1, n_quads), dim3(1024),                            \
+                               sizeof(float2) * 4 * kRow8Lds, st, d_quads, tz, v, pl);                               \
+        else if (pl.N2 > 2 && fused_rows)                                                                            \
             hipLaunchKernelGGL((k_pair_rows_fused_r8<FK>), dim3(pl.N2 / 2 - 1, n_pw), dim3(512),                     \
                                sizeof(float2) * 2 * kRow8Lds, st, d_pw, tz, v, pl);                                  \
         else if (pl.N2 > 2 && ctx->pair_r8)                                                                          \
@@ -555,6 +584,10 @@ int allow_big_lds(tdoa_ctx *ctx)
     if ((rc = set_lds(ctx, k_xcorr_segments<1>, all))) return rc;
     if ((rc = set_lds(ctx, k_xcorr_segments<2>, all))) return rc;
     if ((rc = set_lds(ctx, k_xcorr_segments<4>, all))) return rc;
+    if ((rc = set_lds(ctx, k_xcorr_segments_quad<1>, all))) return rc;
+    if ((rc = set_lds(ctx, k_xcorr_segments_quad<2>, all))) return rc;
+    if ((rc = set_lds(ctx, k_xcorr_segments_quad<4>, all))) return rc;
+    if ((rc = set_lds(ctx, k_rows_tri_fused, all))) return rc;
     return TDOA_OK;
 }
 
@@ -674,7 +707,7 @@ void tdoa_default_params(tdoa_params *p)
     p->device = 0;
     p->windows_per_batch = 0;
     p->k1_smooth = 0;
-    p->reserved = 0;
+    p->k1_gate = 0;
 }
 
 int tdoa_abi_version(void) { return TDOA_ABI_VERSION; }
@@ -768,6 +801,7 @@ int tdoa_create(const tdoa_params *p, tdoa_ctx **out)
     if (const char *e = std::getenv("TDOA_NO_FUSED_ROWS")) ctx->fused_rows = !(e[0] == '1');
     if (const char *e = std::getenv("TDOA_NO_SEGMENT_FORM")) ctx->segment_form = !(e[0] == '1');
     if (const char *e = std::getenv("TDOA_NO_SEGMENT_QUADS")) ctx->segment_quads = !(e[0] == '1');
+    if (const char *e = std::getenv("TDOA_TRI_ROWS")) ctx->tri_rows = e[0] == '1';
     if (const char *e = std::getenv("TDOA_NO_XCD_ROWS")) ctx->xcd_rows = !(e[0] == '1');
     if (const char *e = std::getenv("TDOA_PAIR_R8")) ctx->pair_r8 = e[0] == '1';
     *out = ctx;
@@ -783,7 +817,7 @@ void tdoa_destroy(tdoa_ctx *ctx)
     if (ctx->graph_exec) (void)hipGraphExecDestroy(ctx->graph_exec);
     if (ctx->graph) (void)hipGraphDestroy(ctx->graph);
     tdoa_capture_clear(ctx);
-    DevBuf *bufs[] = {&ctx->k1_table, &ctx->sw_desc, &ctx->pw_desc, &ctx->partials, &ctx->stats, &ctx->codes, &ctx->codes_lp, &ctx->tz, &ctx->v, &ctx->keys,
+    DevBuf *bufs[] = {&ctx->k1_table, &ctx->sw_desc, &ctx->pw_desc, &ctx->partials, &ctx->stats, &ctx->codes, &ctx->codes_lp, &ctx->k1_power, &ctx->tz, &ctx->v, &ctx->keys,
                       &ctx->scales, &ctx->peaks, &ctx->scratch_a, &ctx->scratch_b, &ctx->lagdump,
                       &ctx->ex_a, &ctx->ex_b, &ctx->ex_c, &ctx->ex_d, &ctx->ex_part,
                       &ctx->g_sw_desc, &ctx->g_pw_desc, &ctx->g_quad_desc, &ctx->g_scales, &ctx->g_keys, &ctx->fine_raw, &ctx->fine, &ctx->qual};
@@ -1135,6 +1169,17 @@ static int process_impl(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host,
         }
         q_off[wi + 1] = quads.size();
     }
+    // batches whose quads all have the three-station pattern (a, b | b, c) with the three pairs wanted
+    std::vector<char> tri_batch((mine.size() + per_batch - 1) / (size_t)per_batch + 1, 0);
+    for (size_t w0 = 0; w0 < mine.size(); w0 += per_batch) {
+        const size_t w1 = std::min(mine.size(), w0 + (size_t)per_batch);
+        bool tri = q_off[w1] > q_off[w0];
+        for (size_t qi = q_off[w0]; qi < q_off[w1] && tri; qi++) {
+            const QuadDesc &d = quads[qi];
+            tri = d.sw_tb >= 0 && d.sw_tb == d.sw_sc && d.sw_sd >= 0 && d.pw[0] >= 0 && d.pw[1] >= 0 && d.pw[2] < 0 && d.pw[3] >= 0;
+        }
+        tri_batch[w0 / (size_t)per_batch] = tri ? 1 : 0;
+    }
     const size_t slots = (size_t)W * P;
     hipStream_t st = ctx->stream;
     const int n_first = (int)std::min<size_t>(per_batch, mine.size());
@@ -1159,11 +1204,11 @@ static int process_impl(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host,
 
     // everything the launches depend on: same key => the captured graph can be replayed as is
     std::vector<uint64_t> key = {(uint64_t)S, (uint64_t)rank, (uint64_t)world, (uint64_t)per_batch, (uint64_t)wlen,
-                                 (uint64_t)ctx->prm.max_lag | ((uint64_t)ctx->prm.k1_smooth << 32), (uint64_t)block,
+                                 (uint64_t)ctx->prm.max_lag | ((uint64_t)ctx->prm.k1_smooth << 32) | ((uint64_t)(ctx->prm.k1_gate != 0) << 62), (uint64_t)block,
                                  (uint64_t)ctx->force_generic | ((uint64_t)ctx->short_lag << 1) |
                                      ((uint64_t)ctx->fused_rows << 2) | ((uint64_t)ctx->segment_form << 3) |
                                      ((uint64_t)ctx->xcd_rows << 4) | ((uint64_t)ctx->pair_r8 << 5) |
-                                     ((uint64_t)ctx->segment_quads << 6),
+                                     ((uint64_t)ctx->segment_quads << 6) | ((uint64_t)ctx->tri_rows << 7),
                                  ctx->alloc_gen, (uint64_t)(fine_host != nullptr), 0};
     std::memcpy(&key.back(), &gate, sizeof(double));
     for (auto &c : ctx->caps) {
@@ -1194,7 +1239,7 @@ static int process_impl(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host,
             const int r = run_fm_batch(ctx, d_sw + sw_off[w0], n_sw, (int)wlen, d_pw + pw_off[w0], n_pw, d_keys, pl,
                                        -(ctx->prm.max_lag - 1), ctx->prm.max_lag - 1, nullptr, 1.0f,
                                        (double)wlen * n_sw, fine_raw, pair_major ? 0 : P, d_quads + q_off[w0],
-                                       (int)(q_off[w0 + nw] - q_off[w0]));
+                                       (int)(q_off[w0 + nw] - q_off[w0]), tri_batch[w0 / (size_t)per_batch]);
             if (r) return r;
         }
         if (fine_raw)
@@ -1389,20 +1434,9 @@ int tdoa_fm_preprocess_u8(tdoa_ctx *ctx, const uint8_t *iq, size_t n, float *out
     HIPCHK(ctx, hipMemsetAsync(ctx->partials.p, 0, sizeof(StatsPartial), st));
     HIPCHK(ctx, hipStreamSynchronize(st));
     auto *d_sw = static_cast<SWDesc *>(ctx->sw_desc.p);
-    hipLaunchKernelGGL(k_fm_demod, dim3(std::max(1, std::min((pieces + kDemodItem - 1) / kDemodItem, ctx->n_cu))), dim3(kDemodThreads),
-                       65536 * sizeof(short), st, d_sw, 1, pieces, static_cast<const short *>(ctx->k1_table.p),
-                       static_cast<short *>(ctx->codes.p), code_stride, static_cast<StatsPartial *>(ctx->partials.p));
-    short *codes_used = static_cast<short *>(ctx->codes.p);
-    if (ctx->prm.k1_smooth > 1) {
-        if ((rc = ensure(ctx, ctx->codes_lp, sizeof(short) * (size_t)code_stride))) return rc;
-        HIPCHK(ctx, hipMemsetAsync(ctx->partials.p, 0, sizeof(StatsPartial), st));
-        hipLaunchKernelGGL(k_k1_smooth, dim3((unsigned)((n + 2047) / 2048), 1), dim3(256), 0, st, d_sw, codes_used,
-                           static_cast<short *>(ctx->codes_lp.p), code_stride, ctx->prm.k1_smooth / 2,
-                           static_cast<StatsPartial *>(ctx->partials.p));
-        codes_used = static_cast<short *>(ctx->codes_lp.p);
-    }
-    hipLaunchKernelGGL(k_fm_stats_final, dim3(1), dim3(64), 0, st, d_sw, static_cast<StatsPartial *>(ctx->partials.p),
-                       static_cast<FmStats *>(ctx->stats.p), 1);
+    if (ctx->prm.k1_smooth > 1 && (rc = ensure(ctx, ctx->codes_lp, sizeof(short) * (size_t)code_stride))) return rc;
+    if (ctx->prm.k1_gate && (rc = ensure(ctx, ctx->k1_power, sizeof(unsigned long long)))) return rc;
+    short *codes_used = launch_k1(ctx, st, d_sw, 1, (int)n, pieces, code_stride);
     hipLaunchKernelGGL(k_fm_dump, dim3((unsigned)((n + 255) / 256), 1), dim3(256), 0, st, d_sw,
                        codes_used, static_cast<FmStats *>(ctx->stats.p),
                        static_cast<float *>(ctx->scratch_b.p));
@@ -1452,6 +1486,7 @@ int tdoa_debug_flags(tdoa_ctx *ctx, unsigned flags)
     ctx->segment_form = !(flags & TDOA_DEBUG_NO_SEGMENT_FORM);
     ctx->xcd_rows = !(flags & TDOA_DEBUG_NO_XCD_ROWS);
     ctx->segment_quads = !(flags & TDOA_DEBUG_NO_SEGMENT_QUADS);
+    ctx->tri_rows = (flags & TDOA_DEBUG_TRI_ROWS) != 0;
     ctx->pair_r8 = (flags & TDOA_DEBUG_PAIR_R8) != 0;
     return TDOA_OK;
 }

@@ -129,3 +129,51 @@ def test_optional_k1_smoothing_on_the_gpu(oracle):
     with tdoa_amd.Context(max_lag=ml, window_len=n) as c:                  # k1_smooth = 0: the unsmoothed pipeline
         lag0, corr0 = c.fm_xcorr(a, b, ml)
     assert lag0 == 37 and abs(corr0) < abs(corr)                           # the message is low-pass: smoothing removes noise
+
+
+def test_optional_k1_power_gate_on_the_gpu(oracle):
+    """tdoa_params.k1_gate = 1 (the prebuilt binary's preprocessSignal gate): windows of mean power <= 0.01 carry envelope
+    codes, bit-equal to ob_preprocess_gate_u8; stronger windows are untouched; end to end through tdoa_process against the
+    oracle and the float64 envelope chain; with k1_smooth the envelope windows are not smoothed"""
+    import tdoa_amd
+    n, ml = 300_000, 2000
+    mid_a, mid_b = fp.am_capture(n, 0, 0.07, 5, 1), fp.am_capture(n - 1001, 91, 0.07, 5, 2)
+    strong = oracle.simulate_delayed_fm(n, 0, 4242, 1)
+    with tdoa_amd.Context(max_lag=ml, window_len=n, k1_gate=1) as c:
+        for x, want_cls in ((mid_a, 1), (mid_b, 1), (strong, 0), (mid_a[:2 * 4099], 1), (mid_a[:2 * 7], 1)):
+            got, st = c.fm_preprocess(x)
+            want, ost, cls = oracle.b_preprocess_gate(x)
+            assert cls == want_cls
+            assert (st.s1, st.s2_lo) == (ost.s1, ost.s2_lo)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        lag, corr = c.fm_xcorr(mid_a, mid_b, ml)
+        c.debug_flags(no_short_lag=True)
+        lag_g, corr_g = c.fm_xcorr(mid_a, mid_b, ml)
+    ta, _, _ = oracle.b_preprocess_gate(mid_a)
+    tb, _, _ = oracle.b_preprocess_gate(mid_b)
+    olag, ocorr, _ = oracle.b_xcorr_peak_fft(ta, tb, ml)
+    assert lag == lag_g == olag == 91
+    assert abs(corr - ocorr) <= 1e-5 * abs(ocorr) and abs(corr_g - ocorr) <= 1e-5 * abs(ocorr)
+    flag, fcorr, _ = fp.xcorr_peak_u8(mid_a, mid_b, ml, gate=True)
+    assert lag == flag and abs(corr - fcorr) <= 2e-4 * abs(fcorr)
+    # batched: three stations whose windows fall on both sides of the gate (blocks 1 and 3 moderate, block 2 strong)
+    blk, wl = 140_000, 70_000
+    caps = []
+    for s, d in enumerate((0, 41, -17)):
+        caps.append(np.concatenate([fp.am_capture(blk, 100 + d, 0.06, 7, s), oracle.simulate_delayed_fm(blk, 100 + d, 77, s),
+                                    fp.am_capture(blk, 100 + d, 0.05, 8, s)]))
+    for smooth in (0, 10):
+        with tdoa_amd.Context(max_lag=300, window_len=wl, k1_gate=1, k1_smooth=smooth) as c:
+            peaks = c.process_u8(caps)
+        assert peaks.shape == (6, 3)
+        for wid in range(6):
+            off = (wid // 2) * blk + (wid % 2) * wl
+            pre = [oracle.b_preprocess_gate(cp[2 * off:2 * (off + wl)], window=smooth) for cp in caps]
+            assert all(p[2] == (0 if wid in (2, 3) else 1) for p in pre)
+            for p, (i, j) in enumerate(((0, 1), (0, 2), (1, 2))):
+                olag, ocorr = oracle.b_xcorr_peak(pre[i][0], pre[j][0], 300)
+                assert peaks[wid, p]["lag"] == olag == (0, 41, -17)[j] - (0, 41, -17)[i], (smooth, wid, p)
+                assert abs(peaks[wid, p]["corr"] - ocorr) <= 1e-5 * abs(ocorr)
+    with tdoa_amd.Context(max_lag=ml, window_len=n) as c:                  # k1_gate = 0: the discriminator for every window
+        got, _ = c.fm_preprocess(mid_a)
+        assert np.array_equal(got.view(np.uint32), oracle.b_preprocess(mid_a)[0].view(np.uint32))

@@ -479,3 +479,48 @@ def test_segment_quads_vs_one_pair_at_a_time(oracle, n_st, ml, per_batch):
             olag, ocorr = oracle.b_xcorr_peak(pre[i], pre[j], ml)
             assert quads[wid, p]["lag"] == olag == delays[j] - delays[i], (wid, i, j)
             assert abs(quads[wid, p]["corr"] - ocorr) <= REL_TOL * abs(ocorr)
+
+
+@pytest.mark.parametrize("wl,ml,per_batch", [(70_000, 20000, 0), (300_000, 5000, 1), (70_000, 4096, 4)])
+def test_tri_fused_rows_vs_two_kernel_form(oracle, wl, ml, per_batch):
+    """three stations / three pairs in the general form: k_rows_tri_fused (forward rows of all three stations, K3 and
+    the inverse rows of all three pairs in one 1024-thread workgroup; opt-in) against the separate forward row pass + pair
+    kernel, against the per-pair fused form, and against the f64 oracle; sharded runs fall back where a rank's pairs
+    are not the three-station pattern"""
+    import tdoa_amd
+    blk = 2 * wl
+    delays = [0, 41, -17]
+    caps = [np.concatenate([oracle.simulate_delayed_fm(blk, 100 + d, 310 + k, 10 * s + k) for k in range(3)])
+            for s, d in enumerate(delays)]
+    pairs = [(0, 1), (0, 2), (1, 2)]
+    with tdoa_amd.Context(max_lag=ml, window_len=wl, windows_per_batch=per_batch) as c:
+        for s, cap in enumerate(caps):
+            c.capture_upload(s, cap)
+        c.debug_flags(no_fused_rows=True, tri_rows=True)
+        tri, fine_t = c.process_fine(120.0)
+        c.debug_flags(no_fused_rows=True)
+        two, fine_2 = c.process_fine(120.0)
+        c.debug_flags()
+        fused = c.process()
+        c.debug_flags(no_fused_rows=True, tri_rows=True)
+        for world in (2, 7):
+            merged = np.zeros_like(tri)
+            for r in range(world):
+                part = c.process(rank=r, world=world)
+                own = part["corr"] != 0
+                merged[own] = part[own]
+            assert np.array_equal(merged["lag"], tri["lag"]), world
+            assert np.abs(merged["corr"] - tri["corr"]).max() <= 2e-6 * np.abs(tri["corr"]).max(), world
+    assert tri.shape == (6, 3)
+    scale = np.abs(tri["corr"]).max()
+    for other in (two, fused):
+        assert np.array_equal(other["lag"], tri["lag"])
+        assert np.abs(other["corr"] - tri["corr"]).max() <= 2e-6 * scale
+    assert np.abs(fine_t["frac"] - fine_2["frac"]).max() < 1e-4
+    for wid in (0, 3, 5):
+        off = (wid // 2) * blk + (wid % 2) * wl
+        pre = [oracle.b_preprocess(cp[2 * off:2 * (off + wl)])[0] for cp in caps]
+        for p, (i, j) in enumerate(pairs):
+            olag, ocorr = oracle.b_xcorr_peak(pre[i], pre[j], ml)
+            assert tri[wid, p]["lag"] == olag == delays[j] - delays[i], (wid, i, j)
+            assert abs(tri[wid, p]["corr"] - ocorr) <= REL_TOL * abs(ocorr)

@@ -124,3 +124,42 @@ def test_optional_k1_smoothing_vs_the_binarys_chain(oracle, capsys):
         print("\n  k1_smooth = 10: integer-smoothed codes vs float64 chain in the binary's order")
         for r in rows:
             print("    %-38s lag %6d  corr %12.6f  |dcorr|/|corr| %.2e" % r)
+
+
+def test_optional_k1_power_gate_vs_the_binarys_envelope_branch(oracle, capsys):
+    """tdoa_params.k1_gate = 1: windows of mean power <= 0.01 take envelope -> removeDCBias -> normalizeSignal, as the
+    prebuilt binary's preprocessSignal does.  The integer envelope codes (what the device runs)
+    against sqrt(re^2 + im^2) in float64: same class, same peak lag, corr within 2e-4 (the int16 code resolves |x| to
+    1/90 of half an LSB; at the low end of the class, |x| ~ 4 LSB, that is 1e-3 of the signal per sample, and the rounding
+    is the same function of the bytes at both stations, so it does not average out like noise)."""
+    # the code itself: round-half-up(90 sqrt(m)) for every byte pair, monotone in |x|
+    grid = [(i, q) for i in range(0, 256, 5) for q in range(0, 256, 7)] + [(0, 0), (255, 255), (127, 128), (128, 127)]
+    for i, q in grid:
+        m = (2 * i - 255) ** 2 + (2 * q - 255) ** 2
+        assert oracle.b_envelope_code(i, q) == int(np.floor(90.0 * np.sqrt(np.float64(m)) + 0.5))
+    assert oracle.b_envelope_code(0, 0) == 32456 and oracle.b_envelope_code(127, 128) == 127
+    n, ml = 200_000, 3000
+    rows = []
+    for amp, want_cls in ((0.03, 1), (0.07, 1), (0.09, 1), (0.3, 0)):
+        a, b = fp.am_capture(n, 0, amp, 5, 1), fp.am_capture(n, 91, amp, 5, 2)
+        ta, _, ca = oracle.b_preprocess_gate(a)
+        tb, _, cb = oracle.b_preprocess_gate(b)
+        assert ca == cb == want_cls == int(fp.mean_power(a) <= 0.01), (amp, fp.mean_power(a))
+        olag, ocorr, _ = oracle.b_xcorr_peak_fft(ta, tb, ml)
+        flag, fcorr, _ = fp.xcorr_peak_u8(a, b, ml, gate=True)
+        dev = abs(ocorr - fcorr) / abs(fcorr)
+        rows.append((amp, fp.mean_power(a), want_cls, olag, fcorr, dev))
+        assert olag == flag, amp
+        if want_cls:
+            assert olag == 91, amp               # the envelope carries the common message
+        assert dev < 2e-4, (amp, dev)
+    # gate off, or a strong window: exactly the ungated path
+    strong = oracle.simulate_delayed_fm(50_000, 0, 9, 1)
+    g, _, cls = oracle.b_preprocess_gate(strong)
+    assert cls == 0 and np.array_equal(g, oracle.b_preprocess(strong)[0])
+    weak = fp.am_capture(50_000, 0, 0.05, 6, 1)
+    assert np.array_equal(oracle.b_preprocess_gate(weak, gate=0)[0], oracle.b_preprocess(weak)[0])
+    with capsys.disabled():
+        print("\n  k1_gate = 1: integer envelope codes vs float64 envelope chain")
+        for r in rows:
+            print("    amp %.3f  mean power %.5f  class %d  lag %5d  corr %10.6f  |dcorr|/|corr| %.2e" % r)
