@@ -377,7 +377,9 @@ def main():
             hot = {"k_fm_demod": "k_fm_demod", "k_fwd_col": col, "k_fwd_row": "k_fwd_row4096",
                    "k_inv_row_pair": "k_inv_row_pair4096", "k_inv_col_peak": "k_inv_col_pruned"}
         if max_lag <= 1024 and n1 == 4096:
-            hot = dict(hot, k_inv_row_pair="k_xcorr_segments", k_inv_col_peak="k_segments_reduce")
+            # segment form; with 3+ pairs per window the station transforms are shared (quads)
+            hot = dict(hot, k_inv_row_pair="k_xcorr_segments_quad" if n_pairs >= 3 and os.environ.get("TDOA_NO_SEGMENT_QUADS") != "1"
+                       else "k_xcorr_segments", k_inv_col_peak="k_segments_reduce")
         roof = None
         if rec["launches"]:
             per_launch_bytes = rec["bytes"] / rec["launches"]
@@ -395,6 +397,10 @@ def main():
                     "algorithmic_bytes_per_launch": per_launch_bytes,
                     "avg_launch_us": round(avg_s * 1e6, 2), "launches": rec["launches"],
                     "kernels_ms_per_step": {k: round(v["ms"] / steps, 4) for k, v in prof.items()}}
+            if roof["kernel"].startswith("k_xcorr_segments"):
+                roof["note"] = ("segment form: 4096-point transforms in LDS and registers, limited by vector-instruction issue "
+                                "(DESIGN.md section 3); its HBM traffic is the 2-byte phase codes only, so the HBM fraction "
+                                "says how little it streams, not how well it runs")
         # whole-pipeline algorithmic bytes: k = ceil(log2 N / 12) passes of 4096-point tiles, e = 4 B:
         # 2L + e N (2k - 1) per station-window, e N 2k per pair-window  (k = 2: 2L + 12N and 16N; k = 3: 2L + 20N and 24N)
         k_pass = max(2, math.ceil(math.log2(n_fft) / 12.0))
