@@ -436,7 +436,10 @@ def main():
         if state["fix"] is not None:
             frc, flle, fit = state["fix"]
             out["solve"] = {"status": int(frc), "lat": round(float(flle[0]), 6), "lon": round(float(flle[1]), 6),
-                            "iterations": int(fit)}
+                            "iterations": int(fit),
+                            "note": "the merge + least-squares solve run inside the timed region; the synthetic captures restate "
+                                    "simulator.go (unmodulated tones + noise), so the peaks are noise peaks and a non-zero status "
+                                    "(7 = singular Jacobian, processor.go:997-999) is the solver's honest answer to them"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"], out["parity_window0"] = cpu_baseline_leg(ctx, timed_peaks, block, wl, max_lag, args.cpu_budget)
             if out["parity_window0"] is False:
