@@ -433,6 +433,21 @@ def main():
         }
         if roof and roof.get("traffic") is not None and pmc_total:
             out["pipeline_pmc_GBps"] = round(pmc_total / (dt / steps) / 1e9, 1)
+        if world > 1:
+            # the N = 1 default of this script is the headline config (cfg2); a scaling figure for THIS job needs the
+            # one-GPU rate of the same config, which is a committed measurement, not something this run can time
+            ref_file = os.path.join(ROOT, "profiles", "r02_%s_bench.json" % cfg_name)
+            try:
+                with open(ref_file) as f:
+                    ref = json.loads(f.read().strip().splitlines()[-1])
+                if ref.get("n_gpus") == 1 and ref.get("config", {}).get("name") == cfg_name:
+                    out["same_config_one_gpu"] = {
+                        "value": ref["value"], "ms_per_step": ref["ms_per_step"], "source": "profiles/r02_%s_bench.json" % cfg_name,
+                        "note": "one MI355X, same config and command with --gpus 1 --config %s: the reference for this job's "
+                                "%s-scaling efficiency (bench.py --gpus 1 without --config runs the headline cfg2 instead)"
+                                % (cfg_name, scaling)}
+            except (OSError, ValueError, KeyError, IndexError):
+                pass
         if state["fix"] is not None:
             frc, flle, fit = state["fix"]
             out["solve"] = {"status": int(frc), "lat": round(float(flle[0]), 6), "lon": round(float(flle[1]), 6),
