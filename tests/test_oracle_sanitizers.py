@@ -33,6 +33,11 @@ o.b_xcorr_all_lags(p[:100], p[:90], 64)
 o.block_power(w[:2000])
 o.b_discriminate(w[:2])
 o.simulate_delayed_fm(1000, 17, 1, 2)
+o.b_preprocess_smooth(w[:2 * 777], 10)
+o.b_preprocess_gate(w[:2 * 777], window=10, gate=1)
+o.b_preprocess_gate(o.simulate_delayed_fm(500, 0, 1, 1), window=0, gate=1)
+o.b_preprocess_gate(w[:2], gate=1)
+o.b_envelope_code(0, 255)
 o.solve_tdoa([o.STATIONS[k] for k in o.COLLECTORS], [10.0, -20.0, 0.0])
 print("SANITIZED_OK")
 """
