@@ -268,7 +268,8 @@ int tdoa_debug_flags(tdoa_ctx *ctx, unsigned flags);
  * stations whose two packed transforms per segment serve up to four pairs in the segment form.
  * pairs[2 i], pairs[2 i + 1] = template, signal station of pair i; quads_out gets 8 ints per quad: stations a, b, c, d
  * (-1 = empty slot) and the pair index of (a,c), (a,d), (b,c), (b,d) (-1 = not wanted).  Returns the number of quads
- * (at most n_pairs), or a negative TDOA_ERR_* value. */
+ * (at most n_pairs), or a negative TDOA_ERR_* value (more than 32 stations: the library then runs the segment form one
+ * pair-window at a time and builds no quads). */
 int tdoa_debug_segment_quads(int n_stations, const int32_t *pairs, int n_pairs, int32_t *quads_out, int max_quads);
 
 /* ---- downstream (processor.go:125-163, 932-1045), host side ---------------- */

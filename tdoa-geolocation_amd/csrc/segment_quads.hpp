@@ -13,6 +13,8 @@
 
 namespace tdoa {
 
+constexpr int kMaxQuadStations = 32;     // the greedy search is O(P S^2) per quad; 32 stations (496 pairs) take milliseconds
+
 struct StationQuad {
     int a, b, c, d;        // station numbers; b = -1 / d = -1: slot empty
     int pair[4];           // index into the caller's pair list of (a,c), (a,d), (b,c), (b,d); -1 = not wanted

@@ -1150,7 +1150,8 @@ static int process_impl(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host,
         pw_off[wi + 1] = pw.size();
         // segment form: the quad cover of this window's pairs (the same for every window under window-major sharding).
         // Every pair-window of the rank is in exactly one quad; run_fm_batch takes the quads of a batch or none of them.
-        if (pw_off[wi + 1] > pw_off[wi]) {
+        // (the greedy cover costs O(P S^2) per quad: beyond kMaxQuadStations stations the segment form stays pair by pair)
+        if (pw_off[wi + 1] > pw_off[wi] && S <= kMaxQuadStations) {
             std::vector<int> owned;
             std::vector<std::pair<int, int>> st_pairs;
             p = 0;
@@ -1459,7 +1460,7 @@ int tdoa_debug_force_generic(tdoa_ctx *ctx, int on)
 
 int tdoa_debug_segment_quads(int n_stations, const int32_t *pairs, int n_pairs, int32_t *quads_out, int max_quads)
 {
-    if (n_stations < 2 || n_stations > 1023 || n_pairs < 0 || (n_pairs && !pairs) || max_quads < 0 || (max_quads && !quads_out))
+    if (n_stations < 2 || n_stations > kMaxQuadStations || n_pairs < 0 || (n_pairs && !pairs) || max_quads < 0 || (max_quads && !quads_out))
         return -TDOA_ERR_INVALID;
     std::vector<std::pair<int, int>> pr;
     for (int i = 0; i < n_pairs; i++) {
