@@ -40,7 +40,7 @@ struct DevBuf {
 
 struct ProfRec {
     int kernel;
-    hipEvent_t start, stop;
+    int e0, e1;          // indices into the context's event pool
     double bytes;
 };
 
@@ -67,6 +67,10 @@ struct tdoa_ctx {
     bool profiling = false;
     bool force_generic = false;   // tests: run the any-size kernels even at the hot sizes
     std::vector<ProfRec> recs;
+    std::vector<hipEvent_t> prof_pool;      // events of the profiling path, reused from call to call
+    size_t prof_used = 0;                   // handed out since the last prof_collect
+    int prof_last = -1;                     // stop event of the previous scope: the next scope starts there (one event
+                                            // between two kernels instead of two)
     double prof_ms[TDOA_K_COUNT] = {0};
     int64_t prof_launches[TDOA_K_COUNT] = {0};
     double prof_bytes[TDOA_K_COUNT] = {0};
@@ -199,6 +203,22 @@ int set_lds(tdoa_ctx *ctx, K kernel, size_t bytes)
     return TDOA_OK;
 }
 
+// next free event of the pool, recorded on the context's stream; -1 on failure
+int prof_mark(tdoa_ctx *ctx)
+{
+    if (ctx->prof_used == ctx->prof_pool.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return -1;
+        ctx->prof_pool.push_back(e);
+    }
+    const int id = (int)ctx->prof_used++;
+    if (hipEventRecord(ctx->prof_pool[id], ctx->stream) != hipSuccess) return -1;
+    return id;
+}
+
+// Per-kernel timing of the profiling path: consecutive scopes share the event between them (the stop of one is the
+// start of the next), so a step costs one event per kernel boundary; the few microseconds between two kernels count
+// towards the later one.  Work enqueued outside any scope must reset ctx->prof_last first.
 struct ProfScope {
     tdoa_ctx *ctx;
     ProfRec rec{};
@@ -208,17 +228,15 @@ struct ProfScope {
         if (!on) return;
         rec.kernel = kernel;
         rec.bytes = bytes;
-        if (hipEventCreate(&rec.start) != hipSuccess || hipEventCreate(&rec.stop) != hipSuccess) {
-            on = false;
-            return;
-        }
-        (void)hipEventRecord(rec.start, ctx->stream);
+        rec.e0 = ctx->prof_last >= 0 ? ctx->prof_last : prof_mark(ctx);
+        if (rec.e0 < 0) on = false;
     }
     ~ProfScope()
     {
         if (!on) return;
-        (void)hipEventRecord(rec.stop, ctx->stream);
-        ctx->recs.push_back(rec);
+        rec.e1 = prof_mark(ctx);
+        ctx->prof_last = rec.e1;
+        if (rec.e1 >= 0) ctx->recs.push_back(rec);
     }
 };
 
@@ -226,15 +244,16 @@ void prof_collect(tdoa_ctx *ctx)
 {
     for (auto &r : ctx->recs) {
         float ms = 0;
-        if (hipEventSynchronize(r.stop) == hipSuccess && hipEventElapsedTime(&ms, r.start, r.stop) == hipSuccess) {
+        if (hipEventSynchronize(ctx->prof_pool[r.e1]) == hipSuccess &&
+            hipEventElapsedTime(&ms, ctx->prof_pool[r.e0], ctx->prof_pool[r.e1]) == hipSuccess) {
             ctx->prof_ms[r.kernel] += ms;
             ctx->prof_launches[r.kernel] += 1;
             ctx->prof_bytes[r.kernel] += r.bytes;
         }
-        (void)hipEventDestroy(r.start);
-        (void)hipEventDestroy(r.stop);
     }
     ctx->recs.clear();
+    ctx->prof_used = 0;
+    ctx->prof_last = -1;
 }
 
 // K1 for n_sw station-windows: capture bytes -> 16-bit codes + exact window statistics; every buffer must have been
@@ -459,6 +478,7 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
             hipLaunchKernelGGL(k_segments_reduce<PQ>, dim3(2 * PQ + 1, n_pw), dim3(256), 0, st, v, d_keys, d_pw, pl,  \
                                seg_chunks, mul, lag_lo, lag_hi, lag_dump, dump_scale);                               \
         }                                                                                                            \
+        if (fine_raw) ctx->prof_last = -1;          /* unscoped launch: the next scope records its own start */     \
         if (fine_raw)                                                                                                \
             hipLaunchKernelGGL(k_refine_segments<PQ>, dim3((n_pw + 63) / 64), dim3(64), 0, st, v, d_keys, d_pw, pl,   \
                                n_pw, fine_raw);                                                                      \
@@ -536,6 +556,7 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
     }
     if (n_pw && fine_raw) {   // V (or the short-lag array) of this batch is still in place: peak neighbours for the parabola
         const dim3 g1((n_pw + 63) / 64), b1(64);
+        ctx->prof_last = -1;      // unscoped launches: the next scope records its own start
         if (seg_chunks) { /* done above: k_refine_segments */ }
         else if (fk == 1) hipLaunchKernelGGL(k_refine_fused<1>, g1, b1, 0, st, v, d_keys, d_pw, pl, n_pw, fine_raw);
         else if (fk == 2) hipLaunchKernelGGL(k_refine_fused<2>, g1, b1, 0, st, v, d_keys, d_pw, pl, n_pw, fine_raw);
@@ -659,6 +680,7 @@ int fm_pair(tdoa_ctx *ctx, const uint8_t *iq1, size_t n1, const uint8_t *iq2, si
     double scale = 1.0 / (4.0 * (double)n * std::sqrt((double)n1));
     HIPCHK(ctx, hipMemsetAsync(ctx->keys.p, 0, sizeof(unsigned long long), ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(ctx->scales.p, &scale, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    ctx->prof_last = -1;
     rc = run_fm_batch(ctx, d_sw, 2, (int)std::max(n1, n2), d_pw, 1, static_cast<unsigned long long *>(ctx->keys.p),
                       pl, -(max_lag - 1), max_lag - 1, dump, 1.0f, (double)(n1 + n2),
                       fine ? static_cast<float *>(ctx->fine_raw.p) : nullptr);
@@ -814,6 +836,7 @@ void tdoa_destroy(tdoa_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     prof_collect(ctx);
+    for (hipEvent_t e : ctx->prof_pool) (void)hipEventDestroy(e);
     if (ctx->graph_exec) (void)hipGraphExecDestroy(ctx->graph_exec);
     if (ctx->graph) (void)hipGraphDestroy(ctx->graph);
     tdoa_capture_clear(ctx);
@@ -1232,6 +1255,7 @@ static int process_impl(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host,
     }
 
     auto enqueue = [&]() -> int {
+        ctx->prof_last = -1;
         hipLaunchKernelGGL(k_zero_u64, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, st, d_keys, slots);
         float *fine_raw = fine_host ? static_cast<float *>(ctx->fine_raw.p) : nullptr;
         for (size_t w0 = 0; w0 < mine.size(); w0 += per_batch) {
@@ -1243,6 +1267,7 @@ static int process_impl(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host,
                                        (int)(q_off[w0 + nw] - q_off[w0]), tri_batch[w0 / (size_t)per_batch]);
             if (r) return r;
         }
+        if (fine_raw) ctx->prof_last = -1;
         if (fine_raw)
             hipLaunchKernelGGL(k_decode_fine, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, st, d_keys, d_scales,
                                fine_raw, static_cast<FineOut *>(ctx->fine.p), gate, (int)slots);
