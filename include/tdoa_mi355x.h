@@ -261,6 +261,7 @@ enum {
     TDOA_DEBUG_NO_XCD_ROWS     = 16, /* plain 2-D grid of the pair kernel even with more pairs than stations          */
     TDOA_DEBUG_PAIR_R8         = 32, /* (bit set = form USED) 512-thread / 8-value pair kernel instead of 256 / 16      */
     TDOA_DEBUG_NO_SEGMENT_QUADS = 64, /* segment form one pair-window at a time: no station transforms shared by pairs */
+    TDOA_DEBUG_NO_DECIMATE     = 256, /* full inverse transform even where the decimated one applies (4096 x 256 plans, search ranges above 4095 lags) */
     TDOA_DEBUG_TRI_ROWS        = 128 /* (bit set = form USED) three stations / three pairs: k_rows_tri_fused, all row transforms of a window's row pair in one kernel */
 };
 int tdoa_debug_flags(tdoa_ctx *ctx, unsigned flags);

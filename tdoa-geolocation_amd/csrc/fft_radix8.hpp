@@ -516,6 +516,153 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA
 }
 
 // ---------------------------------------------------------------------------
+// Decimated inverse (N2 = 256; search ranges of a few ten thousand lags in a transform of millions).
+// Only |lag| <= max_lag of the 2 Nc inverse outputs are wanted: ~1 % for the reference's 20 000 lags in N = 2^21.  The
+// general form still runs the whole inverse (row pass: Q -> V, 8 Nc bytes written and read back per pair-window).
+// Multiplying the lag sequence q[m] by a smooth window w[m] that vanishes outside |m| < R - M lets the SPECTRUM be
+// decimated: G[j] = sum_t h[t] Q[16 j + t] (h = the transform of w: a Kaiser-windowed sinc, 213 real taps for 140 dB),
+// and the R = Nc/16-point inverse of G is q[m] w[m] for |m| <= M, exactly up to the stop-band leakage of h (aliases of
+// lags beyond R - M, measured 1e-7 of the peak on noise-level simulator peaks, 3e-10 on FM).  w[m] is known (the
+// host evaluates it from the rounded taps) and is divided out.  So K3 is followed by a 13-tap-per-bin FIR instead of
+// a 4096-point row transform, V shrinks 16 times, and the pair step is one streaming read of the two spectra.
+//
+// k = k2 + 256 k1: consecutive bins run down a column, so a workgroup takes a tile of all 256 rows x 16 columns
+// (4096 consecutive bins, 128-byte row pieces) and, because K3 needs Z[k] and Z[Nc - k] together, the mirrored tile:
+//   tile A: bins [256 c0 - 112, 256 (c0 + 16) + 112), tile B: bins Nc - (those), both with their halos.
+// Q of both tiles goes to LDS phase-major (bin o of a tile at [o & 15][o >> 4]) so that thread i of the FIR reads
+// element i + const of one phase for every tap: conflict-free.  256 outputs per tile, one per thread.
+// G is written as the [16][4096] four-step layout of the R-point inverse (j = j2 + 16 j1).
+// grid (128, n_pw), 512 threads, dynamic LDS 2 x 16 x 273 x 8 B = 70 KB.
+// ---------------------------------------------------------------------------
+constexpr int kDecD = 16, kDecHalo = 112, kDecCols = 16;
+constexpr int kDecLen = 256 * kDecCols + 2 * kDecHalo;      // bins of one LDS tile
+constexpr int kDecPitch = 273;                              // float2 per phase: >= kDecLen / 16 + 2 (the 18-wide reads of the
+                                                            // last output group), = 1 (mod 4) for conflict-free reads
+
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_PLAIN_DS_OPS)) void k_pair_decimate16(const PWDesc *pw, const float2 *Z, float2 *G, FftPlan pl,
+                                                         const float *taps, int T)
+{
+    extern __shared__ float2 lds[];                          // [2][16][kDecPitch]
+    float2 *qa = lds, *qb = lds + 16 * kDecPitch;
+    (void)T;
+    const int t = threadIdx.x;
+    const PWDesc d = pw[blockIdx.y];
+    const float2 *Za = Z + (size_t)d.sw_a * pl.Nc, *Zb = Z + (size_t)d.sw_b * pl.Nc;
+    const int c0 = blockIdx.x * kDecCols;
+    const long long mask = pl.Nc - 1;
+    const long long kA0 = 256ll * c0 - kDecHalo;             // first bin of tile A (mod Nc)
+    const float invNc = 1.0f / (float)pl.Nc;
+    // bin k of tile A at offset e has its partner Nc - k at offset kDecLen - 1 - e of tile B.
+    // One element: loads of the bin and its mirror in both spectra, K3, two LDS stores
+    auto coords = [&](int k2, int col, int &e, long long &k, size_t &at, size_t &atm) {
+        e = k2 + 256 * col + kDecHalo;
+        k = (kA0 + e) & mask;
+        const int k1 = (int)(k >> 8);
+        const int pr = (256 - k2) & 255, pc = ((k2 == 0 ? 4096 : 4095) - k1) & 4095;
+        at = (size_t)k2 * 4096 + k1;
+        atm = (size_t)pr * 4096 + pc;
+    };
+    auto finish = [&](int e, long long k, float2 za, float2 zam, float2 zb, float2 zbm) {
+        float2 q, qm;
+        pair_q(za, zam, zb, zbm, unit_root((float)k, invNc, false), q, qm);
+        const int eb = kDecLen - 1 - e;
+        qa[(e & 15) * kDecPitch + (e >> 4)] = q;
+        qb[(eb & 15) * kDecPitch + (eb >> 4)] = qm;
+    };
+    {
+        // main part: 256 rows x 16 columns, column fastest (128-byte pieces of a row); all 32 loads of a thread first
+        float2 za[8], zam[8], zb[8], zbm[8];
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+            int e; long long k; size_t at, atm;
+            coords((t >> 4) + 32 * it, t & 15, e, k, at, atm);
+            za[it] = Za[at]; zam[it] = Za[atm]; zb[it] = Zb[at]; zbm[it] = Zb[atm];
+        }
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+            int e; long long k; size_t at, atm;
+            coords((t >> 4) + 32 * it, t & 15, e, k, at, atm);
+            finish(e, k, za[it], zam[it], zb[it], zbm[it]);
+        }
+    }
+    if (t < 2 * kDecHalo) {
+        // the two halos of tile A: column c0 - 1, rows 144..255, and column c0 + 16, rows 0..111
+        const int k2 = t < kDecHalo ? 256 - kDecHalo + t : t - kDecHalo, col = t < kDecHalo ? -1 : kDecCols;
+        int e; long long k; size_t at, atm;
+        coords(k2, col, e, k, at, atm);
+        finish(e, k, Za[at], Za[atm], Zb[at], Zb[atm]);
+    }
+    __syncthreads();
+    // FIR + decimation.  Output i of a tile needs the bins at tile offsets 16 i + o, o in [o0, o0 + 2T],
+    // o0 = (112 or 111) - T >= 0, o0 + 2T < 240: with o = 16 s + p the filter is 16 phases x 15 steps, and the host lays
+    // the taps out that way per tile (zeros where o falls outside the filter): taps[tile][p][16], s = 0..14.
+    // A thread takes FOUR consecutive outputs and FOUR phases p = pq + 4 m: element [p][4 g + s'] serves the outputs
+    // o = 0..3 with step s = s' - o, so 18 LDS reads per phase feed 60 multiply-adds (one read per output and tap
+    // would make the kernel LDS-bound: 13 reads of every bin).  Waves 0..3: tile A, 4..7: tile B; lane = 4 g_l + pq.
+    // Bank pairs of a half-wave: kDecPitch pq + 4 g_l, distinct because kDecPitch = 1 (mod 4).
+    const int tile = __builtin_amdgcn_readfirstlane(t >> 8);
+    const int pq = t & 3, g = (t & 255) >> 2;                // g = 0..63: outputs 4 g .. 4 g + 3 of the tile
+    const float2 *src = (tile ? qb : qa) + 4 * g;
+    const float *tab = taps + tile * 256;
+    float2 acc[4];
+#pragma unroll
+    for (int o = 0; o < 4; o++) acc[o] = make_float2(0.0f, 0.0f);
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        const int p = pq + 4 * m;
+        float h[15];
+#pragma unroll
+        for (int s2 = 0; s2 < 15; s2++) h[s2] = tab[16 * p + s2];
+        const float2 *row = src + p * kDecPitch;
+#pragma unroll
+        for (int s1 = 0; s1 < 18; s1++) {
+            const float2 v = row[s1];
+#pragma unroll
+            for (int o = 0; o < 4; o++) {
+                const int s2 = s1 - o;
+                if (s2 >= 0 && s2 < 15) {
+                    acc[o].x += h[s2] * v.x;
+                    acc[o].y += h[s2] * v.y;
+                }
+            }
+        }
+    }
+    // sum over the four phase groups (adjacent lanes); lane pq then writes output 4 g + pq
+#pragma unroll
+    for (int o = 0; o < 4; o++) {
+        acc[o].x += __shfl_xor(acc[o].x, 1, kWave);
+        acc[o].y += __shfl_xor(acc[o].y, 1, kWave);
+        acc[o].x += __shfl_xor(acc[o].x, 2, kWave);
+        acc[o].y += __shfl_xor(acc[o].y, 2, kWave);
+    }
+    const float2 mine = pq == 0 ? acc[0] : pq == 1 ? acc[1] : pq == 2 ? acc[2] : acc[3];
+    // j = 16 c0 + i (tile A) or 16 (4080 - c0) + i (tile B);  G[j & 15][j >> 4]
+    const int j = 16 * (tile ? 4080 - c0 : c0) + 4 * g + pq;
+    G[(size_t)blockIdx.y * (size_t)(pl.Nc / kDecD) + (size_t)(j & 15) * 4096 + (j >> 4)] = mine;
+}
+
+// inverse rows of the decimated spectrum (no K3, no mirror): rows a = 2 bx, b = a + 1 of G[16][4096] -> V'[k2][n1]
+// with the four-step twiddle of the small plan.  grid (N2'/2, n_pw), 512 threads, dynamic LDS 64 KB.
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_PLAIN_DS_OPS)) void k_inv_rows_plain_r8(const float2 *G, float2 *V, FftPlan pl)
+{
+    extern __shared__ float2 lds[];   // 2 * kRow8Lds
+    float2 *la = lds, *lb = lds + kRow8Lds;
+    const int t = threadIdx.x;
+    const int a = 2 * blockIdx.x, b = a + 1;
+    const float2 *g = G + (size_t)blockIdx.y * pl.Nc;
+    float2 va[8], vb[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        va[r] = g[(size_t)a * 4096 + t + 512 * r];
+        vb[r] = g[(size_t)b * 4096 + t + 512 * r];
+    }
+    fft8<true>(va);
+    fft8<true>(vb);
+    rows2_r8_finish<true>(va, vb, la, lb, t, t, t);
+    inv_rows_twiddle_store(va, vb, t, a, b, V + (size_t)blockIdx.y * pl.Nc, pl);
+}
+
+// ---------------------------------------------------------------------------
 // Segment form (search ranges up to 1024 lags): the whole correlation stays in LDS and registers.
 // The deployed geometry bounds |TDOA| by 114 samples (PROJECT_NOTES.md:29-32); a caller who searches a few hundred
 // lags instead of the reference's 20 000 (processor.go:633) does not need a 2^21-point transform.  Overlap-save

@@ -85,6 +85,11 @@ struct tdoa_ctx {
     bool fused_rows = false;                // forward row pass inside the pair kernel when P <= S (TDOA_FUSED_ROWS=1 / tdoa_debug_flags)
     bool segment_form = true;               // TDOA_NO_SEGMENT_FORM=1: no LDS-resident overlap-save form for short searches
     bool segment_quads = true;              // TDOA_NO_SEGMENT_QUADS=1: segment form one pair-window at a time (no shared station transforms)
+    bool decimate = true;                   // TDOA_NO_DECIMATE=1: general form with the full inverse even where the decimated one applies
+    // decimated inverse (k_pair_decimate16): FIR taps and window correction for (Nc, reach); small plan of the R-point inverse
+    DevBuf dec_taps, dec_gain;
+    long long dec_nc = 0;
+    int dec_reach = -1, dec_T = 0;
     bool tri_rows = false;                  // TDOA_TRI_ROWS=1: three stations / three pairs through k_rows_tri_fused (measured slower: 2.59 vs 2.16 ms)
     bool xcd_rows = true;                   // TDOA_NO_XCD_ROWS=1: plain 2-D grid of the pair kernel even with more pairs than stations
     bool pair_r8 = false;                   // TDOA_PAIR_R8=1: the 512-thread / 8-value pair kernel (measured equal on cfg2, 5 % slower on cfg4)
@@ -293,6 +298,77 @@ short *launch_k1(tdoa_ctx *ctx, hipStream_t st, const SWDesc *d_sw, int n_sw, in
     return codes;
 }
 
+// ---- decimated inverse (fft_radix8.hpp, k_pair_decimate16) ----------------------------------------------------------
+// applies to the general form on 4096 x 256 plans when the packed search range M = reach/2 + 2 leaves a transition band:
+// R = Nc/16 = 65536, pass band |m| <= M, stop band |m| >= R - M
+constexpr double kDecAttenuationDb = 140.0;
+bool decimation_applies(const tdoa_ctx *ctx, const FftPlan &pl, int lag_lo, int lag_hi)
+{
+    if (!ctx->decimate || ctx->force_generic || pl.N1 != 4096 || pl.N2 != 256) return false;
+    const int reach = std::max(lag_hi + 1, -(lag_lo - 1));
+    if (reach <= 4095) return false;                       // the short-lag forms take those
+    const long long M = reach / 2 + 2, R = pl.Nc / kDecD;
+    const double dw = 2.0 * M_PI * (double)(R - 2 * M) / (double)pl.Nc;
+    if (R - 2 * M <= 0) return false;
+    const int T = (int)std::ceil((kDecAttenuationDb - 8.0) / (2.285 * dw) / 2.0);
+    return T <= kDecHalo - 1;
+}
+
+// modified Bessel function I0 (Kaiser window)
+double bessel_i0(double x)
+{
+    double sum = 1.0, term = 1.0;
+    for (int k = 1; k < 200; k++) {
+        term *= (x / (2.0 * k)) * (x / (2.0 * k));
+        sum += term;
+        if (term < 1e-18 * sum) break;
+    }
+    return sum;
+}
+
+// taps h[t] = sinc(t/16) * kaiser(t), |t| <= T, rounded to f32; gain[m] = 1 / w[m], w[m] = sum_t h[t] cos(2 pi t m / Nc) / 16
+// evaluated from the ROUNDED taps, so the correction is exact for the filter that runs.  No-op when already built.
+int ensure_decimation(tdoa_ctx *ctx, const FftPlan &pl, int lag_lo, int lag_hi)
+{
+    const int reach = std::max(lag_hi + 1, -(lag_lo - 1));
+    if (ctx->dec_nc == pl.Nc && ctx->dec_reach == reach) return TDOA_OK;
+    const long long M = reach / 2 + 2, R = pl.Nc / kDecD;
+    const double dw = 2.0 * M_PI * (double)(R - 2 * M) / (double)pl.Nc;
+    const int T = (int)std::ceil((kDecAttenuationDb - 8.0) / (2.285 * dw) / 2.0);
+    const double beta = 0.1102 * (kDecAttenuationDb - 8.7), i0b = bessel_i0(beta);
+    std::vector<float> taps(2 * T + 1);
+    for (int t = -T; t <= T; t++) {
+        const double x = (double)t / kDecD, r = (double)t / T;
+        const double sinc = t == 0 ? 1.0 : std::sin(M_PI * x) / (M_PI * x);
+        taps[t + T] = (float)(sinc * bessel_i0(beta * std::sqrt(std::max(0.0, 1.0 - r * r))) / i0b);
+    }
+    std::vector<float> gain(M + 4);
+    for (long long m = 0; m < M + 4; m++) {
+        double w = 0.0;
+        for (int t = -T; t <= T; t++) w += (double)taps[t + T] * std::cos(2.0 * M_PI * (double)t * (double)m / (double)pl.Nc);
+        gain[m] = (float)((double)kDecD / w);
+    }
+    // the kernel's layout: tile (A, B) x phase p x step s: the tap at tile offset o = 16 s + p, o0 = (112 or 111) - T
+    std::vector<float> tab(2 * 256, 0.0f);
+    for (int tile = 0; tile < 2; tile++) {
+        const int o0 = kDecHalo - tile - T;
+        for (int u = 0; u <= 2 * T; u++) {
+            const int o = o0 + u;
+            tab[tile * 256 + 16 * (o & 15) + (o >> 4)] = taps[u];
+        }
+    }
+    int rc;
+    if ((rc = ensure(ctx, ctx->dec_taps, sizeof(float) * tab.size()))) return rc;
+    if ((rc = ensure(ctx, ctx->dec_gain, sizeof(float) * gain.size()))) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->dec_taps.p, tab.data(), sizeof(float) * tab.size(), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->dec_gain.p, gain.data(), sizeof(float) * gain.size(), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));      // host vectors go out of scope
+    ctx->dec_nc = pl.Nc;
+    ctx->dec_reach = reach;
+    ctx->dec_T = T;
+    return TDOA_OK;
+}
+
 // make every workspace buffer of run_fm_batch large enough (no allocation may happen while a
 // stream capture is open)
 int reserve_fm_batch(tdoa_ctx *ctx, int n_sw, int maxlen, int n_pw, const FftPlan &pl, int lag_lo, int lag_hi)
@@ -305,8 +381,7 @@ int reserve_fm_batch(tdoa_ctx *ctx, int n_sw, int maxlen, int n_pw, const FftPla
     if (ctx->prm.k1_smooth > 1 && (rc = ensure(ctx, ctx->codes_lp, sizeof(short) * (size_t)code_stride * n_sw))) return rc;
     if (ctx->prm.k1_gate && (rc = ensure(ctx, ctx->k1_power, sizeof(unsigned long long) * (size_t)n_sw))) return rc;
     if ((rc = ensure(ctx, ctx->tz, sizeof(float2) * (size_t)pl.Nc * n_sw))) return rc;
-    (void)lag_lo;
-    (void)lag_hi;
+    if (n_pw && decimation_applies(ctx, pl, lag_lo, lag_hi) && (rc = ensure_decimation(ctx, pl, lag_lo, lag_hi))) return rc;
     if (n_pw && (rc = ensure(ctx, ctx->v, sizeof(float2) * (size_t)pl.Nc * n_pw))) return rc;
     return TDOA_OK;
 }
@@ -355,6 +430,9 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
     }
     const bool pruned = !ctx->force_generic && pl.N1 >= 128 && pl.N2 <= 4096 && np + nn <= kPruneMax && np + nn <= pl.N2 &&
                         lag_hi < pl.Nc && lag_lo > -pl.Nc;
+    // decimated inverse (general form on 4096 x 256 plans; not with the sub-sample refinement, which reads V)
+    const bool decim = pruned && fk == 0 && !fine_raw && decimation_applies(ctx, pl, lag_lo, lag_hi) &&
+                       ctx->dec_nc == pl.Nc && ctx->dec_reach == std::max(lag_hi + 1, -(lag_lo - 1));
     // segment form (search ranges up to 1024 lags): overlap-save over 4096-point frames entirely in LDS; neither the
     // column pass nor TZ nor V rows are touched.  Its chunk sums and lag array live where the short-lag form keeps its
     // shares (inside this pair-window's V row), which bounds the chunk count by N2 / 2.
@@ -487,6 +565,32 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
         else if (seg_pq == 2) TDOA_SEGMENTS(2);
         else TDOA_SEGMENTS(4);
 #undef TDOA_SEGMENTS
+    } else if (n_pw && decim) {
+        // decimated inverse: K3 + FIR decimation of the pair's spectrum (one read of the two station spectra), then the
+        // R = Nc/16-point inverse on the small plan (rows, pruned column pass with the window divided out, K5)
+        FftPlan ps2;
+        if ((rc = make_plan(2 * (pl.Nc / kDecD), true, &ps2))) return fail(ctx, rc, "decimated plan");
+        const size_t rc_pts = (size_t)(pl.Nc / kDecD);
+        float2 *g = v, *vs = v + rc_pts * (size_t)n_pw;                 // compact: [n_pw][R] each, inside the V workspace
+        int np2 = 0, nn2 = 0;
+        {
+            const long long n_real2 = 2 * ps2.Nc;
+            np2 = lag_hi >= 0 ? (int)((lag_hi / 2) / ps2.N1) + 1 : 0;
+            nn2 = lag_lo < 0 ? ps2.N2 - (int)(((n_real2 + lag_lo) / 2) / ps2.N1) : 0;
+        }
+        {
+            ProfScope ps(ctx, TDOA_K_INV_ROW, 2.0 * nc8 * n_pw + 8.0 * (double)rc_pts * n_pw);      // two spectra read, G written
+            hipLaunchKernelGGL(k_pair_decimate16, dim3(pl.N1 / (2 * kDecCols), n_pw), dim3(512),
+                               sizeof(float2) * 2 * 16 * kDecPitch, st, d_pw, tz, g, pl,
+                               static_cast<const float *>(ctx->dec_taps.p), ctx->dec_T);
+        }
+        {
+            ProfScope ps(ctx, TDOA_K_INV_COL, 3.0 * 8.0 * (double)rc_pts * n_pw);
+            hipLaunchKernelGGL(k_inv_rows_plain_r8, dim3(ps2.N2 / 2, n_pw), dim3(512), sizeof(float2) * 2 * kRow8Lds, st, g, vs, ps2);
+            hipLaunchKernelGGL(k_inv_col_pruned_any, dim3(ps2.N1 / 128, n_pw), dim3(256), sizeof(float2) * (size_t)ps2.N2, st, vs,
+                               d_keys, d_pw, ps2, lag_lo, lag_hi, np2, nn2, lag_dump, dump_scale,
+                               static_cast<const float *>(ctx->dec_gain.p));
+        }
     } else if (n_pw) {
         {
             ProfScope ps(ctx, TDOA_K_INV_ROW, 3.0 * nc8 * n_pw);     // SURVEY's model: two spectra read, V written, per pair
@@ -609,6 +713,8 @@ int allow_big_lds(tdoa_ctx *ctx)
     if ((rc = set_lds(ctx, k_xcorr_segments_quad<2>, all))) return rc;
     if ((rc = set_lds(ctx, k_xcorr_segments_quad<4>, all))) return rc;
     if ((rc = set_lds(ctx, k_rows_tri_fused, all))) return rc;
+    if ((rc = set_lds(ctx, k_pair_decimate16, all))) return rc;
+    if ((rc = set_lds(ctx, k_inv_rows_plain_r8, all))) return rc;
     return TDOA_OK;
 }
 
@@ -824,6 +930,7 @@ int tdoa_create(const tdoa_params *p, tdoa_ctx **out)
     if (const char *e = std::getenv("TDOA_NO_SEGMENT_FORM")) ctx->segment_form = !(e[0] == '1');
     if (const char *e = std::getenv("TDOA_NO_SEGMENT_QUADS")) ctx->segment_quads = !(e[0] == '1');
     if (const char *e = std::getenv("TDOA_TRI_ROWS")) ctx->tri_rows = e[0] == '1';
+    if (const char *e = std::getenv("TDOA_NO_DECIMATE")) ctx->decimate = !(e[0] == '1');
     if (const char *e = std::getenv("TDOA_NO_XCD_ROWS")) ctx->xcd_rows = !(e[0] == '1');
     if (const char *e = std::getenv("TDOA_PAIR_R8")) ctx->pair_r8 = e[0] == '1';
     *out = ctx;
@@ -840,7 +947,7 @@ void tdoa_destroy(tdoa_ctx *ctx)
     if (ctx->graph_exec) (void)hipGraphExecDestroy(ctx->graph_exec);
     if (ctx->graph) (void)hipGraphDestroy(ctx->graph);
     tdoa_capture_clear(ctx);
-    DevBuf *bufs[] = {&ctx->k1_table, &ctx->sw_desc, &ctx->pw_desc, &ctx->partials, &ctx->stats, &ctx->codes, &ctx->codes_lp, &ctx->k1_power, &ctx->tz, &ctx->v, &ctx->keys,
+    DevBuf *bufs[] = {&ctx->k1_table, &ctx->sw_desc, &ctx->pw_desc, &ctx->partials, &ctx->stats, &ctx->codes, &ctx->codes_lp, &ctx->k1_power, &ctx->dec_taps, &ctx->dec_gain, &ctx->tz, &ctx->v, &ctx->keys,
                       &ctx->scales, &ctx->peaks, &ctx->scratch_a, &ctx->scratch_b, &ctx->lagdump,
                       &ctx->ex_a, &ctx->ex_b, &ctx->ex_c, &ctx->ex_d, &ctx->ex_part,
                       &ctx->g_sw_desc, &ctx->g_pw_desc, &ctx->g_quad_desc, &ctx->g_scales, &ctx->g_keys, &ctx->fine_raw, &ctx->fine, &ctx->qual};
@@ -1232,7 +1339,8 @@ static int process_impl(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host,
                                  (uint64_t)ctx->force_generic | ((uint64_t)ctx->short_lag << 1) |
                                      ((uint64_t)ctx->fused_rows << 2) | ((uint64_t)ctx->segment_form << 3) |
                                      ((uint64_t)ctx->xcd_rows << 4) | ((uint64_t)ctx->pair_r8 << 5) |
-                                     ((uint64_t)ctx->segment_quads << 6) | ((uint64_t)ctx->tri_rows << 7),
+                                     ((uint64_t)ctx->segment_quads << 6) | ((uint64_t)ctx->tri_rows << 7) |
+                                     ((uint64_t)ctx->decimate << 8),
                                  ctx->alloc_gen, (uint64_t)(fine_host != nullptr), 0};
     std::memcpy(&key.back(), &gate, sizeof(double));
     for (auto &c : ctx->caps) {
@@ -1513,6 +1621,7 @@ int tdoa_debug_flags(tdoa_ctx *ctx, unsigned flags)
     ctx->xcd_rows = !(flags & TDOA_DEBUG_NO_XCD_ROWS);
     ctx->segment_quads = !(flags & TDOA_DEBUG_NO_SEGMENT_QUADS);
     ctx->tri_rows = (flags & TDOA_DEBUG_TRI_ROWS) != 0;
+    ctx->decimate = !(flags & TDOA_DEBUG_NO_DECIMATE);
     ctx->pair_r8 = (flags & TDOA_DEBUG_PAIR_R8) != 0;
     return TDOA_OK;
 }

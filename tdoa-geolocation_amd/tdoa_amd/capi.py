@@ -426,12 +426,12 @@ class Context:
         self._chk(self._L.tdoa_debug_force_generic(self._h, 1 if on else 0))
 
     def debug_flags(self, generic=False, no_short_lag=False, no_fused_rows=False, no_segment_form=False, no_xcd_rows=False,
-                    pair_r8=False, no_segment_quads=False, tri_rows=False):
+                    pair_r8=False, no_segment_quads=False, tri_rows=False, no_decimate=False):
         """pick kernel variants by hand (tests / measurements): include/tdoa_mi355x.h TDOA_DEBUG_*"""
         self._chk(self._L.tdoa_debug_flags(self._h, (1 if generic else 0) | (2 if no_short_lag else 0) |
                                            (4 if no_fused_rows else 0) | (8 if no_segment_form else 0) |
                                            (16 if no_xcd_rows else 0) | (32 if pair_r8 else 0) |
-                                           (64 if no_segment_quads else 0) | (128 if tri_rows else 0)))
+                                           (64 if no_segment_quads else 0) | (128 if tri_rows else 0) | (256 if no_decimate else 0)))
 
     # ---- measurement -------------------------------------------------------
     def profile_enable(self, on=True):

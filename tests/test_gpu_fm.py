@@ -524,3 +524,33 @@ def test_tri_fused_rows_vs_two_kernel_form(oracle, wl, ml, per_batch):
             olag, ocorr = oracle.b_xcorr_peak(pre[i], pre[j], ml)
             assert tri[wid, p]["lag"] == olag == delays[j] - delays[i], (wid, i, j)
             assert abs(tri[wid, p]["corr"] - ocorr) <= REL_TOL * abs(ocorr)
+
+
+@pytest.mark.parametrize("n1,n2,max_lag,delay", [(2_000_000, 2_000_000, 20000, 57), (1_234_567, 1_999_999, 20000, -19876),
+                                                 (1_500_000, 1_100_000, 4096, 4001), (2_000_000, 2_000_000, 23000, 9),
+                                                 (2_000_000, 2_000_000, 26000, -25001)])
+def test_decimated_inverse_vs_full_inverse(oracle, n1, n2, max_lag, delay):
+    """4096 x 256 plans, search ranges above 4095 lags: K3 + FIR decimation of the pair's spectrum + a 65536-point
+    inverse (k_pair_decimate16) against the full inverse (k_inv_row_pair4096 + k_inv_col_pruned), every lag, and both
+    against the f64 oracle.  26000 lags leave no room for the transition band: that range must fall back by itself."""
+    import tdoa_amd
+    a = oracle.simulate_delayed_fm(n1, max(0, -delay), 91, 1)
+    b = oracle.simulate_delayed_fm(n2, max(0, delay), 91, 2)
+    ta, _ = oracle.b_preprocess(a)
+    tb, _ = oracle.b_preprocess(b)
+    olag, ocorr, want = oracle.b_xcorr_peak_fft(ta, tb, max_lag)
+    assert olag == delay
+    with tdoa_amd.Context(max_lag=max_lag, window_len=max(n1, n2)) as c:
+        dec = c.fm_xcorr_lags(a, b, max_lag)
+        lag, corr = c.fm_xcorr(a, b, max_lag)
+        assert c.plan_info()[1:] == (4096, 256)
+        c.debug_flags(no_decimate=True, no_fused_rows=True)        # (a cleared bit would switch the fused forward rows on)
+        full = c.fm_xcorr_lags(a, b, max_lag)
+        lag_f, corr_f = c.fm_xcorr(a, b, max_lag)
+    _assert_lags_close(dec, want)
+    _assert_lags_close(full, want)
+    _assert_lags_close(dec, full, 2e-6)
+    assert lag == lag_f == olag
+    assert abs(corr - ocorr) <= REL_TOL * abs(ocorr) and abs(corr_f - ocorr) <= REL_TOL * abs(ocorr)
+    if max_lag == 26000:
+        assert np.array_equal(dec, full)          # same kernels: the decimated form did not apply
