@@ -119,18 +119,27 @@ __device__ __forceinline__ void row4096_finish(float2 (&v)[16], float2 *lds, int
 // ---------------------------------------------------------------------------
 // row_mul: row index = blockIdx.x * row_mul (1: every row, grid.x = N2; N2/2: only the two self-mirrored rows 0 and
 // N2/2, grid.x = 2 -- the rest of the rows are then transformed inside k_pair_rows_fused_r8, fft_radix8.hpp)
-__global__ __launch_bounds__(256) void k_fwd_row4096(float2 *TZ, FftPlan pl, int row_mul)
+// tiled != nullptr: the spectrum goes there in 16-column tiles, element (k2, k1) at [k1 >> 4][k2][k1 & 15] -- the layout
+// k_pair_decimate16 streams (a tile of all N2 rows x 16 columns is one contiguous run); TZ keeps the column-pass output.
+__global__ __launch_bounds__(256) void k_fwd_row4096(float2 *TZ, FftPlan pl, int row_mul, float2 *tiled = nullptr)
 {
     __shared__ float2 lds[kRowLds];
-    float2 *row = TZ + (size_t)blockIdx.y * pl.Nc + (size_t)blockIdx.x * row_mul * 4096;
+    const int k2 = blockIdx.x * row_mul;
+    float2 *row = TZ + (size_t)blockIdx.y * pl.Nc + (size_t)k2 * 4096;
     const int j = threadIdx.x;
     float2 v[16];
 #pragma unroll
     for (int r = 0; r < 16; r++) v[r] = row[j + 256 * r];
     fft16<false>(v);
     row4096_finish<false>(v, lds, j);
+    if (tiled) {
+        float2 *out = tiled + (size_t)blockIdx.y * pl.Nc + (size_t)(j >> 4) * ((size_t)pl.N2 * 16) + (size_t)k2 * 16 + (j & 15);
 #pragma unroll
-    for (int k = 0; k < 16; k++) row[j + 256 * k] = v[oreg(k)];
+        for (int k = 0; k < 16; k++) out[(size_t)(16 * k) * ((size_t)pl.N2 * 16)] = v[oreg(k)];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; k++) row[j + 256 * k] = v[oreg(k)];
+    }
 }
 
 // ---------------------------------------------------------------------------

@@ -13,6 +13,8 @@
 // (stage-1 writes, 8 j + k), runs of 8 at stride 64 (stage-2 writes) and runs of 64 (stage-3 writes).
 #pragma once
 
+#include <type_traits>
+
 #include "device_common.hpp"
 #include "fft_stockham.hpp"
 #include "fft_radix16.hpp"
@@ -527,24 +529,31 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA
 // a 4096-point row transform, V shrinks 16 times, and the pair step is one streaming read of the two spectra.
 //
 // k = k2 + 256 k1: consecutive bins run down a column, so a workgroup takes a tile of all 256 rows x 16 columns
-// (4096 consecutive bins, 128-byte row pieces) and, because K3 needs Z[k] and Z[Nc - k] together, the mirrored tile:
+// (4096 consecutive bins; the forward row pass writes the spectra tile by tile for this kernel, so a tile is one
+// contiguous 32 KB run instead of 256 row pieces of 128 bytes) and, because K3 needs Z[k] and Z[Nc - k] together, the
+// mirrored tile:
 //   tile A: bins [256 c0 - 112, 256 (c0 + 16) + 112), tile B: bins Nc - (those), both with their halos.
 // Q of both tiles goes to LDS phase-major (bin o of a tile at [o & 15][o >> 4]) so that thread i of the FIR reads
 // element i + const of one phase for every tap: conflict-free.  256 outputs per tile, one per thread.
 // G is written as the [16][4096] four-step layout of the R-point inverse (j = j2 + 16 j1).
-// grid (128, n_pw), 512 threads, dynamic LDS 2 x 16 x 273 x 8 B = 70 KB.
+// (A variant that kept the template's tiles in registers for up to four pair-windows sharing it read a third fewer
+// bytes and ran 8 - 30 % slower: one more barrier pair per pair-window and 128 VGPRs with spills.)
+// grid (128, n_pw), 512 threads, dynamic LDS 2 x 16 x 296 x 8 B = 74 KB.
 // ---------------------------------------------------------------------------
 constexpr int kDecD = 16, kDecHalo = 112, kDecCols = 16;
 constexpr int kDecLen = 256 * kDecCols + 2 * kDecHalo;      // bins of one LDS tile
-constexpr int kDecPitch = 273;                              // float2 per phase: >= kDecLen / 16 + 2 (the 18-wide reads of the
-                                                            // last output group), = 1 (mod 4) for conflict-free reads
+// LDS image of a tile: bin at tile offset o lives at [o & 15][dec_slot(o >> 4)], dec_slot(i) = i + ((i + 9) >> 4): one pad
+// slot per 16 (= per column of the tile), so that the 16 columns a wave stores side by side (256 bins = 16 slots apart)
+// land in 16 different bank pairs instead of 2.  Pitch 296 = 8 (mod 32): the four phase groups of a reading half-wave
+// then fill the remaining bank pairs (17 g + 8 pq covers 0..31 once for g = 0..7, pq = 0..3).
+constexpr int kDecPitch = 296;                              // >= dec_slot(kDecLen / 16 - 1) + 1 = 287
+__device__ __forceinline__ constexpr int dec_slot(int i) { return i + ((i + 9) >> 4); }
 
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_PLAIN_DS_OPS)) void k_pair_decimate16(const PWDesc *pw, const float2 *Z, float2 *G, FftPlan pl,
-                                                         const float *taps, int T)
+                                                         const float *taps)
 {
     extern __shared__ float2 lds[];                          // [2][16][kDecPitch]
     float2 *qa = lds, *qb = lds + 16 * kDecPitch;
-    (void)T;
     const int t = threadIdx.x;
     const PWDesc d = pw[blockIdx.y];
     const float2 *Za = Z + (size_t)d.sw_a * pl.Nc, *Zb = Z + (size_t)d.sw_b * pl.Nc;
@@ -553,44 +562,51 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_
     const long long kA0 = 256ll * c0 - kDecHalo;             // first bin of tile A (mod Nc)
     const float invNc = 1.0f / (float)pl.Nc;
     // bin k of tile A at offset e has its partner Nc - k at offset kDecLen - 1 - e of tile B.
-    // One element: loads of the bin and its mirror in both spectra, K3, two LDS stores
-    auto coords = [&](int k2, int col, int &e, long long &k, size_t &at, size_t &atm) {
+    // spectra in 16-column tiles (k_fwd_row4096 with a tiled output): element (k2, k1) at [k1 >> 4][k2][k1 & 15]
+    auto coords = [&](int k2, int col, int &e, long long &k, unsigned int &at, unsigned int &atm) {
         e = k2 + 256 * col + kDecHalo;
         k = (kA0 + e) & mask;
         const int k1 = (int)(k >> 8);
         const int pr = (256 - k2) & 255, pc = ((k2 == 0 ? 4096 : 4095) - k1) & 4095;
-        at = (size_t)k2 * 4096 + k1;
-        atm = (size_t)pr * 4096 + pc;
+        at = (unsigned int)(k1 >> 4) * 4096u + (unsigned int)k2 * 16u + (unsigned int)(k1 & 15);
+        atm = (unsigned int)(pc >> 4) * 4096u + (unsigned int)pr * 16u + (unsigned int)(pc & 15);
     };
-    auto finish = [&](int e, long long k, float2 za, float2 zam, float2 zb, float2 zbm) {
-        float2 q, qm;
-        pair_q(za, zam, zb, zbm, unit_root((float)k, invNc, false), q, qm);
+    auto put = [&](int e, float2 q, float2 qm) {
         const int eb = kDecLen - 1 - e;
-        qa[(e & 15) * kDecPitch + (e >> 4)] = q;
-        qb[(eb & 15) * kDecPitch + (eb >> 4)] = qm;
+        qa[(e & 15) * kDecPitch + dec_slot(e >> 4)] = q;
+        qb[(eb & 15) * kDecPitch + dec_slot(eb >> 4)] = qm;
     };
     {
-        // main part: 256 rows x 16 columns, column fastest (128-byte pieces of a row); all 32 loads of a thread first
+        // main part of a tile: 256 rows x 16 columns = 8 elements per thread, t + 512 it in tile order (one contiguous
+        // 4 KB run per trip); all 32 loads of a thread are issued first
         float2 za[8], zam[8], zb[8], zbm[8];
+        int e0; long long k0; unsigned int a0, am0;
+        coords(t >> 4, t & 15, e0, k0, a0, am0);
 #pragma unroll
         for (int it = 0; it < 8; it++) {
-            int e; long long k; size_t at, atm;
+            int e; long long k; unsigned int at, atm;
             coords((t >> 4) + 32 * it, t & 15, e, k, at, atm);
             za[it] = Za[at]; zam[it] = Za[atm]; zb[it] = Zb[at]; zbm[it] = Zb[atm];
         }
+        // w(k) = W_N^k; a thread's bins are 32 apart (k2 = (t >> 4) + 32 it): one root, then a fixed rotation
+        float2 w = unit_root((float)k0, invNc, false);
+        const float2 rot = unit_root(32.0f, invNc, false);
 #pragma unroll
         for (int it = 0; it < 8; it++) {
-            int e; long long k; size_t at, atm;
-            coords((t >> 4) + 32 * it, t & 15, e, k, at, atm);
-            finish(e, k, za[it], zam[it], zb[it], zbm[it]);
+            float2 q, qm;
+            pair_q(za[it], zam[it], zb[it], zbm[it], w, q, qm);
+            put(e0 + 32 * it, q, qm);
+            w = cmul(w, rot);
         }
     }
     if (t < 2 * kDecHalo) {
         // the two halos of tile A: column c0 - 1, rows 144..255, and column c0 + 16, rows 0..111
         const int k2 = t < kDecHalo ? 256 - kDecHalo + t : t - kDecHalo, col = t < kDecHalo ? -1 : kDecCols;
-        int e; long long k; size_t at, atm;
+        int e; long long k; unsigned int at, atm;
         coords(k2, col, e, k, at, atm);
-        finish(e, k, Za[at], Za[atm], Zb[at], Zb[atm]);
+        float2 q, qm;
+        pair_q(Za[at], Za[atm], Zb[at], Zb[atm], unit_root((float)k, invNc, false), q, qm);
+        put(e, q, qm);
     }
     __syncthreads();
     // FIR + decimation.  Output i of a tile needs the bins at tile offsets 16 i + o, o in [o0, o0 + 2T],
@@ -598,35 +614,43 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_
     // the taps out that way per tile (zeros where o falls outside the filter): taps[tile][p][16], s = 0..14.
     // A thread takes FOUR consecutive outputs and FOUR phases p = pq + 4 m: element [p][4 g + s'] serves the outputs
     // o = 0..3 with step s = s' - o, so 18 LDS reads per phase feed 60 multiply-adds (one read per output and tap
-    // would make the kernel LDS-bound: 13 reads of every bin).  Waves 0..3: tile A, 4..7: tile B; lane = 4 g_l + pq.
-    // Bank pairs of a half-wave: kDecPitch pq + 4 g_l, distinct because kDecPitch = 1 (mod 4).
-    const int tile = __builtin_amdgcn_readfirstlane(t >> 8);
-    const int pq = t & 3, g = (t & 255) >> 2;                // g = 0..63: outputs 4 g .. 4 g + 3 of the tile
-    const float2 *src = (tile ? qb : qa) + 4 * g;
+    // would make the kernel LDS-bound: 13 reads of every bin).  Waves 0..3: tile A, 4..7: tile B; wave w takes the
+    // output groups g = 4 g_l + (w & 3), lane = 4 g_l + pq: slot of element 4 g + s' = 17 g_l + [4 wq + s' + ((4 wq + 9 + s') >> 4)],
+    // the bracket a compile-time offset once the wave's wq is fixed (four copies of the loop, wave-uniform switch).
+    const int tile = __builtin_amdgcn_readfirstlane(t >> 8), wq = __builtin_amdgcn_readfirstlane((t >> 6) & 3);
+    const int pq = t & 3, gl = (t & 63) >> 2;
+    const float2 *src = (tile ? qb : qa) + 17 * gl;
     const float *tab = taps + tile * 256;
     float2 acc[4];
 #pragma unroll
     for (int o = 0; o < 4; o++) acc[o] = make_float2(0.0f, 0.0f);
+    auto fir = [&](auto wq_c) {
+        constexpr int WQ = decltype(wq_c)::value;
 #pragma unroll
-    for (int m = 0; m < 4; m++) {
-        const int p = pq + 4 * m;
-        float h[15];
+        for (int m = 0; m < 4; m++) {
+            const int p = pq + 4 * m;
+            float h[15];
 #pragma unroll
-        for (int s2 = 0; s2 < 15; s2++) h[s2] = tab[16 * p + s2];
-        const float2 *row = src + p * kDecPitch;
+            for (int s2 = 0; s2 < 15; s2++) h[s2] = tab[16 * p + s2];
+            const float2 *row = src + p * kDecPitch;
 #pragma unroll
-        for (int s1 = 0; s1 < 18; s1++) {
-            const float2 v = row[s1];
+            for (int s1 = 0; s1 < 18; s1++) {
+                const float2 v = row[4 * WQ + s1 + ((4 * WQ + 9 + s1) >> 4)];
 #pragma unroll
-            for (int o = 0; o < 4; o++) {
-                const int s2 = s1 - o;
-                if (s2 >= 0 && s2 < 15) {
-                    acc[o].x += h[s2] * v.x;
-                    acc[o].y += h[s2] * v.y;
+                for (int o = 0; o < 4; o++) {
+                    const int s2 = s1 - o;
+                    if (s2 >= 0 && s2 < 15) {
+                        acc[o].x += h[s2] * v.x;
+                        acc[o].y += h[s2] * v.y;
+                    }
                 }
             }
         }
-    }
+    };
+    if (wq == 0) fir(std::integral_constant<int, 0>{});
+    else if (wq == 1) fir(std::integral_constant<int, 1>{});
+    else if (wq == 2) fir(std::integral_constant<int, 2>{});
+    else fir(std::integral_constant<int, 3>{});
     // sum over the four phase groups (adjacent lanes); lane pq then writes output 4 g + pq
 #pragma unroll
     for (int o = 0; o < 4; o++) {
@@ -636,8 +660,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_
         acc[o].y += __shfl_xor(acc[o].y, 2, kWave);
     }
     const float2 mine = pq == 0 ? acc[0] : pq == 1 ? acc[1] : pq == 2 ? acc[2] : acc[3];
-    // j = 16 c0 + i (tile A) or 16 (4080 - c0) + i (tile B);  G[j & 15][j >> 4]
-    const int j = 16 * (tile ? 4080 - c0 : c0) + 4 * g + pq;
+    // j = 16 c0 + i (tile A) or 16 (4080 - c0) + i (tile B), i = 4 g + pq;  G[j & 15][j >> 4]
+    const int j = 16 * (tile ? 4080 - c0 : c0) + 4 * (4 * gl + wq) + pq;
     G[(size_t)blockIdx.y * (size_t)(pl.Nc / kDecD) + (size_t)(j & 15) * 4096 + (j >> 4)] = mine;
 }
 

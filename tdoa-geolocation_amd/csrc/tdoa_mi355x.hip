@@ -382,7 +382,10 @@ int reserve_fm_batch(tdoa_ctx *ctx, int n_sw, int maxlen, int n_pw, const FftPla
     if (ctx->prm.k1_gate && (rc = ensure(ctx, ctx->k1_power, sizeof(unsigned long long) * (size_t)n_sw))) return rc;
     if ((rc = ensure(ctx, ctx->tz, sizeof(float2) * (size_t)pl.Nc * n_sw))) return rc;
     if (n_pw && decimation_applies(ctx, pl, lag_lo, lag_hi) && (rc = ensure_decimation(ctx, pl, lag_lo, lag_hi))) return rc;
-    if (n_pw && (rc = ensure(ctx, ctx->v, sizeof(float2) * (size_t)pl.Nc * n_pw))) return rc;
+    size_t v_elems = (size_t)pl.Nc * n_pw;
+    if (n_pw && decimation_applies(ctx, pl, lag_lo, lag_hi))      // G + V' of the pairs, then the tiled spectra of the stations
+        v_elems = std::max(v_elems, 2 * (size_t)(pl.Nc / kDecD) * n_pw + (size_t)pl.Nc * n_sw);
+    if (n_pw && (rc = ensure(ctx, ctx->v, sizeof(float2) * v_elems))) return rc;
     return TDOA_OK;
 }
 
@@ -514,8 +517,8 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
     // three stations / three pairs per window (every quad of the batch has that pattern): all six row transforms of a
     // window's row pair in one kernel, k_rows_tri_fused (general form only)
     const bool tri_rows = row16 && ctx->tri_rows && tri_quads && d_quads && n_quads > 0 && 3 * n_quads == n_pw && !seg_chunks &&
-                          fk == 0 && pl.N2 > 2;
-    const bool fused_rows = tri_rows || (row16 && ctx->fused_rows && n_pw > 0 && n_pw <= n_sw);
+                          fk == 0 && pl.N2 > 2 && !decim;
+    const bool fused_rows = !decim && (tri_rows || (row16 && ctx->fused_rows && n_pw > 0 && n_pw <= n_sw));
     // XCD-aware 1-D grid of the pair kernel when every window of the group carries the same `pairs_per_window` > S pairs
     // (window-major sharding with more pairs than stations): see k_inv_row_pair4096
     int xcd_pairs = 0;
@@ -529,9 +532,12 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
     if (!seg_chunks) {
         ProfScope ps(ctx, TDOA_K_FWD_ROW, fused_rows ? 2.0 * 8.0 * 4096 * 2 * n_sw : 2.0 * nc8 * n_sw);
         if (fused_rows)    // only the two self-mirrored rows 0 and N2/2 (their pair kernel reads finished spectra)
-            hipLaunchKernelGGL(k_fwd_row4096, dim3(2, n_sw), dim3(256), 0, st, tz, pl, pl.N2 / 2);
+            hipLaunchKernelGGL(k_fwd_row4096, dim3(2, n_sw), dim3(256), 0, st, tz, pl, pl.N2 / 2, static_cast<float2 *>(nullptr));
+        else if (row16 && decim)     // spectra in 16-column tiles behind G and V' in the V workspace (k_pair_decimate16 streams them)
+            hipLaunchKernelGGL(k_fwd_row4096, dim3(pl.N2, n_sw), dim3(256), 0, st, tz, pl, 1,
+                               v + 2 * (size_t)(pl.Nc / kDecD) * (size_t)n_pw);
         else if (row16)
-            hipLaunchKernelGGL(k_fwd_row4096, dim3(pl.N2, n_sw), dim3(256), 0, st, tz, pl, 1);
+            hipLaunchKernelGGL(k_fwd_row4096, dim3(pl.N2, n_sw), dim3(256), 0, st, tz, pl, 1, static_cast<float2 *>(nullptr));
         else
             hipLaunchKernelGGL(k_fwd_row, dim3(pl.N2, n_sw), dim3(256), lds_row, st, tz, pl);
     }
@@ -581,8 +587,8 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
         {
             ProfScope ps(ctx, TDOA_K_INV_ROW, 2.0 * nc8 * n_pw + 8.0 * (double)rc_pts * n_pw);      // two spectra read, G written
             hipLaunchKernelGGL(k_pair_decimate16, dim3(pl.N1 / (2 * kDecCols), n_pw), dim3(512),
-                               sizeof(float2) * 2 * 16 * kDecPitch, st, d_pw, tz, g, pl,
-                               static_cast<const float *>(ctx->dec_taps.p), ctx->dec_T);
+                               sizeof(float2) * 2 * 16 * kDecPitch, st, d_pw, vs + rc_pts * (size_t)n_pw, g, pl,
+                               static_cast<const float *>(ctx->dec_taps.p));
         }
         {
             ProfScope ps(ctx, TDOA_K_INV_COL, 3.0 * 8.0 * (double)rc_pts * n_pw);
@@ -1359,6 +1365,7 @@ static int process_impl(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host,
         }
         if (!quads.empty())
             HIPCHK(ctx, hipMemcpyAsync(d_quads, quads.data(), sizeof(QuadDesc) * quads.size(), hipMemcpyHostToDevice, st));
+
         HIPCHK(ctx, hipStreamSynchronize(st));   // host vectors go out of scope below
     }
 
