@@ -119,8 +119,9 @@ __device__ __forceinline__ void row4096_finish(float2 (&v)[16], float2 *lds, int
 // ---------------------------------------------------------------------------
 // row_mul: row index = blockIdx.x * row_mul (1: every row, grid.x = N2; N2/2: only the two self-mirrored rows 0 and
 // N2/2, grid.x = 2 -- the rest of the rows are then transformed inside k_pair_rows_fused_r8, fft_radix8.hpp)
-// tiled != nullptr: the spectrum goes there in 16-column tiles, element (k2, k1) at [k1 >> 4][k2][k1 & 15] -- the layout
-// k_pair_decimate16 streams (a tile of all N2 rows x 16 columns is one contiguous run); TZ keeps the column-pass output.
+// tiled != nullptr: the spectrum goes there in tiles of COLS = 4096/N2 columns, element (k2, k1) at
+// [k1 / COLS][k2][k1 % COLS] -- the layout k_pair_decimate16 streams (a tile of all N2 rows x COLS columns = 4096
+// consecutive bins is one contiguous run); TZ keeps the column-pass output.
 __global__ __launch_bounds__(256) void k_fwd_row4096(float2 *TZ, FftPlan pl, int row_mul, float2 *tiled = nullptr)
 {
     __shared__ float2 lds[kRowLds];
@@ -133,9 +134,11 @@ __global__ __launch_bounds__(256) void k_fwd_row4096(float2 *TZ, FftPlan pl, int
     fft16<false>(v);
     row4096_finish<false>(v, lds, j);
     if (tiled) {
-        float2 *out = tiled + (size_t)blockIdx.y * pl.Nc + (size_t)(j >> 4) * ((size_t)pl.N2 * 16) + (size_t)k2 * 16 + (j & 15);
+        // tiles of COLS = 4096 / N2 columns x N2 rows = 4096 elements: column k1 = j + 256 k -> tile k1 / COLS
+        const int cols = 4096 / pl.N2;
+        float2 *out = tiled + (size_t)blockIdx.y * pl.Nc + (size_t)(j / cols) * 4096 + (size_t)k2 * cols + (j % cols);
 #pragma unroll
-        for (int k = 0; k < 16; k++) out[(size_t)(16 * k) * ((size_t)pl.N2 * 16)] = v[oreg(k)];
+        for (int k = 0; k < 16; k++) out[(size_t)(256 / cols) * k * 4096] = v[oreg(k)];
     } else {
 #pragma unroll
         for (int k = 0; k < 16; k++) row[j + 256 * k] = v[oreg(k)];

@@ -518,7 +518,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA
 }
 
 // ---------------------------------------------------------------------------
-// Decimated inverse (N2 = 256; search ranges of a few ten thousand lags in a transform of millions).
+// Decimated inverse (N2 = 256 or 512; search ranges of a few ten thousand lags in a transform of millions).
 // Only |lag| <= max_lag of the 2 Nc inverse outputs are wanted: ~1 % for the reference's 20 000 lags in N = 2^21.  The
 // general form still runs the whole inverse (row pass: Q -> V, 8 Nc bytes written and read back per pair-window).
 // Multiplying the lag sequence q[m] by a smooth window w[m] that vanishes outside |m| < R - M lets the SPECTRUM be
@@ -528,17 +528,16 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA
 // host evaluates it from the rounded taps) and is divided out.  So K3 is followed by a 13-tap-per-bin FIR instead of
 // a 4096-point row transform, V shrinks 16 times, and the pair step is one streaming read of the two spectra.
 //
-// k = k2 + 256 k1: consecutive bins run down a column, so a workgroup takes a tile of all 256 rows x 16 columns
+// k = k2 + N2 k1: consecutive bins run down a column, so a workgroup takes a tile of all N2 rows x 4096/N2 columns
 // (4096 consecutive bins; the forward row pass writes the spectra tile by tile for this kernel, so a tile is one
-// contiguous 32 KB run instead of 256 row pieces of 128 bytes) and, because K3 needs Z[k] and Z[Nc - k] together, the
-// mirrored tile:
-//   tile A: bins [256 c0 - 112, 256 (c0 + 16) + 112), tile B: bins Nc - (those), both with their halos.
+// contiguous 32 KB run instead of N2 row pieces) and, because K3 needs Z[k] and Z[Nc - k] together, the mirrored tile:
+//   tile A: bins [4096 bx - 112, 4096 (bx + 1) + 112), tile B: bins Nc - (those), both with their halos.
 // Q of both tiles goes to LDS phase-major (bin o of a tile at [o & 15][o >> 4]) so that thread i of the FIR reads
 // element i + const of one phase for every tap: conflict-free.  256 outputs per tile, one per thread.
-// G is written as the [16][4096] four-step layout of the R-point inverse (j = j2 + 16 j1).
+// G is written as the [N2'][4096] four-step layout of the R-point inverse (j = j2 + N2' j1, N2' = N2/16).
 // (A variant that kept the template's tiles in registers for up to four pair-windows sharing it read a third fewer
 // bytes and ran 8 - 30 % slower: one more barrier pair per pair-window and 128 VGPRs with spills.)
-// grid (128, n_pw), 512 threads, dynamic LDS 2 x 16 x 296 x 8 B = 74 KB.
+// grid (N2/2, n_pw), 512 threads, dynamic LDS 2 x 16 x 296 x 8 B = 74 KB.
 // ---------------------------------------------------------------------------
 constexpr int kDecD = 16, kDecHalo = 112, kDecCols = 16;
 constexpr int kDecLen = 256 * kDecCols + 2 * kDecHalo;      // bins of one LDS tile
@@ -549,27 +548,27 @@ constexpr int kDecLen = 256 * kDecCols + 2 * kDecHalo;      // bins of one LDS t
 constexpr int kDecPitch = 296;                              // >= dec_slot(kDecLen / 16 - 1) + 1 = 287
 __device__ __forceinline__ constexpr int dec_slot(int i) { return i + ((i + 9) >> 4); }
 
+template <int LOGN2>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_PLAIN_DS_OPS)) void k_pair_decimate16(const PWDesc *pw, const float2 *Z, float2 *G, FftPlan pl,
-                                                         const float *taps)
+                                                         const float *taps, int small_n2)
 {
+    constexpr int N2 = 1 << LOGN2, COLS = 4096 >> LOGN2;     // a tile: all N2 rows x COLS columns = 4096 consecutive bins
     extern __shared__ float2 lds[];                          // [2][16][kDecPitch]
     float2 *qa = lds, *qb = lds + 16 * kDecPitch;
     const int t = threadIdx.x;
     const PWDesc d = pw[blockIdx.y];
     const float2 *Za = Z + (size_t)d.sw_a * pl.Nc, *Zb = Z + (size_t)d.sw_b * pl.Nc;
-    const int c0 = blockIdx.x * kDecCols;
     const long long mask = pl.Nc - 1;
-    const long long kA0 = 256ll * c0 - kDecHalo;             // first bin of tile A (mod Nc)
+    const long long kA0 = 4096ll * blockIdx.x - kDecHalo;    // first bin of tile A (mod Nc)
     const float invNc = 1.0f / (float)pl.Nc;
     // bin k of tile A at offset e has its partner Nc - k at offset kDecLen - 1 - e of tile B.
-    // spectra in 16-column tiles (k_fwd_row4096 with a tiled output): element (k2, k1) at [k1 >> 4][k2][k1 & 15]
-    auto coords = [&](int k2, int col, int &e, long long &k, unsigned int &at, unsigned int &atm) {
-        e = k2 + 256 * col + kDecHalo;
+    // spectra in COLS-column tiles (k_fwd_row4096 with a tiled output): element (k2, k1) at [k1 / COLS][k2][k1 % COLS]
+    auto coords = [&](int e, long long &k, unsigned int &at, unsigned int &atm) {
         k = (kA0 + e) & mask;
-        const int k1 = (int)(k >> 8);
-        const int pr = (256 - k2) & 255, pc = ((k2 == 0 ? 4096 : 4095) - k1) & 4095;
-        at = (unsigned int)(k1 >> 4) * 4096u + (unsigned int)k2 * 16u + (unsigned int)(k1 & 15);
-        atm = (unsigned int)(pc >> 4) * 4096u + (unsigned int)pr * 16u + (unsigned int)(pc & 15);
+        const int k2 = (int)(k & (N2 - 1)), k1 = (int)(k >> LOGN2);
+        const int pr = (N2 - k2) & (N2 - 1), pc = ((k2 == 0 ? 4096 : 4095) - k1) & 4095;
+        at = (unsigned int)(k1 / COLS) * 4096u + (unsigned int)k2 * COLS + (unsigned int)(k1 % COLS);
+        atm = (unsigned int)(pc / COLS) * 4096u + (unsigned int)pr * COLS + (unsigned int)(pc % COLS);
     };
     auto put = [&](int e, float2 q, float2 qm) {
         const int eb = kDecLen - 1 - e;
@@ -577,33 +576,34 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_
         qb[(eb & 15) * kDecPitch + dec_slot(eb >> 4)] = qm;
     };
     {
-        // main part of a tile: 256 rows x 16 columns = 8 elements per thread, t + 512 it in tile order (one contiguous
-        // 4 KB run per trip); all 32 loads of a thread are issued first
+        // main part of a tile: 4096 elements, 8 per thread, x = t + 512 it in tile order (k2 = x / COLS, column x % COLS:
+        // one contiguous 4 KB run per trip); all 32 loads of a thread are issued first
         float2 za[8], zam[8], zb[8], zbm[8];
-        int e0; long long k0; unsigned int a0, am0;
-        coords(t >> 4, t & 15, e0, k0, a0, am0);
+        const int e0 = t / COLS + N2 * (t % COLS) + kDecHalo;      // x -> tile offset k2 + N2 col + halo; + (512 / COLS) per trip
+        long long k0;
 #pragma unroll
         for (int it = 0; it < 8; it++) {
-            int e; long long k; unsigned int at, atm;
-            coords((t >> 4) + 32 * it, t & 15, e, k, at, atm);
+            long long k; unsigned int at, atm;
+            coords(e0 + (512 / COLS) * it, k, at, atm);
+            if (it == 0) k0 = k;
             za[it] = Za[at]; zam[it] = Za[atm]; zb[it] = Zb[at]; zbm[it] = Zb[atm];
         }
-        // w(k) = W_N^k; a thread's bins are 32 apart (k2 = (t >> 4) + 32 it): one root, then a fixed rotation
+        // w(k) = W_N^k; a thread's bins are 512 / COLS apart: one root, then a fixed rotation
         float2 w = unit_root((float)k0, invNc, false);
-        const float2 rot = unit_root(32.0f, invNc, false);
+        const float2 rot = unit_root((float)(512 / COLS), invNc, false);
 #pragma unroll
         for (int it = 0; it < 8; it++) {
             float2 q, qm;
             pair_q(za[it], zam[it], zb[it], zbm[it], w, q, qm);
-            put(e0 + 32 * it, q, qm);
+            put(e0 + (512 / COLS) * it, q, qm);
             w = cmul(w, rot);
         }
     }
     if (t < 2 * kDecHalo) {
-        // the two halos of tile A: column c0 - 1, rows 144..255, and column c0 + 16, rows 0..111
-        const int k2 = t < kDecHalo ? 256 - kDecHalo + t : t - kDecHalo, col = t < kDecHalo ? -1 : kDecCols;
-        int e; long long k; unsigned int at, atm;
-        coords(k2, col, e, k, at, atm);
+        // the two halos of tile A: the last 112 bins before it and the first 112 after it
+        const int e = t < kDecHalo ? t : 4096 + t;
+        long long k; unsigned int at, atm;
+        coords(e, k, at, atm);
         float2 q, qm;
         pair_q(Za[at], Za[atm], Zb[at], Zb[atm], unit_root((float)k, invNc, false), q, qm);
         put(e, q, qm);
@@ -660,9 +660,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_
         acc[o].y += __shfl_xor(acc[o].y, 2, kWave);
     }
     const float2 mine = pq == 0 ? acc[0] : pq == 1 ? acc[1] : pq == 2 ? acc[2] : acc[3];
-    // j = 16 c0 + i (tile A) or 16 (4080 - c0) + i (tile B), i = 4 g + pq;  G[j & 15][j >> 4]
-    const int j = 16 * (tile ? 4080 - c0 : c0) + 4 * (4 * gl + wq) + pq;
-    G[(size_t)blockIdx.y * (size_t)(pl.Nc / kDecD) + (size_t)(j & 15) * 4096 + (j >> 4)] = mine;
+    // output i = 4 g + pq of tile A is G[256 bx + i], of tile B G[R - 256 (bx + 1) + i]; four-step layout of the small
+    // plan: j = j2 + N2' j1 at [j2][j1]
+    const int rc = (int)(pl.Nc / kDecD);
+    const int j = (tile ? rc - 256 * ((int)blockIdx.x + 1) : 256 * (int)blockIdx.x) + 4 * (4 * gl + wq) + pq;
+    G[(size_t)blockIdx.y * (size_t)rc + (size_t)(j & (small_n2 - 1)) * 4096 + (j / small_n2)] = mine;
 }
 
 // inverse rows of the decimated spectrum (no K3, no mirror): rows a = 2 bx, b = a + 1 of G[16][4096] -> V'[k2][n1]

@@ -304,7 +304,7 @@ short *launch_k1(tdoa_ctx *ctx, hipStream_t st, const SWDesc *d_sw, int n_sw, in
 constexpr double kDecAttenuationDb = 140.0;
 bool decimation_applies(const tdoa_ctx *ctx, const FftPlan &pl, int lag_lo, int lag_hi)
 {
-    if (!ctx->decimate || ctx->force_generic || pl.N1 != 4096 || pl.N2 != 256) return false;
+    if (!ctx->decimate || ctx->force_generic || pl.N1 != 4096 || (pl.N2 != 256 && pl.N2 != 512)) return false;
     const int reach = std::max(lag_hi + 1, -(lag_lo - 1));
     if (reach <= 4095) return false;                       // the short-lag forms take those
     const long long M = reach / 2 + 2, R = pl.Nc / kDecD;
@@ -586,9 +586,12 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
         }
         {
             ProfScope ps(ctx, TDOA_K_INV_ROW, 2.0 * nc8 * n_pw + 8.0 * (double)rc_pts * n_pw);      // two spectra read, G written
-            hipLaunchKernelGGL(k_pair_decimate16, dim3(pl.N1 / (2 * kDecCols), n_pw), dim3(512),
-                               sizeof(float2) * 2 * 16 * kDecPitch, st, d_pw, vs + rc_pts * (size_t)n_pw, g, pl,
-                               static_cast<const float *>(ctx->dec_taps.p));
+            if (pl.N2 == 256)
+                hipLaunchKernelGGL(k_pair_decimate16<8>, dim3(pl.N2 / 2, n_pw), dim3(512), sizeof(float2) * 2 * 16 * kDecPitch, st,
+                                   d_pw, vs + rc_pts * (size_t)n_pw, g, pl, static_cast<const float *>(ctx->dec_taps.p), ps2.N2);
+            else
+                hipLaunchKernelGGL(k_pair_decimate16<9>, dim3(pl.N2 / 2, n_pw), dim3(512), sizeof(float2) * 2 * 16 * kDecPitch, st,
+                                   d_pw, vs + rc_pts * (size_t)n_pw, g, pl, static_cast<const float *>(ctx->dec_taps.p), ps2.N2);
         }
         {
             ProfScope ps(ctx, TDOA_K_INV_COL, 3.0 * 8.0 * (double)rc_pts * n_pw);
@@ -719,7 +722,8 @@ int allow_big_lds(tdoa_ctx *ctx)
     if ((rc = set_lds(ctx, k_xcorr_segments_quad<2>, all))) return rc;
     if ((rc = set_lds(ctx, k_xcorr_segments_quad<4>, all))) return rc;
     if ((rc = set_lds(ctx, k_rows_tri_fused, all))) return rc;
-    if ((rc = set_lds(ctx, k_pair_decimate16, all))) return rc;
+    if ((rc = set_lds(ctx, k_pair_decimate16<8>, all))) return rc;
+    if ((rc = set_lds(ctx, k_pair_decimate16<9>, all))) return rc;
     if ((rc = set_lds(ctx, k_inv_rows_plain_r8, all))) return rc;
     return TDOA_OK;
 }

@@ -528,11 +528,13 @@ def test_tri_fused_rows_vs_two_kernel_form(oracle, wl, ml, per_batch):
 
 @pytest.mark.parametrize("n1,n2,max_lag,delay", [(2_000_000, 2_000_000, 20000, 57), (1_234_567, 1_999_999, 20000, -19876),
                                                  (1_500_000, 1_100_000, 4096, 4001), (2_000_000, 2_000_000, 23000, 9),
-                                                 (2_000_000, 2_000_000, 26000, -25001)])
+                                                 (2_000_000, 2_000_000, 26000, -25001), (4_000_000, 3_999_000, 20000, 1234),
+                                                 (2_200_000, 3_100_000, 20000, -19999)])
 def test_decimated_inverse_vs_full_inverse(oracle, n1, n2, max_lag, delay):
-    """4096 x 256 plans, search ranges above 4095 lags: K3 + FIR decimation of the pair's spectrum + a 65536-point
-    inverse (k_pair_decimate16) against the full inverse (k_inv_row_pair4096 + k_inv_col_pruned), every lag, and both
-    against the f64 oracle.  26000 lags leave no room for the transition band: that range must fall back by itself."""
+    """4096 x 256 and 4096 x 512 plans, search ranges above 4095 lags: K3 + FIR decimation of the pair's spectrum + an
+    Nc/16-point inverse (k_pair_decimate16) against the full inverse (k_inv_row_pair4096 + k_inv_col_pruned), every lag,
+    and both against the f64 oracle.  26000 lags on the 4096 x 256 plan leave no room for the transition band: that
+    range must fall back by itself."""
     import tdoa_amd
     a = oracle.simulate_delayed_fm(n1, max(0, -delay), 91, 1)
     b = oracle.simulate_delayed_fm(n2, max(0, delay), 91, 2)
@@ -543,7 +545,7 @@ def test_decimated_inverse_vs_full_inverse(oracle, n1, n2, max_lag, delay):
     with tdoa_amd.Context(max_lag=max_lag, window_len=max(n1, n2)) as c:
         dec = c.fm_xcorr_lags(a, b, max_lag)
         lag, corr = c.fm_xcorr(a, b, max_lag)
-        assert c.plan_info()[1:] == (4096, 256)
+        assert c.plan_info()[1:] == ((4096, 256) if max(n1, n2) <= 2_000_000 else (4096, 512))
         c.debug_flags(no_decimate=True, no_fused_rows=True)        # (a cleared bit would switch the fused forward rows on)
         full = c.fm_xcorr_lags(a, b, max_lag)
         lag_f, corr_f = c.fm_xcorr(a, b, max_lag)
