@@ -101,6 +101,16 @@ def pmc_traffic(kernel):
         return None, None, None
 
 
+def decimation_fits(nc, max_lag):
+    """the library's rule (tdoa_mi355x.hip decimation_applies): the Kaiser filter for 140 dB between the pass band
+    |m| <= M = max_lag/2 + 2 and the stop band |m| >= Nc/16 - M must fit 111 taps a side"""
+    m, r = max_lag // 2 + 2, nc // 16
+    if r - 2 * m <= 0:
+        return False
+    dw = 2.0 * math.pi * (r - 2 * m) / nc
+    return math.ceil((140.0 - 8.0) / (2.285 * dw) / 2.0) <= 111
+
+
 def cpu_info():
     model, phys = "unknown", set()
     try:
@@ -376,6 +386,10 @@ def main():
                    else "k_fwd_col256_c16<true> + k_fwd_col_finish")
             hot = {"k_fm_demod": "k_fm_demod", "k_fwd_col": col, "k_fwd_row": "k_fwd_row4096",
                    "k_inv_row_pair": "k_inv_row_pair4096", "k_inv_col_peak": "k_inv_col_pruned"}
+        decimated = (n1 == 4096 and n2 in (256, 512) and max_lag > 4096 and os.environ.get("TDOA_NO_DECIMATE") != "1"
+                     and decimation_fits(n1 * n2, max_lag))
+        if decimated:     # K3 + 16:1 FIR decimation of the pair spectrum, then an Nc/16-point inverse
+            hot = dict(hot, k_inv_row_pair="k_pair_decimate16", k_inv_col_peak="k_inv_rows_plain_r8 + k_inv_col_pruned_any")
         if max_lag <= 1024 and n1 == 4096:
             # segment form; with 3+ pairs per window the station transforms are shared (quads)
             hot = dict(hot, k_inv_row_pair="k_xcorr_segments_quad" if n_pairs >= 3 and os.environ.get("TDOA_NO_SEGMENT_QUADS") != "1"
@@ -397,6 +411,11 @@ def main():
                     "algorithmic_bytes_per_launch": per_launch_bytes,
                     "avg_launch_us": round(avg_s * 1e6, 2), "launches": rec["launches"],
                     "kernels_ms_per_step": {k: round(v["ms"] / steps, 4) for k, v in prof.items()}}
+            if roof["kernel"] == "k_pair_decimate16":
+                roof["note"] = ("decimated inverse: this kernel reads the two station spectra of a pair once and writes 1/16 of "
+                                "a spectrum; SURVEY's byte model for the pair step (two spectra read, V written, V read) is "
+                                "24 N bytes per pair-window, this form moves 16.5 N -- pipeline_algorithmic_GBps keeps SURVEY's "
+                                "model, so it now overstates the bytes actually moved by the difference")
             if roof["kernel"].startswith("k_xcorr_segments"):
                 roof["note"] = ("segment form: 4096-point transforms in LDS and registers, limited by vector-instruction issue "
                                 "(DESIGN.md section 3); its HBM traffic is the 2-byte phase codes only, so the HBM fraction "

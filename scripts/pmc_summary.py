@@ -5,6 +5,7 @@ coalesced loads.  Calibration on this pipeline's own kernels (known byte counts,
   k_fwd_row4096 (8 B/lane float2 rows)  : FETCH_SIZE*1024 / bytes read = 0.500  -> x2
   k_inv_col_pruned (16 B/lane)          : 0.500 -> x2      k_fm_demod (16 B/lane): 0.504 -> x2
   k_fwd_col256_c16 (4 B/lane, 128-B runs): 0.94 -> x1 (left uncorrected)
+  k_pair_decimate16 (8 B/lane float2, contiguous 4 KB runs of a tile): as k_fwd_row4096 -> x2 (checked: see DESIGN.md 6)
   WRITE_SIZE*1024 / bytes written = 1.000 for every kernel -> x1
 usage: pmc_summary.py <fetch_dir> <write_dir> <out.json>"""
 import collections
@@ -18,7 +19,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import source_hash  # noqa: E402  (hash of the kernel sources the counters were taken on)
 
 FETCH_CORRECTION = {"k_fm_demod": 2.0, "k_fwd_row4096": 2.0, "k_inv_row_pair4096": 2.0, "k_inv_col_pruned": 2.0,
-                    "k_fwd_col256_c16": 1.0}
+                    "k_fwd_col256_c16": 1.0, "k_pair_decimate16": 2.0, "k_inv_rows_plain_r8": 2.0, "k_inv_col_pruned_any": 2.0}
 
 
 def load(d):
