@@ -539,17 +539,26 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA
 // bytes and ran 8 - 30 % slower: one more barrier pair per pair-window and 128 VGPRs with spills.)
 // grid (N2/2, n_pw), 512 threads, dynamic LDS 2 x 16 x 296 x 8 B = 74 KB.
 // ---------------------------------------------------------------------------
-constexpr int kDecD = 16, kDecHalo = 112, kDecCols = 16;
-constexpr int kDecLen = 256 * kDecCols + 2 * kDecHalo;      // bins of one LDS tile
-// LDS image of a tile: bin at tile offset o lives at [o & 15][dec_slot(o >> 4)], dec_slot(i) = i + ((i + 9) >> 4): one pad
-// slot per 16 (= per column of the tile), so that the 16 columns a wave stores side by side (256 bins = 16 slots apart)
-// land in 16 different bank pairs instead of 2.  Pitch 296 = 8 (mod 32): the four phase groups of a reading half-wave
-// then fill the remaining bank pairs (17 g + 8 pq covers 0..31 once for g = 0..7, pq = 0..3).
-constexpr int kDecPitch = 296;                              // >= dec_slot(kDecLen / 16 - 1) + 1 = 287
-__device__ __forceinline__ constexpr int dec_slot(int i) { return i + ((i + 9) >> 4); }
+constexpr int kDecD = 16;
+constexpr int kDecSteps = 14;                               // a tap t = 16 (s - 7) + p: phase p = 0..15, step s = 0..13, |t| <= T <= 111
+constexpr int kDecEdge = 7;                                 // outputs on either side of a tile boundary that the other tile's bins reach
+// LDS image of a tile (4096 consecutive bins, no halo): bin o lives at [o & 15][dec_slot((o >> 4) + 8)],
+// dec_slot(i) = i + ((i + 8) >> 4).  8 zero slots on either side stand for the neighbouring tiles (their share of an
+// edge output is added by THEIR workgroup, see below); one pad slot per 16 (= per column of the tile) puts the 16 columns
+// a wave stores side by side (256 bins = 16 slots apart) into 16 different bank pairs instead of 2.  Pitch 296 = 8 (mod 32):
+// the four phase groups of a reading half-wave then fill the remaining bank pairs (17 g + 8 pq covers 0..31 once).
+constexpr int kDecPitch = 296;                              // >= dec_slot(271) + 1 = 289
+__device__ __forceinline__ constexpr int dec_slot(int i) { return i + ((i + 8) >> 4); }
 
+// Tile A = bins [4096 bx, 4096 (bx + 1)), tile B = bins [Nc - 4096 (bx + 1), Nc - 4096 bx): bin o >= 1 of A and bin
+// 4096 - o of B are partners (k, Nc - k); the partners of A[0] and B[0] lie in the neighbouring workgroups' tiles and
+// are only read.  An output whose 2T+1 taps cross a tile boundary gets the far side's share from the workgroup that owns
+// those bins: every tile also evaluates the 7 + 7 outputs just outside it over its own bins and leaves them in
+// E[pw][tile][14] (slots 0..6: outputs 249..255 of the previous tile, 7..13: outputs 0..6 of the next one);
+// k_inv_rows_plain_r8 adds them when it loads G.  No halo is fetched: the halo bins of a [tile][k2][col] layout are 8-byte
+// pieces of 224 different lines per tile side and spectrum, which nearly doubled the bytes this kernel pulled in.
 template <int LOGN2>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_PLAIN_DS_OPS)) void k_pair_decimate16(const PWDesc *pw, const float2 *Z, float2 *G, FftPlan pl,
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_PLAIN_DS_OPS)) void k_pair_decimate16(const PWDesc *pw, const float2 *Z, float2 *G, float2 *E, FftPlan pl,
                                                          const float *taps, int small_n2)
 {
     constexpr int N2 = 1 << LOGN2, COLS = 4096 >> LOGN2;     // a tile: all N2 rows x COLS columns = 4096 consecutive bins
@@ -559,68 +568,67 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_
     const PWDesc d = pw[blockIdx.y];
     const float2 *Za = Z + (size_t)d.sw_a * pl.Nc, *Zb = Z + (size_t)d.sw_b * pl.Nc;
     const long long mask = pl.Nc - 1;
-    const long long kA0 = 4096ll * blockIdx.x - kDecHalo;    // first bin of tile A (mod Nc)
+    const long long kA0 = 4096ll * blockIdx.x;               // first bin of tile A
     const float invNc = 1.0f / (float)pl.Nc;
-    // bin k of tile A at offset e has its partner Nc - k at offset kDecLen - 1 - e of tile B.
     // spectra in COLS-column tiles (k_fwd_row4096 with a tiled output): element (k2, k1) at [k1 / COLS][k2][k1 % COLS]
-    auto coords = [&](int e, long long &k, unsigned int &at, unsigned int &atm) {
-        k = (kA0 + e) & mask;
+    auto coords = [&](long long k, unsigned int &at, unsigned int &atm) {
         const int k2 = (int)(k & (N2 - 1)), k1 = (int)(k >> LOGN2);
         const int pr = (N2 - k2) & (N2 - 1), pc = ((k2 == 0 ? 4096 : 4095) - k1) & 4095;
         at = (unsigned int)(k1 / COLS) * 4096u + (unsigned int)k2 * COLS + (unsigned int)(k1 % COLS);
         atm = (unsigned int)(pc / COLS) * 4096u + (unsigned int)pr * COLS + (unsigned int)(pc % COLS);
     };
-    auto put = [&](int e, float2 q, float2 qm) {
-        const int eb = kDecLen - 1 - e;
-        qa[(e & 15) * kDecPitch + dec_slot(e >> 4)] = q;
-        qb[(eb & 15) * kDecPitch + dec_slot(eb >> 4)] = qm;
-    };
+    auto slot_of = [](int o) { return (o & 15) * kDecPitch + dec_slot((o >> 4) + 8); };
+    // zero slots on either side of both images: 16 phases x (8 + 8) x 2 tiles = 512 entries, one per thread
     {
-        // main part of a tile: 4096 elements, 8 per thread, x = t + 512 it in tile order (k2 = x / COLS, column x % COLS:
-        // one contiguous 4 KB run per trip); all 32 loads of a thread are issued first
+        const int img = t >> 8, p = (t >> 4) & 15, z = t & 15;
+        (img ? qb : qa)[p * kDecPitch + dec_slot(z < 8 ? z : 256 + z)] = make_float2(0.0f, 0.0f);
+    }
+    {
+        // a tile's 4096 elements, 8 per thread, x = t + 512 it in tile order (k2 = x / COLS, column x % COLS: one
+        // contiguous 4 KB run per trip); all 32 loads of a thread are issued first
         float2 za[8], zam[8], zb[8], zbm[8];
-        const int e0 = t / COLS + N2 * (t % COLS) + kDecHalo;      // x -> tile offset k2 + N2 col + halo; + (512 / COLS) per trip
-        long long k0;
+        const int o0 = t / COLS + N2 * (t % COLS);                 // x -> bin offset k2 + N2 col; + 512 / COLS per trip
 #pragma unroll
         for (int it = 0; it < 8; it++) {
-            long long k; unsigned int at, atm;
-            coords(e0 + (512 / COLS) * it, k, at, atm);
-            if (it == 0) k0 = k;
+            unsigned int at, atm;
+            coords((kA0 + o0 + (512 / COLS) * it) & mask, at, atm);
             za[it] = Za[at]; zam[it] = Za[atm]; zb[it] = Zb[at]; zbm[it] = Zb[atm];
         }
         // w(k) = W_N^k; a thread's bins are 512 / COLS apart: one root, then a fixed rotation
-        float2 w = unit_root((float)k0, invNc, false);
+        float2 w = unit_root((float)(kA0 + o0), invNc, false);
         const float2 rot = unit_root((float)(512 / COLS), invNc, false);
 #pragma unroll
         for (int it = 0; it < 8; it++) {
+            const int o = o0 + (512 / COLS) * it;
             float2 q, qm;
             pair_q(za[it], zam[it], zb[it], zbm[it], w, q, qm);
-            put(e0 + (512 / COLS) * it, q, qm);
+            qa[slot_of(o)] = q;
+            if (o) qb[slot_of(4096 - o)] = qm;                     // the partner of A[0] is B[0] of the workgroup before
             w = cmul(w, rot);
         }
     }
-    if (t < 2 * kDecHalo) {
-        // the two halos of tile A: the last 112 bins before it and the first 112 after it
-        const int e = t < kDecHalo ? t : 4096 + t;
-        long long k; unsigned int at, atm;
-        coords(e, k, at, atm);
+    if (t == 0) {
+        // B[0]: its partner is A[0] of the next workgroup's tile
+        const long long k = (pl.Nc - 4096ll * ((long long)blockIdx.x + 1)) & mask;
+        unsigned int at, atm;
+        coords(k, at, atm);
         float2 q, qm;
         pair_q(Za[at], Za[atm], Zb[at], Zb[atm], unit_root((float)k, invNc, false), q, qm);
-        put(e, q, qm);
+        qb[slot_of(0)] = q;
     }
     __syncthreads();
-    // FIR + decimation.  Output i of a tile needs the bins at tile offsets 16 i + o, o in [o0, o0 + 2T],
-    // o0 = (112 or 111) - T >= 0, o0 + 2T < 240: with o = 16 s + p the filter is 16 phases x 15 steps, and the host lays
-    // the taps out that way per tile (zeros where o falls outside the filter): taps[tile][p][16], s = 0..14.
-    // A thread takes FOUR consecutive outputs and FOUR phases p = pq + 4 m: element [p][4 g + s'] serves the outputs
-    // o = 0..3 with step s = s' - o, so 18 LDS reads per phase feed 60 multiply-adds (one read per output and tap
-    // would make the kernel LDS-bound: 13 reads of every bin).  Waves 0..3: tile A, 4..7: tile B; wave w takes the
-    // output groups g = 4 g_l + (w & 3), lane = 4 g_l + pq: slot of element 4 g + s' = 17 g_l + [4 wq + s' + ((4 wq + 9 + s') >> 4)],
-    // the bracket a compile-time offset once the wave's wq is fixed (four copies of the loop, wave-uniform switch).
+    // FIR + decimation.  Output i of a tile is sum_t h[t] Q[16 i + t] = sum_{p, s} tab[p][s] img[p][i + s - 7]
+    // (t = 16 (s - 7) + p; the host lays the taps out as taps[p][16], s = 0..13, zero where |t| > T).
+    // A thread takes FOUR consecutive outputs and FOUR phases p = pq + 4 m: image slot 4 g + s' (s' = 0..17, counted from
+    // the 8 zero slots) serves output o = 0..3 with step s = s' - o - 1, so 18 LDS reads per phase feed 56 multiply-adds
+    // (one read per output and tap would make the kernel LDS-bound: 13 reads of every bin).  Waves 0..3: tile A, 4..7:
+    // tile B; wave w takes the output groups g = 4 g_l + (w & 3), lane = 4 g_l + pq: physical slot of 4 g + s' is
+    // 17 g_l + [4 wq + s' + ((4 wq + s' + 8) >> 4)], the bracket a compile-time offset once the wave's wq is fixed (four
+    // copies of the loop, wave-uniform switch).
     const int tile = __builtin_amdgcn_readfirstlane(t >> 8), wq = __builtin_amdgcn_readfirstlane((t >> 6) & 3);
     const int pq = t & 3, gl = (t & 63) >> 2;
-    const float2 *src = (tile ? qb : qa) + 17 * gl;
-    const float *tab = taps + tile * 256;
+    const float2 *img = tile ? qb : qa;
+    const float2 *src = img + 17 * gl;
     float2 acc[4];
 #pragma unroll
     for (int o = 0; o < 4; o++) acc[o] = make_float2(0.0f, 0.0f);
@@ -629,17 +637,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_
 #pragma unroll
         for (int m = 0; m < 4; m++) {
             const int p = pq + 4 * m;
-            float h[15];
+            float h[kDecSteps];
 #pragma unroll
-            for (int s2 = 0; s2 < 15; s2++) h[s2] = tab[16 * p + s2];
+            for (int s2 = 0; s2 < kDecSteps; s2++) h[s2] = taps[16 * p + s2];
             const float2 *row = src + p * kDecPitch;
 #pragma unroll
-            for (int s1 = 0; s1 < 18; s1++) {
-                const float2 v = row[4 * WQ + s1 + ((4 * WQ + 9 + s1) >> 4)];
+            for (int s1 = 1; s1 < 18; s1++) {
+                const float2 v = row[4 * WQ + s1 + ((4 * WQ + s1 + 8) >> 4)];
 #pragma unroll
                 for (int o = 0; o < 4; o++) {
-                    const int s2 = s1 - o;
-                    if (s2 >= 0 && s2 < 15) {
+                    const int s2 = s1 - o - 1;
+                    if (s2 >= 0 && s2 < kDecSteps) {
                         acc[o].x += h[s2] * v.x;
                         acc[o].y += h[s2] * v.y;
                     }
@@ -660,27 +668,71 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_
         acc[o].y += __shfl_xor(acc[o].y, 2, kWave);
     }
     const float2 mine = pq == 0 ? acc[0] : pq == 1 ? acc[1] : pq == 2 ? acc[2] : acc[3];
-    // output i = 4 g + pq of tile A is G[256 bx + i], of tile B G[R - 256 (bx + 1) + i]; four-step layout of the small
-    // plan: j = j2 + N2' j1 at [j2][j1]
+    // tile number in bin order: bx for tile A, N2 - 1 - bx for tile B; its outputs are G[256 tn + i]; four-step layout of
+    // the small plan: j = j2 + N2' j1 at [j2][j1]
     const int rc = (int)(pl.Nc / kDecD);
-    const int j = (tile ? rc - 256 * ((int)blockIdx.x + 1) : 256 * (int)blockIdx.x) + 4 * (4 * gl + wq) + pq;
-    G[(size_t)blockIdx.y * (size_t)rc + (size_t)(j & (small_n2 - 1)) * 4096 + (j / small_n2)] = mine;
+    const int tn = tile ? N2 - 1 - (int)blockIdx.x : (int)blockIdx.x;
+    {
+        const int j = 256 * tn + 4 * (4 * gl + wq) + pq;
+        G[(size_t)blockIdx.y * (size_t)rc + (size_t)(j & (small_n2 - 1)) * 4096 + (j / small_n2)] = mine;
+    }
+    // this tile's share of the 7 outputs before it (i = -7..-1) and the 7 after it (i = 256..262): lane (output, phase),
+    // 14 x 16 = 224 lanes of the tile's first four waves; sum over the steps whose bins lie inside the tile, then over
+    // the phases (16 adjacent lanes)
+    {
+        const int tl = t & 255, eo = tl >> 4, p = tl & 15;         // eo = 0..13 (14, 15: idle lanes of the fourth wave)
+        const int i = eo < kDecEdge ? eo - kDecEdge : 256 + (eo - kDecEdge);
+        float2 e = make_float2(0.0f, 0.0f);
+        if (eo < 2 * kDecEdge) {
+#pragma unroll
+            for (int s2 = 0; s2 < kDecSteps; s2++) {
+                const int idx = i + s2 - 7;                        // slot of the bin group; inside the tile: 0..255
+                if (idx >= 0 && idx < 256) {
+                    const float hh = taps[16 * p + s2];
+                    const float2 v = img[p * kDecPitch + dec_slot(idx + 8)];
+                    e.x += hh * v.x;
+                    e.y += hh * v.y;
+                }
+            }
+        }
+#pragma unroll
+        for (int sh = 1; sh < 16; sh <<= 1) {
+            e.x += __shfl_xor(e.x, sh, kWave);
+            e.y += __shfl_xor(e.y, sh, kWave);
+        }
+        if (p == 0 && eo < 2 * kDecEdge) E[((size_t)blockIdx.y * N2 + tn) * (2 * kDecEdge) + eo] = e;
+    }
 }
 
-// inverse rows of the decimated spectrum (no K3, no mirror): rows a = 2 bx, b = a + 1 of G[16][4096] -> V'[k2][n1]
-// with the four-step twiddle of the small plan.  grid (N2'/2, n_pw), 512 threads, dynamic LDS 64 KB.
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_PLAIN_DS_OPS)) void k_inv_rows_plain_r8(const float2 *G, float2 *V, FftPlan pl)
+// inverse rows of the decimated spectrum (no K3, no mirror): rows a = 2 bx, b = a + 1 of G[N2'][4096] -> V'[k2][n1]
+// with the four-step twiddle of the small plan.  G[j], j = 256 tile + i, still lacks the neighbouring tiles' shares
+// near the tile boundaries (k_pair_decimate16): i < 7 gets E[tile - 1][7 + i], i >= 249 gets E[tile + 1][i - 249].
+// grid (N2'/2, n_pw), 512 threads, dynamic LDS 64 KB.
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_PLAIN_DS_OPS)) void k_inv_rows_plain_r8(const float2 *G, const float2 *E, float2 *V, FftPlan pl, int big_n2)
 {
     extern __shared__ float2 lds[];   // 2 * kRow8Lds
     float2 *la = lds, *lb = lds + kRow8Lds;
     const int t = threadIdx.x;
     const int a = 2 * blockIdx.x, b = a + 1;
     const float2 *g = G + (size_t)blockIdx.y * pl.Nc;
+    const float2 *e = E + (size_t)blockIdx.y * big_n2 * (2 * kDecEdge);
+    auto load = [&](int row, int j1) {
+        float2 v = g[(size_t)row * 4096 + j1];
+        const int j = row + pl.N2 * j1, tn = j >> 8, i = j & 255;
+        if (i < kDecEdge) {
+            const float2 x = e[(size_t)((tn + big_n2 - 1) & (big_n2 - 1)) * (2 * kDecEdge) + kDecEdge + i];
+            v.x += x.x; v.y += x.y;
+        } else if (i >= 256 - kDecEdge) {
+            const float2 x = e[(size_t)((tn + 1) & (big_n2 - 1)) * (2 * kDecEdge) + (i - (256 - kDecEdge))];
+            v.x += x.x; v.y += x.y;
+        }
+        return v;
+    };
     float2 va[8], vb[8];
 #pragma unroll
     for (int r = 0; r < 8; r++) {
-        va[r] = g[(size_t)a * 4096 + t + 512 * r];
-        vb[r] = g[(size_t)b * 4096 + t + 512 * r];
+        va[r] = load(a, t + 512 * r);
+        vb[r] = load(b, t + 512 * r);
     }
     fft8<true>(va);
     fft8<true>(vb);

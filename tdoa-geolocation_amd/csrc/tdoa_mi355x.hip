@@ -311,7 +311,7 @@ bool decimation_applies(const tdoa_ctx *ctx, const FftPlan &pl, int lag_lo, int 
     const double dw = 2.0 * M_PI * (double)(R - 2 * M) / (double)pl.Nc;
     if (R - 2 * M <= 0) return false;
     const int T = (int)std::ceil((kDecAttenuationDb - 8.0) / (2.285 * dw) / 2.0);
-    return T <= kDecHalo - 1;
+    return T <= 111;          // taps t = 16 (s - 7) + p, s = 0..13
 }
 
 // modified Bessel function I0 (Kaiser window)
@@ -324,6 +324,14 @@ double bessel_i0(double x)
         if (term < 1e-18 * sum) break;
     }
     return sum;
+}
+
+// layout of the decimated inverse inside the V workspace (float2 elements): G [n_pw][R], V' [n_pw][R], the tiles' edge
+// shares E [n_pw][N2][14], then the stations' spectra in tiles [n_sw][Nc]
+size_t dec_edge_offset(const FftPlan &pl, int n_pw) { return 2 * (size_t)(pl.Nc / kDecD) * (size_t)n_pw; }
+size_t dec_spectra_offset(const FftPlan &pl, int n_pw)
+{
+    return dec_edge_offset(pl, n_pw) + (size_t)n_pw * (size_t)pl.N2 * (2 * kDecEdge);
 }
 
 // taps h[t] = sinc(t/16) * kaiser(t), |t| <= T, rounded to f32; gain[m] = 1 / w[m], w[m] = sum_t h[t] cos(2 pi t m / Nc) / 16
@@ -348,14 +356,11 @@ int ensure_decimation(tdoa_ctx *ctx, const FftPlan &pl, int lag_lo, int lag_hi)
         for (int t = -T; t <= T; t++) w += (double)taps[t + T] * std::cos(2.0 * M_PI * (double)t * (double)m / (double)pl.Nc);
         gain[m] = (float)((double)kDecD / w);
     }
-    // the kernel's layout: tile (A, B) x phase p x step s: the tap at tile offset o = 16 s + p, o0 = (112 or 111) - T
-    std::vector<float> tab(2 * 256, 0.0f);
-    for (int tile = 0; tile < 2; tile++) {
-        const int o0 = kDecHalo - tile - T;
-        for (int u = 0; u <= 2 * T; u++) {
-            const int o = o0 + u;
-            tab[tile * 256 + 16 * (o & 15) + (o >> 4)] = taps[u];
-        }
+    // the kernel's layout: phase p x step s, the tap t = 16 (s - 7) + p (zero where |t| > T)
+    std::vector<float> tab(256, 0.0f);
+    for (int t = -T; t <= T; t++) {
+        const int p = ((t % 16) + 16) % 16, sidx = (t - p) / 16 + 7;
+        tab[16 * p + sidx] = taps[t + T];
     }
     int rc;
     if ((rc = ensure(ctx, ctx->dec_taps, sizeof(float) * tab.size()))) return rc;
@@ -384,7 +389,7 @@ int reserve_fm_batch(tdoa_ctx *ctx, int n_sw, int maxlen, int n_pw, const FftPla
     if (n_pw && decimation_applies(ctx, pl, lag_lo, lag_hi) && (rc = ensure_decimation(ctx, pl, lag_lo, lag_hi))) return rc;
     size_t v_elems = (size_t)pl.Nc * n_pw;
     if (n_pw && decimation_applies(ctx, pl, lag_lo, lag_hi))      // G + V' of the pairs, then the tiled spectra of the stations
-        v_elems = std::max(v_elems, 2 * (size_t)(pl.Nc / kDecD) * n_pw + (size_t)pl.Nc * n_sw);
+        v_elems = std::max(v_elems, dec_spectra_offset(pl, n_pw) + (size_t)pl.Nc * n_sw);
     if (n_pw && (rc = ensure(ctx, ctx->v, sizeof(float2) * v_elems))) return rc;
     return TDOA_OK;
 }
@@ -534,8 +539,7 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
         if (fused_rows)    // only the two self-mirrored rows 0 and N2/2 (their pair kernel reads finished spectra)
             hipLaunchKernelGGL(k_fwd_row4096, dim3(2, n_sw), dim3(256), 0, st, tz, pl, pl.N2 / 2, static_cast<float2 *>(nullptr));
         else if (row16 && decim)     // spectra in 16-column tiles behind G and V' in the V workspace (k_pair_decimate16 streams them)
-            hipLaunchKernelGGL(k_fwd_row4096, dim3(pl.N2, n_sw), dim3(256), 0, st, tz, pl, 1,
-                               v + 2 * (size_t)(pl.Nc / kDecD) * (size_t)n_pw);
+            hipLaunchKernelGGL(k_fwd_row4096, dim3(pl.N2, n_sw), dim3(256), 0, st, tz, pl, 1, v + dec_spectra_offset(pl, n_pw));
         else if (row16)
             hipLaunchKernelGGL(k_fwd_row4096, dim3(pl.N2, n_sw), dim3(256), 0, st, tz, pl, 1, static_cast<float2 *>(nullptr));
         else
@@ -586,16 +590,18 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
         }
         {
             ProfScope ps(ctx, TDOA_K_INV_ROW, 2.0 * nc8 * n_pw + 8.0 * (double)rc_pts * n_pw);      // two spectra read, G written
+            float2 *edges = v + dec_edge_offset(pl, n_pw), *spectra = v + dec_spectra_offset(pl, n_pw);
             if (pl.N2 == 256)
                 hipLaunchKernelGGL(k_pair_decimate16<8>, dim3(pl.N2 / 2, n_pw), dim3(512), sizeof(float2) * 2 * 16 * kDecPitch, st,
-                                   d_pw, vs + rc_pts * (size_t)n_pw, g, pl, static_cast<const float *>(ctx->dec_taps.p), ps2.N2);
+                                   d_pw, spectra, g, edges, pl, static_cast<const float *>(ctx->dec_taps.p), ps2.N2);
             else
                 hipLaunchKernelGGL(k_pair_decimate16<9>, dim3(pl.N2 / 2, n_pw), dim3(512), sizeof(float2) * 2 * 16 * kDecPitch, st,
-                                   d_pw, vs + rc_pts * (size_t)n_pw, g, pl, static_cast<const float *>(ctx->dec_taps.p), ps2.N2);
+                                   d_pw, spectra, g, edges, pl, static_cast<const float *>(ctx->dec_taps.p), ps2.N2);
         }
         {
             ProfScope ps(ctx, TDOA_K_INV_COL, 3.0 * 8.0 * (double)rc_pts * n_pw);
-            hipLaunchKernelGGL(k_inv_rows_plain_r8, dim3(ps2.N2 / 2, n_pw), dim3(512), sizeof(float2) * 2 * kRow8Lds, st, g, vs, ps2);
+            hipLaunchKernelGGL(k_inv_rows_plain_r8, dim3(ps2.N2 / 2, n_pw), dim3(512), sizeof(float2) * 2 * kRow8Lds, st, g,
+                               v + dec_edge_offset(pl, n_pw), vs, ps2, pl.N2);
             hipLaunchKernelGGL(k_inv_col_pruned_any, dim3(ps2.N1 / 128, n_pw), dim3(256), sizeof(float2) * (size_t)ps2.N2, st, vs,
                                d_keys, d_pw, ps2, lag_lo, lag_hi, np2, nn2, lag_dump, dump_scale,
                                static_cast<const float *>(ctx->dec_gain.p));
