@@ -740,6 +740,76 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_
     inv_rows_twiddle_store(va, vb, t, a, b, V + (size_t)blockIdx.y * pl.Nc, pl);
 }
 
+// column pass + K5 of the small plan (N2' = 16 or 32 rows of 4096): one thread per column n1 reads its N2' values
+// (coalesced 2 KB runs per row), evaluates the np + nn outputs n2 that can hold a searched lag as direct sums, divides the
+// window out (gain[|m|] = 1 / w[m], m = packed lag index) and keeps the best peak key.  Same lag bookkeeping as
+// k_inv_col_pruned_any, which spends most of its time setting up for long columns.
+// grid (N1 / 256, n_pw), 256 threads.
+__global__ __launch_bounds__(256) void k_small_col_peak(const float2 *V, unsigned long long *keys, const PWDesc *pw, FftPlan pl,
+                                                        int lag_lo, int lag_hi, int np, int nn, float *lag_dump,
+                                                        float dump_scale, const float *gain)
+{
+    __shared__ float2 wtab[32];                    // e^{+2 pi i k / N2'}
+    __shared__ unsigned long long red[4];
+    const int N2 = pl.N2, N1 = pl.N1;
+    if (threadIdx.x < N2) wtab[threadIdx.x] = unit_root((float)threadIdx.x, 2.0f / (float)N2, true);
+    __syncthreads();
+    const int n1 = blockIdx.x * 256 + threadIdx.x;
+    const float2 *in = V + (size_t)blockIdx.y * pl.Nc + n1;
+    float2 acc[kPruneMax];
+#pragma unroll
+    for (int o = 0; o < kPruneMax; o++) acc[o] = make_float2(0.0f, 0.0f);
+    const int nout = np + nn;
+    for (int k0 = 0; k0 < N2; k0 += 8) {
+        float2 x[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) x[u] = in[(size_t)(k0 + u) * N1];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+#pragma unroll
+            for (int o = 0; o < kPruneMax; o++) {
+                if (o < nout) {
+                    const int n2 = o < np ? o : N2 - nn + (o - np);
+                    const float2 w = wtab[(n2 * (k0 + u)) & (N2 - 1)];
+                    acc[o].x += x[u].x * w.x - x[u].y * w.y;
+                    acc[o].y += x[u].x * w.y + x[u].y * w.x;
+                }
+            }
+        }
+    }
+    unsigned long long best = 0;
+#pragma unroll
+    for (int o = 0; o < kPruneMax; o++) {
+        if (o < nout) {
+            const int n2 = o < np ? o : N2 - nn + (o - np);
+            long long d = 2 * ((long long)n2 * N1 + n1);           // lags d (real part) and d + 1 (imaginary part)
+            if (d >= pl.Nc) d -= 2 * pl.Nc;
+            if (d + 1 >= lag_lo && d <= lag_hi) {
+                const long long m = d >> 1;
+                const float gg = gain[m < 0 ? -m : m];
+                const float vals[2] = {acc[o].x * gg, acc[o].y * gg};
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const long long dq = d + q;
+                    if (dq >= lag_lo && dq <= lag_hi && vals[q] == vals[q]) {
+                        const unsigned long long k = peak_key(vals[q], (int)dq);
+                        best = k > best ? k : best;
+                        if (lag_dump) lag_dump[dq - lag_lo] = vals[q] * dump_scale;
+                    }
+                }
+            }
+        }
+    }
+    best = wave_max_u64(best);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long bb = red[0];
+        for (int w = 1; w < 4; w++) bb = red[w] > bb ? red[w] : bb;
+        if (bb) atomicMax(&keys[pw[blockIdx.y].out_index], bb);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Segment form (search ranges up to 1024 lags): the whole correlation stays in LDS and registers.
 // The deployed geometry bounds |TDOA| by 114 samples (PROJECT_NOTES.md:29-32); a caller who searches a few hundred

@@ -602,9 +602,8 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
             ProfScope ps(ctx, TDOA_K_INV_COL, 3.0 * 8.0 * (double)rc_pts * n_pw);
             hipLaunchKernelGGL(k_inv_rows_plain_r8, dim3(ps2.N2 / 2, n_pw), dim3(512), sizeof(float2) * 2 * kRow8Lds, st, g,
                                v + dec_edge_offset(pl, n_pw), vs, ps2, pl.N2);
-            hipLaunchKernelGGL(k_inv_col_pruned_any, dim3(ps2.N1 / 128, n_pw), dim3(256), sizeof(float2) * (size_t)ps2.N2, st, vs,
-                               d_keys, d_pw, ps2, lag_lo, lag_hi, np2, nn2, lag_dump, dump_scale,
-                               static_cast<const float *>(ctx->dec_gain.p));
+            hipLaunchKernelGGL(k_small_col_peak, dim3(ps2.N1 / 256, n_pw), dim3(256), 0, st, vs, d_keys, d_pw, ps2, lag_lo, lag_hi,
+                               np2, nn2, lag_dump, dump_scale, static_cast<const float *>(ctx->dec_gain.p));
         }
     } else if (n_pw) {
         {
