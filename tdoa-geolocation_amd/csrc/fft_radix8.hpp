@@ -716,24 +716,28 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_
     const int a = 2 * blockIdx.x, b = a + 1;
     const float2 *g = G + (size_t)blockIdx.y * pl.Nc;
     const float2 *e = E + (size_t)blockIdx.y * big_n2 * (2 * kDecEdge);
-    auto load = [&](int row, int j1) {
-        float2 v = g[(size_t)row * 4096 + j1];
-        const int j = row + pl.N2 * j1, tn = j >> 8, i = j & 255;
-        if (i < kDecEdge) {
-            const float2 x = e[(size_t)((tn + big_n2 - 1) & (big_n2 - 1)) * (2 * kDecEdge) + kDecEdge + i];
-            v.x += x.x; v.y += x.y;
-        } else if (i >= 256 - kDecEdge) {
-            const float2 x = e[(size_t)((tn + 1) & (big_n2 - 1)) * (2 * kDecEdge) + (i - (256 - kDecEdge))];
-            v.x += x.x; v.y += x.y;
-        }
-        return v;
-    };
     float2 va[8], vb[8];
 #pragma unroll
     for (int r = 0; r < 8; r++) {
-        va[r] = load(a, t + 512 * r);
-        vb[r] = load(b, t + 512 * r);
+        va[r] = g[(size_t)a * 4096 + t + 512 * r];
+        vb[r] = g[(size_t)b * 4096 + t + 512 * r];
     }
+    // j = row + N2' (t + 512 r): its place in the tile, i = j & 255, does not depend on r (N2' 512 is a multiple of 256),
+    // so a thread either needs an edge share for all eight of its elements of a row or for none (one lane in 16 does)
+    auto merge = [&](int row, float2 (&v)[8]) {
+        const int i = (row + pl.N2 * t) & 255;
+        if (i >= kDecEdge && i < 256 - kDecEdge) return;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int tn = (row + pl.N2 * (t + 512 * r)) >> 8;
+            const float2 x = i < kDecEdge ? e[(size_t)((tn + big_n2 - 1) & (big_n2 - 1)) * (2 * kDecEdge) + kDecEdge + i]
+                                          : e[(size_t)((tn + 1) & (big_n2 - 1)) * (2 * kDecEdge) + (i - (256 - kDecEdge))];
+            v[r].x += x.x;
+            v[r].y += x.y;
+        }
+    };
+    merge(a, va);
+    merge(b, vb);
     fft8<true>(va);
     fft8<true>(vb);
     rows2_r8_finish<true>(va, vb, la, lb, t, t, t);
