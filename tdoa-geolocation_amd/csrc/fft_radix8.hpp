@@ -585,25 +585,44 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_
     }
     {
         // a tile's 4096 elements, 8 per thread, x = t + 512 it in tile order (k2 = x / COLS, column x % COLS: one
-        // contiguous 4 KB run per trip); all 32 loads of a thread are issued first
+        // contiguous 4 KB run per trip); all 32 loads of a thread are issued first.  From trip 1 on everything is linear in
+        // the trip (k2 >= 512 / COLS > 0: the partner's row just counts down, no wrap): own element + 512 it, partner
+        // - 512 (it - 1); for N2 = 256 also the image slots (+- 2 per trip, inside one column of the image: constant pad).
+        constexpr int DK = 512 / COLS;                             // bins between a thread's consecutive elements
+        static_assert(DK % 16 == 0, "a thread's elements share their phase");
         float2 za[8], zam[8], zb[8], zbm[8];
-        const int o0 = t / COLS + N2 * (t % COLS);                 // x -> bin offset k2 + N2 col; + 512 / COLS per trip
+        const int o0 = t / COLS + N2 * (t % COLS);                 // x -> bin offset k2 + N2 col
+        unsigned int at0, atm0, at1, atm1;
+        coords(kA0 + o0, at0, atm0);
+        coords(kA0 + o0 + DK, at1, atm1);
+        za[0] = Za[at0]; zam[0] = Za[atm0]; zb[0] = Zb[at0]; zbm[0] = Zb[atm0];
 #pragma unroll
-        for (int it = 0; it < 8; it++) {
-            unsigned int at, atm;
-            coords((kA0 + o0 + (512 / COLS) * it) & mask, at, atm);
-            za[it] = Za[at]; zam[it] = Za[atm]; zb[it] = Zb[at]; zbm[it] = Zb[atm];
+        for (int it = 1; it < 8; it++) {
+            za[it] = Za[at1 + 512u * (it - 1)]; zam[it] = Za[atm1 - 512u * (it - 1)];
+            zb[it] = Zb[at1 + 512u * (it - 1)]; zbm[it] = Zb[atm1 - 512u * (it - 1)];
         }
-        // w(k) = W_N^k; a thread's bins are 512 / COLS apart: one root, then a fixed rotation
+        // w(k) = W_N^k; a thread's bins are DK apart: one root, then a fixed rotation
         float2 w = unit_root((float)(kA0 + o0), invNc, false);
-        const float2 rot = unit_root((float)(512 / COLS), invNc, false);
+        const float2 rot = unit_root((float)DK, invNc, false);
+        const int sa1 = slot_of(o0 + DK), sb1 = slot_of(4096 - o0 - DK);
+        {
+            float2 q, qm;
+            pair_q(za[0], zam[0], zb[0], zbm[0], w, q, qm);
+            qa[slot_of(o0)] = q;
+            if (o0) qb[slot_of(4096 - o0)] = qm;                   // the partner of A[0] is B[0] of the workgroup before
+            w = cmul(w, rot);
+        }
 #pragma unroll
-        for (int it = 0; it < 8; it++) {
-            const int o = o0 + (512 / COLS) * it;
+        for (int it = 1; it < 8; it++) {
             float2 q, qm;
             pair_q(za[it], zam[it], zb[it], zbm[it], w, q, qm);
-            qa[slot_of(o)] = q;
-            if (o) qb[slot_of(4096 - o)] = qm;                     // the partner of A[0] is B[0] of the workgroup before
+            if constexpr (LOGN2 == 8) {                            // N2 = 256: a thread's slots stay inside one column of the image
+                qa[sa1 + (DK / 16) * (it - 1)] = q;
+                qb[sb1 - (DK / 16) * (it - 1)] = qm;
+            } else {
+                qa[slot_of(o0 + DK * it)] = q;
+                qb[slot_of(4096 - o0 - DK * it)] = qm;
+            }
             w = cmul(w, rot);
         }
     }
