@@ -342,8 +342,10 @@ __global__ void k_decode_peaks(const unsigned long long *keys, const double *sca
 // part).  3*N2 scattered reads per unit -- nothing next to the passes that produced V.
 // grid n_pw, 64 threads; raw[3*slot + q] unscaled like the keys.
 // ---------------------------------------------------------------------------
+// gain (decimated inverse): V is then the row-pass output of the small plan and value (lag l) is multiplied by
+// gain[|floor(l / 2)|], the window of the decimation divided out.
 __global__ __launch_bounds__(64) void k_refine_peaks(const float2 *V, const unsigned long long *keys,
-                                                    const PWDesc *pw, FftPlan pl, float *raw)
+                                                    const PWDesc *pw, FftPlan pl, float *raw, const float *gain = nullptr)
 {
     const int slot = pw[blockIdx.x].out_index;
     const unsigned long long k = keys[slot];
@@ -368,7 +370,10 @@ __global__ __launch_bounds__(64) void k_refine_peaks(const float2 *V, const unsi
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, kWave);
-        if (threadIdx.x == 0) raw[3 * (size_t)slot + q] = acc;
+        if (threadIdx.x == 0) {
+            const long long ms = ((long long)lag - 1 + q) >> 1;        // signed packed index (arithmetic shift = floor)
+            raw[3 * (size_t)slot + q] = gain ? acc * gain[ms < 0 ? -ms : ms] : acc;
+        }
     }
 }
 

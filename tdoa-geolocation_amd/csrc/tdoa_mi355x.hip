@@ -438,8 +438,8 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
     }
     const bool pruned = !ctx->force_generic && pl.N1 >= 128 && pl.N2 <= 4096 && np + nn <= kPruneMax && np + nn <= pl.N2 &&
                         lag_hi < pl.Nc && lag_lo > -pl.Nc;
-    // decimated inverse (general form on 4096 x 256 plans; not with the sub-sample refinement, which reads V)
-    const bool decim = pruned && fk == 0 && !fine_raw && decimation_applies(ctx, pl, lag_lo, lag_hi) &&
+    // decimated inverse (general form on 4096 x 256 and 4096 x 512 plans)
+    const bool decim = pruned && fk == 0 && decimation_applies(ctx, pl, lag_lo, lag_hi) &&
                        ctx->dec_nc == pl.Nc && ctx->dec_reach == std::max(lag_hi + 1, -(lag_lo - 1));
     // segment form (search ranges up to 1024 lags): overlap-save over 4096-point frames entirely in LDS; neither the
     // column pass nor TZ nor V rows are touched.  Its chunk sums and lag array live where the short-lag form keeps its
@@ -680,7 +680,13 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
         else if (fk == 2) hipLaunchKernelGGL(k_refine_fused<2>, g1, b1, 0, st, v, d_keys, d_pw, pl, n_pw, fine_raw);
         else if (fk == 4) hipLaunchKernelGGL(k_refine_fused<4>, g1, b1, 0, st, v, d_keys, d_pw, pl, n_pw, fine_raw);
         else if (fk == 8) hipLaunchKernelGGL(k_refine_fused<8>, g1, b1, 0, st, v, d_keys, d_pw, pl, n_pw, fine_raw);
-        else hipLaunchKernelGGL(k_refine_peaks, dim3(n_pw), dim3(64), 0, st, v, d_keys, d_pw, pl, fine_raw);
+        else if (decim) {      // the row-pass output of the small plan is still in place behind G; window divided out per lag
+            FftPlan ps2;
+            if ((rc = make_plan(2 * (pl.Nc / kDecD), true, &ps2))) return fail(ctx, rc, "decimated plan");
+            hipLaunchKernelGGL(k_refine_peaks, dim3(n_pw), dim3(64), 0, st, v + (size_t)(pl.Nc / kDecD) * (size_t)n_pw, d_keys, d_pw,
+                               ps2, fine_raw, static_cast<const float *>(ctx->dec_gain.p));
+        }
+        else hipLaunchKernelGGL(k_refine_peaks, dim3(n_pw), dim3(64), 0, st, v, d_keys, d_pw, pl, fine_raw, static_cast<const float *>(nullptr));
     }
     HIPCHK(ctx, hipGetLastError());
     return TDOA_OK;

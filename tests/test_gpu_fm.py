@@ -545,14 +545,20 @@ def test_decimated_inverse_vs_full_inverse(oracle, n1, n2, max_lag, delay):
     with tdoa_amd.Context(max_lag=max_lag, window_len=max(n1, n2)) as c:
         dec = c.fm_xcorr_lags(a, b, max_lag)
         lag, corr = c.fm_xcorr(a, b, max_lag)
+        _, fine = c.fm_xcorr_fine(a, b, max_lag, 1e9)
         assert c.plan_info()[1:] == ((4096, 256) if max(n1, n2) <= 2_000_000 else (4096, 512))
         c.debug_flags(no_decimate=True, no_fused_rows=True)        # (a cleared bit would switch the fused forward rows on)
         full = c.fm_xcorr_lags(a, b, max_lag)
         lag_f, corr_f = c.fm_xcorr(a, b, max_lag)
+        _, fine_f = c.fm_xcorr_fine(a, b, max_lag, 1e9)
     _assert_lags_close(dec, want)
     _assert_lags_close(full, want)
     _assert_lags_close(dec, full, 2e-6)
     assert lag == lag_f == olag
     assert abs(corr - ocorr) <= REL_TOL * abs(ocorr) and abs(corr_f - ocorr) <= REL_TOL * abs(ocorr)
+    # sub-sample refinement: the three neighbours come from the small plan's row-pass output, window divided out
+    ofine = oracle.b_refine_peak(ta, tb, olag, 1e9)
+    assert np.abs(fine["y"] - ofine["y"]).max() <= REL_TOL * abs(ocorr) and np.abs(fine_f["y"] - ofine["y"]).max() <= REL_TOL * abs(ocorr)
+    assert abs(fine["frac"] - ofine["frac"]) < 1e-4 and abs(fine_f["frac"] - ofine["frac"]) < 1e-4
     if max_lag == 26000:
         assert np.array_equal(dec, full)          # same kernels: the decimated form did not apply
