@@ -445,6 +445,9 @@ def main():
             "timed_path": "kernels launched one by one with per-kernel HIP events (the roofline's source); graph replay: graph_replay",
             "graph_replay": graph_leg,
             "pipeline_algorithmic_GBps": round(a_bytes / (dt / steps) / 1e9, 1),
+            # the bytes the launched kernels are actually charged with by the library (per-kernel figures of tdoa_profile_get:
+            # code round trip included, the decimated pair step at its own 16.5 N instead of the model's 24 N per pair-window)
+            "pipeline_kernel_bytes_GBps": round(sum(v["bytes"] for v in prof.values()) / max(steps, 1) / (dt / steps) / 1e9, 1),
             "pipeline_frac_of_hbm_peak": round(a_bytes / (dt / steps) / 1e9 / HBM_PEAK_GBS / world, 4),
             # SURVEY.md 8d secondary figure: pair-samples correlated per second (P*W*L/t), whole job
             "pair_Msamples_per_s": round(samples_per_step / S * n_pairs / (dt / steps) / 1e6, 2),
