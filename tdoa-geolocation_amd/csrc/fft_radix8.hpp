@@ -583,6 +583,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_
         const int img = t >> 8, p = (t >> 4) & 15, z = t & 15;
         (img ? qb : qa)[p * kDecPitch + dec_slot(z < 8 ? z : 256 + z)] = make_float2(0.0f, 0.0f);
     }
+    // B[0]: its partner is A[0] of the next workgroup's tile.  One thread (of the last wave) fetches the four values
+    // up front, next to everybody's main loads, and forms Q after its main work
+    const bool has_b0 = t == 511;
+    const long long kb0 = (pl.Nc - 4096ll * ((long long)blockIdx.x + 1)) & mask;
+    float2 b0[4] = {};
+    if (has_b0) {
+        unsigned int at, atm;
+        coords(kb0, at, atm);
+        b0[0] = Za[at]; b0[1] = Za[atm]; b0[2] = Zb[at]; b0[3] = Zb[atm];
+    }
     {
         // a tile's 4096 elements, 8 per thread, x = t + 512 it in tile order (k2 = x / COLS, column x % COLS: one
         // contiguous 4 KB run per trip); all 32 loads of a thread are issued first.  From trip 1 on everything is linear in
@@ -626,13 +636,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_
             w = cmul(w, rot);
         }
     }
-    if (t == 0) {
-        // B[0]: its partner is A[0] of the next workgroup's tile
-        const long long k = (pl.Nc - 4096ll * ((long long)blockIdx.x + 1)) & mask;
-        unsigned int at, atm;
-        coords(k, at, atm);
+    if (has_b0) {
         float2 q, qm;
-        pair_q(Za[at], Za[atm], Zb[at], Zb[atm], unit_root((float)k, invNc, false), q, qm);
+        pair_q(b0[0], b0[1], b0[2], b0[3], unit_root((float)kb0, invNc, false), q, qm);
         qb[slot_of(0)] = q;
     }
     __syncthreads();
