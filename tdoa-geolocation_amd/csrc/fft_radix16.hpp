@@ -610,9 +610,8 @@ constexpr int kPruneMax = 8;
 // (row group: rows g, g+4, ...); 16-byte loads -> 1 KB contiguous per row, 8 rows in flight per thread
 __global__ __launch_bounds__(256) void k_inv_col_pruned_any(const float2 *V, unsigned long long *keys, const PWDesc *pw,
                                                        FftPlan pl, int lag_lo, int lag_hi, int np, int nn,
-                                                       float *lag_dump, float dump_scale, const float *gain = nullptr)
+                                                       float *lag_dump, float dump_scale)
 {
-    // gain (decimated inverse, fft_radix8.hpp): the lags 2m and 2m+1 are multiplied by gain[|m|] = 1 / w[m]
     extern __shared__ float2 wtab[];               // e^{+2 pi i k/N2}, N2 entries (dynamic LDS)
     __shared__ float4 part[4][kPruneMax][64];
     __shared__ unsigned long long red[4];
@@ -664,15 +663,9 @@ __global__ __launch_bounds__(256) void k_inv_col_pruned_any(const float2 *V, uns
             s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
         }
         const int n2 = o < np ? o : N2 - nn + (o - np);
-        float vals[4] = {s.x, s.y, s.z, s.w};         // lags 2m .. 2m+3 with m = n2*N1 + n1
+        const float vals[4] = {s.x, s.y, s.z, s.w};   // lags 2m .. 2m+3 with m = n2*N1 + n1
         long long d = 2 * ((long long)n2 * N1 + (blockIdx.x << 7) + 2 * c);
         if (d >= pl.Nc) d -= 2 * pl.Nc;
-        if (gain) {
-            const long long m0 = d >> 1, m1 = m0 + 1;      // d is even
-            const bool in0 = d >= lag_lo - 1 && d <= lag_hi, in1 = d + 2 >= lag_lo - 1 && d + 2 <= lag_hi;
-            const float g0 = in0 ? gain[m0 < 0 ? -m0 : m0] : 0.0f, g1 = in1 ? gain[m1 < 0 ? -m1 : m1] : 0.0f;
-            vals[0] *= g0; vals[1] *= g0; vals[2] *= g1; vals[3] *= g1;
-        }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const long long dq = d + q;

@@ -79,3 +79,48 @@ def test_batched_path_equals_pair_calls(oracle, n_st, block, wlen, per_batch, ma
                     assert (int(peaks[wid, p]["lag"]), float(peaks[wid, p]["corr"])) == (lag, corr), (wid, i, j)
                     assert lag == delays[j] - delays[i]
                     p += 1
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13, 14, 15, 16])
+def test_decimated_inverse_fuzz_batched(oracle, seed):
+    """seeded sweep of the batched path on 4096 x 256 / 4096 x 512 plans: stations, window length, search range, batch
+    split and sharding drawn at random; decimated inverse (default) against the full inverse, lag for lag, and a
+    sample of (window, pair) units against the f64 oracle"""
+    import tdoa_amd
+    rng = np.random.default_rng(seed)
+    n_st = int(rng.integers(2, 5))
+    wl = int(rng.integers(1_060_000, 2_000_001)) if seed % 3 else int(rng.integers(2_100_000, 3_000_001))
+    ml = int(rng.integers(4096, 23001))
+    per_batch = int(rng.integers(0, 3))
+    half = min((ml - 1) // 2, 9000)                               # every pair's delay difference stays inside the search range
+    delays = [0] + [int(x) for x in rng.integers(-half, half, size=n_st - 1)]
+    base = 10_000
+    caps = [np.concatenate([oracle.simulate_delayed_fm(wl, base + d, 500 + seed + k, 10 * s + k) for k in range(3)])
+            for s, d in enumerate(delays)]
+    pairs = [(i, j) for i in range(n_st) for j in range(i + 1, n_st)]
+    with tdoa_amd.Context(max_lag=ml, window_len=wl, windows_per_batch=per_batch) as c:
+        for s, cap in enumerate(caps):
+            c.capture_upload(s, cap)
+        dec = c.process()
+        n_fft, n1, n2 = c.plan_info()
+        assert (n1, n2) in ((4096, 256), (4096, 512))
+        world = int(rng.integers(2, 5))
+        merged = np.zeros_like(dec)
+        for r in range(world):
+            part = c.process(rank=r, world=world)
+            own = part["corr"] != 0
+            merged[own] = part[own]
+        c.debug_flags(no_decimate=True, no_fused_rows=True)
+        full = c.process()
+    assert dec.shape == (3, len(pairs))
+    scale = np.abs(full["corr"]).max()
+    for got in (dec, merged):
+        assert np.array_equal(got["lag"], full["lag"])
+        assert np.abs(got["corr"] - full["corr"]).max() <= 3e-6 * scale
+    wid = int(rng.integers(0, 3))
+    pre = [oracle.b_preprocess(cp[2 * wid * wl:2 * (wid + 1) * wl])[0] for cp in caps]
+    p = int(rng.integers(0, len(pairs)))
+    i, j = pairs[p]
+    olag, ocorr, _ = oracle.b_xcorr_peak_fft(pre[i], pre[j], ml)
+    assert dec[wid, p]["lag"] == olag == delays[j] - delays[i]
+    assert abs(dec[wid, p]["corr"] - ocorr) <= 1e-5 * abs(ocorr)
