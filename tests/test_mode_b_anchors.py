@@ -163,3 +163,45 @@ def test_optional_k1_power_gate_vs_the_binarys_envelope_branch(oracle, capsys):
         print("\n  k1_gate = 1: integer envelope codes vs float64 envelope chain")
         for r in rows:
             print("    amp %.3f  mean power %.5f  class %d  lag %5d  corr %10.6f  |dcorr|/|corr| %.2e" % r)
+
+
+def test_spectrum_decimation_math_in_float64(oracle, capsys):
+    """the decimated inverse (k_pair_decimate16) restated in numpy float64 with the library's
+    filter design: G[j] = sum_t h[t] Q[16 j + t], h = sinc(t/16) x Kaiser(140 dB) rounded to f32; the Nc/16-point
+    inverse of G divided by w[m] = sum_t h[t] cos(2 pi t m / Nc) / 16 must reproduce the packed lags q[m] of the full
+    inverse for |m| <= max_lag/2 + 2; what is left is the stop-band leakage of lags beyond Nc/16 - m"""
+    L, N, D, ML = 2_000_000, 1 << 21, 16, 20000
+    nc, r = N // 2, N // 2 // D
+    mp = ML // 2 + 2
+    att = 140.0
+    dw = 2 * np.pi * (r - 2 * mp) / nc
+    th = int(np.ceil((att - 8.0) / (2.285 * dw) / 2.0))
+    assert th == 106 and th <= 111                        # 213 taps: 14 steps of 16 phases in the kernel
+    beta = 0.1102 * (att - 8.7)
+    t = np.arange(-th, th + 1)
+    h = (np.sinc(t / D) * np.i0(beta * np.sqrt(1.0 - (t / th) ** 2)) / np.i0(beta)).astype(np.float32).astype(np.float64)
+    m = np.arange(-mp, mp + 1)
+    w = (h[None, :] * np.cos(2 * np.pi * t[None, :] * m[:, None] / nc)).sum(axis=1) / D
+    assert np.abs(w - 1.0).max() < 3e-7                   # the pass band is flat; it is divided out anyway
+    rows = []
+    sim = [oracle.simulate_station(nm, L, oracle.SEED_BASE + i) for i, nm in enumerate(oracle.COLLECTORS)]
+    cases = [("delayed_fm", oracle.simulate_delayed_fm(L, 0, 4242, 1), oracle.simulate_delayed_fm(L, 37, 4242, 2)),
+             ("simulator.go ref 0-1", sim[0][:2 * L], sim[1][:2 * L])]
+    for name, a, b in cases:
+        ta, tb = oracle.b_preprocess(a)[0].astype(np.float64), oracle.b_preprocess(b)[0].astype(np.float64)
+        c = np.fft.irfft(np.conj(np.fft.rfft(ta, N)) * np.fft.rfft(tb, N), N)
+        q = c[0::2] + 1j * c[1::2]                        # packed lags; Q = their Nc-point spectrum (what K3 produces)
+        Q = np.fft.fft(q)
+        idx = np.arange(r) * D
+        G = np.zeros(r, dtype=complex)
+        for tt, ht in zip(t, h):
+            G += ht * Q[(idx + tt) % nc]
+        est = (np.fft.ifft(G) * r)[m % r] / w
+        ref = (q * nc)[m % nc]
+        err = np.abs(est - ref).max() / np.abs(ref).max()
+        rows.append((name, 0.0, err))
+        assert err < 5e-7, (name, err)
+    with capsys.disabled():
+        print("\n  spectrum decimation 16:1, 213 taps (float64): max error of the %d packed lags, relative to the peak" % m.size)
+        for name, _, err in rows:
+            print("    %-24s %.2e" % (name, err))
