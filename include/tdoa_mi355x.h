@@ -73,11 +73,12 @@ typedef struct {
     double  corr;       /* signed, reference scale sum/sqrt(n_template)      */
 } tdoa_peak;
 
-/* Exact statistics of one FM-discriminated window (mode B preprocessing). */
+/* Exact statistics of one FM-discriminated window (mode B preprocessing).  The discriminator output is held as an
+ * integer phase code in units of pi/2^23 (-2^23 < code <= 2^23: exact in a float). */
 typedef struct {
-    int64_t  s1;
-    uint64_t s2_lo, s2_hi;
-    float    mean, scale;
+    int64_t  s1;              /* sum of the codes                                              */
+    uint64_t s2_lo, s2_hi;    /* sum of code^2 (128 bits: code^2 < 2^46 per sample)             */
+    float    mean, scale;     /* f32(s1 / n); f32(1 / sqrt(variance)), 1 if the variance is 0   */
 } tdoa_fm_stats;
 
 /* ---- lifecycle ------------------------------------------------------------ */
@@ -243,26 +244,28 @@ int tdoa_window_quality_all(tdoa_ctx *ctx, int rank, int world, tdoa_window_qual
 /* the same statistics of one host buffer of raw IQ */
 int tdoa_window_quality_u8(tdoa_ctx *ctx, const uint8_t *iq, size_t n_samples, tdoa_window_quality *out);
 
-/* inspection hooks used by the parity tests */
+/* inspection hooks used by the parity tests.  tdoa_fm_preprocess_u8: the normalised discriminator output of one window
+ * and its statistics; out_f32 == NULL runs the statistics-only pass of the default (fused) path instead of the one that
+ * also writes the codes -- both must give the same statistics */
 int tdoa_fm_preprocess_u8(tdoa_ctx *ctx, const uint8_t *iq, size_t n, float *out_f32, tdoa_fm_stats *stats);
 int tdoa_fm_xcorr_lags_u8(tdoa_ctx *ctx, const uint8_t *iq1, size_t n1, const uint8_t *iq2, size_t n2,
                           int max_lag, double *lags_out /* [2*max_lag-1] */);
 
 /* tests only: run the any-size fallback kernels even where a hot-size kernel exists */
 int tdoa_debug_force_generic(tdoa_ctx *ctx, int on);
-/* tests / measurements only: pick kernel variants by hand (a bit set = that specialised form is NOT used).
- * The same switches can be given once, at tdoa_create time, through the environment (TDOA_NO_SHORT_LAG=1,
- * TDOA_NO_FUSED_ROWS=1, TDOA_NO_SEGMENT_FORM=1); results are the same to rounding whichever form runs. */
+/* tests / measurements only: pick kernel variants by hand.  flags == 0 is the library's default path; every bit
+ * set switches one specialised form OFF.  The same switches can be given once, at tdoa_create time, through the
+ * environment (TDOA_NO_SHORT_LAG=1, TDOA_NO_SEGMENT_FORM=1, TDOA_NO_SEGMENT_QUADS=1, TDOA_NO_XCD_ROWS=1,
+ * TDOA_NO_DECIMATE=1, TDOA_NO_FUSED_K1=1); results are the same to rounding whichever form runs. */
 enum {
     TDOA_DEBUG_GENERIC_KERNELS = 1,  /* any-size LDS radix-4 kernels instead of the radix-16 register kernels        */
     TDOA_DEBUG_NO_SHORT_LAG    = 2,  /* general pruned inverse even when the search range is below 4095 lags          */
-    TDOA_DEBUG_NO_FUSED_ROWS   = 4,  /* separate forward row pass even when every station is in at most two pairs     */
+    TDOA_DEBUG_NO_FUSED_K1     = 4,  /* K1 always writes its 24-bit codes to memory (int32); the forward column kernels
+                                        read them instead of evaluating the discriminator on the capture bytes      */
     TDOA_DEBUG_NO_SEGMENT_FORM = 8,  /* no LDS-resident overlap-save correlation for search ranges up to 1024 lags    */
     TDOA_DEBUG_NO_XCD_ROWS     = 16, /* plain 2-D grid of the pair kernel even with more pairs than stations          */
-    TDOA_DEBUG_PAIR_R8         = 32, /* (bit set = form USED) 512-thread / 8-value pair kernel instead of 256 / 16      */
     TDOA_DEBUG_NO_SEGMENT_QUADS = 64, /* segment form one pair-window at a time: no station transforms shared by pairs */
-    TDOA_DEBUG_NO_DECIMATE     = 256, /* full inverse transform even where the decimated one applies (4096 x 256 plans, search ranges above 4095 lags) */
-    TDOA_DEBUG_TRI_ROWS        = 128 /* (bit set = form USED) three stations / three pairs: k_rows_tri_fused, all row transforms of a window's row pair in one kernel */
+    TDOA_DEBUG_NO_DECIMATE     = 256 /* full inverse transform even where the decimated one applies (4096 x 256 / x 512 plans, search ranges above 4095 lags) */
 };
 int tdoa_debug_flags(tdoa_ctx *ctx, unsigned flags);
 /* tests only (host, no GPU): the cover of a window's station pairs by "quads" -- two template stations x two signal

@@ -60,8 +60,8 @@ def lib():
         L.o_fast_snr.restype = C.c_double
         L.o_rand_float64.restype = C.c_double
         L.o_rand_float64.argtypes = [C.c_uint64, C.c_uint64]
-        L.ob_octant_angle.restype = C.c_float
-        L.ob_octant_angle.argtypes = [C.c_int, C.c_int]
+        L.ob_octant_code.restype = C.c_int32
+        L.ob_octant_code.argtypes = [C.c_int, C.c_int]
         L.ob_angle_code.restype = C.c_int
         L.ob_angle_code.argtypes = [C.c_int, C.c_int]
         L.o_lowpass.argtypes = [fp, sz, C.c_int, fp]
@@ -352,8 +352,8 @@ def rand_float64(seed, counter):
 
 # --- mode B ------------------------------------------------------------------------
 
-def b_octant_angle(mn, mx):
-    return lib().ob_octant_angle(int(mn), int(mx))
+def b_octant_code(mn, mx):
+    return lib().ob_octant_code(int(mn), int(mx))
 
 
 def b_angle_code(i, q):
@@ -361,7 +361,7 @@ def b_angle_code(i, q):
 
 
 def b_discriminate(iq_u8):
-    """u8 IQ -> phase codes in units of pi/32768, -32767 .. +32768 (int32)."""
+    """u8 IQ -> phase codes in units of pi/2^23, -2^23 < code <= 2^23 (int32)."""
     s = np.ascontiguousarray(iq_u8, dtype=np.uint8)
     n = s.size // 2
     out = np.empty(n, dtype=np.int32)

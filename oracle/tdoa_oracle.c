@@ -952,34 +952,16 @@ void o_simulate_delayed_fm(uint8_t *out, size_t n, int delay, double mod_index, 
 
 /* K1 sample angle code.  I = 2 b_I - 255, Q = 2 b_Q - 255 are odd integers proportional to
  * (b - 127.5)/127.5 of processor.go:198-199, never zero.  The angle code of one sample,
- *   a(I, Q) = arg(I + iQ) in units of pi/32768, rounded,
- * is built so that (i) collinear samples share one code and (ii) a(-I, -Q) = a(I, Q) -+ 32768
- * EXACTLY -- property (ii) is what lets the discriminator below tell an exactly reversed sample:
+ *   a(I, Q) = arg(I + iQ) in units of pi/2^23, rounded to the nearest integer,
+ * is built so that (i) collinear samples share one code and (ii) a(-I, -Q) = a(I, Q) -+ 2^23
+ * EXACTLY -- property (ii) is what makes an exactly reversed sample come out as +pi below:
  *   1. reduce (|I|, |Q|) by their gcd                      (collinear samples -> one direction)
- *   2. first-octant angle of the reduced direction as an explicit sequence of correctly rounded
- *      f32 operations that the device kernel repeats bit for bit:
- *        t = mn * RCP[mx]     RCP[m] = f32(1/m), mn = min, mx = max of the reduced pair
- *        a = t * P(t*t)       P: degree-7 Horner with fused multiply-adds (max error 1.7e-7 rad)
- *        c = rint(a * f32(32768/pi))                        0 < c <= 8192
- *   3. octant / quadrant placement in INTEGER arithmetic: |Q| > |I| -> 16384 - c; I < 0 -> 32768 - c;
- *      Q < 0 -> negate.  |a| <= 32768 - 41. */
-static const float K1_C[8] = {
-    0x1.fffffcp-1f, -0x1.5551bcp-2f, 0x1.98f84ep-3f, -0x1.1f0f46p-3f,
-    0x1.95c0f4p-4f, -0x1.e655d6p-5f, 0x1.8bf058p-6f, -0x1.31f904p-8f,
-};
-#define K1_CODE_SCALE 10430.3779296875f   /* f32(32768/pi) */
-
-/* atan(mn/mx) for 0 < mn <= mx <= 255 */
-float ob_octant_angle(int mn, int mx)
-{
-    float r = 1.0f / (float)mx;                  /* == RCP[mx] */
-    float t = (float)mn * r;
-    float z = t * t;
-    float p = K1_C[7];
-    for (int k = 6; k >= 0; k--)
-        p = fmaf(p, z, K1_C[k]);
-    return p * t;
-}
+ *   2. first-octant angle of the reduced direction (mn <= mx): c = llround(atan2(mn, mx) * 2^23/pi) in f64
+ *      (0 < c <= 2^21; 8256 distinct (mn, mx) pairs -- the product keeps them as a table, built by its host side
+ *      with the same expression)
+ *   3. octant / quadrant placement in INTEGER arithmetic: |Q| > |I| -> 2^22 - c; I < 0 -> 2^23 - c; Q < 0 -> negate.
+ * The step (3.7e-7 rad) is what a float32 holds at this magnitude: f32(code) is exact, |code| <= 2^23. */
+#define K1_HALF_TURN 8388608          /* 2^23 code units = pi */
 
 static int gcd_int(int a, int b)
 {
@@ -987,41 +969,41 @@ static int gcd_int(int a, int b)
     return a;
 }
 
+/* first-octant code of the direction (mx, mn), 0 < mn <= mx <= 255 odd */
+int32_t ob_octant_code(int mn, int mx)
+{
+    int g = gcd_int(mx, mn);
+    return (int32_t)llround(atan2((double)(mn / g), (double)(mx / g)) * (8388608.0 / M_PI));
+}
+
 int ob_angle_code(int I, int Q)
 {
     int ax = I < 0 ? -I : I, ay = Q < 0 ? -Q : Q;
-    int g = gcd_int(ax, ay);
-    ax /= g;
-    ay /= g;
     int mx = ax > ay ? ax : ay, mn = ax > ay ? ay : ax;
-    int c = (int)lrintf(ob_octant_angle(mn, mx) * K1_CODE_SCALE);
-    if (ay > ax) c = 16384 - c;
-    if (I < 0) c = 32768 - c;
+    int c = ob_octant_code(mn, mx);
+    if (ay > ax) c = K1_HALF_TURN / 2 - c;
+    if (I < 0) c = K1_HALF_TURN - c;
     if (Q < 0) c = -c;
     return c;
 }
 
-/* K1: u8 IQ -> phase-difference FM discriminator -> phase code in units of pi/32768.
+/* K1: u8 IQ -> phase-difference FM discriminator -> phase code in units of pi/2^23.
  * The definition being quantised is the discriminator of the prebuilt reference binary (SURVEY.md
  * section 8, row K1): p = x_i * conj(x_{i-1}), y_i = atan2(Im p, Re p), y_0 := y_1.  x_i is never 0
  * for byte data, so its |p|^2 > 1e-10 gate never fires.  atan2 returns values in (-pi, +pi]: an
  * exactly reversed sample (Im p = +0, Re p < 0) is +pi, never -pi.  Hence
- *   w      = int16 wrap of (a_i - a_{i-1})              (two's-complement wrap = the phase circle)
- *   code_i = w                                           if w != -32768
- *          = +32768 if Im p >= 0 else -32767             if the two angle codes are exactly opposite
- * (Im p has the sign of Q_i I_{i-1} - I_i Q_{i-1}; by property (ii) every exactly reversed pair has
- * opposite codes).  code_i is within one step of y_i * 32768/pi AS A REAL NUMBER, -32767 <= code_i <= 32768.
- * The step (9.6e-5 rad) is far below the phase noise 8-bit I/Q quantisation itself causes
- * (>= 2e-3 rad at full scale).  The device stores -code_i as an int16. */
+ *   code_i = the integer congruent to a_i - a_{i-1} modulo 2^24 in (-2^23, +2^23]
+ * Two directions that are not collinear differ by at least 1/(|x_i||x_{i-1}|) >= 1/130050 rad = 20 code steps from
+ * an exact reversal, so a_i - a_{i-1} = -+2^23 happens for exactly reversed samples ONLY (property (ii)), where
+ * Im p = 0 and atan2 gives +pi: the half-open interval is the whole rule, no sign test is needed.
+ * code_i is within one step of y_i * 2^23/pi AS A REAL NUMBER. */
 static int32_t phase_code(const uint8_t *cur, const uint8_t *prev)
 {
     int I = 2 * (int)cur[0] - 255, Q = 2 * (int)cur[1] - 255;
     int Ip = 2 * (int)prev[0] - 255, Qp = 2 * (int)prev[1] - 255;
-    int a1 = ob_angle_code(I, Q), a0 = ob_angle_code(Ip, Qp);
-    int w = (int16_t)(uint16_t)((a1 - a0) & 0xffff);
-    if (w == -32768)
-        return (Q * Ip - I * Qp) >= 0 ? 32768 : -32767;
-    return w;
+    int32_t u = (ob_angle_code(Ip, Qp) - ob_angle_code(I, Q)) & 0xffffff;      /* -(code) modulo 2^24 */
+    if (u & 0x800000) u -= 0x1000000;                                          /* into [-2^23, 2^23) */
+    return -u;
 }
 
 void ob_discriminate_u8(const uint8_t *iq, size_t n, int32_t *code)
@@ -1038,19 +1020,21 @@ void ob_discriminate_u8(const uint8_t *iq, size_t n, int32_t *code)
     code[0] = code[1];
 }
 
-/* exact, order-independent statistics of the phase codes */
+/* exact, order-independent statistics of the codes: S1 = sum code (int64), S2 = sum code^2 (128 bits: up to
+ * 2^46 per sample).  mean = f32(S1 / n); var = (S2 - S1^2/n) / n in f64 with S2 converted as
+ * (double)(S2 >> 32) * 2^32 + (double)(S2 & 0xffffffff) -- the expression the device uses. */
 void ob_phase_stats(const int32_t *code, size_t n, ob_stats *st)
 {
     int64_t s1 = 0;
-    uint64_t s2 = 0;
+    unsigned __int128 s2 = 0;
     for (size_t i = 0; i < n; i++) {
         int64_t q = code[i];
         s1 += q;
         s2 += (uint64_t)(q * q);
     }
     st->s1 = s1;
-    st->s2_lo = s2;
-    st->s2_hi = 0;
+    st->s2_lo = (uint64_t)s2;
+    st->s2_hi = (uint64_t)(s2 >> 64);
     if (n == 0) {
         st->mean = 0.0f; st->scale = 1.0f; st->var = 0.0;
         return;
@@ -1058,7 +1042,8 @@ void ob_phase_stats(const int32_t *code, size_t n, ob_stats *st)
     double dn = (double)n;
     st->mean = (float)((double)s1 / dn);
     double m2 = ((double)s1 * (double)s1) / dn;
-    double var = ((double)s2 - m2) / dn;
+    double s2d = (double)(uint64_t)(s2 >> 32) * 4294967296.0 + (double)(uint64_t)(s2 & 0xffffffffu);
+    double var = (s2d - m2) / dn;
     st->var = var;
     st->scale = (var > 0) ? (float)(1.0 / sqrt(var)) : 1.0f;
 }
@@ -1104,8 +1089,9 @@ void ob_preprocess_smooth_u8(const uint8_t *iq, size_t n, int window, float *out
  * p > 0.01: discriminator chain; p <= 0.01: envelope |x| -> removeDCBias -> normalizeSignal.  (Below 0.001 the binary
  * band-passes the complex samples instead; mode B has no complex path and keeps the envelope there -- DESIGN.md 3.)
  * Integers: M = sum (2I-255)^2 + (2Q-255)^2, p = M / (65025 n), so p <= 0.01  <=>  100 M <= 65025 n.
- * Envelope code = round-half-up(90 sqrt(m)) = (isqrt(32400 m) + 1) >> 1 with m = (2I-255)^2 + (2Q-255)^2 <= 130050
- * (|x| = sqrt(m)/255; 32400 m < 2^32; code <= 32456): an int16 like the phase codes, same statistics and normalisation. */
+ * Envelope code = round-half-up(16384 sqrt(m)) = (isqrt(m << 30) + 1) >> 1 with m = (2I-255)^2 + (2Q-255)^2 <= 130050
+ * (|x| = sqrt(m)/255; m << 30 < 2^47; code <= 5 908 471 < 2^23): an integer a float32 holds exactly, like the phase codes,
+ * same statistics and normalisation. */
 uint64_t ob_power_sum_u8(const uint8_t *iq, size_t n)
 {
     uint64_t m = 0;
@@ -1121,7 +1107,7 @@ int ob_envelope_class(uint64_t power_sum, size_t n) { return 100u * power_sum <=
 int32_t ob_envelope_code(unsigned I, unsigned Q)
 {
     int64_t a = 2 * (int64_t)I - 255, b = 2 * (int64_t)Q - 255;
-    uint64_t x = 32400u * (uint64_t)(a * a + b * b);
+    uint64_t x = (uint64_t)(a * a + b * b) << 30;          /* (2 * 16384 sqrt(m))^2 */
     uint64_t r = (uint64_t)sqrt((double)x);
     while (r * r > x) r--;
     while ((r + 1) * (r + 1) <= x) r++;

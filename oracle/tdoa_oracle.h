@@ -122,14 +122,14 @@ void   o_simulate_delayed_fm(uint8_t *out, size_t n_samples, int delay_samples,
 double o_rand_float64(uint64_t seed, uint64_t counter);
 
 /* ---- mode B oracle (north-star pipeline) ----------- */
-float  ob_octant_angle(int mn, int mx);          /* atan(mn/mx), 0 < mn <= mx <= 255, explicit f32 ops */
-int    ob_angle_code(int I, int Q);               /* arg(I + iQ) in units of pi/32768 */
-/* phase codes in units of pi/32768, -32767 <= code <= 32768 (+pi for an exactly reversed sample) */
+int32_t ob_octant_code(int mn, int mx);          /* atan(mn/mx) in units of pi/2^23, 0 < mn <= mx <= 255 odd */
+int    ob_angle_code(int I, int Q);               /* arg(I + iQ) in units of pi/2^23 */
+/* phase codes in units of pi/2^23, -2^23 < code <= 2^23 (+pi for an exactly reversed sample) */
 void   ob_discriminate_u8(const uint8_t *iq, size_t n, int32_t *code);
 typedef struct {
     int64_t  s1;        /* sum of the phase codes                       */
-    uint64_t s2_lo;     /* sum of code^2                                */
-    uint64_t s2_hi;     /* always 0 (kept for layout)                   */
+    uint64_t s2_lo;     /* sum of code^2, low 64 bits                   */
+    uint64_t s2_hi;     /* high 64 bits (code^2 < 2^46 per sample)      */
     float    mean;      /* f32((double)s1 / n), in code units           */
     float    scale;     /* f32(1/sqrt(var)), 1.0f if var <= 0           */
     double   var;

@@ -20,7 +20,7 @@ for max_lag in (128, 512, 1023, 2047, 4095, 20000):
     for mode in ("segment", "segment_pairwise", "short", "general"):
         with tdoa_amd.Context(max_lag=max_lag) as c:
             c.debug_flags(no_short_lag=(mode == "general"), no_segment_form=not mode.startswith("segment"),
-                          no_segment_quads=(mode == "segment_pairwise"), no_fused_rows=True)
+                          no_segment_quads=(mode == "segment_pairwise"))
             for s in range(3):
                 c.synth_capture(s, 66_666_666, ST[s], TX, 0x5D0A0000 + s)
             c.process(want_host=False)

@@ -8,6 +8,8 @@
 // element per 16 so that the stride-16 writes of the first stage do not pile onto one bank.
 #pragma once
 
+#include <type_traits>
+
 #include "device_common.hpp"
 #include "fft_stockham.hpp"
 #include "k1_discriminator.hpp"
@@ -77,6 +79,10 @@ __device__ __forceinline__ void mul_base_step16(float2 (&v)[16], float2 base, fl
 }
 
 __device__ __forceinline__ int pad16(int i) { return i + (i >> 4); }
+
+// a fetched code pair rides in the registers of the float2 it will become
+__device__ __forceinline__ float2 code_park(int2 w) { return make_float2(__int_as_float(w.x), __int_as_float(w.y)); }
+__device__ __forceinline__ int2 code_unpark(float2 v) { return make_int2(__float_as_int(v.x), __float_as_int(v.y)); }
 
 // A value the compiler must treat as unknown.  The stage twiddles of a row transform are the same for every row a
 // workgroup handles; when a kernel transforms several rows one after the other, common-subexpression elimination
@@ -155,26 +161,24 @@ __global__ __launch_bounds__(256) void k_fwd_row4096(float2 *TZ, FftPlan pl, int
 // and leaves Y_a[kb] in row a*256 + kb; k_fwd_col_finish<G> then runs the G-point transforms over a.
 // ---------------------------------------------------------------------------
 template <bool SUB>
-__global__ __launch_bounds__(512) void k_fwd_col256_c16(const SWDesc *sw, const short *codes, long long code_stride,
+__global__ __launch_bounds__(512) void k_fwd_col256_c16(const SWDesc *sw, const int *codes, long long code_stride,
                                                         const FmStats *stats, float2 *T, FftPlan pl)
 {
     const int G = SUB ? pl.N2 >> 8 : 1, a = SUB ? (int)blockIdx.z : 0;
     extern __shared__ float2 lds[];   // [256][32]
     const int len = sw[blockIdx.y].len;
-    const short *row = codes + (size_t)blockIdx.y * code_stride;
+    const int *row = codes + (size_t)blockIdx.y * code_stride;
     const float mean = stats[blockIdx.y].mean, scale = stats[blockIdx.y].scale;
     const int c = threadIdx.x & 31, j = threadIdx.x >> 5;     // column, item (0..15)
     const int n1 = (blockIdx.x << 5) + c;
     const int N1 = pl.N1;
     float2 v[16];
 #pragma unroll
-    for (int r = 0; r < 16; r++) {     // all 16 loads first (the packed codes are one dword each)
-        const unsigned int w = code_fetch(row, (long long)(a + G * (j + 16 * r)) * N1 + n1, len);
-        v[r].x = __uint_as_float(w);
-    }
+    for (int r = 0; r < 16; r++)       // all 16 loads first (two codes = 8 bytes each, parked in the value's own registers)
+        v[r] = code_park(code_fetch(row, (long long)(a + G * (j + 16 * r)) * N1 + n1, len));
 #pragma unroll
     for (int r = 0; r < 16; r++)
-        v[r] = code_convert(__float_as_uint(v[r].x), (long long)(a + G * (j + 16 * r)) * N1 + n1, len, mean, scale);
+        v[r] = code_convert(code_unpark(v[r]), (long long)(a + G * (j + 16 * r)) * N1 + n1, len, mean, scale);
     fft16<false>(v);
 #pragma unroll
     for (int k = 0; k < 16; k++) lds[((16 * j + k) << 5) + c] = v[oreg(k)];
@@ -198,6 +202,122 @@ __global__ __launch_bounds__(512) void k_fwd_col256_c16(const SWDesc *sw, const 
         mul_base_step16(v, unit_root((float)e0, inv2, false), unit_root((float)e1, inv2, false));
 #pragma unroll
         for (int k = 0; k < 16; k++) out[(size_t)(j + 16 * k) * N1 + n1] = v[oreg(k)];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K1 fused into the forward column pass: the same transform as k_fwd_col256_c16, but the workgroup reads the CAPTURE
+// BYTES and evaluates the discriminator itself (k1_discriminator.hpp) -- no code array is written or read (-8 B per
+// sample of HBM traffic against materialised 24-bit codes, -4 B against the 16-bit codes of rounds 1-2), and the
+// samples are the float discriminator to float32 resolution.  The window statistics come from the k_fm_demod<false>
+// pre-pass.
+//
+// Element m of the packed window needs the angle codes of samples 2m-1, 2m, 2m+1: one 4-byte load (samples 2m, 2m+1)
+// and one 2-byte load (sample 2m-1, the same cache line), three table lookups.
+// LDS: the angle table (33 KB) has to sit next to the tile, and two workgroups must still fit a CU: the exchange between
+// the two radix-16 stages therefore goes through ONE float plane [256][32] (32 KB), real parts first, then imaginary
+// parts (the tile of the code-reading kernel is 64 KB).  The workgroups are persistent -- grid = 2 per CU, tiles dealt
+// round-robin -- so the table is loaded once per workgroup, not once per tile.
+// Tile t = (w A + a) (N1/32) + bx: consecutive workgroups take adjacent 32-column blocks of the same rows.
+// grid (2 n_cu), 512 threads (c = t & 31 column, j = t >> 5 item), dynamic LDS 32 KB + kK1TableBytes.
+// ---------------------------------------------------------------------------
+constexpr size_t kColK1Lds = sizeof(float) * 256 * 32 + kK1TableBytes;
+
+struct K1Raw {             // what a thread fetched for one element: the dword of samples (2m, 2m+1), the sample before
+    unsigned int w, prev;
+};
+
+// ODD: the window has an odd number of samples, so its last element holds one sample only (2m+1 = len); the dword is then
+// fetched one sample earlier (samples 2m-1, 2m: nothing is read beyond the window) and re-sorted in k1_element_convert.
+template <bool ODD>
+__device__ __forceinline__ K1Raw k1_element_fetch(gptr16 p, long long m, int len)
+{
+    const long long i0 = 2 * m;
+    const bool full = i0 + 1 < len, part = ODD && i0 + 1 == len;
+    K1Raw r;
+    r.w = k1_fetch2(p, full ? i0 : (part ? i0 - 1 : 0));
+    r.prev = p[(full || part) && m > 0 ? i0 - 1 : 0];
+    return r;
+}
+
+template <bool ODD>
+__device__ __forceinline__ float2 k1_element_convert(K1Raw r, long long m, int len, float mean, float scale, const int *lut,
+                                                     bool head)      // head: m may be 0 (the window's first element)
+{
+    const long long i0 = 2 * m;
+    const bool full = i0 + 1 < len, part = ODD && i0 + 1 == len;
+    unsigned int s0 = r.w & 0xffffu, s1 = r.w >> 16, sp = r.prev;
+    if (ODD && part) { sp = s0; s0 = s1; }
+    const int ap = k1_angle(sp, lut), a0 = k1_angle(s0, lut), a1 = k1_angle(s1, lut);
+    const int st1 = k1_stored_code(a1, a0);
+    const int st0 = head && m == 0 ? st1 : k1_stored_code(a0, ap);      // code_0 := code_1
+    const float v0 = k1_normalise(st0, mean, scale), v1 = k1_normalise(st1, mean, scale);
+    return make_float2(full || part ? v0 : 0.0f, full ? v1 : 0.0f);
+}
+
+template <bool SUB>
+__global__ __launch_bounds__(512) void k_fwd_col256_k1(const SWDesc *sw, const int *table, const FmStats *stats, float2 *T,
+                                                       FftPlan pl, int n_sw)
+{
+    extern __shared__ float lds_f[];
+    float *plane = lds_f;                                        // [256][32]
+    int *lut = reinterpret_cast<int *>(lds_f + 256 * 32);
+    k1_load_table(lut, table);
+    const int G = SUB ? pl.N2 >> 8 : 1;
+    const int c = threadIdx.x & 31, j = threadIdx.x >> 5;     // column, item (0..15)
+    const int N1 = pl.N1, nbx = N1 >> 5;
+    const int n_tiles = n_sw * G * nbx;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int bx = tile % nbx, wa = tile / nbx, a = SUB ? wa % G : 0, w = SUB ? wa / G : wa;
+        const SWDesc d = sw[w];
+        const int len = d.len;
+        const gptr16 p = k1_global(d.base);
+        const float mean = stats[w].mean, scale = stats[w].scale;
+        const int n1 = (bx << 5) + c;
+        float2 v[16];
+        auto load_convert = [&](auto odd_c) {
+            constexpr bool ODD = decltype(odd_c)::value;
+            K1Raw raw[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) raw[r] = k1_element_fetch<ODD>(p, (long long)(a + G * (j + 16 * r)) * N1 + n1, len);
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                v[r] = k1_element_convert<ODD>(raw[r], (long long)(a + G * (j + 16 * r)) * N1 + n1, len, mean, scale, lut, r == 0);
+        };
+        if (len & 1) load_convert(std::true_type{});
+        else load_convert(std::false_type{});
+        fft16<false>(v);
+        // exchange through one float plane: real parts, then imaginary parts
+#pragma unroll
+        for (int k = 0; k < 16; k++) plane[((16 * j + k) << 5) + c] = v[oreg(k)].x;
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; r++) v[r].x = plane[((j + 16 * r) << 5) + c];      // .y still holds stage-1 outputs (oreg order)
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; k++) plane[((16 * j + k) << 5) + c] = v[oreg(k)].y;
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; r++) v[r].y = plane[((j + 16 * r) << 5) + c];
+        __syncthreads();                                         // the next tile writes the plane again
+        mul_powers16(v, unit_root((float)j, 2.0f / 256.0f, false));
+        fft16<false>(v);
+        float2 *out = T + (size_t)w * pl.Nc;
+        if (SUB) {
+            // Y_a[kb = j + 16k] *= W_(256G)^(a kb) = W^(a j) * (W^(16 a))^k
+            const float invg = 2.0f / (float)pl.N2;
+            if (a) mul_base_step16(v, unit_root((float)(a * j), invg, false), unit_root((float)(16 * a), invg, false));
+#pragma unroll
+            for (int k = 0; k < 16; k++) out[(size_t)(a * 256 + j + 16 * k) * N1 + n1] = v[oreg(k)];
+        } else {
+            // Y[k2 = j + 16k] *= W_Nc^(n1*k2) = W^(n1*j) * (W^(16*n1))^k
+            const float inv2 = 2.0f / (float)pl.Nc;
+            const long long e0 = ((long long)n1 * j) & (pl.Nc - 1);
+            const long long e1 = ((long long)n1 * 16) & (pl.Nc - 1);
+            mul_base_step16(v, unit_root((float)e0, inv2, false), unit_root((float)e1, inv2, false));
+#pragma unroll
+            for (int k = 0; k < 16; k++) out[(size_t)(j + 16 * k) * N1 + n1] = v[oreg(k)];
+        }
     }
 }
 
@@ -234,14 +354,14 @@ __global__ __launch_bounds__(256) void k_fwd_col_finish(float2 *T, FftPlan pl)
 // 32/F columns per workgroup: grid (N1 F/32, n_sw), 512 threads, dynamic LDS 64 KB.
 // ---------------------------------------------------------------------------
 template <int F>
-__global__ __launch_bounds__(512) void k_fwd_colx_c16(const SWDesc *sw, const short *codes, long long code_stride,
+__global__ __launch_bounds__(512) void k_fwd_colx_c16(const SWDesc *sw, const int *codes, long long code_stride,
                                                       const FmStats *stats, float2 *T, FftPlan pl)
 {
     static_assert(F == 2 || F == 4, "last stage is radix 2 or 4");
     constexpr int C = 32 / F, LOGC = F == 2 ? 4 : 3;
     extern __shared__ float2 lds[];   // [F][256][C]
     const int len = sw[blockIdx.y].len;
-    const short *row = codes + (size_t)blockIdx.y * code_stride;
+    const int *row = codes + (size_t)blockIdx.y * code_stride;
     const float mean = stats[blockIdx.y].mean, scale = stats[blockIdx.y].scale;
     const int c = threadIdx.x & (C - 1), j = (threadIdx.x >> LOGC) & 15, par = threadIdx.x >> (LOGC + 4);
     const int n1 = blockIdx.x * C + c;
@@ -249,10 +369,10 @@ __global__ __launch_bounds__(512) void k_fwd_colx_c16(const SWDesc *sw, const sh
     float2 *img = lds + par * 256 * C;
     float2 v[16];
 #pragma unroll
-    for (int r = 0; r < 16; r++) v[r].x = __uint_as_float(code_fetch(row, (long long)(F * (j + 16 * r) + par) * N1 + n1, len));
+    for (int r = 0; r < 16; r++) v[r] = code_park(code_fetch(row, (long long)(F * (j + 16 * r) + par) * N1 + n1, len));
 #pragma unroll
     for (int r = 0; r < 16; r++)
-        v[r] = code_convert(__float_as_uint(v[r].x), (long long)(F * (j + 16 * r) + par) * N1 + n1, len, mean, scale);
+        v[r] = code_convert(code_unpark(v[r]), (long long)(F * (j + 16 * r) + par) * N1 + n1, len, mean, scale);
     fft16<false>(v);
 #pragma unroll
     for (int k = 0; k < 16; k++) img[(16 * j + k) * C + c] = v[oreg(k)];
@@ -303,23 +423,23 @@ __global__ __launch_bounds__(512) void k_fwd_colx_c16(const SWDesc *sw, const sh
 // grid (N1 F/256, n_sw), 256 threads, static LDS 32 KB.
 // ---------------------------------------------------------------------------
 template <int F>
-__global__ __launch_bounds__(256) void k_fwd_col16x_c16(const SWDesc *sw, const short *codes, long long code_stride,
+__global__ __launch_bounds__(256) void k_fwd_col16x_c16(const SWDesc *sw, const int *codes, long long code_stride,
                                                         const FmStats *stats, float2 *T, FftPlan pl)
 {
     static_assert(F == 1 || F == 2 || F == 4 || F == 8, "N2 = 16, 32, 64 or 128");
     constexpr int C = 256 / F;
     __shared__ float2 img[F == 1 ? 1 : F * 16 * C];   // [part][k][column]
     const int len = sw[blockIdx.y].len;
-    const short *row = codes + (size_t)blockIdx.y * code_stride;
+    const int *row = codes + (size_t)blockIdx.y * code_stride;
     const float mean = stats[blockIdx.y].mean, scale = stats[blockIdx.y].scale;
     const int c = threadIdx.x % C, p = threadIdx.x / C;
     const int n1 = blockIdx.x * C + c;
     const int N1 = pl.N1;
     float2 v[16];
 #pragma unroll
-    for (int r = 0; r < 16; r++) v[r].x = __uint_as_float(code_fetch(row, (long long)(F * r + p) * N1 + n1, len));
+    for (int r = 0; r < 16; r++) v[r] = code_park(code_fetch(row, (long long)(F * r + p) * N1 + n1, len));
 #pragma unroll
-    for (int r = 0; r < 16; r++) v[r] = code_convert(__float_as_uint(v[r].x), (long long)(F * r + p) * N1 + n1, len, mean, scale);
+    for (int r = 0; r < 16; r++) v[r] = code_convert(code_unpark(v[r]), (long long)(F * r + p) * N1 + n1, len, mean, scale);
     fft16<false>(v);
     const int q = p;
     if constexpr (F > 1) {

@@ -1,10 +1,8 @@
 // fft_radix8.hpp -- 4096-point row transforms on 512 threads: 8 complex values per thread, radix-8 Stockham stages
 // 8 x 8 x 8 x 8 with three LDS exchanges.  Same math and layouts as fft_radix16.hpp; what changes is the register
-// footprint.  A workgroup that has to hold the spectra of several rows at once (the forward row pass fused into the
-// pair kernel, below) needs 4 rows x 16 values x 8 B = 128 VGPRs on 256 threads before the first temporary; the
-// compiler answers with spills or two waves per SIMD, and at two waves per SIMD a VALU-heavy kernel only issues on
-// every other slot (one wave alone gets a vector instruction every 4 cycles, MI355X_MICROARCH.md).  On 512 threads
-// the same rows cost 64 VGPRs, the kernel fits 128 and runs four waves per SIMD.
+// footprint: a VALU-heavy kernel that holds several rows at once (the segment form's frames, the decimated inverse)
+// fits 128 VGPRs on 512 threads and runs four waves per SIMD, where 256 threads x 16 values get two (one wave alone
+// gets a vector instruction every 4 cycles, MI355X_MICROARCH.md).
 //
 // LDS images are 4096 float2 (32 KB) with an XOR swizzle instead of padding: element i lives at
 //   swz(i) = i ^ ((i >> 5) & 7) ^ (((i >> 6) & 3) << 3)
@@ -87,10 +85,10 @@ __device__ __forceinline__ int swz(int i) { return i ^ ((i >> 5) & 7) ^ (((i >> 
 #define TDOA_PLAIN_DS_OPS
 #endif
 
-// phase code at a 32-bit unsigned byte offset from a uniform row pointer (global_load_sshort v, v_off, s[base])
-__device__ __forceinline__ int code_at(const short *row, unsigned byte_off)
+// stored phase code at a 32-bit unsigned byte offset from a uniform row pointer (global_load_dword v, v_off, s[base])
+__device__ __forceinline__ int code_at(const int *row, unsigned byte_off)
 {
-    return *reinterpret_cast<const short *>(reinterpret_cast<const char *>(row) + byte_off);
+    return *reinterpret_cast<const int *>(reinterpret_cast<const char *>(row) + byte_off);
 }
 
 __device__ __forceinline__ int opaque_i(int v)
@@ -191,209 +189,7 @@ __device__ __forceinline__ void rows2_r8_finish(float2 (&x)[8], float2 (&y)[8], 
                            opaque(unit_root((float)j, 2.0f / 4096.0f, INV)));
 }
 
-// second half of the radix-8 pair kernels: Q of rows a (va: stage-1 item t, inputs in natural order) and b (vb: stage-1
-// item 511 - t) -> two inverse row transforms -> four-step twiddle -> the two V rows (FK = 0) or the row pair's share of
-// the short-lag column sums (FK > 0).  All 512 threads; the LDS images must be free to overwrite on entry.
-template <int FK>
-__device__ __forceinline__ void inv_row_pair_tail_r8(float2 (&va)[8], float2 (&vb)[8], float2 *la, float2 *lb, const int t,
-                                                     const int a, const int b, const int pw_index, float2 *V,
-                                                     const FftPlan &pl)
-{
-    const int N2 = pl.N2;
-    fft8<true>(va);
-    fft8<true>(vb);
-    rows2_r8_finish<true>(va, vb, la, lb, t, t, 511 - t);
-    // V[k2][n1] = y[n1] * W_Nc^(-n1 k2), n1 = t + 512 k
-    float2 *out = V + (size_t)pw_index * pl.Nc;
-    const float inv2 = 2.0f / (float)pl.Nc;
-    {
-        const long long e0 = ((long long)t * a) & (pl.Nc - 1), e1 = ((long long)512 * a) & (pl.Nc - 1);
-        mul_base_step8(va, unit_root((float)e0, inv2, true), unit_root((float)e1, inv2, true));
-        const long long f0 = ((long long)t * b) & (pl.Nc - 1), f1 = ((long long)512 * b) & (pl.Nc - 1);
-        mul_base_step8(vb, unit_root((float)f0, inv2, true), unit_root((float)f1, inv2, true));
-    }
-    if constexpr (FK == 0) {
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            out[(size_t)a * 4096 + t + 512 * k] = va[oreg8(k)];
-            out[(size_t)b * 4096 + t + 512 * k] = vb[oreg8(k)];
-        }
-    } else {
-        // short-lag form (see k_inv_row_pair4096): P0[n1] = V[a][n1] + V[b][n1] for n1 < 256 FK,
-        // P1[n1 - (4096 - 256 FK)] = V[a][n1] conj(w_a) + V[b][n1] conj(w_b) for n1 >= 4096 - 256 FK
-        const float2 ca = unit_root((float)a, 2.0f / (float)N2, false);
-        const float2 cb = unit_root((float)b, 2.0f / (float)N2, false);
-        float2 *part = out + (size_t)a * (2 * 256 * FK);
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const int n1 = t + 512 * k;
-            if (512 * k < 256 * FK && n1 < 256 * FK) part[n1] = cadd(va[oreg8(k)], vb[oreg8(k)]);
-            if (512 * (k + 1) > 4096 - 256 * FK && n1 >= 4096 - 256 * FK)
-                part[256 * FK + n1 - (4096 - 256 * FK)] = cadd(cmul(va[oreg8(k)], ca), cmul(vb[oreg8(k)], cb));
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------
-// Inverse row pair kernel on 512 threads (rows a and b = N2 - a, a >= 1): the same work as k_inv_row_pair4096<false, FK>
-// -- K3 on finished spectra, two inverse row transforms, twiddle, V rows or short-lag shares -- with 8 values per thread,
-// 128 VGPRs and four waves per SIMD instead of 16 values, ~230 VGPRs and two.  The pair kernel issues vector
-// instructions for 0.74 of its 1.19 ms (cfg2); at two waves per SIMD a wave that waits leaves every other issue slot
-// empty.  Grid as k_inv_row_pair4096 (2-D, or the XCD-aware 1-D form with group_pairs > 0), dynamic LDS 64 KB.
-// ---------------------------------------------------------------------------
-template <int FK>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_PLAIN_DS_OPS)) void k_inv_row_pair_r8(const PWDesc *pw, const float2 *Z, float2 *V, FftPlan pl, int group_pairs, int n_pw)
-{
-    extern __shared__ float2 lds[];   // 2 * kRow8Lds
-    const int N2 = pl.N2;
-    int pw_index = blockIdx.y, a = blockIdx.x + 1;
-    if (group_pairs > 0) {            // XCD-aware 1-D grid: see k_inv_row_pair4096
-        const int RP = N2 / 2 - 1;
-        const unsigned int L = blockIdx.x, xcd = L & 7u, slot = L >> 3;
-        const unsigned int g = slot / (unsigned int)group_pairs, p = slot % (unsigned int)group_pairs;
-        const unsigned int G = g * 8u + xcd;
-        const unsigned int w = G / (unsigned int)RP;
-        if (w * (unsigned int)group_pairs >= (unsigned int)n_pw) return;
-        a = (int)(G % (unsigned int)RP) + 1;
-        pw_index = (int)(w * (unsigned int)group_pairs + p);
-    }
-    const int b = N2 - a;
-    const PWDesc d = pw[pw_index];
-    const float2 *ZaA = Z + (size_t)d.sw_a * pl.Nc + (size_t)a * 4096;
-    const float2 *ZaB = Z + (size_t)d.sw_a * pl.Nc + (size_t)b * 4096;
-    const float2 *ZbA = Z + (size_t)d.sw_b * pl.Nc + (size_t)a * 4096;
-    const float2 *ZbB = Z + (size_t)d.sw_b * pl.Nc + (size_t)b * 4096;
-    const int t = threadIdx.x;
-    float2 *la = lds, *lb = lds + kRow8Lds;
-    float2 va[8], vb[8];
-    {
-        float2 za[8], zam[8], zb[8], zbm[8];
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-            const int k1 = t + 512 * r;
-            za[r] = ZaA[k1];
-            zam[r] = ZaB[4095 - k1];
-            zb[r] = ZbA[k1];
-            zbm[r] = ZbB[4095 - k1];
-        }
-        // w(k) = W_N^k, k = (t + 512 r) N2 + a  =>  w = w0 * W_16^r, re-anchored half way
-        const float invNc = 1.0f / (float)pl.Nc;
-        const long long k0 = (long long)t * N2 + a;
-        const float2 st = make_float2(0.92387953251128674f, -0.38268343236508977f);   // e^{-2 pi i/16}
-        float2 w = unit_root((float)k0, invNc, false);
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-            float2 q, qm;
-            pair_q(za[r], zam[r], zb[r], zbm[r], w, q, qm);
-            va[r] = q;              // Q[a][t + 512 r]:                 row a, stage-1 item t, input r
-            vb[7 - r] = qm;         // Q[b][(511 - t) + 512 (7 - r)]:   row b, stage-1 item 511 - t, input 7 - r
-            if (r == 3)
-                w = unit_root((float)(k0 + (long long)4 * 512 * N2), invNc, false);
-            else
-                w = cmul(w, st);
-        }
-    }
-    inv_row_pair_tail_r8<FK>(va, vb, la, lb, t, a, b, pw_index, V, pl);
-}
-
-// ---------------------------------------------------------------------------
-// Forward row pass FUSED into the inverse row pair kernel, rows a and b = N2 - a (a >= 1): the workgroup reads the
-// COLUMN-pass output T of both stations (the same 4 x 32 KB the pair kernel reads anyway), runs the four forward
-// row transforms itself, parks the two rows b in LDS to get at their mirrored elements, forms Q (K3) and runs the two
-// inverse rows.  The separate forward row pass (16 Nc bytes per station-window, read + write) disappears; the price
-// is that a station's row pair is transformed once per pair the station is in, so the host takes this form when a
-// launch group has no more pair-windows than station-windows (3 stations / 3 pairs, or a single pair).
-// The self-mirrored rows 0 and N2/2 keep the two-kernel form (k_fwd_row4096 on those two rows, then
-// k_inv_row_pair4096<true, FK>).
-// FK as in k_inv_row_pair4096: 0 writes the two V rows, FK > 0 the row pair's share of the short-lag column sums.
-// grid (N2/2 - 1, n_pw), 512 threads, dynamic LDS 64 KB (two workgroups per CU, four waves per SIMD).
-// ---------------------------------------------------------------------------
-template <int FK>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_PLAIN_DS_OPS)) void k_pair_rows_fused_r8(const PWDesc *pw, const float2 *T, float2 *V, FftPlan pl)
-{
-    extern __shared__ float2 lds[];   // 2 * kRow8Lds
-    const int N2 = pl.N2;
-    const int pw_index = blockIdx.y;
-    const int a = blockIdx.x + 1, b = N2 - a;
-    const PWDesc d = pw[pw_index];
-    const float2 *TaA = T + (size_t)d.sw_a * pl.Nc + (size_t)a * 4096;
-    const float2 *TaB = T + (size_t)d.sw_a * pl.Nc + (size_t)b * 4096;
-    const float2 *TbA = T + (size_t)d.sw_b * pl.Nc + (size_t)a * 4096;
-    const float2 *TbB = T + (size_t)d.sw_b * pl.Nc + (size_t)b * 4096;
-    const int t = threadIdx.x;
-    float2 *la = lds, *lb = lds + kRow8Lds;
-    float2 xa[8], ya[8], xb[8], yb[8];     // x: template station, y: signal station; a / b: the row
-#pragma unroll
-    for (int r = 0; r < 8; r++) {
-        xa[r] = TaA[t + 512 * r];
-        ya[r] = TbA[t + 512 * r];
-    }
-#pragma unroll
-    for (int r = 0; r < 8; r++) {
-        xb[r] = TaB[t + 512 * r];
-        yb[r] = TbB[t + 512 * r];
-    }
-    fft8<false>(xa);
-    fft8<false>(ya);
-    rows2_r8_finish<false>(xa, ya, la, lb, t, t, t);       // Z[a][t + 512 k] in [oreg8(k)]
-    __syncthreads();
-    fft8<false>(xb);
-    fft8<false>(yb);
-    rows2_r8_finish<false>(xb, yb, la, lb, t, t, t);
-    __syncthreads();
-    // park the rows b in natural order; the pair stage reads their mirrored elements Z[b][4095 - t - 512 r]
-    {
-        const int rb = swz(t);
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            la[rb + 512 * k] = xb[oreg8(k)];
-            lb[rb + 512 * k] = yb[oreg8(k)];
-        }
-    }
-    __syncthreads();
-    float2 va[8], vb[8];
-    {
-        // w(k) = W_N^k, k = (t + 512 r) N2 + a  =>  w = w0 * W_16^r, re-anchored half way
-        const float invNc = 1.0f / (float)pl.Nc;
-        const long long k0 = (long long)t * N2 + a;
-        const float2 st = make_float2(0.92387953251128674f, -0.38268343236508977f);   // e^{-2 pi i/16}
-        const int mb = swz(4095 - t);      // element (4095 - t) - 512 r lives at swz(4095 - t) - 512 r
-        float2 w = unit_root((float)k0, invNc, false);
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-            float2 q, qm;
-            pair_q(xa[oreg8(r)], la[mb - 512 * r], ya[oreg8(r)], lb[mb - 512 * r], w, q, qm);
-            va[r] = q;              // Q[a][t + 512 r]:                 row a, stage-1 item t, input r
-            vb[7 - r] = qm;         // Q[b][(511 - t) + 512 (7 - r)]:   row b, stage-1 item 511 - t, input 7 - r
-            if (r == 3)
-                w = unit_root((float)(k0 + (long long)4 * 512 * N2), invNc, false);
-            else
-                w = cmul(w, st);
-        }
-    }
-    __syncthreads();      // every mirrored read is done before the inverse stages overwrite the images
-    inv_row_pair_tail_r8<FK>(va, vb, la, lb, t, a, b, pw_index, V, pl);
-}
-
-// ---------------------------------------------------------------------------
-// Three stations, three pairs (the reference's deployment): forward row pass AND pair step in one kernel, every station
-// row transformed ONCE.  k_pair_rows_fused_r8 above transforms a station's row pair once per pair the station is in
-// (9 two-row transforms per window and row pair for 3 pairs) and loses to its own VALU issue time; here a workgroup
-// takes the row pair (a, b = N2 - a) of all three stations of a window: 3 forward + 3 inverse two-row transforms, the
-// same arithmetic as k_fwd_row4096 + k_inv_row_pair4096 together, but T is read once (3 x 64 KB) and only V is written
-// (3 x 64 KB): 48 Nc bytes per window against 120 Nc for the two kernels.
-// Six rows of spectra do not fit two 512-thread workgroups per CU, so ONE workgroup of 1024 threads = two teams of 512
-// (team = wave-uniform), four LDS images (128 KB), 128 VGPRs:
-//   F1  team 0: forward rows of station 0        | team 1: forward rows of station 1
-//   Q1  team 0: loads the rows of station 2      | team 1: K3 for the pair (0, 1) (station 0 through team 0's images)
-//   F2  team 0: forward rows of station 2        | team 1: inverse rows of (0, 1) -> V
-//   Q2  team 0: K3 for (0, 2)                    | team 1: K3 for (1, 2)
-//   F3  team 0: inverse rows of (0, 2) -> V      | team 1: inverse rows of (1, 2) -> V
-// Every transform is the same forward code for both teams (one s_barrier stream): an inverse transform is run as
-// conj(forward(conj(.))) in F2, where the two teams go opposite ways.
-// quads[blockIdx.y] must have the three-station pattern (sw_tb == sw_sc, pw[2] < 0, the other three wanted); the host
-// checks.  grid (N2/2 - 1, n_quads), 1024 threads, dynamic LDS 128 KB.  Rows 0 and N2/2 keep the two-kernel form.
-// ---------------------------------------------------------------------------
+// two inverse rows a, b (outputs of rows2_r8_finish<true>) -> four-step twiddle -> V[k2][n1]
 __device__ __forceinline__ void inv_rows_twiddle_store(float2 (&va)[8], float2 (&vb)[8], const int t, const int a, const int b,
                                                        float2 *out, const FftPlan &pl)
 {
@@ -410,112 +206,11 @@ __device__ __forceinline__ void inv_rows_twiddle_store(float2 (&va)[8], float2 (
     }
 }
 
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_PLAIN_DS_OPS)) void k_rows_tri_fused(const QuadDesc *quads, const float2 *T, float2 *V, FftPlan pl)
-{
-    extern __shared__ float2 lds[];   // 4 * kRow8Lds
-    const int N2 = pl.N2;
-    const int team = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 9));
-    const int t = threadIdx.x & 511;
-    const int a = blockIdx.x + 1, b = N2 - a;
-    const QuadDesc qd = quads[blockIdx.y];
-    float2 *la = lds + (size_t)team * 2 * kRow8Lds, *lb = la + kRow8Lds;            // this team's images
-    float2 *oa = lds + (size_t)(1 - team) * 2 * kRow8Lds;                           // the other team's first image
-    const int rb = swz(t), mb = swz(4095 - t);
-    const float2 w2 = unit_root((float)(t & 7), 2.0f / 64.0f, false), w3 = unit_root((float)(t & 63), 2.0f / 512.0f, false),
-                 w4 = unit_root((float)t, 2.0f / 4096.0f, false);
-    const float invNc = 1.0f / (float)pl.Nc;
-    const long long k0 = (long long)t * N2 + a;                                     // w(k) = W_N^k, k = (t + 512 r) N2 + a
-    const float2 st = make_float2(0.92387953251128674f, -0.38268343236508977f);     // e^{-2 pi i/16}
-
-    // F1: forward rows of station 0 (team 0) / station 1 (team 1)
-    float2 xa[8], xb[8];
-    {
-        const float2 *Ts = T + (size_t)(team ? qd.sw_tb : qd.sw_ta) * pl.Nc;
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-            xa[r] = Ts[(size_t)a * 4096 + t + 512 * r];
-            xb[r] = Ts[(size_t)b * 4096 + t + 512 * r];
-        }
-    }
-    fft8<false>(xa);
-    fft8<false>(xb);
-    rows2_r8_finish_w<false>(xa, xb, la, lb, t, t, t, opaque(w2), opaque(w3), opaque(w4));   // Z[a][t + 512 k] in xa[oreg8(k)], Z[b][.] in xb
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 8; k++) {          // both rows in natural order: team 1 needs row a of station 0 and the mirrored rows b
-        la[rb + 512 * k] = xa[oreg8(k)];
-        lb[rb + 512 * k] = xb[oreg8(k)];
-    }
-    __syncthreads();
-    // Q1: team 1 forms conj(Q) of the pair (0, 1); team 0 fetches station 2
-    float2 va[8], vb[8];
-    if (team) {
-        float2 w = unit_root((float)k0, invNc, false);
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-            float2 q, qm;
-            pair_q(oa[rb + 512 * r], oa[kRow8Lds + mb - 512 * r], xa[oreg8(r)], lb[mb - 512 * r], w, q, qm);
-            va[r] = cconj(q);              // Q[a][t + 512 r]:                 row a, stage-1 item t, input r
-            vb[7 - r] = cconj(qm);         // Q[b][(511 - t) + 512 (7 - r)]:   row b, stage-1 item 511 - t, input 7 - r
-            w = r == 3 ? unit_root((float)(k0 + (long long)4 * 512 * N2), invNc, false) : cmul(w, st);
-        }
-    } else {
-        const float2 *Ts = T + (size_t)qd.sw_sd * pl.Nc;
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-            va[r] = Ts[(size_t)a * 4096 + t + 512 * r];
-            vb[r] = Ts[(size_t)b * 4096 + t + 512 * r];
-        }
-    }
-    __syncthreads();      // team 1 has read team 0's images
-    // F2: the same forward code: station 2 (team 0), conj(Q01) (team 1: conj(forward(conj Q)) = inverse(Q))
-    fft8<false>(va);
-    fft8<false>(vb);
-    rows2_r8_finish_w<false>(va, vb, la, lb, t, t, team ? 511 - t : t, opaque(w2), opaque(w3), opaque(w4));
-    if (team) {
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            va[k] = cconj(va[k]);
-            vb[k] = cconj(vb[k]);
-        }
-        inv_rows_twiddle_store(va, vb, t, a, b, V + (size_t)qd.pw[0] * pl.Nc, pl);
-    }
-    __syncthreads();      // the images are free again
-    // S2: lb0 = Z0[b], la0 = Z2[b], la1 = Z2[a] (team 0 writes all three), lb1 = Z1[b]
-    if (team) {
-#pragma unroll
-        for (int k = 0; k < 8; k++) lb[rb + 512 * k] = xb[oreg8(k)];
-    } else {
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            lb[rb + 512 * k] = xb[oreg8(k)];
-            la[rb + 512 * k] = vb[oreg8(k)];
-            oa[rb + 512 * k] = va[oreg8(k)];
-        }
-    }
-    __syncthreads();
-    // Q2: team 0 the pair (0, 2), team 1 the pair (1, 2); the signal is station 2 for both
-    float2 qa[8], qb[8];
-    {
-        const float2 *z2b = team ? oa : la;        // Z2[b] lives in la0
-        float2 w = unit_root((float)k0, invNc, false);
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-            const float2 z2a = team ? la[rb + 512 * r] : va[oreg8(r)];
-            float2 q, qm;
-            pair_q(xa[oreg8(r)], lb[mb - 512 * r], z2a, z2b[mb - 512 * r], w, q, qm);
-            qa[r] = q;
-            qb[7 - r] = qm;
-            w = r == 3 ? unit_root((float)(k0 + (long long)4 * 512 * N2), invNc, false) : cmul(w, st);
-        }
-    }
-    __syncthreads();
-    // F3: two inverse rows per team
-    fft8<true>(qa);
-    fft8<true>(qb);
-    rows2_r8_finish<true>(qa, qb, la, lb, t, t, 511 - t);
-    inv_rows_twiddle_store(qa, qb, t, a, b, V + (size_t)qd.pw[team ? 3 : 1] * pl.Nc, pl);
-}
+// (Rounds 1-2 also kept three opt-in pair-step variants here -- k_inv_row_pair_r8 (512 threads x 8 values),
+// k_pair_rows_fused_r8 (forward rows inside the pair kernel) and k_rows_tri_fused (all six row transforms of a
+// three-station window's row pair in one 1024-thread workgroup).  Each was parity-green and each lost to the two-kernel
+// form on every BASELINE configuration (DESIGN.md section 3 keeps the measurements and the counters); they were
+// removed in round 3 -- last present in commit 3ec148d.)
 
 // ---------------------------------------------------------------------------
 // Decimated inverse (N2 = 256 or 512; search ranges of a few ten thousand lags in a transform of millions).
@@ -855,7 +550,7 @@ __global__ __launch_bounds__(256) void k_small_col_peak(const float2 *V, unsigne
 // k_segments_reduce adds the chunks in a fixed order.
 // ---------------------------------------------------------------------------
 template <int PQ>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_PLAIN_DS_OPS)) void k_xcorr_segments(const SWDesc *sw, const PWDesc *pw, const short *codes, long long code_stride, const FmStats *stats, float2 *V, FftPlan pl, int n_chunks)
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_PLAIN_DS_OPS)) void k_xcorr_segments(const SWDesc *sw, const PWDesc *pw, const int *codes, long long code_stride, const FmStats *stats, float2 *V, FftPlan pl, int n_chunks)
 {
     constexpr int P = 256 * PQ, H = 4096 - 2 * P;
     extern __shared__ float2 lds[];   // 2 * kRow8Lds
@@ -863,7 +558,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_
     const int t = threadIdx.x;
     const PWDesc d = pw[blockIdx.y];
     const int len_t = sw[d.sw_a].len, len_s = sw[d.sw_b].len;
-    const short *ct = codes + (size_t)d.sw_a * code_stride, *cs = codes + (size_t)d.sw_b * code_stride;
+    const int *ct = codes + (size_t)d.sw_a * code_stride, *cs = codes + (size_t)d.sw_b * code_stride;
     const float mean_t = stats[d.sw_a].mean, scale_t = stats[d.sw_a].scale;
     const float mean_s = stats[d.sw_b].mean, scale_s = stats[d.sw_b].scale;
     const int n_seg = (len_t + H - 1) / H, len_min = len_t < len_s ? len_t : len_s;
@@ -971,7 +666,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_
 // grid (n_chunks, n_quads), 512 threads, dynamic LDS 64 KB; chunk c takes the segments c, c + n_chunks, ...; output
 // layout as above, one part row per wanted pair-window.
 template <int PQ>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_PLAIN_DS_OPS)) void k_xcorr_segments_quad(const SWDesc *sw, const QuadDesc *quads, const short *codes, long long code_stride, const FmStats *stats, float2 *V, FftPlan pl, int n_chunks)
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_PLAIN_DS_OPS)) void k_xcorr_segments_quad(const SWDesc *sw, const QuadDesc *quads, const int *codes, long long code_stride, const FmStats *stats, float2 *V, FftPlan pl, int n_chunks)
 {
     constexpr int P = 256 * PQ, H = 4096 - 2 * P;
     extern __shared__ float2 lds[];   // 2 * kRow8Lds
@@ -981,8 +676,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_
     const bool has_b = q.sw_tb >= 0, has_d = q.sw_sd >= 0;
     const int ia = q.sw_ta, ib = has_b ? q.sw_tb : q.sw_ta, ic = q.sw_sc, id = has_d ? q.sw_sd : q.sw_sc;
     const int len_a = sw[ia].len, len_b = has_b ? sw[ib].len : 0, len_c = sw[ic].len, len_d = has_d ? sw[id].len : 0;
-    const short *ca = codes + (size_t)ia * code_stride, *cb = codes + (size_t)ib * code_stride;
-    const short *cc = codes + (size_t)ic * code_stride, *cd = codes + (size_t)id * code_stride;
+    const int *ca = codes + (size_t)ia * code_stride, *cb = codes + (size_t)ib * code_stride;
+    const int *cc = codes + (size_t)ic * code_stride, *cd = codes + (size_t)id * code_stride;
     const float mean_a = stats[ia].mean, scale_a = stats[ia].scale, mean_b = stats[ib].mean, scale_b = stats[ib].scale;
     const float mean_c = stats[ic].mean, scale_c = stats[ic].scale, mean_d = stats[id].mean, scale_d = stats[id].scale;
     const int len_t = len_a > len_b ? len_a : len_b, n_seg = (len_t + H - 1) / H;
@@ -1002,12 +697,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_
         if (s0 * H - P >= 0 && s0 * H - P + 4096 <= len_min) {
             // uniform row pointer (SGPR pair) + unsigned 32-bit byte offset of the lane: one offset register serves all
             // four streams, where signed sample indices would cost a 64-bit address pair per stream and position
-            const unsigned bo = 2u * (unsigned)i0;
+            const unsigned bo = 4u * (unsigned)i0;
 #pragma unroll
             for (int r = 0; r < 8; r++) {
                 const bool tpos = t + 512 * r >= P && t + 512 * r < P + H;
-                const int a0 = tpos ? code_at(ca, bo + 1024u * r) : 0, b0 = tpos ? code_at(cb, bo + 1024u * r) : 0;
-                const int c0 = code_at(cc, bo + 1024u * r), d0 = code_at(cd, bo + 1024u * r);
+                const int a0 = tpos ? code_at(ca, bo + 2048u * r) : 0, b0 = tpos ? code_at(cb, bo + 2048u * r) : 0;
+                const int c0 = code_at(cc, bo + 2048u * r), d0 = code_at(cd, bo + 2048u * r);
                 x[r] = make_float2(tpos ? k1_normalise(a0, mean_a, scale_a) : 0.0f, tpos ? k1_normalise(b0, mean_b, scale_b) : 0.0f);
                 y[r] = make_float2(k1_normalise(c0, mean_c, scale_c), k1_normalise(d0, mean_d, scale_d));
             }

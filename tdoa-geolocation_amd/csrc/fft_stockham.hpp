@@ -103,30 +103,26 @@ struct FftPlan {
 };
 
 // ---------------------------------------------------------------------------
-// element m of the packed window: phase codes (2m, 2m+1) -> normalised float2, zero beyond len
+// element m of the packed window from MATERIALISED phase codes (int32, stored negated: k1_discriminator.hpp):
+// codes (2m, 2m+1) -> normalised float2, zero beyond len.  Rows are 32-byte aligned.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ float2 code_element(const short *codes, long long m, int len, float mean, float scale)
+__device__ __forceinline__ int2 code_fetch(const int *codes, long long m, int len)
 {
-    const long long i0 = 2 * m;
-    const bool ok0 = i0 < len, ok1 = i0 + 1 < len;
-    const unsigned int w = reinterpret_cast<const unsigned int *>(codes)[ok0 ? m : 0];
-    const float v0 = k1_normalise((int)(short)(w & 0xffffu), mean, scale);
-    const float v1 = k1_normalise((int)(short)(w >> 16), mean, scale);
-    return make_float2(ok0 ? v0 : 0.0f, ok1 ? v1 : 0.0f);
+    return reinterpret_cast<const int2 *>(codes)[2 * m < len ? m : 0];
 }
 
-// the same in two steps, so that a thread can issue all its loads before it converts the first one
-__device__ __forceinline__ unsigned int code_fetch(const short *codes, long long m, int len)
-{
-    return reinterpret_cast<const unsigned int *>(codes)[2 * m < len ? m : 0];
-}
-
-__device__ __forceinline__ float2 code_convert(unsigned int w, long long m, int len, float mean, float scale)
+// (two steps, so that a thread can issue all its loads before it converts the first one)
+__device__ __forceinline__ float2 code_convert(int2 w, long long m, int len, float mean, float scale)
 {
     const long long i0 = 2 * m;
-    const float v0 = k1_normalise((int)(short)(w & 0xffffu), mean, scale);
-    const float v1 = k1_normalise((int)(short)(w >> 16), mean, scale);
+    const float v0 = k1_normalise(w.x, mean, scale);
+    const float v1 = k1_normalise(w.y, mean, scale);
     return make_float2(i0 < len ? v0 : 0.0f, i0 + 1 < len ? v1 : 0.0f);
+}
+
+__device__ __forceinline__ float2 code_element(const int *codes, long long m, int len, float mean, float scale)
+{
+    return code_convert(code_fetch(codes, m, len), m, len, mean, scale);
 }
 
 // ---------------------------------------------------------------------------
@@ -134,13 +130,13 @@ __device__ __forceinline__ float2 code_convert(unsigned int w, long long m, int 
 // columns -> twiddle -> T[k2][n1]
 // grid: (N1 / C, n_station_windows), dynamic LDS: 2 * N2 * C * 8 bytes
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_fwd_col_c16(const SWDesc *sw, const short *codes, long long code_stride,
+__global__ __launch_bounds__(256) void k_fwd_col_c16(const SWDesc *sw, const int *codes, long long code_stride,
                                                      const FmStats *stats, float2 *T, FftPlan pl)
 {
     extern __shared__ float2 lds[];
     const int tile = pl.N2 << pl.logC;
     const int len = sw[blockIdx.y].len;
-    const short *row = codes + (size_t)blockIdx.y * code_stride;
+    const int *row = codes + (size_t)blockIdx.y * code_stride;
     const float mean = stats[blockIdx.y].mean, scale = stats[blockIdx.y].scale;
     const int c0 = blockIdx.x << pl.logC;
     for (int e = threadIdx.x; e < tile; e += blockDim.x) {

@@ -60,7 +60,7 @@ struct tdoa_ctx {
     };
     std::vector<Capture> caps;
 
-    DevBuf k1_table;                        // 65536 int16 angle codes (k_k1_build_table)
+    DevBuf k1_table;                        // kK1TableEntries first-octant angle codes (k1_build_table_host)
     DevBuf sw_desc, pw_desc, partials, stats, codes, codes_lp, k1_power, tz, v, keys, scales, peaks, scratch_a, scratch_b, lagdump;
     DevBuf ex_a, ex_b, ex_c, ex_d, ex_part;
 
@@ -82,17 +82,15 @@ struct tdoa_ctx {
     int n_cu = 256;                         // multiprocessors of this device
     bool use_graph = true;                  // TDOA_NO_GRAPH=1 at tdoa_create time turns the whole-step hipGraph off
     bool short_lag = true;                  // TDOA_NO_SHORT_LAG=1 at tdoa_create time forces the general inverse for short searches
-    bool fused_rows = false;                // forward row pass inside the pair kernel when P <= S (TDOA_FUSED_ROWS=1 / tdoa_debug_flags)
     bool segment_form = true;               // TDOA_NO_SEGMENT_FORM=1: no LDS-resident overlap-save form for short searches
     bool segment_quads = true;              // TDOA_NO_SEGMENT_QUADS=1: segment form one pair-window at a time (no shared station transforms)
+    bool fused_k1 = true;                   // TDOA_NO_FUSED_K1=1: K1 always materialises its codes (no discriminator inside the column kernels)
     bool decimate = true;                   // TDOA_NO_DECIMATE=1: general form with the full inverse even where the decimated one applies
     // decimated inverse (k_pair_decimate16): FIR taps and window correction for (Nc, reach); small plan of the R-point inverse
     DevBuf dec_taps, dec_gain;
     long long dec_nc = 0;
     int dec_reach = -1, dec_T = 0;
-    bool tri_rows = false;                  // TDOA_TRI_ROWS=1: three stations / three pairs through k_rows_tri_fused (measured slower: 2.59 vs 2.16 ms)
     bool xcd_rows = true;                   // TDOA_NO_XCD_ROWS=1: plain 2-D grid of the pair kernel even with more pairs than stations
-    bool pair_r8 = false;                   // TDOA_PAIR_R8=1: the 512-thread / 8-value pair kernel (measured equal on cfg2, 5 % slower on cfg4)
     uint64_t alloc_gen = 0;                 // bumped whenever a workspace buffer moves
     std::vector<uint64_t> graph_key;
     hipGraph_t graph = nullptr;
@@ -261,16 +259,45 @@ void prof_collect(tdoa_ctx *ctx)
     ctx->prof_last = -1;
 }
 
-// K1 for n_sw station-windows: capture bytes -> 16-bit codes + exact window statistics; every buffer must have been
-// reserved (no allocation here: the caller may be capturing a graph).  Returns the code array downstream reads.
+// The K1 angle table (k1_discriminator.hpp): first-octant directions (mn, mx), index mx (mx + 1) / 2 + mn over the
+// indices of the odd magnitudes 2 idx + 1; entry = llround(atan2(mn', mx') 2^23 / pi) of the gcd-reduced pair, float64.
+// (oracle/tdoa_oracle.c: ob_octant_code states the same expression; tests compare the device's codes with it bit for bit)
+void k1_build_table_host(std::vector<int32_t> &tab)
+{
+    tab.resize(kK1TableEntries);
+    for (int mx = 0; mx < 128; mx++)
+        for (int mn = 0; mn <= mx; mn++) {
+            int a = 2 * mx + 1, b = 2 * mn + 1;
+            int g = a, h = b;
+            while (h) { const int t = g % h; g = h; h = t; }
+            a /= g;
+            b /= g;
+            tab[(size_t)mx * (mx + 1) / 2 + mn] = (int32_t)std::llround(std::atan2((double)b, (double)a) * (8388608.0 / M_PI));
+        }
+}
+
+// zero n_sw window accumulators (a kernel node: the captured step holds kernel nodes only)
+void zero_partials(hipStream_t st, StatsPartial *partials, int n_sw)
+{
+    static_assert(sizeof(StatsPartial) == 32, "four 64-bit words per station-window");
+    const size_t words = 4 * (size_t)n_sw;
+    hipLaunchKernelGGL(k_zero_u64, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st,
+                       reinterpret_cast<unsigned long long *>(partials), words);
+}
+
+// K1 for n_sw station-windows: capture bytes -> exact window statistics, and -- when `materialise` -- the 24-bit codes
+// (int32) for the consumers that read them from memory; every buffer must have been reserved (no allocation here: the
+// caller may be capturing a graph).  Returns the code array downstream reads (nullptr: fused path, the forward column
+// kernels evaluate the discriminator themselves).
 // Optional steps (tdoa_params): k1_gate -- the prebuilt binary's power gate (windows of mean power <= 0.01 get envelope
-// codes instead of phase codes); k1_smooth -- its moving average on the discriminator output.
-short *launch_k1(tdoa_ctx *ctx, hipStream_t st, const SWDesc *d_sw, int n_sw, int maxlen, int pieces, long long code_stride)
+// codes instead of phase codes); k1_smooth -- its moving average on the discriminator output.  Both need the codes.
+int *launch_k1(tdoa_ctx *ctx, hipStream_t st, const SWDesc *d_sw, int n_sw, int maxlen, int pieces, long long code_stride,
+               bool materialise)
 {
     auto *partials = static_cast<StatsPartial *>(ctx->partials.p);
     auto *stats = static_cast<FmStats *>(ctx->stats.p);
-    auto *codes = static_cast<short *>(ctx->codes.p);
-    static_assert(sizeof(StatsPartial) == 16, "two 64-bit words per station-window");
+    auto *codes = static_cast<int *>(ctx->codes.p);
+    const auto *table = static_cast<const int *>(ctx->k1_table.p);
     const dim3 per_chunk((unsigned)((maxlen + 2047) / 2048), n_sw);
     unsigned long long *power = nullptr;
     if (ctx->prm.k1_gate) {
@@ -278,24 +305,26 @@ short *launch_k1(tdoa_ctx *ctx, hipStream_t st, const SWDesc *d_sw, int n_sw, in
         hipLaunchKernelGGL(k_zero_u64, dim3((unsigned)(((size_t)n_sw + 255) / 256)), dim3(256), 0, st, power, (size_t)n_sw);
         hipLaunchKernelGGL(k_k1_power, per_chunk, dim3(256), 0, st, d_sw, power);
     }
-    hipLaunchKernelGGL(k_zero_u64, dim3((unsigned)((2 * (size_t)n_sw + 255) / 256)), dim3(256), 0, st,
-                       reinterpret_cast<unsigned long long *>(partials), 2 * (size_t)n_sw);
+    zero_partials(st, partials, n_sw);
     const long long items = (long long)((pieces + kDemodItem - 1) / kDemodItem) * n_sw;      // workgroup items
-    const int blocks = (int)std::max<long long>(1, std::min<long long>(items, ctx->n_cu));
-    hipLaunchKernelGGL(k_fm_demod, dim3(blocks), dim3(kDemodThreads), 65536 * sizeof(short), st, d_sw, n_sw, pieces,
-                       static_cast<const short *>(ctx->k1_table.p), codes, code_stride, partials, power);
+    const int blocks = (int)std::max<long long>(1, std::min<long long>(items, 2ll * ctx->n_cu));   // two workgroups per CU
+    if (materialise)
+        hipLaunchKernelGGL(k_fm_demod<true>, dim3(blocks), dim3(kDemodThreads), kK1TableBytes, st, d_sw, n_sw, pieces, table,
+                           codes, code_stride, partials, power);
+    else
+        hipLaunchKernelGGL(k_fm_demod<false>, dim3(blocks), dim3(kDemodThreads), kK1TableBytes, st, d_sw, n_sw, pieces, table,
+                           static_cast<int *>(nullptr), code_stride, partials, power);
     if (power) hipLaunchKernelGGL(k_k1_envelope, per_chunk, dim3(256), 0, st, d_sw, power, codes, code_stride, partials);
     if (ctx->prm.k1_smooth > 1) {
         // statistics of the smoothed codes replace those of the raw ones
-        auto *lp = static_cast<short *>(ctx->codes_lp.p);
-        hipLaunchKernelGGL(k_zero_u64, dim3((unsigned)((2 * (size_t)n_sw + 255) / 256)), dim3(256), 0, st,
-                           reinterpret_cast<unsigned long long *>(partials), 2 * (size_t)n_sw);
+        auto *lp = static_cast<int *>(ctx->codes_lp.p);
+        zero_partials(st, partials, n_sw);
         hipLaunchKernelGGL(k_k1_smooth, per_chunk, dim3(256), 0, st, d_sw, codes, lp, code_stride, ctx->prm.k1_smooth / 2,
                            partials, power);
         codes = lp;
     }
     hipLaunchKernelGGL(k_fm_stats_final, dim3((n_sw + 63) / 64), dim3(64), 0, st, d_sw, partials, stats, n_sw);
-    return codes;
+    return materialise ? codes : nullptr;
 }
 
 // ---- decimated inverse (fft_radix8.hpp, k_pair_decimate16) ----------------------------------------------------------
@@ -376,14 +405,36 @@ int ensure_decimation(tdoa_ctx *ctx, const FftPlan &pl, int lag_lo, int lag_hi)
 
 // make every workspace buffer of run_fm_batch large enough (no allocation may happen while a
 // stream capture is open)
-int reserve_fm_batch(tdoa_ctx *ctx, int n_sw, int maxlen, int n_pw, const FftPlan &pl, int lag_lo, int lag_hi)
+// segment form (search ranges up to 1024 lags, hot row size): 256-lag quarter count of its frames, 0 = does not apply
+int segment_pq(const tdoa_ctx *ctx, const FftPlan &pl, int lag_lo, int lag_hi, int n_pw)
+{
+    // lags lag_lo - 1 .. lag_hi + 1 (refinement neighbours included) must lie in [-P, P], P = 256 seg_pq
+    const int reach = std::max(lag_hi + 1, -(lag_lo - 1));
+    const int pq = reach <= 256 ? 1 : reach <= 512 ? 2 : reach <= 1024 ? 4 : 0;
+    const bool row16 = pl.N1 == 4096 && !ctx->force_generic;
+    return pq && row16 && ctx->short_lag && ctx->segment_form && n_pw > 0 && pl.N2 >= 8 ? pq : 0;
+}
+
+// K1 evaluated inside the forward column kernels (no code array): the plans with a k_fwd_col*_k1 kernel, unless a
+// consumer needs the codes in memory (segment form, k1_smooth, k1_gate) or a window may be shorter than two samples
+bool fused_k1_applies(const tdoa_ctx *ctx, const FftPlan &pl, int lag_lo, int lag_hi, int n_pw, bool allow)
+{
+    if (!allow || !ctx->fused_k1 || ctx->force_generic || ctx->prm.k1_smooth > 1 || ctx->prm.k1_gate) return false;
+    if (pl.N1 != 4096 || !(pl.N2 == 256 || pl.N2 == 2048 || pl.N2 == 4096)) return false;
+    return segment_pq(ctx, pl, lag_lo, lag_hi, n_pw) == 0;
+}
+
+int reserve_fm_batch(tdoa_ctx *ctx, int n_sw, int maxlen, int n_pw, const FftPlan &pl, int lag_lo, int lag_hi,
+                     bool allow_fused_k1)
 {
     int rc;
     const long long code_stride = ((long long)maxlen + 15) / 8 * 8;
     if ((rc = ensure(ctx, ctx->partials, sizeof(StatsPartial) * (size_t)n_sw))) return rc;
     if ((rc = ensure(ctx, ctx->stats, sizeof(FmStats) * (size_t)n_sw))) return rc;
-    if ((rc = ensure(ctx, ctx->codes, sizeof(short) * (size_t)code_stride * n_sw))) return rc;
-    if (ctx->prm.k1_smooth > 1 && (rc = ensure(ctx, ctx->codes_lp, sizeof(short) * (size_t)code_stride * n_sw))) return rc;
+    if (!fused_k1_applies(ctx, pl, lag_lo, lag_hi, n_pw, allow_fused_k1)) {
+        if ((rc = ensure(ctx, ctx->codes, sizeof(int) * (size_t)code_stride * n_sw))) return rc;
+        if (ctx->prm.k1_smooth > 1 && (rc = ensure(ctx, ctx->codes_lp, sizeof(int) * (size_t)code_stride * n_sw))) return rc;
+    }
     if (ctx->prm.k1_gate && (rc = ensure(ctx, ctx->k1_power, sizeof(unsigned long long) * (size_t)n_sw))) return rc;
     if ((rc = ensure(ctx, ctx->tz, sizeof(float2) * (size_t)pl.Nc * n_sw))) return rc;
     if (n_pw && decimation_applies(ctx, pl, lag_lo, lag_hi) && (rc = ensure_decimation(ctx, pl, lag_lo, lag_hi))) return rc;
@@ -399,18 +450,17 @@ int reserve_fm_batch(tdoa_ctx *ctx, int n_sw, int maxlen, int n_pw, const FftPla
 int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const PWDesc *d_pw, int n_pw,
                  unsigned long long *d_keys, const FftPlan &pl, int lag_lo, int lag_hi, float *lag_dump,
                  float dump_scale, double sum_len, float *fine_raw = nullptr, int pairs_per_window = 0,
-                 const QuadDesc *d_quads = nullptr, int n_quads = 0, bool tri_quads = false)
+                 const QuadDesc *d_quads = nullptr, int n_quads = 0, bool allow_fused_k1 = true)
 {
     int rc;
     const int pieces = std::max(1, (maxlen + kDemodPiece - 1) / kDemodPiece);
     const long long code_stride = ((long long)maxlen + 15) / 8 * 8;      // rows stay 16-byte aligned
     if ((rc = ensure(ctx, ctx->partials, sizeof(StatsPartial) * (size_t)n_sw))) return rc;
     if ((rc = ensure(ctx, ctx->stats, sizeof(FmStats) * (size_t)n_sw))) return rc;
-    if ((rc = ensure(ctx, ctx->codes, sizeof(short) * (size_t)code_stride * n_sw))) return rc;
     if ((rc = ensure(ctx, ctx->tz, sizeof(float2) * (size_t)pl.Nc * n_sw))) return rc;
-    if ((rc = reserve_fm_batch(ctx, n_sw, maxlen, n_pw, pl, lag_lo, lag_hi))) return rc;
+    if ((rc = reserve_fm_batch(ctx, n_sw, maxlen, n_pw, pl, lag_lo, lag_hi, allow_fused_k1))) return rc;
     auto *stats = static_cast<FmStats *>(ctx->stats.p);
-    auto *codes = static_cast<short *>(ctx->codes.p);
+    const int *codes = nullptr;
     auto *tz = static_cast<float2 *>(ctx->tz.p);
     auto *v = static_cast<float2 *>(ctx->v.p);
     hipStream_t st = ctx->stream;
@@ -444,16 +494,12 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
     // segment form (search ranges up to 1024 lags): overlap-save over 4096-point frames entirely in LDS; neither the
     // column pass nor TZ nor V rows are touched.  Its chunk sums and lag array live where the short-lag form keeps its
     // shares (inside this pair-window's V row), which bounds the chunk count by N2 / 2.
-    int seg_chunks = 0, seg_pq = 0;
-    {
-        // lags lag_lo - 1 .. lag_hi + 1 (refinement neighbours included) must lie in [-P, P], P = 256 seg_pq
-        const int reach = std::max(lag_hi + 1, -(lag_lo - 1));
-        seg_pq = reach <= 256 ? 1 : reach <= 512 ? 2 : reach <= 1024 ? 4 : 0;
-    }
+    int seg_chunks = 0;
+    const int seg_pq = segment_pq(ctx, pl, lag_lo, lag_hi, n_pw);
     // quads (two station transforms per segment serve up to four pair-windows) when that is fewer transforms than one
     // per pair-window
     const bool seg_quads = ctx->segment_quads && d_quads && n_quads > 0 && 2 * n_quads < n_pw;
-    if (seg_pq && row16 && ctx->short_lag && ctx->segment_form && n_pw > 0 && pl.N2 >= 8) {
+    if (seg_pq) {
         const int hop = 4096 - 512 * seg_pq;
         const int frames = (maxlen + hop - 1) / hop;
         const int trips = seg_quads ? frames : (frames + 1) / 2;        // the pair kernel takes two frames per trip
@@ -471,10 +517,12 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
             if (cost(c) <= 1.03 * best) seg_chunks = c;
         if (const char *e = std::getenv("TDOA_SEG_CHUNKS")) seg_chunks = std::max(1, std::min({std::atoi(e), trips, pl.N2 / 2 - 1}));
     }
+    const bool fused_k1 = fused_k1_applies(ctx, pl, lag_lo, lag_hi, n_pw, allow_fused_k1);
     {
-        // K1: capture bytes -> 16-bit phase codes + exact window statistics
-        ProfScope ps(ctx, TDOA_K_STATS, 4.0 * sum_len);
-        codes = launch_k1(ctx, st, d_sw, n_sw, maxlen, pieces, code_stride);
+        // K1: capture bytes -> exact window statistics (fused: nothing else; the column pass evaluates the discriminator
+        // itself) and, materialised, the 24-bit phase codes as int32
+        ProfScope ps(ctx, TDOA_K_STATS, (fused_k1 ? 2.0 : 6.0) * sum_len);
+        codes = launch_k1(ctx, st, d_sw, n_sw, maxlen, pieces, code_stride, !fused_k1);
     }
     const size_t lds_col = sizeof(float2) * 2 * (size_t)pl.N2 * pl.C;
     const size_t lds_row = sizeof(float2) * 2 * (size_t)pl.N1;
@@ -483,8 +531,20 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
     const size_t lds_pair16 = sizeof(float2) * 2 * kRowLds;
     if (!seg_chunks) {
         // two-sweep column pass (N2 = 2048, 4096): 8 Nc written, read and written again -- SURVEY's third pass
-        ProfScope ps(ctx, TDOA_K_FWD_COL, 2.0 * sum_len + (col2pass ? 3.0 : 1.0) * nc8 * n_sw);
-        if (col16)
+        ProfScope ps(ctx, TDOA_K_FWD_COL, (fused_k1 ? 2.0 : 4.0) * sum_len + (col2pass ? 3.0 : 1.0) * nc8 * n_sw);
+        const auto *table = static_cast<const int *>(ctx->k1_table.p);
+        if (fused_k1 && col16)
+            hipLaunchKernelGGL(k_fwd_col256_k1<false>, dim3(2 * ctx->n_cu), dim3(512), kColK1Lds, st, d_sw, table, stats, tz, pl,
+                               n_sw);
+        else if (fused_k1 && col2pass) {
+            hipLaunchKernelGGL(k_fwd_col256_k1<true>, dim3(2 * ctx->n_cu), dim3(512), kColK1Lds, st, d_sw, table, stats, tz, pl,
+                               n_sw);
+            if (pl.N2 == 4096)
+                hipLaunchKernelGGL(k_fwd_col_finish<16>, dim3(pl.N1 / 256, 256, n_sw), dim3(256), 0, st, tz, pl);
+            else
+                hipLaunchKernelGGL(k_fwd_col_finish<8>, dim3(pl.N1 / 256, 256, n_sw), dim3(256), 0, st, tz, pl);
+        }
+        else if (col16)
             hipLaunchKernelGGL(k_fwd_col256_c16<false>, dim3(pl.N1 / 32, n_sw), dim3(512), lds_col16, st, d_sw, codes,
                                code_stride, stats, tz, pl);
         else if (col2pass) {
@@ -517,13 +577,6 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
             hipLaunchKernelGGL(k_fwd_col_c16, dim3(pl.N1 / pl.C, n_sw), dim3(256), lds_col, st, d_sw, codes,
                                code_stride, stats, tz, pl);
     }
-    // forward row pass fused into the pair kernel: pays when a station's rows are re-transformed at most as often as
-    // they would be written and read back (no more pair-windows than station-windows: 3 stations, or a single pair)
-    // three stations / three pairs per window (every quad of the batch has that pattern): all six row transforms of a
-    // window's row pair in one kernel, k_rows_tri_fused (general form only)
-    const bool tri_rows = row16 && ctx->tri_rows && tri_quads && d_quads && n_quads > 0 && 3 * n_quads == n_pw && !seg_chunks &&
-                          fk == 0 && pl.N2 > 2 && !decim;
-    const bool fused_rows = !decim && (tri_rows || (row16 && ctx->fused_rows && n_pw > 0 && n_pw <= n_sw));
     // XCD-aware 1-D grid of the pair kernel when every window of the group carries the same `pairs_per_window` > S pairs
     // (window-major sharding with more pairs than stations): see k_inv_row_pair4096
     int xcd_pairs = 0;
@@ -535,10 +588,8 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
         if (blocks < (1ll << 31)) { xcd_pairs = pairs_per_window; xcd_grid = (unsigned int)blocks; }
     }
     if (!seg_chunks) {
-        ProfScope ps(ctx, TDOA_K_FWD_ROW, fused_rows ? 2.0 * 8.0 * 4096 * 2 * n_sw : 2.0 * nc8 * n_sw);
-        if (fused_rows)    // only the two self-mirrored rows 0 and N2/2 (their pair kernel reads finished spectra)
-            hipLaunchKernelGGL(k_fwd_row4096, dim3(2, n_sw), dim3(256), 0, st, tz, pl, pl.N2 / 2, static_cast<float2 *>(nullptr));
-        else if (row16 && decim)     // spectra in 16-column tiles behind G and V' in the V workspace (k_pair_decimate16 streams them)
+        ProfScope ps(ctx, TDOA_K_FWD_ROW, 2.0 * nc8 * n_sw);
+        if (row16 && decim)     // spectra in 16-column tiles behind G and V' in the V workspace (k_pair_decimate16 streams them)
             hipLaunchKernelGGL(k_fwd_row4096, dim3(pl.N2, n_sw), dim3(256), 0, st, tz, pl, 1, v + dec_spectra_offset(pl, n_pw));
         else if (row16)
             hipLaunchKernelGGL(k_fwd_row4096, dim3(pl.N2, n_sw), dim3(256), 0, st, tz, pl, 1, static_cast<float2 *>(nullptr));
@@ -611,16 +662,7 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
             if (fk) {
 #define TDOA_PAIR_ROWS(FK)                                                                                           \
     do {                                                                                                             \
-        if (tri_rows)                                                                                                \
-            hipLaunchKernelGGL(k_rows_tri_fused, dim3(pl.N2 / 2 - 1, n_quads), dim3(1024),                            \
-                               sizeof(float2) * 4 * kRow8Lds, st, d_quads, tz, v, pl);                               \
-        else if (pl.N2 > 2 && fused_rows)                                                                            \
-            hipLaunchKernelGGL((k_pair_rows_fused_r8<FK>), dim3(pl.N2 / 2 - 1, n_pw), dim3(512),                     \
-                               sizeof(float2) * 2 * kRow8Lds, st, d_pw, tz, v, pl);                                  \
-        else if (pl.N2 > 2 && ctx->pair_r8)                                                                          \
-            hipLaunchKernelGGL((k_inv_row_pair_r8<FK>), xcd_pairs ? dim3(xcd_grid) : dim3(pl.N2 / 2 - 1, n_pw),      \
-                               dim3(512), sizeof(float2) * 2 * kRow8Lds, st, d_pw, tz, v, pl, xcd_pairs, n_pw);      \
-        else if (pl.N2 > 2)                                                                                          \
+        if (pl.N2 > 2)                                                                                               \
             hipLaunchKernelGGL((k_inv_row_pair4096<false, FK>), xcd_pairs ? dim3(xcd_grid) : dim3(pl.N2 / 2 - 1, n_pw), \
                                dim3(256), lds_pair16, st, d_pw, tz, v, pl, xcd_pairs, n_pw);                         \
         hipLaunchKernelGGL((k_inv_row_pair4096<true, FK>), dim3(1, n_pw), dim3(256), lds_pair16, st, d_pw, tz, v, pl, \
@@ -697,7 +739,10 @@ int allow_big_lds(tdoa_ctx *ctx)
 {
     int rc;
     const size_t all = 136 * 1024;   // largest dynamic request: 128 KiB (kLdsCap tiles, generic row pair); static LDS comes on top
-    if ((rc = set_lds(ctx, k_fm_demod, all))) return rc;
+    if ((rc = set_lds(ctx, k_fm_demod<true>, all))) return rc;
+    if ((rc = set_lds(ctx, k_fm_demod<false>, all))) return rc;
+    if ((rc = set_lds(ctx, k_fwd_col256_k1<false>, all))) return rc;
+    if ((rc = set_lds(ctx, k_fwd_col256_k1<true>, all))) return rc;
     if ((rc = set_lds(ctx, k_fwd_col_c16, all))) return rc;
     if ((rc = set_lds(ctx, k_fwd_row, all))) return rc;
     if ((rc = set_lds(ctx, k_inv_row_pair, all))) return rc;
@@ -716,23 +761,12 @@ int allow_big_lds(tdoa_ctx *ctx)
     if ((rc = set_lds(ctx, k_inv_row_pair4096<true, 4>, all))) return rc;
     if ((rc = set_lds(ctx, k_inv_row_pair4096<false, 8>, all))) return rc;
     if ((rc = set_lds(ctx, k_inv_row_pair4096<true, 8>, all))) return rc;
-    if ((rc = set_lds(ctx, k_pair_rows_fused_r8<0>, all))) return rc;
-    if ((rc = set_lds(ctx, k_pair_rows_fused_r8<1>, all))) return rc;
-    if ((rc = set_lds(ctx, k_pair_rows_fused_r8<2>, all))) return rc;
-    if ((rc = set_lds(ctx, k_pair_rows_fused_r8<4>, all))) return rc;
-    if ((rc = set_lds(ctx, k_pair_rows_fused_r8<8>, all))) return rc;
-    if ((rc = set_lds(ctx, k_inv_row_pair_r8<0>, all))) return rc;
-    if ((rc = set_lds(ctx, k_inv_row_pair_r8<1>, all))) return rc;
-    if ((rc = set_lds(ctx, k_inv_row_pair_r8<2>, all))) return rc;
-    if ((rc = set_lds(ctx, k_inv_row_pair_r8<4>, all))) return rc;
-    if ((rc = set_lds(ctx, k_inv_row_pair_r8<8>, all))) return rc;
     if ((rc = set_lds(ctx, k_xcorr_segments<1>, all))) return rc;
     if ((rc = set_lds(ctx, k_xcorr_segments<2>, all))) return rc;
     if ((rc = set_lds(ctx, k_xcorr_segments<4>, all))) return rc;
     if ((rc = set_lds(ctx, k_xcorr_segments_quad<1>, all))) return rc;
     if ((rc = set_lds(ctx, k_xcorr_segments_quad<2>, all))) return rc;
     if ((rc = set_lds(ctx, k_xcorr_segments_quad<4>, all))) return rc;
-    if ((rc = set_lds(ctx, k_rows_tri_fused, all))) return rc;
     if ((rc = set_lds(ctx, k_pair_decimate16<8>, all))) return rc;
     if ((rc = set_lds(ctx, k_pair_decimate16<9>, all))) return rc;
     if ((rc = set_lds(ctx, k_inv_rows_plain_r8, all))) return rc;
@@ -810,7 +844,7 @@ int fm_pair(tdoa_ctx *ctx, const uint8_t *iq1, size_t n1, const uint8_t *iq2, si
     ctx->prof_last = -1;
     rc = run_fm_batch(ctx, d_sw, 2, (int)std::max(n1, n2), d_pw, 1, static_cast<unsigned long long *>(ctx->keys.p),
                       pl, -(max_lag - 1), max_lag - 1, dump, 1.0f, (double)(n1 + n2),
-                      fine ? static_cast<float *>(ctx->fine_raw.p) : nullptr);
+                      fine ? static_cast<float *>(ctx->fine_raw.p) : nullptr, 0, nullptr, 0, n1 >= 2 && n2 >= 2);
     if (rc) return rc;
     hipLaunchKernelGGL(k_decode_peaks, dim3(1), dim3(64), 0, ctx->stream,
                        static_cast<unsigned long long *>(ctx->keys.p), static_cast<double *>(ctx->scales.p),
@@ -930,15 +964,16 @@ int tdoa_create(const tdoa_params *p, tdoa_ctx **out)
     }
     {   // K1 angle table, once per context
         void *t = nullptr;
-        if (hipMalloc(&t, 65536 * sizeof(short)) != hipSuccess) {
+        if (hipMalloc(&t, kK1TableBytes) != hipSuccess) {
             (void)hipStreamDestroy(ctx->stream);
             delete ctx;
             return TDOA_ERR_NOMEM;
         }
         ctx->k1_table.p = t;
-        ctx->k1_table.cap = 65536 * sizeof(short);
-        hipLaunchKernelGGL(k_k1_build_table, dim3(256), dim3(256), 0, ctx->stream, static_cast<short *>(t));
-        if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        ctx->k1_table.cap = kK1TableBytes;
+        std::vector<int32_t> tab;
+        k1_build_table_host(tab);
+        if (hipMemcpy(t, tab.data(), kK1TableBytes, hipMemcpyHostToDevice) != hipSuccess) {
             tdoa_destroy(ctx);
             return TDOA_ERR_HIP;
         }
@@ -946,14 +981,11 @@ int tdoa_create(const tdoa_params *p, tdoa_ctx **out)
     // run-time switches are read ONCE here (a captured graph must not depend on an environment that changes later)
     if (const char *e = std::getenv("TDOA_NO_GRAPH")) ctx->use_graph = !(e[0] == '1');
     if (const char *e = std::getenv("TDOA_NO_SHORT_LAG")) ctx->short_lag = !(e[0] == '1');
-    if (const char *e = std::getenv("TDOA_FUSED_ROWS")) ctx->fused_rows = e[0] == '1';
-    if (const char *e = std::getenv("TDOA_NO_FUSED_ROWS")) ctx->fused_rows = !(e[0] == '1');
     if (const char *e = std::getenv("TDOA_NO_SEGMENT_FORM")) ctx->segment_form = !(e[0] == '1');
     if (const char *e = std::getenv("TDOA_NO_SEGMENT_QUADS")) ctx->segment_quads = !(e[0] == '1');
-    if (const char *e = std::getenv("TDOA_TRI_ROWS")) ctx->tri_rows = e[0] == '1';
     if (const char *e = std::getenv("TDOA_NO_DECIMATE")) ctx->decimate = !(e[0] == '1');
+    if (const char *e = std::getenv("TDOA_NO_FUSED_K1")) ctx->fused_k1 = !(e[0] == '1');
     if (const char *e = std::getenv("TDOA_NO_XCD_ROWS")) ctx->xcd_rows = !(e[0] == '1');
-    if (const char *e = std::getenv("TDOA_PAIR_R8")) ctx->pair_r8 = e[0] == '1';
     *out = ctx;
     return TDOA_OK;
 }
@@ -1321,17 +1353,6 @@ static int process_impl(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host,
         }
         q_off[wi + 1] = quads.size();
     }
-    // batches whose quads all have the three-station pattern (a, b | b, c) with the three pairs wanted
-    std::vector<char> tri_batch((mine.size() + per_batch - 1) / (size_t)per_batch + 1, 0);
-    for (size_t w0 = 0; w0 < mine.size(); w0 += per_batch) {
-        const size_t w1 = std::min(mine.size(), w0 + (size_t)per_batch);
-        bool tri = q_off[w1] > q_off[w0];
-        for (size_t qi = q_off[w0]; qi < q_off[w1] && tri; qi++) {
-            const QuadDesc &d = quads[qi];
-            tri = d.sw_tb >= 0 && d.sw_tb == d.sw_sc && d.sw_sd >= 0 && d.pw[0] >= 0 && d.pw[1] >= 0 && d.pw[2] < 0 && d.pw[3] >= 0;
-        }
-        tri_batch[w0 / (size_t)per_batch] = tri ? 1 : 0;
-    }
     const size_t slots = (size_t)W * P;
     hipStream_t st = ctx->stream;
     const int n_first = (int)std::min<size_t>(per_batch, mine.size());
@@ -1346,7 +1367,7 @@ static int process_impl(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host,
         if ((rc = ensure(ctx, ctx->fine, sizeof(FineOut) * slots))) return rc;
     }
     if (n_first && (rc = reserve_fm_batch(ctx, n_first * S, (int)wlen, n_first * P, pl, -(ctx->prm.max_lag - 1),
-                                          ctx->prm.max_lag - 1)))
+                                          ctx->prm.max_lag - 1, true)))
         return rc;
     auto *d_sw = static_cast<SWDesc *>(ctx->g_sw_desc.p);
     auto *d_pw = static_cast<PWDesc *>(ctx->g_pw_desc.p);
@@ -1358,10 +1379,9 @@ static int process_impl(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host,
     std::vector<uint64_t> key = {(uint64_t)S, (uint64_t)rank, (uint64_t)world, (uint64_t)per_batch, (uint64_t)wlen,
                                  (uint64_t)ctx->prm.max_lag | ((uint64_t)ctx->prm.k1_smooth << 32) | ((uint64_t)(ctx->prm.k1_gate != 0) << 62), (uint64_t)block,
                                  (uint64_t)ctx->force_generic | ((uint64_t)ctx->short_lag << 1) |
-                                     ((uint64_t)ctx->fused_rows << 2) | ((uint64_t)ctx->segment_form << 3) |
-                                     ((uint64_t)ctx->xcd_rows << 4) | ((uint64_t)ctx->pair_r8 << 5) |
-                                     ((uint64_t)ctx->segment_quads << 6) | ((uint64_t)ctx->tri_rows << 7) |
-                                     ((uint64_t)ctx->decimate << 8),
+                                     ((uint64_t)ctx->segment_form << 3) | ((uint64_t)ctx->xcd_rows << 4) |
+                                     ((uint64_t)ctx->segment_quads << 6) |
+                                     ((uint64_t)ctx->decimate << 8) | ((uint64_t)ctx->fused_k1 << 9),
                                  ctx->alloc_gen, (uint64_t)(fine_host != nullptr), 0};
     std::memcpy(&key.back(), &gate, sizeof(double));
     for (auto &c : ctx->caps) {
@@ -1394,7 +1414,7 @@ static int process_impl(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host,
             const int r = run_fm_batch(ctx, d_sw + sw_off[w0], n_sw, (int)wlen, d_pw + pw_off[w0], n_pw, d_keys, pl,
                                        -(ctx->prm.max_lag - 1), ctx->prm.max_lag - 1, nullptr, 1.0f,
                                        (double)wlen * n_sw, fine_raw, pair_major ? 0 : P, d_quads + q_off[w0],
-                                       (int)(q_off[w0 + nw] - q_off[w0]), tri_batch[w0 / (size_t)per_batch]);
+                                       (int)(q_off[w0 + nw] - q_off[w0]));
             if (r) return r;
         }
         if (fine_raw) ctx->prof_last = -1;
@@ -1582,20 +1602,22 @@ int tdoa_fm_preprocess_u8(tdoa_ctx *ctx, const uint8_t *iq, size_t n, float *out
     const long long code_stride = ((long long)n + 15) / 8 * 8;
     if ((rc = ensure(ctx, ctx->partials, sizeof(StatsPartial)))) return rc;
     if ((rc = ensure(ctx, ctx->stats, sizeof(FmStats)))) return rc;
-    if ((rc = ensure(ctx, ctx->codes, sizeof(short) * (size_t)code_stride))) return rc;
+    if ((rc = ensure(ctx, ctx->codes, sizeof(int) * (size_t)code_stride))) return rc;
     hipStream_t st = ctx->stream;
     SWDesc sw = {static_cast<uint8_t *>(ctx->scratch_a.p), (int32_t)n, 0};
     HIPCHK(ctx, hipMemcpyAsync(ctx->scratch_a.p, iq, 2 * n, hipMemcpyHostToDevice, st));
     HIPCHK(ctx, hipMemcpyAsync(ctx->sw_desc.p, &sw, sizeof(sw), hipMemcpyHostToDevice, st));
-    HIPCHK(ctx, hipMemsetAsync(ctx->partials.p, 0, sizeof(StatsPartial), st));
     HIPCHK(ctx, hipStreamSynchronize(st));
     auto *d_sw = static_cast<SWDesc *>(ctx->sw_desc.p);
-    if (ctx->prm.k1_smooth > 1 && (rc = ensure(ctx, ctx->codes_lp, sizeof(short) * (size_t)code_stride))) return rc;
+    if (ctx->prm.k1_smooth > 1 && (rc = ensure(ctx, ctx->codes_lp, sizeof(int) * (size_t)code_stride))) return rc;
     if (ctx->prm.k1_gate && (rc = ensure(ctx, ctx->k1_power, sizeof(unsigned long long)))) return rc;
-    short *codes_used = launch_k1(ctx, st, d_sw, 1, (int)n, pieces, code_stride);
-    hipLaunchKernelGGL(k_fm_dump, dim3((unsigned)((n + 255) / 256), 1), dim3(256), 0, st, d_sw,
-                       codes_used, static_cast<FmStats *>(ctx->stats.p),
-                       static_cast<float *>(ctx->scratch_b.p));
+    // no output array wanted and no option that needs the codes: the reduce-only pass of the fused path
+    const bool stats_only = !out_f32 && ctx->prm.k1_smooth <= 1 && !ctx->prm.k1_gate;
+    int *codes_used = launch_k1(ctx, st, d_sw, 1, (int)n, pieces, code_stride, !stats_only);
+    if (codes_used)
+        hipLaunchKernelGGL(k_fm_dump, dim3((unsigned)((n + 255) / 256), 1), dim3(256), 0, st, d_sw,
+                           codes_used, static_cast<FmStats *>(ctx->stats.p),
+                           static_cast<float *>(ctx->scratch_b.p));
     HIPCHK(ctx, hipGetLastError());
     if (out_f32) HIPCHK(ctx, hipMemcpyAsync(out_f32, ctx->scratch_b.p, sizeof(float) * n, hipMemcpyDeviceToHost, st));
     if (stats) HIPCHK(ctx, hipMemcpyAsync(stats, ctx->stats.p, sizeof(FmStats), hipMemcpyDeviceToHost, st));
@@ -1638,13 +1660,11 @@ int tdoa_debug_flags(tdoa_ctx *ctx, unsigned flags)
     if (!ctx) return TDOA_ERR_INVALID;
     ctx->force_generic = (flags & TDOA_DEBUG_GENERIC_KERNELS) != 0;
     ctx->short_lag = !(flags & TDOA_DEBUG_NO_SHORT_LAG);
-    ctx->fused_rows = !(flags & TDOA_DEBUG_NO_FUSED_ROWS);
     ctx->segment_form = !(flags & TDOA_DEBUG_NO_SEGMENT_FORM);
     ctx->xcd_rows = !(flags & TDOA_DEBUG_NO_XCD_ROWS);
     ctx->segment_quads = !(flags & TDOA_DEBUG_NO_SEGMENT_QUADS);
-    ctx->tri_rows = (flags & TDOA_DEBUG_TRI_ROWS) != 0;
     ctx->decimate = !(flags & TDOA_DEBUG_NO_DECIMATE);
-    ctx->pair_r8 = (flags & TDOA_DEBUG_PAIR_R8) != 0;
+    ctx->fused_k1 = !(flags & TDOA_DEBUG_NO_FUSED_K1);
     return TDOA_OK;
 }
 

@@ -422,16 +422,24 @@ class Context:
         self._chk(self._L.tdoa_fm_preprocess_u8(self._h, _u8(a), a.size // 2, _f(out), C.byref(st)))
         return out, st
 
+    def fm_stats(self, iq):
+        """window statistics from the reduce-only pass of the fused path (tdoa_fm_preprocess_u8 with out_f32 = NULL)"""
+        a = np.ascontiguousarray(iq, dtype=np.uint8)
+        st = FmStats()
+        self._chk(self._L.tdoa_fm_preprocess_u8(self._h, _u8(a), a.size // 2, None, C.byref(st)))
+        return st
+
     def force_generic(self, on=True):
         self._chk(self._L.tdoa_debug_force_generic(self._h, 1 if on else 0))
 
-    def debug_flags(self, generic=False, no_short_lag=False, no_fused_rows=False, no_segment_form=False, no_xcd_rows=False,
-                    pair_r8=False, no_segment_quads=False, tri_rows=False, no_decimate=False):
-        """pick kernel variants by hand (tests / measurements): include/tdoa_mi355x.h TDOA_DEBUG_*"""
+    def debug_flags(self, generic=False, no_short_lag=False, no_fused_k1=False, no_segment_form=False, no_xcd_rows=False,
+                    no_segment_quads=False, no_decimate=False):
+        """pick kernel variants by hand (tests / measurements): include/tdoa_mi355x.h TDOA_DEBUG_*; no argument = the
+        library's default path, every argument switches one specialised form off"""
         self._chk(self._L.tdoa_debug_flags(self._h, (1 if generic else 0) | (2 if no_short_lag else 0) |
-                                           (4 if no_fused_rows else 0) | (8 if no_segment_form else 0) |
-                                           (16 if no_xcd_rows else 0) | (32 if pair_r8 else 0) |
-                                           (64 if no_segment_quads else 0) | (128 if tri_rows else 0) | (256 if no_decimate else 0)))
+                                           (4 if no_fused_k1 else 0) | (8 if no_segment_form else 0) |
+                                           (16 if no_xcd_rows else 0) | (64 if no_segment_quads else 0) |
+                                           (256 if no_decimate else 0)))
 
     # ---- measurement -------------------------------------------------------
     def profile_enable(self, on=True):

@@ -2,7 +2,7 @@
 (L = 2 000 000, max_lag 20000, N = 2^21) -- VERDICT r01 item 1.
 
 (i)  oracle/float_pipeline.py: float64 atan2 discriminator (the prebuilt binary's definition),
-     f64 FFT correlation; no table, no 16-bit code, nothing shared with the kernels or with ob_*.
+     f64 FFT correlation; no table, no integer code, nothing shared with the kernels or with ob_*.
 (ii) processor.go:646-736 timeDomainCorrelation (o_time_domain_all_lags) on the same normalised signals, unequal
      lengths so that the lag search is not trivial; the FFT path restricted to [0, maxLag_eff) must pick the same index.
 Measured deviations are printed (quoted in DESIGN.md section 5)."""
@@ -28,8 +28,9 @@ def _inputs(oracle):
 
 
 def test_gpu_vs_float_definition_full_size(oracle, capsys):
-    """lag identical everywhere; corr within 1e-5 on the real-amplitude FM pair, within 1e-4 on the simulators'
-    +-1..3 LSB captures (the 16-bit phase code: see tests/test_mode_b_anchors.py); constant windows give (0, 0.0)"""
+    """lag identical everywhere and corr within north_star's 1e-5 of the float64 definition on EVERY case, the simulators'
+    +-1..3 LSB captures included (where the 16-bit phase code of rounds 1-2 measured up to 4.6e-5: see
+    tests/test_mode_b_anchors.py); constant windows give (0, 0.0)"""
     import tdoa_amd
     rows = []
     with tdoa_amd.Context(max_lag=ML, window_len=L) as c:
@@ -43,7 +44,7 @@ def test_gpu_vs_float_definition_full_size(oracle, capsys):
                 continue
             dev = abs(corr - fcorr) / abs(fcorr)
             rows.append((name, lag, corr, dev))
-            assert dev < (1e-5 if name == "delayed_fm" else 1e-4), (name, dev)
+            assert dev < 1e-5, (name, dev)
     with capsys.disabled():
         print("\n  GPU mode B vs float64 atan2 pipeline, L = %d, max_lag %d" % (L, ML))
         for r in rows:
@@ -92,12 +93,12 @@ def test_k1_exact_reversals_bit_exact(oracle):
         for lo, n in ((0, 70000), (2, 69999), (4096, 30001)):
             got, st = c.fm_preprocess(iq[lo:lo + 2 * n])
             want, ost = oracle.b_preprocess(iq[lo:lo + 2 * n])
-            assert (st.s1, st.s2_lo) == (ost.s1, ost.s2_lo)
+            assert (st.s1, st.s2_lo, st.s2_hi) == (ost.s1, ost.s2_lo, ost.s2_hi)
             assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
         sim = oracle.simulate_station("n3pay", 50000, 3)[:100000]          # +-1..3 LSB: reversals everywhere
         got, st = c.fm_preprocess(sim)
         want, ost = oracle.b_preprocess(sim)
-        assert (st.s1, st.s2_lo) == (ost.s1, ost.s2_lo) and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        assert (st.s1, st.s2_lo, st.s2_hi) == (ost.s1, ost.s2_lo, ost.s2_hi) and np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
 def test_optional_k1_smoothing_on_the_gpu(oracle):
@@ -112,7 +113,7 @@ def test_optional_k1_smoothing_on_the_gpu(oracle):
         for x in (a, b, a[:2 * 4099], a[:2 * 7]):
             got, st = c.fm_preprocess(x)
             want, ost = oracle.b_preprocess_smooth(x, 10)
-            assert (st.s1, st.s2_lo) == (ost.s1, ost.s2_lo)
+            assert (st.s1, st.s2_lo, st.s2_hi) == (ost.s1, ost.s2_lo, ost.s2_hi)
             assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
         lag, corr = c.fm_xcorr(a, b, ml)
         lags = c.fm_xcorr_lags(a, b, ml)
@@ -125,7 +126,7 @@ def test_optional_k1_smoothing_on_the_gpu(oracle):
     assert abs(corr - ocorr) <= 1e-5 * abs(ocorr) and abs(corr_g - ocorr) <= 1e-5 * abs(ocorr)
     assert np.abs(lags - want).max() <= 1e-5 * np.abs(want).max()
     flag, fcorr, _ = fp.xcorr_peak_u8(a, b, ml, smooth=10)
-    assert lag == flag and abs(corr - fcorr) <= 1e-4 * abs(fcorr)
+    assert lag == flag and abs(corr - fcorr) <= 1e-5 * abs(fcorr)
     with tdoa_amd.Context(max_lag=ml, window_len=n) as c:                  # k1_smooth = 0: the unsmoothed pipeline
         lag0, corr0 = c.fm_xcorr(a, b, ml)
     assert lag0 == 37 and abs(corr0) < abs(corr)                           # the message is low-pass: smoothing removes noise
@@ -144,7 +145,7 @@ def test_optional_k1_power_gate_on_the_gpu(oracle):
             got, st = c.fm_preprocess(x)
             want, ost, cls = oracle.b_preprocess_gate(x)
             assert cls == want_cls
-            assert (st.s1, st.s2_lo) == (ost.s1, ost.s2_lo)
+            assert (st.s1, st.s2_lo, st.s2_hi) == (ost.s1, ost.s2_lo, ost.s2_hi)
             assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
         lag, corr = c.fm_xcorr(mid_a, mid_b, ml)
         c.debug_flags(no_short_lag=True)
@@ -155,7 +156,7 @@ def test_optional_k1_power_gate_on_the_gpu(oracle):
     assert lag == lag_g == olag == 91
     assert abs(corr - ocorr) <= 1e-5 * abs(ocorr) and abs(corr_g - ocorr) <= 1e-5 * abs(ocorr)
     flag, fcorr, _ = fp.xcorr_peak_u8(mid_a, mid_b, ml, gate=True)
-    assert lag == flag and abs(corr - fcorr) <= 2e-4 * abs(fcorr)
+    assert lag == flag and abs(corr - fcorr) <= 1e-5 * abs(fcorr)
     # batched: three stations whose windows fall on both sides of the gate (blocks 1 and 3 moderate, block 2 strong)
     blk, wl = 140_000, 70_000
     caps = []

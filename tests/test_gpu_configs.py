@@ -66,7 +66,7 @@ def test_cfg3_weak_capture_mode_b_full_window(oracle, capsys):
     assert lag == olag and abs(corr - ocorr) <= REL_TOL * abs(ocorr)
     flag, fcorr, _ = fp.xcorr_peak_u8(tgt[0], tgt[1], ml)
     dev = abs(corr - fcorr) / abs(fcorr)
-    assert lag == flag and dev < 1e-4
+    assert lag == flag and dev < 1e-5            # north_star's tolerance, against the float64 atan2 definition
     with capsys.disabled():
         print("\n  cfg3 window (L = 2e7): lag %d corr %.6f, vs ob_* %.2e, vs float64 atan2 pipeline %.2e"
               % (lag, corr, abs(corr - ocorr) / abs(ocorr), dev))

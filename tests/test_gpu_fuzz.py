@@ -62,10 +62,7 @@ def test_batched_path_equals_pair_calls(oracle, n_st, block, wlen, per_batch, ma
     caps = [np.concatenate([oracle.simulate_delayed_fm(block, d, 900 + 7 * seed + k, 100 * s + k) for k in range(3)])
             for s, d in enumerate(delays)]
     with tdoa_amd.Context(max_lag=max_lag, window_len=wlen, windows_per_batch=per_batch) as c:
-        # a single pair call takes the fused forward-row form (1 pair-window <= 2 station-windows); a batch of more
-        # than 3 stations does not (more pairs than stations): same arithmetic, different instruction order.  Pin
-        # both to one form so that "bit for bit" compares like with like.
-        c.debug_flags(no_fused_rows=n_st > 3)
+        # flags == 0: the library's default kernels on both sides (the batch and the single pair call)
         peaks = c.process_u8(caps)
         wpb = max(1, block // wlen)
         wl = min(wlen, block)
@@ -110,7 +107,7 @@ def test_decimated_inverse_fuzz_batched(oracle, seed):
             part = c.process(rank=r, world=world)
             own = part["corr"] != 0
             merged[own] = part[own]
-        c.debug_flags(no_decimate=True, no_fused_rows=True)
+        c.debug_flags(no_decimate=True)
         full = c.process()
     assert dec.shape == (3, len(pairs))
     scale = np.abs(full["corr"]).max()

@@ -254,47 +254,76 @@ def test_simulator_shape_and_determinism(oracle):
 def test_k1_codes_agree_with_the_elf_discriminator_definition(oracle):
     """SURVEY section 8, row K1 (read off the prebuilt binary): x = ((I-127.5)/127.5, (Q-127.5)/127.5),
     p = x_i conj(x_{i-1}), y_i = atan2(Im p, Re p) unless |p|^2 <= 1e-10, y_0 := y_1.  The phase code is that
-    angle in units of pi/32768 AS A REAL NUMBER in (-pi, +pi] (no modulo 2 pi: an exactly reversed sample is +pi,
+    angle in units of pi/2^23 AS A REAL NUMBER in (-pi, +pi] (no modulo 2 pi: an exactly reversed sample is +pi,
     a near reversal keeps the sign of Im p), up to the two roundings of the angle codes it is the difference of."""
     from oracle import float_pipeline as fp
+    unit = np.pi / 2.0 ** 23
     rng = np.random.default_rng(2024)
     iq = rng.integers(0, 256, size=2 * 200000, dtype=np.uint8)
     iq[:12] = [0, 0, 255, 255, 0, 255, 255, 0, 127, 128, 128, 127]       # corners and the centre
     # exactly reversed samples: equal magnitude, and collinear with different magnitudes (Im p = 0, Re p < 0)
     iq[20:28] = [129, 129, 126, 126, 128, 126, 127, 129]                    # (3,3)->(-3,-3), (1,-3)->(-1,3)
     iq[28:36] = [128, 128, 126, 126, 129, 129, 127, 127]                    # (1,1)->(-3,-3), (3,3)->(-1,-1)
-    # near reversals at full scale whose two angle codes are exactly opposite although the samples are not collinear:
-    # the sign of Im p decides (sample 21: Im p < 0 -> -pi side; sample 23: Im p > 0 -> +pi side)
+    # the nearest a pair of NON-collinear samples gets to a reversal is 1/(|x_i||x_{i-1}|) rad (full scale: 7.7e-6 rad =
+    # 20 code steps): the sign of Im p decides the side, and the code follows it without a special case
+    # (sample 21: Im p < 0 -> -pi side; sample 23: Im p > 0 -> +pi side)
     iq[40:48] = [254, 253, 0, 1, 234, 229, 0, 6]
     code = oracle.b_discriminate(iq).astype(np.float64)
-    assert code.min() >= -32767 and code.max() <= 32768
+    assert code.min() > -2.0 ** 23 and code.max() <= 2.0 ** 23
     y = fp.discriminate(iq)                                                # exact-product float64 statement
-    diff = code * (np.pi / 32768.0) - y                                    # NOT wrapped
-    assert np.abs(diff).max() <= 1.01 * (np.pi / 32768.0)                   # two half-step roundings
+    diff = code * unit - y                                                 # NOT wrapped
+    assert np.abs(diff).max() <= 1.01 * unit                               # two half-step roundings
     assert code[0] == code[1]
-    assert code[11] == 32768 and code[13] == 32768 and code[15] == 32768 and code[17] == 32768
-    assert code[21] == -32767 and -np.pi < y[21] < -3.1415 and code[23] == 32768 and 3.1415 < y[23] < np.pi
+    assert code[11] == 2 ** 23 and code[13] == 2 ** 23 and code[15] == 2 ** 23 and code[17] == 2 ** 23
+    assert -2 ** 23 < code[21] < -2 ** 23 + 4096 and -np.pi < y[21] < -3.1415
+    assert 2 ** 23 - 4096 < code[23] < 2 ** 23 and 3.1415 < y[23] < np.pi
     # a small-amplitude capture (simulator.go: I/Q of +-1, +-3 LSB) is full of exact reversals
     sim = oracle.simulate_station("kx0u", 20000, 7)
     cs, ys = oracle.b_discriminate(sim).astype(np.float64), fp.discriminate(sim)
     assert (ys == np.pi).sum() > 100 and (ys == -np.pi).sum() == 0
-    assert np.abs(cs * (np.pi / 32768.0) - ys).max() <= 1.01 * (np.pi / 32768.0)
+    assert ((cs == 2.0 ** 23) == (ys == np.pi)).all()
+    assert np.abs(cs * unit - ys).max() <= 1.01 * unit
+
+
+def test_k1_exact_reversal_is_the_only_half_turn(oracle):
+    """a_i - a_{i-1} = -+2^23 must mean 'exactly reversed' (then Im p = 0 and atan2 gives +pi): over ALL pairs of the
+    65536 byte pairs, the directions whose angle codes are exactly opposite are collinear and opposite."""
+    code = np.array([[oracle.b_angle_code(2 * i - 255, 2 * q - 255) for q in range(256)] for i in range(256)], dtype=np.int64)
+    ii, qq = np.meshgrid(2 * np.arange(256) - 255, 2 * np.arange(256) - 255, indexing="ij")
+    flat, fi, fq = code.ravel(), ii.ravel(), qq.ravel()
+    order = np.argsort(flat, kind="stable")
+    sc = flat[order]
+    # partner codes: c + 2^23 (for c <= 0) -- every sample whose code equals that must be collinear and opposite
+    for lo in range(0, sc.size, 8192):
+        blk = order[lo:lo + 8192]
+        c = flat[blk]
+        tgt = np.where(c <= 0, c + 2 ** 23, c - 2 ** 23)
+        left, right = np.searchsorted(sc, tgt, "left"), np.searchsorted(sc, tgt, "right")
+        assert (right > left).all()                                          # (-I, -Q) always exists
+        for k in np.nonzero(right - left > 0)[0]:
+            other = order[left[k]:right[k]]
+            cross = fq[blk[k]] * fi[other] - fi[blk[k]] * fq[other]
+            dot = fi[blk[k]] * fi[other] + fq[blk[k]] * fq[other]
+            assert (cross == 0).all() and (dot < 0).all()
 
 
 def test_k1_angle_table_properties(oracle):
-    """every one of the 65536 byte pairs: within half a step (+ the 1.7e-7 rad of the polynomial) of atan2,
+    """every one of the 65536 byte pairs: the correctly rounded atan2 in units of pi/2^23,
     collinear samples share a code, opposite samples differ by exactly half a turn"""
     from math import gcd
     code = np.array([[oracle.b_angle_code(2 * i - 255, 2 * q - 255) for q in range(256)] for i in range(256)])
     bi, bq = np.meshgrid(np.arange(256), np.arange(256), indexing="ij")
-    want = np.arctan2(2.0 * bq - 255.0, 2.0 * bi - 255.0) * (32768.0 / np.pi)
-    assert np.abs(code - want).max() <= 0.5 + 0.01
-    assert np.abs(code).max() <= 32768 - 41
+    want = np.arctan2(2.0 * bq - 255.0, 2.0 * bi - 255.0) * (2.0 ** 23 / np.pi)
+    assert np.abs(code - want).max() <= 0.5 + 1e-6
+    assert np.abs(code).max() < 2 ** 23
     opp = code[::-1, ::-1]                                                  # (b_I, b_Q) -> (255 - b_I, 255 - b_Q)
-    assert (np.abs(code - opp) == 32768).all()
+    assert (np.abs(code - opp) == 2 ** 23).all()
     for (i, q, k) in [(1, 1, 3), (1, 3, 5), (3, 5, 7), (7, 1, 9), (5, 11, 21), (1, 1, 255)]:
         for si in (1, -1):
             for sq in (1, -1):
                 assert oracle.b_angle_code(si * i, sq * q) == oracle.b_angle_code(si * i * k, sq * q * k)
-    assert gcd(3, 9) == 3 and oracle.b_angle_code(1, 1) == 8192 and oracle.b_angle_code(-1, 1) == 24576
-    assert oracle.b_angle_code(-1, -1) == -24576 and oracle.b_angle_code(1, -1) == -8192
+    assert gcd(3, 9) == 3 and oracle.b_angle_code(1, 1) == 2 ** 21 and oracle.b_angle_code(-1, 1) == 3 * 2 ** 21
+    assert oracle.b_angle_code(-1, -1) == -3 * 2 ** 21 and oracle.b_angle_code(1, -1) == -2 ** 21
+    # the first-octant table the product keeps: 8256 directions, strictly inside (0, 2^21]
+    tab = np.array([oracle.b_octant_code(2 * mn + 1, 2 * mx + 1) for mx in range(128) for mn in range(mx + 1)])
+    assert tab.size == 8256 and tab.min() > 0 and tab.max() == 2 ** 21
