@@ -92,6 +92,14 @@ __global__ void k_zero_u64(unsigned long long *p, size_t n)
     if (i < n) p[i] = 0ull;
 }
 
+// A value the compiler must treat as unknown: addresses derived from it are rebuilt where they are used instead of being
+// hoisted out of a loop as dozens of invariants (which then spill).
+__device__ __forceinline__ int opaque_i(int v)
+{
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k)
 {
 #pragma unroll

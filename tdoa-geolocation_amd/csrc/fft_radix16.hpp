@@ -212,80 +212,101 @@ __global__ __launch_bounds__(512) void k_fwd_col256_c16(const SWDesc *sw, const 
 // samples are the float discriminator to float32 resolution.  The window statistics come from the k_fm_demod<false>
 // pre-pass.
 //
-// Element m of the packed window needs the angle codes of samples 2m-1, 2m, 2m+1: one 4-byte load (samples 2m, 2m+1)
-// and one 2-byte load (sample 2m-1, the same cache line), three table lookups.
+// Element m of the packed window (samples 2m, 2m+1) needs the angle codes of samples 2m-1, 2m, 2m+1.  A thread loads
+// the dword of its two samples and looks both up; the angle of sample 2m-1 is the second angle of the lane to its
+// LEFT (the 32 lanes of a half-wave hold 32 adjacent elements): one DPP move instead of a third load and lookup.  Only
+// the first column of the tile has no left neighbour: those 16 rows x 2 half-waves = 32 "boundary" samples of a wave
+// are loaded and looked up by its lanes 0..31 in one go and handed out by lane permutes.
 // LDS: the angle table (33 KB) has to sit next to the tile, and two workgroups must still fit a CU: the exchange between
 // the two radix-16 stages therefore goes through ONE float plane [256][32] (32 KB), real parts first, then imaginary
 // parts (the tile of the code-reading kernel is 64 KB).  The workgroups are persistent -- grid = 2 per CU, tiles dealt
 // round-robin -- so the table is loaded once per workgroup, not once per tile.
 // Tile t = (w A + a) (N1/32) + bx: consecutive workgroups take adjacent 32-column blocks of the same rows.
-// grid (2 n_cu), 512 threads (c = t & 31 column, j = t >> 5 item), dynamic LDS 32 KB + kK1TableBytes.
+// grid (2 n_cu), 512 threads (c = t & 31 column, j = t >> 5 item), dynamic LDS 33 KB (table) + 32 KB (plane).
 // ---------------------------------------------------------------------------
-constexpr size_t kColK1Lds = sizeof(float) * 256 * 32 + kK1TableBytes;
+constexpr size_t kColK1Lds = kK1TableBytes + sizeof(float) * 256 * 32;
 
-struct K1Raw {             // what a thread fetched for one element: the dword of samples (2m, 2m+1), the sample before
-    unsigned int w, prev;
-};
-
-// ODD: the window has an odd number of samples, so its last element holds one sample only (2m+1 = len); the dword is then
-// fetched one sample earlier (samples 2m-1, 2m: nothing is read beyond the window) and re-sorted in k1_element_convert.
-template <bool ODD>
-__device__ __forceinline__ K1Raw k1_element_fetch(gptr16 p, long long m, int len)
+// store at a 32-bit unsigned byte offset from a wave-uniform base (global_store v_off, v[data], s[base]): one offset
+// register per store instead of a 64-bit address pair (a window's transform is at most 2^27 bytes)
+__device__ __forceinline__ void store_at(float2 *base, unsigned int byte_off, float2 v)
 {
-    const long long i0 = 2 * m;
-    const bool full = i0 + 1 < len, part = ODD && i0 + 1 == len;
-    K1Raw r;
-    r.w = k1_fetch2(p, full ? i0 : (part ? i0 - 1 : 0));
-    r.prev = p[(full || part) && m > 0 ? i0 - 1 : 0];
-    return r;
+    *reinterpret_cast<float2 *>(reinterpret_cast<char *>(base) + byte_off) = v;
 }
 
-template <bool ODD>
-__device__ __forceinline__ float2 k1_element_convert(K1Raw r, long long m, int len, float mean, float scale, const int *lut,
-                                                     bool head)      // head: m may be 0 (the window's first element)
+// One element from the dword `w` its thread fetched at sample index min(2m, len - 2) (never beyond the window) and the
+// angle code `ap` of sample 2m - 1.  Returns the normalised pair; `a1` = angle of the element's LAST valid sample (what
+// the lane to the right needs).  head: m may be 0 (code_0 := code_1).  len >= 2.
+__device__ __forceinline__ float2 k1_element(unsigned int w, int ap, int i0, int len, float mean, float scale, const int *lut,
+                                             bool head)
 {
-    const long long i0 = 2 * m;
-    const bool full = i0 + 1 < len, part = ODD && i0 + 1 == len;
-    unsigned int s0 = r.w & 0xffffu, s1 = r.w >> 16, sp = r.prev;
-    if (ODD && part) { sp = s0; s0 = s1; }
-    const int ap = k1_angle(sp, lut), a0 = k1_angle(s0, lut), a1 = k1_angle(s1, lut);
+    int a0, a1;
+    k1_angle2(w, lut, a0, a1);
+    if (len & 1) {                       // wave-uniform: only then can a last element hold ONE sample (2m + 1 = len);
+        if (i0 + 1 == len) {             // its dword was fetched one sample early: (2m - 1, 2m)
+            ap = a0;
+            a0 = a1;
+        }
+    }
     const int st1 = k1_stored_code(a1, a0);
-    const int st0 = head && m == 0 ? st1 : k1_stored_code(a0, ap);      // code_0 := code_1
+    const int st0 = head && i0 == 0 ? st1 : k1_stored_code(a0, ap);
     const float v0 = k1_normalise(st0, mean, scale), v1 = k1_normalise(st1, mean, scale);
-    return make_float2(full || part ? v0 : 0.0f, full ? v1 : 0.0f);
+    return make_float2(i0 < len ? v0 : 0.0f, i0 + 1 < len ? v1 : 0.0f);
 }
 
 template <bool SUB>
-__global__ __launch_bounds__(512) void k_fwd_col256_k1(const SWDesc *sw, const int *table, const FmStats *stats, float2 *T,
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_fwd_col256_k1(const SWDesc *sw, const int *table, const FmStats *stats, float2 *T,
                                                        FftPlan pl, int n_sw)
 {
-    extern __shared__ float lds_f[];
-    float *plane = lds_f;                                        // [256][32]
-    int *lut = reinterpret_cast<int *>(lds_f + 256 * 32);
+    extern __shared__ int lds_k1[];                             // the table at offset 0 (immediate offsets), then the plane
+    int *lut = lds_k1;
+    float *plane = reinterpret_cast<float *>(lds_k1 + kK1TableEntries);      // [256][32]
     k1_load_table(lut, table);
     const int G = SUB ? pl.N2 >> 8 : 1;
-    const int c = threadIdx.x & 31, j = threadIdx.x >> 5;     // column, item (0..15)
     const int N1 = pl.N1, nbx = N1 >> 5;
     const int n_tiles = n_sw * G * nbx;
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        // (laundered per tile: the row / plane / output addresses derived from the thread index are rebuilt inside the
+        // trip -- hoisted out of this loop as ~80 invariants they spilled 112 VGPRs)
+        const int tid = opaque_i((int)threadIdx.x);
+        const int lane = tid & 63;
+        const int c = tid & 31, j = tid >> 5;                    // column, item (0..15)
         const int bx = tile % nbx, wa = tile / nbx, a = SUB ? wa % G : 0, w = SUB ? wa / G : wa;
         const SWDesc d = sw[w];
         const int len = d.len;
         const gptr16 p = k1_global(d.base);
         const float mean = stats[w].mean, scale = stats[w].scale;
         const int n1 = (bx << 5) + c;
+        // sample index of element (row, n1): 2 (row N1 + n1) < 2^25 (Nc <= 2^24)
+        const int last = len - 2;
         float2 v[16];
-        auto load_convert = [&](auto odd_c) {
-            constexpr bool ODD = decltype(odd_c)::value;
-            K1Raw raw[16];
+        {
+            unsigned int raw[16];
 #pragma unroll
-            for (int r = 0; r < 16; r++) raw[r] = k1_element_fetch<ODD>(p, (long long)(a + G * (j + 16 * r)) * N1 + n1, len);
+            for (int r = 0; r < 16; r++) {
+                const int i0 = 2 * ((a + G * (j + 16 * r)) * N1 + n1);
+                raw[r] = k1_fetch2(p, i0 < last ? i0 : last);
+            }
+            // boundary samples: lane L < 32 takes row r = L >> 1 of half-wave h = L & 1 (item j_b = (j & ~1) + h, column
+            // 32 bx): the sample before that element, if there is one inside the window
+            int ab;
+            {
+                const int jb = (j & ~1) + (lane & 1), rb = (lane & 31) >> 1;
+                const int ib = 2 * ((a + G * (jb + 16 * rb)) * N1 + (bx << 5)) - 1;
+                const unsigned int sb = p[ib >= 0 && ib < len ? ib : 0];
+                ab = k1_angle(sb, lut);
+            }
 #pragma unroll
-            for (int r = 0; r < 16; r++)
-                v[r] = k1_element_convert<ODD>(raw[r], (long long)(a + G * (j + 16 * r)) * N1 + n1, len, mean, scale, lut, r == 0);
-        };
-        if (len & 1) load_convert(std::true_type{});
-        else load_convert(std::false_type{});
+            for (int r = 0; r < 16; r++) {
+                const int i0 = 2 * ((a + G * (j + 16 * r)) * N1 + n1);
+                // the angle of this element's last valid sample travels one lane to the right; it is computed inside
+                // k1_element too -- the compiler merges the two evaluations
+                int a0, a1;
+                k1_angle2(raw[r], lut, a0, a1);
+                const int left = wave_shift_right1(a1);
+                const int bnd = __shfl(ab, 2 * r + (lane >> 5), kWave);
+                v[r] = k1_element(raw[r], c ? left : bnd, i0, len, mean, scale, lut, r == 0);
+            }
+        }
         fft16<false>(v);
         // exchange through one float plane: real parts, then imaginary parts
 #pragma unroll
@@ -303,20 +324,25 @@ __global__ __launch_bounds__(512) void k_fwd_col256_k1(const SWDesc *sw, const i
         mul_powers16(v, unit_root((float)j, 2.0f / 256.0f, false));
         fft16<false>(v);
         float2 *out = T + (size_t)w * pl.Nc;
+        // (the output offsets are 4 x the input sample indices of the same rows: rebuilt from a laundered n1 here, or the
+        // 16 load offsets stay alive through both transforms for the sake of one shift each -- and spill)
+        const int n1o = opaque_i(n1);
         if (SUB) {
             // Y_a[kb = j + 16k] *= W_(256G)^(a kb) = W^(a j) * (W^(16 a))^k
             const float invg = 2.0f / (float)pl.N2;
             if (a) mul_base_step16(v, unit_root((float)(a * j), invg, false), unit_root((float)(16 * a), invg, false));
+            __builtin_amdgcn_sched_barrier(0);                   // offsets are formed here, not during the transform
 #pragma unroll
-            for (int k = 0; k < 16; k++) out[(size_t)(a * 256 + j + 16 * k) * N1 + n1] = v[oreg(k)];
+            for (int k = 0; k < 16; k++) store_at(out, 8u * (unsigned)((a * 256 + j + 16 * k) * N1 + opaque_i(n1o)), v[oreg(k)]);
         } else {
             // Y[k2 = j + 16k] *= W_Nc^(n1*k2) = W^(n1*j) * (W^(16*n1))^k
             const float inv2 = 2.0f / (float)pl.Nc;
-            const long long e0 = ((long long)n1 * j) & (pl.Nc - 1);
-            const long long e1 = ((long long)n1 * 16) & (pl.Nc - 1);
+            const int e0 = (n1 * j) & (int)(pl.Nc - 1);              // n1 j < 2^16, Nc <= 2^24
+            const int e1 = (n1 * 16) & (int)(pl.Nc - 1);
             mul_base_step16(v, unit_root((float)e0, inv2, false), unit_root((float)e1, inv2, false));
+            __builtin_amdgcn_sched_barrier(0);                   // offsets are formed here, not during the transform
 #pragma unroll
-            for (int k = 0; k < 16; k++) out[(size_t)(j + 16 * k) * N1 + n1] = v[oreg(k)];
+            for (int k = 0; k < 16; k++) store_at(out, 8u * (unsigned)((j + 16 * k) * N1 + opaque_i(n1o)), v[oreg(k)]);
         }
     }
 }

@@ -91,12 +91,6 @@ __device__ __forceinline__ int code_at(const int *row, unsigned byte_off)
     return *reinterpret_cast<const int *>(reinterpret_cast<const char *>(row) + byte_off);
 }
 
-__device__ __forceinline__ int opaque_i(int v)
-{
-    asm volatile("" : "+v"(v));
-    return v;
-}
-
 constexpr int kRow8Lds = 4096;       // float2 per row image (no padding)
 
 // Stages 2..4 of TWO 4096-point row transforms side by side (row x through image la, row y through lb), whose

@@ -36,18 +36,96 @@ constexpr int kK1Half = 1 << 23;                 // code units per half turn (pi
 constexpr int kK1TableEntries = 128 * 129 / 2;   // first-octant directions, mn <= mx
 constexpr size_t kK1TableBytes = sizeof(int) * kK1TableEntries;      // 33 024
 
-// angle code of the IQ sample s = b_I | b_Q << 8 (I = 2 b_I - 255, Q = 2 b_Q - 255); |code| < 2^23
+// Angle code of an IQ sample (I = 2 b_I - 255, Q = 2 b_Q - 255) from the first-octant table, |code| < 2^23.
+// This runs once per sample of the capture inside kernels that are bound by vector-instruction issue (SQ counters:
+// 80 % VALU-busy), so the sequence is pinned in inline assembly: 17 instructions per sample, no compare, no select
+// (left to itself the compiler turns the masks back into v_cmp + 2 v_cndmask per step -- plus their wait states on
+// gfx950 -- and came out at 30).
+//   x   = index bytes (|2 b - 255| - 1) / 2 = b ^ (b >= 128 ? 0x80 : 0x7f)          (formed per dword by the caller)
+//   neg = ~b: bit 7 set = the component is negative
+//   c   = table[mx (mx + 1) / 2 + mn]                                               first-octant angle
+//   each placement step is  c -> K - c  under a condition, written  (c ^ m) + (m & (K + 1))  with m = 0 or -1:
+//   |Q| > |I|: K = 2^22;  I < 0: K = 2^23;  Q < 0: K = 0.
+// HI = false: the sample in the low half of the dword, true: the high half.
+template <bool HI>
+__device__ __forceinline__ int k1_angle_from(unsigned int x, unsigned int neg, const int *lut)
+{
+    unsigned int mx, mn, p, off;
+    int d, msw, k, mi, mq, c;
+    if (!HI) {
+        asm("v_max_u32_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_1" : "=v"(mx) : "v"(x));
+        asm("v_min_u32_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_1" : "=v"(mn) : "v"(x));
+        asm("v_sub_u32_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_1" : "=v"(d) : "v"(x));
+    } else {
+        asm("v_max_u32_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:BYTE_3" : "=v"(mx) : "v"(x));
+        asm("v_min_u32_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:BYTE_3" : "=v"(mn) : "v"(x));
+        asm("v_sub_u32_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:BYTE_3" : "=v"(d) : "v"(x));
+    }
+    asm("v_mad_u32_u24 %0, %1, %1, %1" : "=v"(p) : "v"(mx));                    // mx^2 + mx
+    asm("v_lshlrev_b32 %0, 2, %1" : "=v"(mn) : "v"(mn));
+    asm("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(off) : "v"(p), "v"(mn));         // byte offset 2 (mx^2 + mx) + 4 mn
+    c = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(lut) + off);
+    asm("v_ashrrev_i32 %0, 31, %1" : "=v"(msw) : "v"(d));                       // -1: |Q| > |I|
+    asm("v_and_b32 %0, 0x400001, %1" : "=v"(k) : "v"(msw));
+    asm("v_xad_u32 %0, %1, %2, %3" : "=v"(c) : "v"(c), "v"(msw), "v"(k));      // (c ^ m) + k
+    if (!HI) asm("v_bfe_i32 %0, %1, 7, 1" : "=v"(mi) : "v"(neg));               // -1: I < 0
+    else asm("v_bfe_i32 %0, %1, 23, 1" : "=v"(mi) : "v"(neg));
+    asm("v_and_b32 %0, 0x800001, %1" : "=v"(k) : "v"(mi));
+    asm("v_xad_u32 %0, %1, %2, %3" : "=v"(c) : "v"(c), "v"(mi), "v"(k));
+    if (!HI) asm("v_bfe_i32 %0, %1, 15, 1" : "=v"(mq) : "v"(neg));              // -1: Q < 0
+    else asm("v_ashrrev_i32 %0, 31, %1" : "=v"(mq) : "v"(neg));
+    asm("v_xor_b32 %0, %1, %2" : "=v"(c) : "v"(c), "v"(mq));
+    asm("v_sub_u32 %0, %1, %2" : "=v"(c) : "v"(c), "v"(mq));                    // (c ^ m) - m
+    return c;
+}
+
+__device__ __forceinline__ unsigned int k1_index_bytes(unsigned int w) { return w ^ (0x7f7f7f7fu + ((w >> 7) & 0x01010101u)); }
+
+// the two samples of a dword w = b_I0 | b_Q0 << 8 | b_I1 << 16 | b_Q1 << 24
+__device__ __forceinline__ void k1_angle2(unsigned int w, const int *lut, int &a0, int &a1)
+{
+    const unsigned int x = k1_index_bytes(w), neg = ~w;
+    a0 = k1_angle_from<false>(x, neg, lut);
+    a1 = k1_angle_from<true>(x, neg, lut);
+}
+
+// one sample s = b_I | b_Q << 8
 __device__ __forceinline__ int k1_angle(unsigned int s, const int *lut)
 {
-    // per byte: (|2 b - 255| - 1) / 2 = b - 128 for b >= 128, 127 - b below
-    const unsigned int x = s ^ (0x7f7fu + ((s >> 7) & 0x0101u));
-    const unsigned int ia = x & 0xffu, iq = (x >> 8) & 0xffu;
-    const unsigned int mx = ia > iq ? ia : iq, mn = ia > iq ? iq : ia;
-    int c = lut[((mx * mx + mx) >> 1) + mn];
-    if (iq > ia) c = (kK1Half >> 1) - c;          // |Q| > |I|
-    if (!(s & 0x80u)) c = kK1Half - c;            // I < 0
-    if (!(s & 0x8000u)) c = -c;                   // Q < 0
-    return c;
+    return k1_angle_from<false>(k1_index_bytes(s), ~s, lut);
+}
+
+// The streaming K1 kernel (k_fm_demod) has the LDS to itself and keeps a DIRECT table instead: the point reflection
+// (I, Q) -> (-I, -Q) is b -> 255 - b = ~b on both bytes and changes the angle by exactly half a turn, so 32768 entries
+// cover the half plane Q > 0: D[b_I | (b_Q & 0x7f) << 8] = a(I, Q) in (0, 2^23), b_Q >= 128  (128 KB, built by the host
+// from the same first-octant codes).  Lookup of the two samples of a dword: 11 instructions, against 2 x 17 above.
+// Returns the angle modulo 2^24 (in [0, 2^24)); only differences of angles are ever used.
+constexpr int kK1DirectEntries = 32768;
+constexpr size_t kK1DirectBytes = sizeof(int) * kK1DirectEntries;      // 131 072
+
+__device__ __forceinline__ void k1_direct_angle2(unsigned int w, const int *dlut, int &a0, int &a1)
+{
+    typedef short short2v __attribute__((ext_vector_type(2)));
+    const short2v nq = __builtin_bit_cast(short2v, ~w) >> (short)15;          // per half: 0xffff if Q < 0 (v_pk_ashrrev_i16)
+    const unsigned int pm = __builtin_bit_cast(unsigned int, nq);
+    const unsigned int fw = w ^ pm;                                            // reflected where Q < 0: now b_Q >= 128
+    const int c0 = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(dlut) + ((fw << 2) & 0x1fffcu));
+    const int c1 = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(dlut) + ((fw >> 14) & 0x1fffcu));
+    a0 = c0 | (int)((pm << 8) & 0x800000u);                                    // + half a turn (mod 2^24) if reflected
+    a1 = c1 | (int)((pm >> 8) & 0x800000u);
+}
+
+__device__ __forceinline__ int k1_direct_angle(unsigned int s, const int *dlut)
+{
+    int a0, a1;
+    k1_direct_angle2(s | 0x80000000u, dlut, a0, a1);                           // (high half: any sample with Q > 0)
+    return a0;
+}
+
+// lane i takes the value of lane i - 1 (lane 0 keeps its own): one DPP move
+__device__ __forceinline__ int wave_shift_right1(int v)
+{
+    return __builtin_amdgcn_update_dpp(v, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
 }
 
 // stored (negated) phase code of a sample with angle code a_cur after one with a_prev: -(code) in [-2^23, 2^23)
@@ -246,7 +324,7 @@ __global__ __launch_bounds__(256) void k_k1_envelope(const SWDesc *sw, const uns
     k1_block_stats_256(s1, s2, &acc[blockIdx.y]);
 }
 
-// K1 streaming pass: persistent 1024-thread workgroups keep the angle table in LDS (33 KB: two workgroups per CU);
+// K1 streaming pass: persistent 1024-thread workgroups (one per CU) keep the DIRECT angle table in LDS (128 KB);
 // after loading it the 16 waves of a workgroup run independently, each taking (station-window, 2048-sample piece)
 // work items round-robin.  Window sums go straight into per-window integer accumulators with atomic adds: exact,
 // hence independent of arrival order.
@@ -256,11 +334,13 @@ __global__ __launch_bounds__(256) void k_k1_envelope(const SWDesc *sw, const uns
 // envelope class are skipped here).
 template <bool WRITE>
 __global__ __launch_bounds__(kDemodThreads) void k_fm_demod(const SWDesc *sw, int n_sw, int pieces_per_window,
-                                                            const int *table, int *codes, long long code_stride,
+                                                            const int *dtable, int *codes, long long code_stride,
                                                             StatsPartial *acc, const unsigned long long *power)
 {
-    extern __shared__ int lut[];                 // kK1TableEntries angle codes
-    k1_load_table(lut, table);
+    extern __shared__ int dlut[];                // kK1DirectEntries angles (128 KB: one workgroup per CU)
+    for (int k = threadIdx.x; k < kK1DirectEntries / 4; k += kDemodThreads)
+        reinterpret_cast<int4 *>(dlut)[k] = reinterpret_cast<const int4 *>(dtable)[k];
+    __syncthreads();
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
     // work item of a WORKGROUP = kDemodItem consecutive pieces of one window; at every step its 16 waves take 16
     // adjacent pieces, so the workgroup streams 64 KB of contiguous capture bytes per step (one DRAM-friendly run,
@@ -282,72 +362,51 @@ __global__ __launch_bounds__(kDemodThreads) void k_fm_demod(const SWDesc *sw, in
         for (int piece = run * kDemodItem + wv; piece < (run + 1) * kDemodItem; piece += kDemodThreads / kWave) {
             const int start = piece * kDemodPiece;
             if (start >= len) break;
-            // a lane owns samples [i0, i0+8) of each 512-sample chunk; all loads are issued before any is used
-            uint4 qs[kDemodChunks];
-            unsigned int prev[kDemodChunks];
-            bool fastc[kDemodChunks];
-            bool interior = true;
-#pragma unroll
-            for (int h = 0; h < kDemodChunks; h++) {
-                const int i0 = start + h * 512 + lane * 8;
-                fastc[h] = i0 >= 1 && i0 + 8 <= len;                              // interior (fast) chunks
-                interior = interior && fastc[h];
-                qs[h] = make_uint4(0, 0, 0, 0);
-                prev[h] = 0;
-            }
-            if (__all(interior)) {
-                // whole piece inside the window: the sample before a lane's chunk is the last sample of the lane to
-                // its left (lane 0: lane 63 of the previous chunk; chunk 0: one broadcast load) -- no 2-byte gathers
+            if (start >= 1 && start + kDemodPiece <= len) {
+                // whole piece inside the window (all but the first and last pieces): a lane owns samples [i0, i0 + 8) of
+                // each 512-sample chunk; all loads are issued before any is used.  Every sample is looked up ONCE: the
+                // angle before a lane's chunk is the last angle of the lane to its left (one DPP move); lane 0 takes lane
+                // 63 of the previous chunk, and for chunk 0 the one sample before the piece.
+                uint4 qs[kDemodChunks];
                 const unsigned int before = p[start - 1];
 #pragma unroll
                 for (int h = 0; h < kDemodChunks; h++) qs[h] = k1_fetch8(p, start + h * 512 + lane * 8);
+                int carry = k1_direct_angle(before, dlut);
+                int t1 = 0;                      // 32 stored codes of |.| <= 2^23: fits
 #pragma unroll
                 for (int h = 0; h < kDemodChunks; h++) {
-                    const unsigned int left = __shfl_up(qs[h].w >> 16, 1, kWave);
-                    const unsigned int wrap = h ? __shfl(qs[h ? h - 1 : 0].w >> 16, kWave - 1, kWave) : before;
-                    prev[h] = lane ? left : wrap;
-                }
-            } else {
-#pragma unroll
-                for (int h = 0; h < kDemodChunks; h++) {
-                    const int i0 = start + h * 512 + lane * 8;
-                    if (fastc[h]) { qs[h] = k1_fetch8(p, i0); prev[h] = p[i0 - 1]; }
-                }
-            }
-#pragma unroll
-            for (int half = 0; half < kDemodChunks; half++) {
-                const int i0 = start + half * 512 + lane * 8;
-                const bool fast = fastc[half];
-                if (i0 >= len) continue;
-                int c[8];
-                if (fast) {
-                    unsigned int sm[9];
-                    k1_unpack8(qs[half], sm);
-                    sm[0] = prev[half];
-                    int a[9];
-#pragma unroll
-                    for (int k = 0; k < 9; k++) a[k] = k1_angle(sm[k], lut);
-                    int t1 = 0;                  // 8 codes of |.| <= 2^23: fits
-                    double t2 = 0.0;             // code^2 < 2^46 is exact in a double, and so is the sum of 8 of them
+                    int a[9], c[8];
+                    k1_direct_angle2(qs[h].x, dlut, a[1], a[2]);
+                    k1_direct_angle2(qs[h].y, dlut, a[3], a[4]);
+                    k1_direct_angle2(qs[h].z, dlut, a[5], a[6]);
+                    k1_direct_angle2(qs[h].w, dlut, a[7], a[8]);
+                    const int left = wave_shift_right1(a[8]);
+                    a[0] = lane ? left : carry;
+                    carry = __builtin_amdgcn_readlane(a[8], kWave - 1);
 #pragma unroll
                     for (int k = 0; k < 8; k++) {
                         c[k] = k1_stored_code(a[k + 1], a[k]);
                         t1 -= c[k];
-                        const double cd = (double)c[k];
-                        t2 = __builtin_fma(cd, cd, t2);
+                        s2 += (unsigned long long)((long long)c[k] * c[k]);      // v_mul_i32_i24 / v_mul_hi_i32_i24 + 64-bit add
                     }
-                    s1 += t1;
-                    s2 += (unsigned long long)t2;
-                } else {
-                    // window head (code_0 := code_1) and tail; samples beyond len carry code 0 in memory
-                    // and do not enter the sums
+                    if (WRITE) k1_store8(out + start + h * 512 + lane * 8, c);
+                }
+                s1 += t1;
+            } else {
+                // window head (code_0 := code_1) and tail, sample by sample; samples beyond len carry code 0 in memory and
+                // do not enter the sums
+#pragma unroll 1
+                for (int h = 0; h < kDemodChunks; h++) {
+                    const int i0 = start + h * 512 + lane * 8;
+                    if (i0 >= len) continue;
+                    int c[8];
 #pragma unroll
                     for (int k = 0; k < 8; k++) {
                         const int i = i0 + k;
                         int v = 0;
                         if (i < len && len >= 2) {
                             const int ii = i == 0 ? 1 : i;
-                            v = k1_stored_code(k1_angle(p[ii], lut), k1_angle(p[ii - 1], lut));
+                            v = k1_stored_code(k1_direct_angle(p[ii], dlut), k1_direct_angle(p[ii - 1], dlut));
                         }
                         c[k] = v;
                         if (i < len) {
@@ -355,8 +414,8 @@ __global__ __launch_bounds__(kDemodThreads) void k_fm_demod(const SWDesc *sw, in
                             s2 += (unsigned long long)((long long)v * v);
                         }
                     }
+                    if (WRITE) k1_store8(out + i0, c);
                 }
-                if (WRITE) k1_store8(out + i0, c);
             }
         }
 #pragma unroll

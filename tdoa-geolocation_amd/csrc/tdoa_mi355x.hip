@@ -61,6 +61,7 @@ struct tdoa_ctx {
     std::vector<Capture> caps;
 
     DevBuf k1_table;                        // kK1TableEntries first-octant angle codes (k1_build_table_host)
+    DevBuf k1_direct;                       // kK1DirectEntries half-plane angle codes of the streaming K1 kernel
     DevBuf sw_desc, pw_desc, partials, stats, codes, codes_lp, k1_power, tz, v, keys, scales, peaks, scratch_a, scratch_b, lagdump;
     DevBuf ex_a, ex_b, ex_c, ex_d, ex_part;
 
@@ -262,7 +263,7 @@ void prof_collect(tdoa_ctx *ctx)
 // The K1 angle table (k1_discriminator.hpp): first-octant directions (mn, mx), index mx (mx + 1) / 2 + mn over the
 // indices of the odd magnitudes 2 idx + 1; entry = llround(atan2(mn', mx') 2^23 / pi) of the gcd-reduced pair, float64.
 // (oracle/tdoa_oracle.c: ob_octant_code states the same expression; tests compare the device's codes with it bit for bit)
-void k1_build_table_host(std::vector<int32_t> &tab)
+void k1_build_table_host(std::vector<int32_t> &tab, std::vector<int32_t> &direct)
 {
     tab.resize(kK1TableEntries);
     for (int mx = 0; mx < 128; mx++)
@@ -273,6 +274,18 @@ void k1_build_table_host(std::vector<int32_t> &tab)
             a /= g;
             b /= g;
             tab[(size_t)mx * (mx + 1) / 2 + mn] = (int32_t)std::llround(std::atan2((double)b, (double)a) * (8388608.0 / M_PI));
+        }
+    // the direct half-plane table of the streaming kernel: D[b_I | (b_Q & 0x7f) << 8] = a(I, Q) for b_Q >= 128 (Q > 0),
+    // placed from the first-octant codes by the integer rules of k1_angle_from
+    direct.resize(kK1DirectEntries);
+    for (int bq = 128; bq < 256; bq++)
+        for (int bi = 0; bi < 256; bi++) {
+            const int ia = bi >= 128 ? bi - 128 : 127 - bi, iq = bq - 128;
+            const int mx = std::max(ia, iq), mn = std::min(ia, iq);
+            int c = tab[(size_t)mx * (mx + 1) / 2 + mn];
+            if (iq > ia) c = (kK1Half >> 1) - c;
+            if (bi < 128) c = kK1Half - c;
+            direct[(size_t)bi | ((size_t)(bq & 0x7f) << 8)] = c;
         }
 }
 
@@ -297,7 +310,7 @@ int *launch_k1(tdoa_ctx *ctx, hipStream_t st, const SWDesc *d_sw, int n_sw, int 
     auto *partials = static_cast<StatsPartial *>(ctx->partials.p);
     auto *stats = static_cast<FmStats *>(ctx->stats.p);
     auto *codes = static_cast<int *>(ctx->codes.p);
-    const auto *table = static_cast<const int *>(ctx->k1_table.p);
+    const auto *table = static_cast<const int *>(ctx->k1_direct.p);
     const dim3 per_chunk((unsigned)((maxlen + 2047) / 2048), n_sw);
     unsigned long long *power = nullptr;
     if (ctx->prm.k1_gate) {
@@ -307,12 +320,12 @@ int *launch_k1(tdoa_ctx *ctx, hipStream_t st, const SWDesc *d_sw, int n_sw, int 
     }
     zero_partials(st, partials, n_sw);
     const long long items = (long long)((pieces + kDemodItem - 1) / kDemodItem) * n_sw;      // workgroup items
-    const int blocks = (int)std::max<long long>(1, std::min<long long>(items, 2ll * ctx->n_cu));   // two workgroups per CU
+    const int blocks = (int)std::max<long long>(1, std::min<long long>(items, ctx->n_cu));        // one workgroup per CU (128 KB table)
     if (materialise)
-        hipLaunchKernelGGL(k_fm_demod<true>, dim3(blocks), dim3(kDemodThreads), kK1TableBytes, st, d_sw, n_sw, pieces, table,
+        hipLaunchKernelGGL(k_fm_demod<true>, dim3(blocks), dim3(kDemodThreads), kK1DirectBytes, st, d_sw, n_sw, pieces, table,
                            codes, code_stride, partials, power);
     else
-        hipLaunchKernelGGL(k_fm_demod<false>, dim3(blocks), dim3(kDemodThreads), kK1TableBytes, st, d_sw, n_sw, pieces, table,
+        hipLaunchKernelGGL(k_fm_demod<false>, dim3(blocks), dim3(kDemodThreads), kK1DirectBytes, st, d_sw, n_sw, pieces, table,
                            static_cast<int *>(nullptr), code_stride, partials, power);
     if (power) hipLaunchKernelGGL(k_k1_envelope, per_chunk, dim3(256), 0, st, d_sw, power, codes, code_stride, partials);
     if (ctx->prm.k1_smooth > 1) {
@@ -971,9 +984,17 @@ int tdoa_create(const tdoa_params *p, tdoa_ctx **out)
         }
         ctx->k1_table.p = t;
         ctx->k1_table.cap = kK1TableBytes;
-        std::vector<int32_t> tab;
-        k1_build_table_host(tab);
-        if (hipMemcpy(t, tab.data(), kK1TableBytes, hipMemcpyHostToDevice) != hipSuccess) {
+        std::vector<int32_t> tab, direct;
+        k1_build_table_host(tab, direct);
+        void *dt = nullptr;
+        if (hipMalloc(&dt, kK1DirectBytes) != hipSuccess) {
+            tdoa_destroy(ctx);
+            return TDOA_ERR_NOMEM;
+        }
+        ctx->k1_direct.p = dt;
+        ctx->k1_direct.cap = kK1DirectBytes;
+        if (hipMemcpy(t, tab.data(), kK1TableBytes, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(dt, direct.data(), kK1DirectBytes, hipMemcpyHostToDevice) != hipSuccess) {
             tdoa_destroy(ctx);
             return TDOA_ERR_HIP;
         }
@@ -1000,7 +1021,7 @@ void tdoa_destroy(tdoa_ctx *ctx)
     if (ctx->graph_exec) (void)hipGraphExecDestroy(ctx->graph_exec);
     if (ctx->graph) (void)hipGraphDestroy(ctx->graph);
     tdoa_capture_clear(ctx);
-    DevBuf *bufs[] = {&ctx->k1_table, &ctx->sw_desc, &ctx->pw_desc, &ctx->partials, &ctx->stats, &ctx->codes, &ctx->codes_lp, &ctx->k1_power, &ctx->dec_taps, &ctx->dec_gain, &ctx->tz, &ctx->v, &ctx->keys,
+    DevBuf *bufs[] = {&ctx->k1_table, &ctx->k1_direct, &ctx->sw_desc, &ctx->pw_desc, &ctx->partials, &ctx->stats, &ctx->codes, &ctx->codes_lp, &ctx->k1_power, &ctx->dec_taps, &ctx->dec_gain, &ctx->tz, &ctx->v, &ctx->keys,
                       &ctx->scales, &ctx->peaks, &ctx->scratch_a, &ctx->scratch_b, &ctx->lagdump,
                       &ctx->ex_a, &ctx->ex_b, &ctx->ex_c, &ctx->ex_d, &ctx->ex_part,
                       &ctx->g_sw_desc, &ctx->g_pw_desc, &ctx->g_quad_desc, &ctx->g_scales, &ctx->g_keys, &ctx->fine_raw, &ctx->fine, &ctx->qual};
