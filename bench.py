@@ -82,23 +82,58 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(kernel):
+def _latest_profile(pattern):
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    return files[-1] if files else None
+
+
+def pmc_traffic(kernels):
     """HBM-side bytes per launch from the committed rocprofv3 --pmc passes (scripts/collect_pmc.sh); bench.py cannot
     profile itself, so this is read back from profiles/ -- and only if the file was taken on the current kernel sources.
-    returns (bytes per launch of `kernel`, source label, sum over the step's kernels)"""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
-    if not files:
+    `kernels`: the kernel names one profiling scope of the library covers.
+    returns (bytes per launch summed over `kernels`, source label, sum over the step's kernels)"""
+    f = _latest_profile("*pmc_traffic.json")
+    if not f:
         return None, None, None
     try:
-        doc = json.load(open(files[-1]))
+        doc = json.load(open(f))
         if doc.get("source_sha16") != source_hash():
-            return None, "stale: %s was taken on other kernel sources" % os.path.basename(files[-1]), None
-        rec = doc["kernels"].get(kernel)
+            return None, "stale: %s was taken on other kernel sources" % os.path.basename(f), None
+        recs = [doc["kernels"].get(k) for k in kernels]
         total = sum(v["traffic_bytes_per_launch"] for v in doc["kernels"].values())
-        return (rec["traffic_bytes_per_launch"] if rec else None), os.path.basename(files[-1]), total
+        mine = sum(r["traffic_bytes_per_launch"] for r in recs if r) if any(recs) else None
+        return mine, os.path.basename(f), total
     except Exception:
         return None, None, None
+
+
+N_SIMD, N_SE = 1024, 32          # MI355X: 256 CUs x 4 SIMDs; 8 XCDs x 4 shader engines
+
+
+def sq_issue(kernel):
+    """vector-instruction issue share of a kernel from the committed SQ counter table (scripts/collect_sq.sh):
+    SQ_ACTIVE_INST_VALU counts quad-cycles summed over the SIMDs, SQ_BUSY_CYCLES cycles summed over the shader engines
+    (MI355X_MICROARCH.md, SQ PMC units).  None unless the table was taken on the current kernel sources."""
+    f = _latest_profile("*sq_cfg2.csv")
+    if not f:
+        return None
+    try:
+        lines = open(f).read().strip().splitlines()
+        if not lines[0].startswith("# source_sha16=") or lines[0].split("=", 1)[1].strip() != source_hash():
+            return None
+        import csv
+        for r in csv.DictReader(lines[1:]):
+            if r["kernel"].split("<")[0] == kernel:
+                valu, busy, waves = float(r["SQ_ACTIVE_INST_VALU"]), float(r["SQ_BUSY_CYCLES"]), float(r["SQ_WAVES"])
+                lds, conf = float(r.get("SQ_LDS_IDX_ACTIVE", "nan")), float(r.get("SQ_LDS_BANK_CONFLICT", "nan"))
+                return {"valu_issue_frac": round(valu * 4.0 / N_SIMD / (busy / N_SE), 3),
+                        "valu_instructions_per_wave": round(float(r["SQ_INSTS_VALU"]) / waves, 1),
+                        "lds_conflict_frac": None if not lds or lds != lds else round(conf / lds, 3),
+                        "source": os.path.basename(f)}
+    except Exception:
+        pass
+    return None
 
 
 def decimation_fits(nc, max_lag):
@@ -200,15 +235,21 @@ def cpu_baseline_leg(ctx, peaks, block, wlen, max_lag, budget_s):
     # --- same algorithm as the GPU path, float64, on the CPU cores (one (pair, window) per worker process)
     try:
         import multiprocessing as mp
-        workers = max(1, min(phys, 12))
+        # one worker process per physical core (CPU-fft-N: all host cores); a worker holds
+        # ~0.3 GB of float64 arrays for a 2 000 000-sample pair
+        workers = max(1, phys)
         n_f = min(wlen, 2_000_000)
         segs = [ctx.capture_download(s, 0, n_f).tobytes() for s in range(3)]
-        units = [(segs[i], segs[j], max_lag) for (i, j) in [(0, 1), (0, 2), (1, 2)]] * max(1, workers // 3)
-        with mp.get_context("spawn").Pool(min(workers, len(units))) as pool:
-            pool.map(_mode_b_f64_unit, units[:min(workers, len(units))])            # start-up outside the clock
+        units = ([(segs[i], segs[j], max_lag) for (i, j) in [(0, 1), (0, 2), (1, 2)]] * ((workers + 2) // 3))[:max(workers, 3)]
+        pool = mp.get_context("spawn").Pool(min(workers, len(units)))
+        try:
+            pool.map(_mode_b_f64_unit, units[:min(workers, len(units))], chunksize=1)      # start-up outside the clock
             t0 = time.perf_counter()
-            pool.map(_mode_b_f64_unit, units)
+            pool.map(_mode_b_f64_unit, units, chunksize=1)
             tf = time.perf_counter() - t0
+        finally:                                             # every child is ended and reaped on every path
+            pool.terminate()
+            pool.join()
         fft = {"value": round(len(units) * n_f / tf / 1e6, 3), "unit": "pair-Msamples/s",
                "cores": min(workers, len(units)),
                "sample": "float64 atan2 discriminator + numpy FFT cross-correlation (oracle/float_pipeline.py), %d (pair, window) "
@@ -241,6 +282,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph-leg", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=10.0)
+    ap.add_argument("--sim", choices=("config", "fm", "random"), default="config",
+                    help="capture bytes: the config's simulator (+-1..3 LSB tones + noise), 'fm' = frequency-modulated carriers at "
+                         "half scale like oracle simulate_delayed_fm (what a well-set RTL-SDR gain delivers), 'random' = uniform "
+                         "random bytes (every table entry of K1 equally likely)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="at --gpus 1: initialise torch.distributed (nccl = RCCL, world size 1) and run the multi-GPU step -- "
+                         "tdoa_process(rank, world), all_gather_into_tensor of the peak records, owner merge, solve -- on one GPU")
     args = ap.parse_args()
 
     import numpy as np
@@ -255,7 +303,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     cfg_name = args.config or ("cfg2" if world == 1 else "cfg4")
     cfg = dict(CONFIGS[cfg_name])
-    scaling = args.scaling or ("weak" if world == 1 else "strong")
+    scaling = args.scaling or ("strong" if (world > 1 or args.force_dist) else "weak")
     steps = args.steps if args.steps is not None else cfg["steps"]
     # one rank per GPU; TDOA_BENCH_BACKEND=gloo is a rehearsal mode (several ranks may then share
     # a GPU and the peak records travel through host memory) -- the driver always runs nccl (= RCCL)
@@ -263,14 +311,16 @@ def main():
     device = local_rank % torch.cuda.device_count() if backend == "gloo" else local_rank
     torch.cuda.set_device(device)
     dist = None
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
+        kw = {} if world > 1 else {"rank": 0, "world_size": 1}
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device))
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device), **kw)
         else:
-            dist.init_process_group(backend=backend)
+            dist.init_process_group(backend=backend, **kw)
 
     fs, wlen, max_lag = cfg["fs"], cfg["wlen"], args.max_lag
     S = cfg["stations"]
@@ -278,8 +328,33 @@ def main():
     stations = station_table(S)
     ctx = tdoa_amd.Context(device=device, window_len=wlen, max_lag=max_lag, sample_rate=fs, windows_per_batch=args.batch)
     seed0 = SEED_BASE + (16 * rank if scaling == "weak" else 0)        # strong: every rank holds the SAME capture set
+    attached = []                                                      # torch buffers the library reads in place
     for s in range(S):
-        if cfg["sim"] == "weak":
+        if args.sim != "config":
+            # byte distributions K1's table lookups see on real captures; generated by torch in HBM
+            # in pieces, attached without a copy
+            n = 3 * block
+            buf = torch.empty(2 * n, dtype=torch.uint8, device="cuda")
+            gen = torch.Generator(device="cuda")
+            gen.manual_seed(seed0 + s)
+            piece = 1 << 24
+            phase0 = 0.0
+            for lo in range(0, n, piece):
+                m = min(piece, n - lo)
+                if args.sim == "random":
+                    buf[2 * lo:2 * (lo + m)] = torch.randint(0, 256, (2 * m,), dtype=torch.uint8, device="cuda", generator=gen)
+                else:
+                    # x = 0.5 exp(i phi), phi = running sum of a smoothed noise message (modulation index 1), noise 0.02
+                    msg = torch.randn(m + 63, device="cuda", generator=gen)
+                    msg = torch.nn.functional.conv1d(msg.view(1, 1, -1), torch.full((1, 1, 64), 1.0 / 8.0, device="cuda")).view(-1)
+                    phi = torch.cumsum(msg.double(), 0) + phase0
+                    phase0 = float(phi[-1])
+                    noise = (torch.rand(2 * m, device="cuda", generator=gen) * 2 - 1) * 0.02
+                    iq = torch.stack([0.5 * torch.cos(phi).float(), 0.5 * torch.sin(phi).float()], dim=1).view(-1) + noise
+                    buf[2 * lo:2 * (lo + m)] = torch.clamp(torch.trunc(iq * 127.5 + 127.5), 0, 255).to(torch.uint8)
+            ctx.capture_attach_device(s, buf.data_ptr(), n)
+            attached.append(buf)
+        elif cfg["sim"] == "weak":
             ctx.synth_weak_capture(s, block, stations[s], TX, seed0 + s, tgt_power=20000.0)
         else:
             ctx.synth_capture(s, block, stations[s], TX, seed0 + s)
@@ -291,7 +366,7 @@ def main():
 
     peak_bytes = n_windows * n_pairs * 16
     dev_peaks = torch.zeros(peak_bytes, dtype=torch.uint8, device="cuda")
-    gathered = torch.zeros(peak_bytes * world, dtype=torch.uint8, device="cuda") if world > 1 else None
+    gathered = torch.zeros(peak_bytes * world, dtype=torch.uint8, device="cuda") if use_dist else None
     state = {"peaks": None, "fix": None}
     tgt_rows = np.arange(wpb, 2 * wpb)                                    # windows of the target block
 
@@ -306,7 +381,7 @@ def main():
         return tdoa_amd.capi.solve_nstation(stations, rd, weights=np.maximum(wgt, 1e-12))
 
     def step():
-        if world == 1:
+        if not use_dist:
             state["peaks"] = ctx.process(0, 1, out_dev_ptr=dev_peaks.data_ptr(), want_host=True)     # peaks on the host
             return
         if scaling == "strong":
@@ -326,7 +401,7 @@ def main():
             state["fix"] = solve(state["peaks"])
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -337,7 +412,7 @@ def main():
             step()
         fence()
         dt_ = time.perf_counter() - t0
-        if world > 1:
+        if use_dist:
             tt = torch.tensor([dt_], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt_ = float(tt.item())
@@ -380,54 +455,81 @@ def main():
         value = samples_per_step / (dt / steps) / 1e6
         n_fft, n1, n2 = ctx.plan_info()
         name, rec = max(prof.items(), key=lambda kv: kv[1]["ms"])
+        # kernels behind every profiling scope of the library on this plan (names as rocprofv3 prints them, no template suffix)
         hot = {}
         if n1 == 4096:          # the radix-16 register kernels (fft_radix16.hpp); the column pass depends on N2
-            col = ("k_fwd_col16x_c16" if n2 <= 128 else "k_fwd_col256_c16" if n2 == 256 else "k_fwd_colx_c16" if n2 <= 1024
-                   else "k_fwd_col256_c16<true> + k_fwd_col_finish")
-            hot = {"k_fm_demod": "k_fm_demod", "k_fwd_col": col, "k_fwd_row": "k_fwd_row4096",
-                   "k_inv_row_pair": "k_inv_row_pair4096", "k_inv_col_peak": "k_inv_col_pruned"}
-        decimated = (n1 == 4096 and n2 in (256, 512) and max_lag > 4096 and os.environ.get("TDOA_NO_DECIMATE") != "1"
+            fused_k1 = n2 in (256, 2048, 4096) and os.environ.get("TDOA_NO_FUSED_K1") != "1" and max_lag > 1024
+            if fused_k1:
+                col = ["k_fwd_col256_k1"] + (["k_fwd_col_finish"] if n2 > 256 else [])
+            else:
+                col = (["k_fwd_col16x_c16"] if n2 <= 128 else ["k_fwd_col256_c16"] if n2 == 256 else ["k_fwd_colx_c16"] if n2 <= 1024
+                       else ["k_fwd_col256_c16", "k_fwd_col_finish"])
+            hot = {"k_fm_demod": ["k_fm_demod"], "k_fwd_col": col, "k_fwd_row": ["k_fwd_row4096"],
+                   "k_inv_row_pair": ["k_inv_row_pair4096"], "k_inv_col_peak": ["k_inv_col_pruned"]}
+        reach = max_lag                     # lags -(max_lag - 1) .. max_lag - 1 plus the refinement neighbours
+        decimated = (n1 == 4096 and n2 in (256, 512) and reach > 4095 and os.environ.get("TDOA_NO_DECIMATE") != "1"
                      and decimation_fits(n1 * n2, max_lag))
         if decimated:     # K3 + 16:1 FIR decimation of the pair spectrum, then an Nc/16-point inverse
-            hot = dict(hot, k_inv_row_pair="k_pair_decimate16", k_inv_col_peak="k_inv_rows_plain_r8 + k_inv_col_pruned_any")
+            hot = dict(hot, k_inv_row_pair=["k_pair_decimate16"], k_inv_col_peak=["k_inv_rows_plain_r8", "k_small_col_peak"])
         if max_lag <= 1024 and n1 == 4096:
             # segment form; with 3+ pairs per window the station transforms are shared (quads)
-            hot = dict(hot, k_inv_row_pair="k_xcorr_segments_quad" if n_pairs >= 3 and os.environ.get("TDOA_NO_SEGMENT_QUADS") != "1"
-                       else "k_xcorr_segments", k_inv_col_peak="k_segments_reduce")
+            hot = dict(hot, k_inv_row_pair=["k_xcorr_segments_quad" if n_pairs >= 3 and os.environ.get("TDOA_NO_SEGMENT_QUADS") != "1"
+                                            else "k_xcorr_segments"], k_inv_col_peak=["k_segments_reduce"])
         roof = None
+        pmc_total = None
         if rec["launches"]:
             per_launch_bytes = rec["bytes"] / rec["launches"]
             avg_s = rec["ms"] / rec["launches"] / 1e3
             achieved = per_launch_bytes / avg_s / 1e9
-            traffic, src, pmc_total = (None, None, None)
-            default_cfg = cfg_name == "cfg2" and args.seconds is None and args.batch == 0 and world == 1 and max_lag == 20000
+            traffic, src = None, None
+            default_cfg = cfg_name == "cfg2" and args.seconds is None and args.batch == 0 and world == 1 and max_lag == 20000 \
+                and args.sim == "config"
+            kernels = hot.get(name, [name])
+            sq = None
             if default_cfg and name in hot:
-                traffic, src, pmc_total = pmc_traffic(hot[name])
-            roof = {"bound": "hbm", "kernel": hot.get(name, name),
+                traffic, src, pmc_total = pmc_traffic(kernels)
+                sq = sq_issue(kernels[0])
+            # what limits the kernel, from the evidence at hand: its vector-instruction issue share (SQ counters) against
+            # its share of the HBM peak
+            hbm_frac = None if traffic is None else traffic / avg_s / 1e9 / HBM_PEAK_GBS
+            limiter = None
+            if sq is not None:
+                limiter = "valu_issue" if sq["valu_issue_frac"] > max(0.6, hbm_frac or 0.0) else "hbm"
+            roof = {"bound": "hbm", "kernel": " + ".join(kernels),
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                     "frac_of_measured_achievable": round(achieved / 6290.0, 4),   # guide: 6.29 TB/s achievable
                     "traffic": traffic, "traffic_source": src,
+                    # HBM side: bytes the memory-side counters saw per launch / launch time / 8 TB/s
+                    "hbm_frac": None if hbm_frac is None else round(hbm_frac, 4),
+                    "valu_issue_frac": None if sq is None else sq["valu_issue_frac"],
+                    "valu_instructions_per_wave": None if sq is None else sq["valu_instructions_per_wave"],
+                    "lds_conflict_frac": None if sq is None else sq["lds_conflict_frac"],
+                    "sq_source": None if sq is None else sq["source"],
+                    "limiter": limiter,
                     "algorithmic_bytes_per_launch": per_launch_bytes,
                     "avg_launch_us": round(avg_s * 1e6, 2), "launches": rec["launches"],
-                    "kernels_ms_per_step": {k: round(v["ms"] / steps, 4) for k, v in prof.items()}}
+                    "kernels_ms_per_step": {k: round(v["ms"] / steps, 4) for k, v in prof.items()},
+                    "note": "frac = algorithmic bytes of the launch (the library's per-kernel byte model, DESIGN.md section 3) / "
+                            "HIP-event time / 8 TB/s: a request rate.  hbm_frac = what the memory-side counters saw "
+                            "(profiles/, same kernel sources) over the same time.  valu_issue_frac = share of the kernel's time "
+                            "its SIMDs spend issuing vector instructions: above ~0.8 the kernel is bound by instruction "
+                            "issue, whatever its bytes"}
             if roof["kernel"] == "k_pair_decimate16":
-                roof["note"] = ("decimated inverse: this kernel reads the two station spectra of a pair once and writes 1/16 of "
-                                "a spectrum; SURVEY's byte model for the pair step (two spectra read, V written, V read) is "
-                                "24 N bytes per pair-window, this form moves 16.5 N -- pipeline_algorithmic_GBps keeps SURVEY's "
-                                "model, so it now overstates the bytes actually moved by the difference")
+                roof["note"] += ("; decimated inverse: the kernel reads the two station spectra of a pair once (16 Nc bytes) and "
+                                 "writes 1/16 of a spectrum (Nc/2): 16.5 Nc = 8.25 N per pair-window, where SURVEY's model of the "
+                                 "pair step (two spectra read, V written, V read) charges 32 Nc = 16 N")
             if roof["kernel"].startswith("k_xcorr_segments"):
-                roof["note"] = ("segment form: 4096-point transforms in LDS and registers, limited by vector-instruction issue "
-                                "(DESIGN.md section 3); its HBM traffic is the 2-byte phase codes only, so the HBM fraction "
-                                "says how little it streams, not how well it runs")
+                roof["note"] += ("; segment form: 4096-point transforms in LDS and registers, limited by vector-instruction issue "
+                                 "(DESIGN.md section 3); its HBM traffic is the 4-byte phase codes only")
         # whole-pipeline algorithmic bytes: k = ceil(log2 N / 12) passes of 4096-point tiles, e = 4 B:
         # 2L + e N (2k - 1) per station-window, e N 2k per pair-window  (k = 2: 2L + 12N and 16N; k = 3: 2L + 20N and 24N)
         k_pass = max(2, math.ceil(math.log2(n_fft) / 12.0))
         units_w = n_windows * (world if scaling == "weak" else 1)
         a_bytes = units_w * (S * (2 * wl + 4 * n_fft * (2 * k_pass - 1)) + n_pairs * 4 * n_fft * 2 * k_pass)
-        if world > 1 and scaling == "strong":
-            par = ("one capture set, windows dealt wid %% %d to the ranks, RCCL all-gather of the peak records, owner merge + "
-                   "least-squares solve on rank 0, all inside the timed region" % world)
+        if use_dist and scaling == "strong":
+            par = ("one capture set, windows dealt wid %% %d to the ranks, %s all-gather of the peak records, owner merge + "
+                   "least-squares solve on rank 0, all inside the timed region" % (world, "RCCL" if backend == "nccl" else backend))
         elif world > 1:
             par = "independent capture set per GPU x%d + RCCL all-gather of the peak records" % world
         else:
@@ -435,26 +537,28 @@ def main():
         out = {
             "metric": "IQ Msamples/s through demod+xcorr", "value": round(value, 2), "unit": "Msamples/s",
             "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32",      # K1: integer phase codes of pi/2^23 per step, exact in f32; transforms in f32
             "data": "synthetic",
             "config": {"workload": "%s%s, %d pairs x %d windows of %d samples, FFT N=%d (%dx%d), max_lag %d; peaks on the host"
                                    % (cfg["label"], " per GPU" if (scaling == "weak" and world > 1) else "", n_pairs, n_windows, wl,
                                       n_fft, n1, n2, max_lag),
-                       "name": cfg_name, "stations": S, "pairs": n_pairs, "windows": n_windows, "window_len": wl,
+                       "name": cfg_name, "capture_bytes": args.sim, "stations": S, "pairs": n_pairs, "windows": n_windows, "window_len": wl,
                        "fft_n": n_fft, "sample_rate": fs, "parallelism": par},
             "timed_path": "kernels launched one by one with per-kernel HIP events (the roofline's source); graph replay: graph_replay",
             "graph_replay": graph_leg,
-            "pipeline_algorithmic_GBps": round(a_bytes / (dt / steps) / 1e9, 1),
-            # the bytes the launched kernels are actually charged with by the library (per-kernel figures of tdoa_profile_get:
-            # code round trip included, the decimated pair step at its own 16.5 N instead of the model's 24 N per pair-window)
+            # SURVEY.md 8d byte model (a fixed price list per sample, NOT what this pipeline moves: the decimated inverse and
+            # the fused K1 move less) -- kept under its own name
+            "pipeline_survey_model_GBps": round(a_bytes / (dt / steps) / 1e9, 1),
+            # the bytes the launched kernels are charged with by the library (per-kernel figures of tdoa_profile_get: the
+            # decimated pair step at its own 16.5 Nc per pair-window, the fused K1 with no code round trip)
             "pipeline_kernel_bytes_GBps": round(sum(v["bytes"] for v in prof.values()) / max(steps, 1) / (dt / steps) / 1e9, 1),
-            "pipeline_frac_of_hbm_peak": round(a_bytes / (dt / steps) / 1e9 / HBM_PEAK_GBS / world, 4),
+            # HBM side of the whole step: memory-side counters of every kernel of a step (profiles/, same sources) / step time
+            "pipeline_pmc_GBps": None if not pmc_total else round(pmc_total / (dt / steps) / 1e9, 1),
+            "pipeline_frac_of_hbm_peak": None if not pmc_total else round(pmc_total / (dt / steps) / 1e9 / HBM_PEAK_GBS / world, 4),
             # SURVEY.md 8d secondary figure: pair-samples correlated per second (P*W*L/t), whole job
             "pair_Msamples_per_s": round(samples_per_step / S * n_pairs / (dt / steps) / 1e6, 2),
             "roofline": roof,
         }
-        if roof and roof.get("traffic") is not None and pmc_total:
-            out["pipeline_pmc_GBps"] = round(pmc_total / (dt / steps) / 1e9, 1)
         if world > 1:
             # the N = 1 default of this script is the headline config (cfg2); a scaling figure for THIS job needs the
             # one-GPU rate of the same config, which is a committed measurement, not something this run can time
@@ -483,7 +587,7 @@ def main():
                 rc = 3
         print(json.dumps(out), flush=True)
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     if rc:

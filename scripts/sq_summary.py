@@ -4,7 +4,11 @@ usage: sq_summary.py <dir prefix> <n groups>"""
 import collections
 import csv
 import glob
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import source_hash  # noqa: E402  (hash of the kernel sources the counters were taken on)
 
 
 def main():
@@ -17,6 +21,7 @@ def main():
                 if name.startswith("k_") and not name.startswith("k_synth"):
                     table[name][r["Counter_Name"]] = float(r["Counter_Value"])     # last launch wins
     ctrs = sorted({c for v in table.values() for c in v})
+    print("# source_sha16=" + source_hash())
     print("kernel," + ",".join(ctrs))
     for k in sorted(table):
         print(k + "," + ",".join("%.6g" % table[k].get(c, float("nan")) for c in ctrs))
