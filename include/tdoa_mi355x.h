@@ -268,6 +268,10 @@ enum {
     TDOA_DEBUG_NO_DECIMATE     = 256 /* full inverse transform even where the decimated one applies (4096 x 256 / x 512 plans, search ranges above 4095 lags) */
 };
 int tdoa_debug_flags(tdoa_ctx *ctx, unsigned flags);
+/* tests only: structure of the hipGraph the last tdoa_process captured -- info = {nodes, edges, root nodes, memset nodes};
+ * dot_path (may be NULL): also writes the graph in Graphviz form (hipGraphDebugDotPrint).  The library itself refuses a
+ * captured step that is not ONE dependency chain of kernel nodes (TDOA_ERR_STATE), see DESIGN.md section 7. */
+int tdoa_debug_graph_info(tdoa_ctx *ctx, int32_t info[4], const char *dot_path);
 /* tests only (host, no GPU): the cover of a window's station pairs by "quads" -- two template stations x two signal
  * stations whose two packed transforms per segment serve up to four pairs in the segment form.
  * pairs[2 i], pairs[2 i + 1] = template, signal station of pair i; quads_out gets 8 ints per quad: stations a, b, c, d

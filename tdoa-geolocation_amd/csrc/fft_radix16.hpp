@@ -295,16 +295,29 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 const unsigned int sb = p[ib >= 0 && ib < len ? ib : 0];
                 ab = k1_angle(sb, lut);
             }
+            // rows are classified per wave (its two half-waves hold items jw and jw + 1 of every r): entirely inside the
+            // window -- no bounds selects, the common case --, entirely beyond it -- zero padding, nothing to look up
+            // (40 % of the rows of a 10 s window in N = 2^25) --, or general
+            const int jw = __builtin_amdgcn_readfirstlane(j & ~1);
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int i0 = 2 * ((a + G * (j + 16 * r)) * N1 + n1);
-                // the angle of this element's last valid sample travels one lane to the right; it is computed inside
-                // k1_element too -- the compiler merges the two evaluations
+                const int i_first = 2 * ((a + G * (jw + 16 * r)) * N1 + (bx << 5));
+                const int i_end = 2 * ((a + G * (jw + 1 + 16 * r)) * N1 + (bx << 5) + 32);      // one past the wave's last sample of this r
+                if (i_first >= len) {
+                    v[r] = make_float2(0.0f, 0.0f);
+                    continue;
+                }
                 int a0, a1;
                 k1_angle2(raw[r], lut, a0, a1);
-                const int left = wave_shift_right1(a1);
+                const int left = wave_shift_right1(a1);        // the angle of sample 2m - 1 is the left lane's second angle
                 const int bnd = __shfl(ab, 2 * r + (lane >> 5), kWave);
-                v[r] = k1_element(raw[r], c ? left : bnd, i0, len, mean, scale, lut, r == 0);
+                const int ap = c ? left : bnd;
+                if (i_first > 0 && i_end <= len) {
+                    v[r] = make_float2(k1_normalise(k1_stored_code(a0, ap), mean, scale), k1_normalise(k1_stored_code(a1, a0), mean, scale));
+                } else {
+                    v[r] = k1_element(raw[r], ap, i0, len, mean, scale, lut, r == 0);     // (its two lookups are the ones above)
+                }
             }
         }
         fft16<false>(v);

@@ -85,6 +85,10 @@ struct tdoa_ctx {
     bool short_lag = true;                  // TDOA_NO_SHORT_LAG=1 at tdoa_create time forces the general inverse for short searches
     bool segment_form = true;               // TDOA_NO_SEGMENT_FORM=1: no LDS-resident overlap-save form for short searches
     bool segment_quads = true;              // TDOA_NO_SEGMENT_QUADS=1: segment form one pair-window at a time (no shared station transforms)
+    bool memset_nodes = false;              // TDOA_DEBUG_MEMSET_NODES=1 (probe only): zero the step's accumulators with
+                                            // hipMemsetAsync nodes instead of k_zero_u64 kernel nodes
+    int seg_chunks_override = 0;            // TDOA_SEG_CHUNKS=n at tdoa_create time: chunk count of the segment form
+    int graph_nodes = 0, graph_edges = 0, graph_roots = 0, graph_memsets = 0;      // structure of the captured step (tdoa_debug_graph_info)
     bool fused_k1 = true;                   // TDOA_NO_FUSED_K1=1: K1 always materialises its codes (no discriminator inside the column kernels)
     bool decimate = true;                   // TDOA_NO_DECIMATE=1: general form with the full inverse even where the decimated one applies
     // decimated inverse (k_pair_decimate16): FIR taps and window correction for (Nc, reach); small plan of the R-point inverse
@@ -290,10 +294,14 @@ void k1_build_table_host(std::vector<int32_t> &tab, std::vector<int32_t> &direct
 }
 
 // zero n_sw window accumulators (a kernel node: the captured step holds kernel nodes only)
-void zero_partials(hipStream_t st, StatsPartial *partials, int n_sw)
+void zero_partials(hipStream_t st, StatsPartial *partials, int n_sw, bool memset_node = false)
 {
     static_assert(sizeof(StatsPartial) == 32, "four 64-bit words per station-window");
     const size_t words = 4 * (size_t)n_sw;
+    if (memset_node) {                       // probe only (TDOA_DEBUG_MEMSET_NODES=1)
+        (void)hipMemsetAsync(partials, 0, 8 * words, st);
+        return;
+    }
     hipLaunchKernelGGL(k_zero_u64, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st,
                        reinterpret_cast<unsigned long long *>(partials), words);
 }
@@ -318,7 +326,7 @@ int *launch_k1(tdoa_ctx *ctx, hipStream_t st, const SWDesc *d_sw, int n_sw, int 
         hipLaunchKernelGGL(k_zero_u64, dim3((unsigned)(((size_t)n_sw + 255) / 256)), dim3(256), 0, st, power, (size_t)n_sw);
         hipLaunchKernelGGL(k_k1_power, per_chunk, dim3(256), 0, st, d_sw, power);
     }
-    zero_partials(st, partials, n_sw);
+    zero_partials(st, partials, n_sw, ctx->memset_nodes);
     const long long items = (long long)((pieces + kDemodItem - 1) / kDemodItem) * n_sw;      // workgroup items
     const int blocks = (int)std::max<long long>(1, std::min<long long>(items, ctx->n_cu));        // one workgroup per CU (128 KB table)
     if (materialise)
@@ -528,7 +536,7 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
         for (int c = 2; c <= c_max; c++) best = std::min(best, cost(c));
         for (int c = 1; c <= c_max; c++)
             if (cost(c) <= 1.03 * best) seg_chunks = c;
-        if (const char *e = std::getenv("TDOA_SEG_CHUNKS")) seg_chunks = std::max(1, std::min({std::atoi(e), trips, pl.N2 / 2 - 1}));
+        if (ctx->seg_chunks_override > 0) seg_chunks = std::max(1, std::min({ctx->seg_chunks_override, trips, pl.N2 / 2 - 1}));
     }
     const bool fused_k1 = fused_k1_applies(ctx, pl, lag_lo, lag_hi, n_pw, allow_fused_k1);
     {
@@ -1006,6 +1014,8 @@ int tdoa_create(const tdoa_params *p, tdoa_ctx **out)
     if (const char *e = std::getenv("TDOA_NO_SEGMENT_QUADS")) ctx->segment_quads = !(e[0] == '1');
     if (const char *e = std::getenv("TDOA_NO_DECIMATE")) ctx->decimate = !(e[0] == '1');
     if (const char *e = std::getenv("TDOA_NO_FUSED_K1")) ctx->fused_k1 = !(e[0] == '1');
+    if (const char *e = std::getenv("TDOA_SEG_CHUNKS")) ctx->seg_chunks_override = std::max(0, std::atoi(e));
+    if (const char *e = std::getenv("TDOA_DEBUG_MEMSET_NODES")) ctx->memset_nodes = e[0] == '1';
     if (const char *e = std::getenv("TDOA_NO_XCD_ROWS")) ctx->xcd_rows = !(e[0] == '1');
     *out = ctx;
     return TDOA_OK;
@@ -1402,7 +1412,8 @@ static int process_impl(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host,
                                  (uint64_t)ctx->force_generic | ((uint64_t)ctx->short_lag << 1) |
                                      ((uint64_t)ctx->segment_form << 3) | ((uint64_t)ctx->xcd_rows << 4) |
                                      ((uint64_t)ctx->segment_quads << 6) |
-                                     ((uint64_t)ctx->decimate << 8) | ((uint64_t)ctx->fused_k1 << 9),
+                                     ((uint64_t)ctx->decimate << 8) | ((uint64_t)ctx->fused_k1 << 9) |
+                                     ((uint64_t)ctx->memset_nodes << 10) | ((uint64_t)ctx->seg_chunks_override << 16),
                                  ctx->alloc_gen, (uint64_t)(fine_host != nullptr), 0};
     std::memcpy(&key.back(), &gate, sizeof(double));
     for (auto &c : ctx->caps) {
@@ -1427,7 +1438,10 @@ static int process_impl(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host,
 
     auto enqueue = [&]() -> int {
         ctx->prof_last = -1;
-        hipLaunchKernelGGL(k_zero_u64, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, st, d_keys, slots);
+        if (ctx->memset_nodes)               // probe only (TDOA_DEBUG_MEMSET_NODES=1)
+            (void)hipMemsetAsync(d_keys, 0, sizeof(unsigned long long) * slots, st);
+        else
+            hipLaunchKernelGGL(k_zero_u64, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, st, d_keys, slots);
         float *fine_raw = fine_host ? static_cast<float *>(ctx->fine_raw.p) : nullptr;
         for (size_t w0 = 0; w0 < mine.size(); w0 += per_batch) {
             const int nw = (int)std::min<size_t>(per_batch, mine.size() - w0);
@@ -1461,6 +1475,28 @@ static int process_impl(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host,
         if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
         if (e != hipSuccess) return fail(ctx, TDOA_ERR_HIP, "hipStreamEndCapture", e);
         ctx->graph = g;
+        // the step was captured from ONE stream: it must come out as one dependency chain -- every node but the first has
+        // a predecessor (a node without one would replay unordered against the kernels that feed or consume it)
+        {
+            size_t n_nodes = 0, n_edges = 0, n_roots = 0;
+            HIPCHK(ctx, hipGraphGetNodes(g, nullptr, &n_nodes));
+            HIPCHK(ctx, hipGraphGetEdges(g, nullptr, nullptr, &n_edges));
+            HIPCHK(ctx, hipGraphGetRootNodes(g, nullptr, &n_roots));
+            std::vector<hipGraphNode_t> nodes(n_nodes);
+            if (n_nodes) HIPCHK(ctx, hipGraphGetNodes(g, nodes.data(), &n_nodes));
+            int memsets = 0;
+            for (hipGraphNode_t nd : nodes) {
+                hipGraphNodeType ty;
+                if (hipGraphNodeGetType(nd, &ty) == hipSuccess && ty == hipGraphNodeTypeMemset) memsets++;
+            }
+            ctx->graph_nodes = (int)n_nodes;
+            ctx->graph_edges = (int)n_edges;
+            ctx->graph_roots = (int)n_roots;
+            ctx->graph_memsets = memsets;
+            if (n_nodes && (n_roots != 1 || n_edges + 1 < n_nodes))
+                return fail(ctx, TDOA_ERR_STATE, "captured step is not one dependency chain");
+            if (memsets && !ctx->memset_nodes) return fail(ctx, TDOA_ERR_STATE, "captured step holds a memset node");
+        }
         HIPCHK(ctx, hipGraphInstantiate(&ctx->graph_exec, g, nullptr, nullptr, 0));
         ctx->graph_key = key;
         HIPCHK(ctx, hipGraphLaunch(ctx->graph_exec, st));
@@ -1674,6 +1710,19 @@ int tdoa_debug_segment_quads(int n_stations, const int32_t *pairs, int n_pairs, 
         for (int k = 0; k < 4; k++) o[4 + k] = q[i].pair[k];
     }
     return (int)q.size();
+}
+
+int tdoa_debug_graph_info(tdoa_ctx *ctx, int32_t info[4], const char *dot_path)
+{
+    if (!ctx || !info) return TDOA_ERR_INVALID;
+    if (!ctx->graph) return fail(ctx, TDOA_ERR_STATE, "no captured step");
+    info[0] = ctx->graph_nodes;
+    info[1] = ctx->graph_edges;
+    info[2] = ctx->graph_roots;
+    info[3] = ctx->graph_memsets;
+    if (dot_path && dot_path[0])
+        HIPCHK(ctx, hipGraphDebugDotPrint(ctx->graph, dot_path, hipGraphDebugDotFlagsVerbose));
+    return TDOA_OK;
 }
 
 int tdoa_debug_flags(tdoa_ctx *ctx, unsigned flags)

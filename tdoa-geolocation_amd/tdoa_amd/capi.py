@@ -69,7 +69,7 @@ SYMBOLS = [
     "tdoa_num_windows", "tdoa_num_pairs", "tdoa_process", "tdoa_process_u8",
     "tdoa_process_fine", "tdoa_fm_xcorr_fine_u8", "tdoa_window_quality_all", "tdoa_window_quality_u8",
     "tdoa_fm_xcorr_u8", "tdoa_fm_preprocess_u8", "tdoa_fm_xcorr_lags_u8", "tdoa_debug_force_generic",
-    "tdoa_debug_flags", "tdoa_debug_segment_quads", "tdoa_cross_correlate_batch_c64",
+    "tdoa_debug_flags", "tdoa_debug_graph_info", "tdoa_debug_segment_quads", "tdoa_cross_correlate_batch_c64",
     "tdoa_latlon_to_ecef", "tdoa_ecef_to_latlon", "tdoa_solve_3station", "tdoa_solve_nstation",
     "tdoa_profile_enable", "tdoa_profile_reset", "tdoa_profile_get", "tdoa_kernel_name",
     "tdoa_plan_info",
@@ -139,6 +139,7 @@ def load(build_if_missing=True):
     L.tdoa_fm_xcorr_lags_u8.argtypes = [vp, u8p, sz, u8p, sz, C.c_int, dp]
     L.tdoa_debug_force_generic.argtypes = [vp, C.c_int]
     L.tdoa_debug_flags.argtypes = [vp, C.c_uint]
+    L.tdoa_debug_graph_info.argtypes = [vp, C.POINTER(C.c_int32), C.c_char_p]
     L.tdoa_debug_segment_quads.argtypes = [C.c_int, C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_int32), C.c_int]
     L.tdoa_latlon_to_ecef.argtypes = [C.c_double, C.c_double, C.c_double, dp]
     L.tdoa_latlon_to_ecef.restype = None
@@ -421,6 +422,12 @@ class Context:
         st = FmStats()
         self._chk(self._L.tdoa_fm_preprocess_u8(self._h, _u8(a), a.size // 2, _f(out), C.byref(st)))
         return out, st
+
+    def graph_info(self, dot_path=None):
+        """{nodes, edges, roots, memsets} of the step graph the last process() captured (tdoa_debug_graph_info)"""
+        info = (C.c_int32 * 4)()
+        self._chk(self._L.tdoa_debug_graph_info(self._h, info, dot_path.encode() if dot_path else None))
+        return dict(nodes=info[0], edges=info[1], roots=info[2], memsets=info[3])
 
     def fm_stats(self, iq):
         """window statistics from the reduce-only pass of the fused path (tdoa_fm_preprocess_u8 with out_f32 = NULL)"""

@@ -73,10 +73,16 @@ def test_two_rank_sharding_allgather_merge(oracle):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    results = dict(q.get(timeout=240) for _ in procs)
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    try:
+        results = dict(q.get(timeout=240) for _ in procs)
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+    finally:                                          # no child outlives the test
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+            p.join(timeout=30)
     n_windows = 3 * (BLOCK // WLEN)
     want = _peaks_for(oracle, _captures(oracle), range(n_windows))
     for r in range(2):
@@ -131,10 +137,16 @@ def test_eight_rank_ownership_allgather_merge(n_windows, n_pairs, label):
     procs = [ctx.Process(target=_worker8, args=(r, world, port, n_windows, n_pairs, q)) for r in range(world)]
     for p in procs:
         p.start()
-    results = [q.get(timeout=240) for _ in procs]
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    try:
+        results = [q.get(timeout=240) for _ in procs]
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+    finally:                                          # no child outlives the test, whatever happened above
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+            p.join(timeout=30)
     want = _fake_peaks(n_windows, n_pairs, [(w, p) for w in range(n_windows) for p in range(n_pairs)])
     assert sum(n for _, n, _ in results) == n_windows * n_pairs, label          # every unit has exactly one owner
     counts = sorted(n for _, n, _ in results)
