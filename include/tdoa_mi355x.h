@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TDOA_ABI_VERSION 3
+#define TDOA_ABI_VERSION 4
 
 typedef struct tdoa_ctx tdoa_ctx;
 
@@ -64,7 +64,20 @@ typedef struct {
                                 not smoothed).  The binary's third branch (<= 0.001: band-passed complex samples) has no
                                 mode-B counterpart; such windows take the envelope too -- tdoa_window_quality_all
                                 reports every window's mean power */
+    int32_t lag_mode;        /* which lags mode B searches (K5):
+                                TDOA_LAGS_SIGNED (0, default): -max_lag < lag < max_lag, template = the first input, peak =
+                                largest |corr|, ties -> smaller |lag|, then the positive lag;
+                                TDOA_LAGS_GO (1): the lag set and peak rule of timeDomainCorrelation (processor.go:646-736):
+                                template = the SHORTER input (ties: the first, :650-655), only its first B corr_block samples
+                                count (B = number of block starts 0, corr_block, ... below Lt - corr_block, :691; B = 0 gives
+                                (0, 0.0)), lags 0 <= lag < max(1, min(max_lag, Ls - Lt)) (:668-678), first strictly larger
+                                |corr| wins = the lowest lag among equals (:722-725), corr scaled by 1/sqrt(B corr_block)
+                                (:719-720).  Windows of tdoa_process have equal lengths: lag 0 only, as in the reference's
+                                own call pattern.  Not available with the sub-sample refinement (TDOA_ERR_UNSUPPORTED). */
+    int32_t reserved;        /* 0 */
 } tdoa_params;
+
+enum { TDOA_LAGS_SIGNED = 0, TDOA_LAGS_GO = 1 };
 
 /* One correlation peak.  lag > 0: the second station of the pair lags the first. */
 typedef struct {

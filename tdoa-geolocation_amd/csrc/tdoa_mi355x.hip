@@ -471,7 +471,9 @@ int reserve_fm_batch(tdoa_ctx *ctx, int n_sw, int maxlen, int n_pw, const FftPla
 int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const PWDesc *d_pw, int n_pw,
                  unsigned long long *d_keys, const FftPlan &pl, int lag_lo, int lag_hi, float *lag_dump,
                  float dump_scale, double sum_len, float *fine_raw = nullptr, int pairs_per_window = 0,
-                 const QuadDesc *d_quads = nullptr, int n_quads = 0, bool allow_fused_k1 = true)
+                 const QuadDesc *d_quads = nullptr, int n_quads = 0, bool allow_fused_k1 = true,
+                 const SWDesc *d_sw_stats = nullptr)      // d_sw_stats: the windows K1 and its statistics run over when the
+                                                          // transforms see truncated ones (TDOA_LAGS_GO); default: d_sw
 {
     int rc;
     const int pieces = std::max(1, (maxlen + kDemodPiece - 1) / kDemodPiece);
@@ -543,7 +545,7 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
         // K1: capture bytes -> exact window statistics (fused: nothing else; the column pass evaluates the discriminator
         // itself) and, materialised, the 24-bit phase codes as int32
         ProfScope ps(ctx, TDOA_K_STATS, (fused_k1 ? 2.0 : 6.0) * sum_len);
-        codes = launch_k1(ctx, st, d_sw, n_sw, maxlen, pieces, code_stride, !fused_k1);
+        codes = launch_k1(ctx, st, d_sw_stats ? d_sw_stats : d_sw, n_sw, maxlen, pieces, code_stride, !fused_k1);
     }
     const size_t lds_col = sizeof(float2) * 2 * (size_t)pl.N2 * pl.C;
     const size_t lds_row = sizeof(float2) * 2 * (size_t)pl.N1;
@@ -802,9 +804,14 @@ int check_ctx(tdoa_ctx *ctx)
     return TDOA_OK;
 }
 
+// timeDomainCorrelation's block count for a template of lt samples (processor.go:691: starts 0, cb, 2 cb, ... < lt - cb)
+long long go_blocks(long long lt, long long cb) { return lt > cb ? (lt - cb + cb - 1) / cb : 0; }
+
 // copy two host IQ windows into scratch and build 2 sw + 1 pw descriptors
+// (corr_len1: samples of the first window the transforms see, <= n1; the descriptors with the full lengths follow at
+// d_sw + 2 for K1 and its statistics)
 int stage_pair_u8(tdoa_ctx *ctx, const uint8_t *iq1, size_t n1, const uint8_t *iq2, size_t n2,
-                  SWDesc **d_sw, PWDesc **d_pw)
+                  SWDesc **d_sw, PWDesc **d_pw, size_t corr_len1)
 {
     int rc;
     size_t b1 = (2 * n1 + 15) & ~(size_t)15;
@@ -812,8 +819,8 @@ int stage_pair_u8(tdoa_ctx *ctx, const uint8_t *iq1, size_t n1, const uint8_t *i
     auto *base = static_cast<uint8_t *>(ctx->scratch_a.p);
     if (n1) HIPCHK(ctx, hipMemcpyAsync(base, iq1, 2 * n1, hipMemcpyHostToDevice, ctx->stream));
     if (n2) HIPCHK(ctx, hipMemcpyAsync(base + b1, iq2, 2 * n2, hipMemcpyHostToDevice, ctx->stream));
-    SWDesc sw[2] = {{base, (int32_t)n1, 0}, {base + b1, (int32_t)n2, 0}};
-    PWDesc pw = {0, 1, 0, (int32_t)n1};
+    SWDesc sw[4] = {{base, (int32_t)corr_len1, 0}, {base + b1, (int32_t)n2, 0}, {base, (int32_t)n1, 0}, {base + b1, (int32_t)n2, 0}};
+    PWDesc pw = {0, 1, 0, (int32_t)corr_len1};
     if ((rc = ensure(ctx, ctx->sw_desc, sizeof(sw)))) return rc;
     if ((rc = ensure(ctx, ctx->pw_desc, sizeof(pw)))) return rc;
     HIPCHK(ctx, hipMemcpyAsync(ctx->sw_desc.p, sw, sizeof(sw), hipMemcpyHostToDevice, ctx->stream));
@@ -837,6 +844,28 @@ int fm_pair(tdoa_ctx *ctx, const uint8_t *iq1, size_t n1, const uint8_t *iq2, si
         return TDOA_OK;
     }
     if (n1 > 0x7fffffff / 2 || n2 > 0x7fffffff / 2) return fail(ctx, TDOA_ERR_UNSUPPORTED, "window too long");
+    // TDOA_LAGS_GO: template = the shorter input (ties: the first), its first B corr_block samples, lags [0, eff)
+    const bool go = ctx->prm.lag_mode == TDOA_LAGS_GO;
+    if (go && fine) return fail(ctx, TDOA_ERR_UNSUPPORTED, "sub-sample refinement with TDOA_LAGS_GO");
+    if (go && n2 < n1) {                                      // processor.go:650-655
+        std::swap(iq1, iq2);
+        std::swap(n1, n2);
+    }
+    const int nl = 2 * max_lag - 1;
+    size_t corr_len = n1;
+    int lag_lo = -(max_lag - 1), lag_hi = max_lag - 1;
+    if (go) {
+        const long long blocks = go_blocks((long long)n1, ctx->prm.corr_block);
+        if (blocks == 0) {                                    // processor.go:708-717: no block, (0, 0.0)
+            if (peak) *peak = tdoa_peak{0, 0.0f, 0.0};
+            if (lags_out) std::fill(lags_out, lags_out + nl, 0.0);
+            return TDOA_OK;
+        }
+        corr_len = (size_t)(blocks * ctx->prm.corr_block);
+        const long long eff = std::max<long long>(1, std::min<long long>(max_lag, (long long)n2 - (long long)n1));   // :668-678
+        lag_lo = 0;
+        lag_hi = (int)eff - 1;
+    }
     long long n = std::max<long long>(next_pow2((long long)std::max(n1, n2) + max_lag), 64);
     FftPlan pl;
     if ((rc = make_plan(n, true, &pl))) return fail(ctx, rc, "FFT size unsupported");
@@ -844,7 +873,7 @@ int fm_pair(tdoa_ctx *ctx, const uint8_t *iq1, size_t n1, const uint8_t *iq2, si
     ctx->plan_n = n;
     SWDesc *d_sw;
     PWDesc *d_pw;
-    if ((rc = stage_pair_u8(ctx, iq1, n1, iq2, n2, &d_sw, &d_pw))) return rc;
+    if ((rc = stage_pair_u8(ctx, iq1, n1, iq2, n2, &d_sw, &d_pw, corr_len))) return rc;
     if ((rc = ensure(ctx, ctx->keys, sizeof(unsigned long long)))) return rc;
     if ((rc = ensure(ctx, ctx->scales, sizeof(double)))) return rc;
     if ((rc = ensure(ctx, ctx->peaks, sizeof(PeakOut)))) return rc;
@@ -852,20 +881,21 @@ int fm_pair(tdoa_ctx *ctx, const uint8_t *iq1, size_t n1, const uint8_t *iq2, si
         if ((rc = ensure(ctx, ctx->fine_raw, 3 * sizeof(float)))) return rc;
         if ((rc = ensure(ctx, ctx->fine, sizeof(FineOut)))) return rc;
     }
-    const int nl = 2 * max_lag - 1;
+    const int n_dump = lag_hi - lag_lo + 1;                   // the kernels write lag d at dump[d - lag_lo]
     float *dump = nullptr;
     if (lags_out) {
-        if ((rc = ensure(ctx, ctx->lagdump, sizeof(float) * (size_t)nl))) return rc;
+        if ((rc = ensure(ctx, ctx->lagdump, sizeof(float) * (size_t)n_dump))) return rc;
         dump = static_cast<float *>(ctx->lagdump.p);
-        HIPCHK(ctx, hipMemsetAsync(dump, 0, sizeof(float) * (size_t)nl, ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(dump, 0, sizeof(float) * (size_t)n_dump, ctx->stream));
     }
-    double scale = 1.0 / (4.0 * (double)n * std::sqrt((double)n1));
+    double scale = 1.0 / (4.0 * (double)n * std::sqrt((double)corr_len));
     HIPCHK(ctx, hipMemsetAsync(ctx->keys.p, 0, sizeof(unsigned long long), ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(ctx->scales.p, &scale, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     ctx->prof_last = -1;
     rc = run_fm_batch(ctx, d_sw, 2, (int)std::max(n1, n2), d_pw, 1, static_cast<unsigned long long *>(ctx->keys.p),
-                      pl, -(max_lag - 1), max_lag - 1, dump, 1.0f, (double)(n1 + n2),
-                      fine ? static_cast<float *>(ctx->fine_raw.p) : nullptr, 0, nullptr, 0, n1 >= 2 && n2 >= 2);
+                      pl, lag_lo, lag_hi, dump, 1.0f, (double)(n1 + n2),
+                      fine ? static_cast<float *>(ctx->fine_raw.p) : nullptr, 0, nullptr, 0, n1 >= 2 && n2 >= 2 && corr_len >= 2,
+                      corr_len != n1 ? d_sw + 2 : nullptr);
     if (rc) return rc;
     hipLaunchKernelGGL(k_decode_peaks, dim3(1), dim3(64), 0, ctx->stream,
                        static_cast<unsigned long long *>(ctx->keys.p), static_cast<double *>(ctx->scales.p),
@@ -881,15 +911,17 @@ int fm_pair(tdoa_ctx *ctx, const uint8_t *iq1, size_t n1, const uint8_t *iq2, si
     }
     std::vector<float> hl;
     if (lags_out) {
-        hl.resize(nl);
-        HIPCHK(ctx, hipMemcpyAsync(hl.data(), dump, sizeof(float) * (size_t)nl, hipMemcpyDeviceToHost, ctx->stream));
+        hl.resize(n_dump);
+        HIPCHK(ctx, hipMemcpyAsync(hl.data(), dump, sizeof(float) * (size_t)n_dump, hipMemcpyDeviceToHost, ctx->stream));
     }
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     prof_collect(ctx);
     if (peak) *peak = pk;
     if (fine) *fine = fk;
-    if (lags_out)
-        for (int i = 0; i < nl; i++) lags_out[i] = (double)hl[i] * scale;
+    if (lags_out) {                                           // layout [2 max_lag - 1]: lag d at d + max_lag - 1
+        std::fill(lags_out, lags_out + nl, 0.0);
+        for (int i = 0; i < n_dump; i++) lags_out[i + lag_lo + (max_lag - 1)] = (double)hl[i] * scale;
+    }
     return TDOA_OK;
 }
 
@@ -912,6 +944,8 @@ void tdoa_default_params(tdoa_params *p)
     p->windows_per_batch = 0;
     p->k1_smooth = 0;
     p->k1_gate = 0;
+    p->lag_mode = TDOA_LAGS_SIGNED;
+    p->reserved = 0;
 }
 
 int tdoa_abi_version(void) { return TDOA_ABI_VERSION; }
@@ -960,7 +994,7 @@ int tdoa_create(const tdoa_params *p, tdoa_ctx **out)
     else
         tdoa_default_params(&prm);
     if (prm.max_lag < 1 || prm.corr_block < 1 || prm.window_len < 2 || !(prm.sample_rate > 0) || prm.k1_smooth < 0 ||
-        prm.k1_smooth > 2001)
+        prm.k1_smooth > 2001 || (prm.lag_mode != TDOA_LAGS_SIGNED && prm.lag_mode != TDOA_LAGS_GO))
         return TDOA_ERR_INVALID;
     int ndev = tdoa_device_count();
     if (ndev <= 0 || prm.device < 0 || prm.device >= ndev) return TDOA_ERR_NO_DEVICE;
@@ -1317,6 +1351,13 @@ static int process_impl(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host,
     if ((rc = make_plan(n, true, &pl))) return fail(ctx, rc, "FFT size unsupported");
     ctx->plan = pl;
     ctx->plan_n = n;
+    // TDOA_LAGS_GO: every window has the same length, so timeDomainCorrelation evaluates lag 0 only (processor.go:668-678)
+    // over the first B corr_block samples; with the template cut there the signal's samples beyond do not enter lag 0
+    // either, so every station-window is cut for the transforms (K1 and its statistics see the whole window)
+    const bool go = ctx->prm.lag_mode == TDOA_LAGS_GO;
+    if (go && fine_host) return fail(ctx, TDOA_ERR_UNSUPPORTED, "sub-sample refinement with TDOA_LAGS_GO");
+    const long long corr_len = go ? go_blocks(wlen, ctx->prm.corr_block) * ctx->prm.corr_block : wlen;
+    const int lag_lo = go ? 0 : -(ctx->prm.max_lag - 1), lag_hi = go ? 0 : ctx->prm.max_lag - 1;
 
     // Sharding: window-major -- rank r owns the windows wid = r (mod world), so a station-window
     // is transformed once and reused by all its pairs.  With fewer windows than ranks that would leave ranks idle:
@@ -1356,9 +1397,9 @@ static int process_impl(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host,
                     if (slot[s] < 0) {
                         const long long off = (long long)(wid / wpb) * (long long)(ctx->caps[s].n / 3) + (long long)(wid % wpb) * wlen;
                         slot[s] = (int)(sw.size() - batch_base);
-                        sw.push_back(SWDesc{ctx->caps[s].dev + 2 * off, (int32_t)wlen, 0});
+                        sw.push_back(SWDesc{ctx->caps[s].dev + 2 * off, (int32_t)corr_len, 0});
                     }
-                pw.push_back(PWDesc{slot[i], slot[j], wid * P + p, (int32_t)wlen});
+                pw.push_back(PWDesc{slot[i], slot[j], wid * P + p, (int32_t)corr_len});
             }
         sw_off[wi + 1] = sw.size();
         pw_off[wi + 1] = pw.size();
@@ -1385,20 +1426,25 @@ static int process_impl(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host,
         q_off[wi + 1] = quads.size();
     }
     const size_t slots = (size_t)W * P;
+    if (go && corr_len == 0) {                                 // windows of at most one block: (0, 0.0) everywhere (:708-717)
+        if (out_host) std::memset(out_host, 0, sizeof(tdoa_peak) * slots);
+        if (out_dev) HIPCHK(ctx, hipMemset(out_dev, 0, sizeof(PeakOut) * slots));
+        return TDOA_OK;
+    }
     hipStream_t st = ctx->stream;
     const int n_first = (int)std::min<size_t>(per_batch, mine.size());
     if ((rc = ensure(ctx, ctx->peaks, sizeof(PeakOut) * slots))) return rc;
     if ((rc = ensure(ctx, ctx->g_keys, sizeof(unsigned long long) * slots))) return rc;
     if ((rc = ensure(ctx, ctx->g_scales, sizeof(double) * slots))) return rc;
-    if ((rc = ensure(ctx, ctx->g_sw_desc, sizeof(SWDesc) * std::max<size_t>(sw.size(), 1)))) return rc;
+    // TDOA_LAGS_GO: a second copy of the station-window descriptors with the full window length follows the first
+    if ((rc = ensure(ctx, ctx->g_sw_desc, sizeof(SWDesc) * std::max<size_t>(2 * sw.size(), 1)))) return rc;
     if ((rc = ensure(ctx, ctx->g_pw_desc, sizeof(PWDesc) * std::max<size_t>(pw.size(), 1)))) return rc;
     if ((rc = ensure(ctx, ctx->g_quad_desc, sizeof(QuadDesc) * std::max<size_t>(quads.size(), 1)))) return rc;
     if (fine_host) {
         if ((rc = ensure(ctx, ctx->fine_raw, 3 * sizeof(float) * slots))) return rc;
         if ((rc = ensure(ctx, ctx->fine, sizeof(FineOut) * slots))) return rc;
     }
-    if (n_first && (rc = reserve_fm_batch(ctx, n_first * S, (int)wlen, n_first * P, pl, -(ctx->prm.max_lag - 1),
-                                          ctx->prm.max_lag - 1, true)))
+    if (n_first && (rc = reserve_fm_batch(ctx, n_first * S, (int)wlen, n_first * P, pl, lag_lo, lag_hi, true)))
         return rc;
     auto *d_sw = static_cast<SWDesc *>(ctx->g_sw_desc.p);
     auto *d_pw = static_cast<PWDesc *>(ctx->g_pw_desc.p);
@@ -1408,7 +1454,8 @@ static int process_impl(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host,
 
     // everything the launches depend on: same key => the captured graph can be replayed as is
     std::vector<uint64_t> key = {(uint64_t)S, (uint64_t)rank, (uint64_t)world, (uint64_t)per_batch, (uint64_t)wlen,
-                                 (uint64_t)ctx->prm.max_lag | ((uint64_t)ctx->prm.k1_smooth << 32) | ((uint64_t)(ctx->prm.k1_gate != 0) << 62), (uint64_t)block,
+                                 (uint64_t)ctx->prm.max_lag | ((uint64_t)ctx->prm.k1_smooth << 32) | ((uint64_t)(ctx->prm.k1_gate != 0) << 62) |
+                                     ((uint64_t)go << 61), (uint64_t)block,
                                  (uint64_t)ctx->force_generic | ((uint64_t)ctx->short_lag << 1) |
                                      ((uint64_t)ctx->segment_form << 3) | ((uint64_t)ctx->xcd_rows << 4) |
                                      ((uint64_t)ctx->segment_quads << 6) |
@@ -1423,11 +1470,17 @@ static int process_impl(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host,
     const bool graph_ok = ctx->use_graph && !ctx->profiling;
     const bool replay = graph_ok && ctx->graph_exec && key == ctx->graph_key;
 
+    std::vector<SWDesc> sw_full;
     if (!replay) {
-        std::vector<double> scales(slots, 1.0 / (4.0 * (double)n * std::sqrt((double)wlen)));
+        std::vector<double> scales(slots, 1.0 / (4.0 * (double)n * std::sqrt((double)corr_len)));
         HIPCHK(ctx, hipMemcpyAsync(d_scales, scales.data(), sizeof(double) * slots, hipMemcpyHostToDevice, st));
         if (!sw.empty()) {
             HIPCHK(ctx, hipMemcpyAsync(d_sw, sw.data(), sizeof(SWDesc) * sw.size(), hipMemcpyHostToDevice, st));
+            if (go) {
+                sw_full = sw;
+                for (auto &d : sw_full) d.len = (int32_t)wlen;
+                HIPCHK(ctx, hipMemcpyAsync(d_sw + sw.size(), sw_full.data(), sizeof(SWDesc) * sw.size(), hipMemcpyHostToDevice, st));
+            }
             HIPCHK(ctx, hipMemcpyAsync(d_pw, pw.data(), sizeof(PWDesc) * pw.size(), hipMemcpyHostToDevice, st));
         }
         if (!quads.empty())
@@ -1447,9 +1500,10 @@ static int process_impl(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host,
             const int nw = (int)std::min<size_t>(per_batch, mine.size() - w0);
             const int n_sw = (int)(sw_off[w0 + nw] - sw_off[w0]), n_pw = (int)(pw_off[w0 + nw] - pw_off[w0]);
             const int r = run_fm_batch(ctx, d_sw + sw_off[w0], n_sw, (int)wlen, d_pw + pw_off[w0], n_pw, d_keys, pl,
-                                       -(ctx->prm.max_lag - 1), ctx->prm.max_lag - 1, nullptr, 1.0f,
+                                       lag_lo, lag_hi, nullptr, 1.0f,
                                        (double)wlen * n_sw, fine_raw, pair_major ? 0 : P, d_quads + q_off[w0],
-                                       (int)(q_off[w0 + nw] - q_off[w0]));
+                                       (int)(q_off[w0 + nw] - q_off[w0]), corr_len >= 2,
+                                       go ? d_sw + sw.size() + sw_off[w0] : nullptr);
             if (r) return r;
         }
         if (fine_raw) ctx->prof_last = -1;

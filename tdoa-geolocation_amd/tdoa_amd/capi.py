@@ -21,7 +21,10 @@ class Params(C.Structure):
     _fields_ = [("sample_rate", C.c_double), ("max_lag", C.c_int32), ("corr_block", C.c_int32),
                 ("weak_threshold", C.c_double), ("window_len", C.c_int64),
                 ("device", C.c_int32), ("windows_per_batch", C.c_int32),
-                ("k1_smooth", C.c_int32), ("k1_gate", C.c_int32)]
+                ("k1_smooth", C.c_int32), ("k1_gate", C.c_int32), ("lag_mode", C.c_int32), ("reserved", C.c_int32)]
+
+
+LAGS_SIGNED, LAGS_GO = 0, 1
 
 
 class Peak(C.Structure):

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol(capi):
     missing = [f for f in declared if not hasattr(L, f)]
     assert not missing, missing
     assert sorted(capi.SYMBOLS) == declared          # the ctypes binding covers the whole header
-    assert L.tdoa_abi_version() == 3          # 3: tdoa_params grew k1_smooth (round 2)
+    assert L.tdoa_abi_version() == 4          # 4: tdoa_params grew lag_mode (round 3); 3: k1_smooth, k1_gate (round 2)
 
 
 def test_default_params_are_the_reference_constants(capi):
@@ -40,6 +40,9 @@ def test_default_params_are_the_reference_constants(capi):
     assert p.corr_block == 1000            # processor.go:682
     assert p.weak_threshold == 0.001       # processor.go:476
     assert p.window_len == 2_000_000       # processor.go:772
+    assert p.lag_mode == capi.LAGS_SIGNED and p.k1_smooth == 0 and p.k1_gate == 0 and p.reserved == 0
+    import ctypes as C
+    assert C.sizeof(capi.Params) == 56     # the C struct: 8 + 4 + 4 + 8 + 8 + 6 x 4, in the header's order
 
 
 def test_no_cpu_fallback(capi):
@@ -59,6 +62,9 @@ def test_invalid_params_rejected(capi):
     p = capi.default_params()
     p.max_lag = 0
     h = C.c_void_p()
+    assert L.tdoa_create(C.byref(p), C.byref(h)) == 1 and not h.value
+    p = capi.default_params()
+    p.lag_mode = 2                          # neither TDOA_LAGS_SIGNED nor TDOA_LAGS_GO
     assert L.tdoa_create(C.byref(p), C.byref(h)) == 1 and not h.value
     assert L.tdoa_create(None, None) == 1
     L.tdoa_destroy(None)                    # must be a no-op

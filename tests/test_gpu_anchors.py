@@ -80,6 +80,68 @@ def test_gpu_fft_path_vs_go_time_domain_correlation(oracle, blocks, ns, delay, c
         print("\n  FFT path vs timeDomainCorrelation: %d lags, template %d, max |diff| %.2e of the peak, index %d" % (eff, nt, err, gd))
 
 
+@pytest.mark.parametrize("nt,ns,delay", [(1_990_000, 2_000_000, 4321), (1_999_000, 2_000_000, 0), (500_000, 600_000, 19999),
+                                         (600_000, 500_000, 777), (70_001, 90_000, 12345)])
+def test_k5_go_lag_set_through_the_abi(oracle, nt, ns, delay, capsys):
+    """tdoa_params.lag_mode = TDOA_LAGS_GO: template = the shorter input, its first B*1000 samples, lags [0, maxLag_eff),
+    first strict maximum (processor.go:650-678, 691, 719-725).  The index the C ABI returns must EQUAL the one
+    timeDomainCorrelation (oracle restatement, f64 time domain) picks on the same preprocessed inputs, the value within
+    1e-5, and the lag array must be its lag array -- whichever input comes first."""
+    import tdoa_amd
+    # the LONGER input is the signal and carries the delay; (600 000, 500 000): the second input is the template
+    a = oracle.simulate_delayed_fm(nt, delay if nt > ns else 0, 777, 1)
+    b = oracle.simulate_delayed_fm(ns, delay if nt <= ns else 0, 777, 2)
+    with tdoa_amd.Context(max_lag=ML, window_len=L, lag_mode=tdoa_amd.capi.LAGS_GO) as c:
+        lag, corr = c.fm_xcorr(a, b, ML)
+        lags = c.fm_xcorr_lags(a, b, ML)
+        va, _ = c.fm_preprocess(a)
+        vb, _ = c.fm_preprocess(b)
+    gd, gc = oracle.time_domain_correlation(va.astype(np.complex64), vb.astype(np.complex64), ML)
+    go = oracle.time_domain_all_lags(va.astype(np.complex64), vb.astype(np.complex64), ML)
+    eff = max(1, min(ML, abs(ns - nt)))
+    assert go.size == eff
+    assert lag == gd == delay and abs(corr - gc) <= 1e-5 * abs(gc)
+    got = lags[ML - 1:ML - 1 + eff]
+    assert np.abs(got - go).max() <= 1e-5 * np.abs(go).max()
+    assert not lags[:ML - 1].any() and not lags[ML - 1 + eff:].any()            # no other lag is searched or reported
+    with capsys.disabled():
+        print("\n  TDOA_LAGS_GO: template %d signal %d -> index %d (timeDomainCorrelation: %d), %d lags" % (min(nt, ns), max(nt, ns), lag, gd, eff))
+
+
+def test_k5_go_lag_set_edge_cases(oracle):
+    """equal lengths -> lag 0 only (the reference's own call pattern, processor.go:668-675); a template of at most one
+    block -> (0, 0.0) (:708-717); tdoa_process windows all have one length: lag 0 everywhere, value = timeDomainCorrelation's"""
+    import tdoa_amd
+    n = 300_000
+    a = oracle.simulate_delayed_fm(n, 0, 31, 1)
+    b = oracle.simulate_delayed_fm(n, 41, 31, 2)
+    with tdoa_amd.Context(max_lag=2000, window_len=n, lag_mode=tdoa_amd.capi.LAGS_GO) as c:
+        lag, corr = c.fm_xcorr(a, b, 2000)
+        va, _ = c.fm_preprocess(a)
+        vb, _ = c.fm_preprocess(b)
+        assert c.fm_xcorr(a[:2 * 1000], b, 2000) == (0, 0.0) and c.fm_xcorr(a, b[:2 * 700], 2000) == (0, 0.0)
+        with pytest.raises(tdoa_amd.TdoaError):
+            c.fm_xcorr_fine(a, b, 2000, 120.0)
+    gd, gc = oracle.time_domain_correlation(va.astype(np.complex64), vb.astype(np.complex64), 2000)
+    assert lag == gd == 0 and abs(corr - gc) <= 1e-5 * abs(gc)
+    blk, wl = 140_000, 70_000
+    caps = [np.concatenate([oracle.simulate_delayed_fm(blk, 100 + d, 310 + k, 10 * s + k) for k in range(3)])
+            for s, d in enumerate((0, 41, -17))]
+    with tdoa_amd.Context(max_lag=20000, window_len=wl, lag_mode=tdoa_amd.capi.LAGS_GO) as c:
+        peaks = c.process_u8(caps)
+        assert c.graph_info()["roots"] == 1
+        again = c.process()                                                       # replayed graph
+    assert peaks.shape == (6, 3) and not peaks["lag"].any() and np.array_equal(again, peaks)
+    for wid in (0, 3, 5):
+        off = (wid // 2) * blk + (wid % 2) * wl
+        pre = [oracle.b_preprocess(cp[2 * off:2 * (off + wl)])[0].astype(np.complex64) for cp in caps]
+        for p, (i, j) in enumerate(((0, 1), (0, 2), (1, 2))):
+            gd, gc = oracle.time_domain_correlation(pre[i], pre[j], 20000)
+            # lag 0 is not where these windows correlate (their delays are 41, -17, -58 samples): the value there is noise
+            # of order 1 against a full-scale sqrt(69 000) = 263, so the bound is 1e-6 of full scale
+            assert gd == 0 and abs(peaks[wid, p]["corr"] - gc) <= 1e-6 * np.sqrt(69000.0), (wid, p, peaks[wid, p], gc)
+
+
 def test_k1_exact_reversals_bit_exact(oracle):
     """exactly reversed samples (+pi), collinear reversals of different magnitude, and non-collinear samples whose
     angle codes are exactly opposite (sign of Im p decides), in the vector fast path and in the window head / tail"""
