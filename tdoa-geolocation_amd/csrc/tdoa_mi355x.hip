@@ -665,12 +665,15 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
         {
             ProfScope ps(ctx, TDOA_K_INV_ROW, 2.0 * nc8 * n_pw + 8.0 * (double)rc_pts * n_pw);      // two spectra read, G written
             float2 *edges = v + dec_edge_offset(pl, n_pw), *spectra = v + dec_spectra_offset(pl, n_pw);
+            // persistent: two workgroups per CU (74 KB of LDS each) walk the (pair-window, tile pair) items
+            const long long dec_items = (long long)(pl.N2 / 2) * n_pw;
+            const dim3 dec_grid((unsigned)std::max<long long>(1, std::min<long long>(dec_items, 2ll * ctx->n_cu)));
             if (pl.N2 == 256)
-                hipLaunchKernelGGL(k_pair_decimate16<8>, dim3(pl.N2 / 2, n_pw), dim3(512), sizeof(float2) * 2 * 16 * kDecPitch, st,
-                                   d_pw, spectra, g, edges, pl, static_cast<const float *>(ctx->dec_taps.p), ps2.N2);
+                hipLaunchKernelGGL(k_pair_decimate16<8>, dec_grid, dim3(512), sizeof(float2) * 2 * 16 * kDecPitch, st,
+                                   d_pw, spectra, g, edges, pl, static_cast<const float *>(ctx->dec_taps.p), ps2.N2, n_pw);
             else
-                hipLaunchKernelGGL(k_pair_decimate16<9>, dim3(pl.N2 / 2, n_pw), dim3(512), sizeof(float2) * 2 * 16 * kDecPitch, st,
-                                   d_pw, spectra, g, edges, pl, static_cast<const float *>(ctx->dec_taps.p), ps2.N2);
+                hipLaunchKernelGGL(k_pair_decimate16<9>, dec_grid, dim3(512), sizeof(float2) * 2 * 16 * kDecPitch, st,
+                                   d_pw, spectra, g, edges, pl, static_cast<const float *>(ctx->dec_taps.p), ps2.N2, n_pw);
         }
         {
             ProfScope ps(ctx, TDOA_K_INV_COL, 3.0 * 8.0 * (double)rc_pts * n_pw);
