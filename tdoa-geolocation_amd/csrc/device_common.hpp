@@ -92,6 +92,22 @@ __global__ void k_zero_u64(unsigned long long *p, size_t n)
     if (i < n) p[i] = 0ull;
 }
 
+// streaming accesses: data that is read once, or written for a reader that comes after gigabytes of other traffic, should
+// not displace what the caches could still serve
+typedef float f2v_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float2 load_nt(const float2 *p)
+{
+    const f2v_t x = __builtin_nontemporal_load(reinterpret_cast<const f2v_t *>(p));
+    return make_float2(x.x, x.y);
+}
+__device__ __forceinline__ void store_nt(float2 *p, float2 v)
+{
+    f2v_t y;
+    y.x = v.x;
+    y.y = v.y;
+    __builtin_nontemporal_store(y, reinterpret_cast<f2v_t *>(p));
+}
+
 // A value the compiler must treat as unknown: addresses derived from it are rebuilt where they are used instead of being
 // hoisted out of a loop as dozens of invariants (which then spill).
 __device__ __forceinline__ int opaque_i(int v)
