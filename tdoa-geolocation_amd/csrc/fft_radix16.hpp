@@ -363,26 +363,44 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // second half, G = 16 (N2 = 4096) or 8 (N2 = 2048): X[kb + 256 ka] = sum_a W_G^(a ka) Y_a[kb] in registers
 // (G = 8 runs the 16-point butterfly on inputs spread to the even slots: W_16^(2a k) = W_8^(a k)), then the
 // four-step twiddle W_Nc^(n1 k2) = W^(n1 kb) * (W^(256 n1))^ka; in place (a thread rewrites the rows it read).
-// grid (N1/256, 256, n_sw), 256 threads = 256 adjacent columns.
+// grid (N1/512, 256, n_sw), 256 threads = 512 adjacent columns.
 template <int G>
 __global__ __launch_bounds__(256) void k_fwd_col_finish(float2 *T, FftPlan pl)
 {
     static_assert(G == 8 || G == 16, "two-sweep column pass: N2 = 2048 or 4096");
-    const int n1 = (blockIdx.x << 8) + threadIdx.x, kb = blockIdx.y;
+    // a thread takes TWO adjacent columns (one 16-byte access per row): a workgroup moves 4 KB runs of each of its 16 rows
+    const int n1 = ((blockIdx.x << 8) + threadIdx.x) * 2, kb = blockIdx.y;
     float2 *base = T + (size_t)blockIdx.z * pl.Nc + (size_t)kb * pl.N1 + n1;
     const size_t stride = (size_t)256 * pl.N1;
-    float2 v[16];
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    float2 v[16], u[16];
 #pragma unroll
-    for (int r = 0; r < 16; r++) v[r] = make_float2(0.0f, 0.0f);
+    for (int r = 0; r < 16; r++) v[r] = u[r] = make_float2(0.0f, 0.0f);
 #pragma unroll
-    for (int a = 0; a < G; a++) v[(16 / G) * a] = load_nt(base + a * stride);      // read once
+    for (int a = 0; a < G; a++) {
+        const f4v x = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(base + a * stride));      // read once
+        v[(16 / G) * a] = make_float2(x.x, x.y);
+        u[(16 / G) * a] = make_float2(x.z, x.w);
+    }
     fft16<false>(v);
+    fft16<false>(u);
     const float inv2 = 2.0f / (float)pl.Nc;
-    const long long e0 = ((long long)n1 * kb) & (pl.Nc - 1);
-    const long long e1 = ((long long)n1 * 256) & (pl.Nc - 1);
-    mul_base_step16(v, unit_root((float)e0, inv2, false), unit_root((float)e1, inv2, false));
+    {
+        const long long e0 = ((long long)n1 * kb) & (pl.Nc - 1);
+        const long long e1 = ((long long)n1 * 256) & (pl.Nc - 1);
+        mul_base_step16(v, unit_root((float)e0, inv2, false), unit_root((float)e1, inv2, false));
+    }
+    {
+        const long long e0 = ((long long)(n1 + 1) * kb) & (pl.Nc - 1);
+        const long long e1 = ((long long)(n1 + 1) * 256) & (pl.Nc - 1);
+        mul_base_step16(u, unit_root((float)e0, inv2, false), unit_root((float)e1, inv2, false));
+    }
 #pragma unroll
-    for (int ka = 0; ka < G; ka++) store_nt(base + ka * stride, v[oreg(ka)]);
+    for (int ka = 0; ka < G; ka++) {
+        f4v y;
+        y.x = v[oreg(ka)].x; y.y = v[oreg(ka)].y; y.z = u[oreg(ka)].x; y.w = u[oreg(ka)].y;
+        __builtin_nontemporal_store(y, reinterpret_cast<f4v *>(base + ka * stride));
+    }
 }
 
 // ---------------------------------------------------------------------------

@@ -563,9 +563,9 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
             hipLaunchKernelGGL(k_fwd_col256_k1<true>, dim3(2 * ctx->n_cu), dim3(512), kColK1Lds, st, d_sw, table, stats, tz, pl,
                                n_sw);
             if (pl.N2 == 4096)
-                hipLaunchKernelGGL(k_fwd_col_finish<16>, dim3(pl.N1 / 256, 256, n_sw), dim3(256), 0, st, tz, pl);
+                hipLaunchKernelGGL(k_fwd_col_finish<16>, dim3(pl.N1 / 512, 256, n_sw), dim3(256), 0, st, tz, pl);
             else
-                hipLaunchKernelGGL(k_fwd_col_finish<8>, dim3(pl.N1 / 256, 256, n_sw), dim3(256), 0, st, tz, pl);
+                hipLaunchKernelGGL(k_fwd_col_finish<8>, dim3(pl.N1 / 512, 256, n_sw), dim3(256), 0, st, tz, pl);
         }
         else if (col16)
             hipLaunchKernelGGL(k_fwd_col256_c16<false>, dim3(pl.N1 / 32, n_sw), dim3(512), lds_col16, st, d_sw, codes,
@@ -574,9 +574,9 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
             hipLaunchKernelGGL(k_fwd_col256_c16<true>, dim3(pl.N1 / 32, n_sw, pl.N2 / 256), dim3(512), lds_col16, st,
                                d_sw, codes, code_stride, stats, tz, pl);
             if (pl.N2 == 4096)
-                hipLaunchKernelGGL(k_fwd_col_finish<16>, dim3(pl.N1 / 256, 256, n_sw), dim3(256), 0, st, tz, pl);
+                hipLaunchKernelGGL(k_fwd_col_finish<16>, dim3(pl.N1 / 512, 256, n_sw), dim3(256), 0, st, tz, pl);
             else
-                hipLaunchKernelGGL(k_fwd_col_finish<8>, dim3(pl.N1 / 256, 256, n_sw), dim3(256), 0, st, tz, pl);
+                hipLaunchKernelGGL(k_fwd_col_finish<8>, dim3(pl.N1 / 512, 256, n_sw), dim3(256), 0, st, tz, pl);
         }
         else if (col16x == 1)
             hipLaunchKernelGGL(k_fwd_col16x_c16<1>, dim3(pl.N1 / 256, n_sw), dim3(256), 0, st, d_sw, codes, code_stride,
