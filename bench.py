@@ -458,9 +458,9 @@ def main():
         # kernels behind every profiling scope of the library on this plan (names as rocprofv3 prints them, no template suffix)
         hot = {}
         if n1 == 4096:          # the radix-16 register kernels (fft_radix16.hpp); the column pass depends on N2
-            fused_k1 = n2 in (256, 2048, 4096) and os.environ.get("TDOA_NO_FUSED_K1") != "1" and max_lag > 1024
+            fused_k1 = n2 in (256, 512, 2048, 4096) and os.environ.get("TDOA_NO_FUSED_K1") != "1" and max_lag > 1024
             if fused_k1:
-                col = ["k_fwd_col256_k1"] + (["k_fwd_col_finish"] if n2 > 256 else [])
+                col = ["k_fwd_col512_k1"] if n2 == 512 else ["k_fwd_col256_k1"] + (["k_fwd_col_finish"] if n2 > 256 else [])
             else:
                 col = (["k_fwd_col16x_c16"] if n2 <= 128 else ["k_fwd_col256_c16"] if n2 == 256 else ["k_fwd_colx_c16"] if n2 <= 1024
                        else ["k_fwd_col256_c16", "k_fwd_col_finish"])

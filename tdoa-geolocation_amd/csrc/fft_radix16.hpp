@@ -473,6 +473,130 @@ __global__ __launch_bounds__(512) void k_fwd_colx_c16(const SWDesc *sw, const in
 }
 
 // ---------------------------------------------------------------------------
+// K1 fused into the forward column pass for N2 = 512 (1 s windows at 4 Msps, N = 2^22: BASELINE config 5): k_fwd_colx_c16<2>
+// with the capture bytes as its input, built like k_fwd_col256_k1 -- persistent workgroups, angle table in LDS, the angle
+// of the sample before an element taken from the lane to the left, rows classified per wave, both exchanges through float
+// planes.  16 columns per workgroup; thread (c = t & 15, j = (t >> 4) & 15, par = t >> 8) transforms the rows
+// n2 = 2 (j + 16 r) + par; a wave holds 4 consecutive items j of one parity.
+// grid (2 n_cu), 512 threads, dynamic LDS kColK1Lds (table + plane [2][256][16]).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_fwd_col512_k1(const SWDesc *sw, const int *table, const FmStats *stats, float2 *T,
+                                                       FftPlan pl, int n_sw)
+{
+    constexpr int F = 2, C = 16, LOGC = 4;
+    extern __shared__ int lds_k1[];                             // the table at offset 0 (immediate offsets), then the planes
+    int *lut = lds_k1;
+    float *plane = reinterpret_cast<float *>(lds_k1 + kK1TableEntries);      // [F][256][C]
+    k1_load_table(lut, table);
+    const int N1 = pl.N1, nbx = N1 / C;
+    const int n_tiles = n_sw * nbx;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int tid = opaque_i((int)threadIdx.x);              // (laundered per tile: see k_fwd_col256_k1)
+        const int lane = tid & 63;
+        const int c = tid & (C - 1), j = (tid >> LOGC) & 15, par = tid >> (LOGC + 4);
+        const int bx = tile % nbx, w = tile / nbx;
+        const SWDesc d = sw[w];
+        const int len = d.len;
+        const gptr16 p = k1_global(d.base);
+        const float mean = stats[w].mean, scale = stats[w].scale;
+        const int n1 = bx * C + c;
+        const int last = len - 2;
+        float *img = plane + par * 256 * C;
+        float2 v[16];
+        {
+            unsigned int raw[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int i0 = 2 * ((F * (j + 16 * r) + par) * N1 + n1);
+                raw[r] = k1_fetch2(p, i0 < last ? i0 : last);
+            }
+            // boundary samples (first column of the tile): 16 rows x 4 items of the wave = 64, one per lane:
+            // lane L takes row r = L >> 2 of the wave's item (j & ~3) + (L & 3)
+            int ab;
+            {
+                const int jb = (j & ~3) + (lane & 3), rb = lane >> 2;
+                const int ib = 2 * ((F * (jb + 16 * rb) + par) * N1 + bx * C) - 1;
+                ab = k1_angle(p[ib >= 0 && ib < len ? ib : 0], lut);
+            }
+            const int jw = __builtin_amdgcn_readfirstlane(j & ~3), pw = __builtin_amdgcn_readfirstlane(par);
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int i0 = 2 * ((F * (j + 16 * r) + par) * N1 + n1);
+                const int i_first = 2 * ((F * (jw + 16 * r) + pw) * N1 + bx * C);
+                const int i_end = 2 * ((F * (jw + 3 + 16 * r) + pw) * N1 + bx * C + C);      // one past the wave's last sample of this r
+                if (i_first >= len) {
+                    v[r] = make_float2(0.0f, 0.0f);
+                    continue;
+                }
+                int a0, a1;
+                k1_angle2(raw[r], lut, a0, a1);
+                const int left = wave_shift_right1(a1);
+                const int bnd = __shfl(ab, 4 * r + ((lane >> LOGC) & 3), kWave);
+                const int ap = c ? left : bnd;
+                if (i_first > 0 && i_end <= len)
+                    v[r] = make_float2(k1_normalise(k1_stored_code(a0, ap), mean, scale), k1_normalise(k1_stored_code(a1, a0), mean, scale));
+                else
+                    v[r] = k1_element(raw[r], ap, i0, len, mean, scale, lut, r == 0);
+            }
+        }
+        fft16<false>(v);
+        // first exchange (inside the image of this parity), real parts then imaginary parts
+#pragma unroll
+        for (int k = 0; k < 16; k++) img[(16 * j + k) * C + c] = v[oreg(k)].x;
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; r++) v[r].x = img[(j + 16 * r) * C + c];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; k++) img[(16 * j + k) * C + c] = v[oreg(k)].y;
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; r++) v[r].y = img[(j + 16 * r) * C + c];
+        __syncthreads();
+        mul_powers16(v, unit_root((float)j, 2.0f / 256.0f, false));
+        fft16<false>(v);
+        // Y_par[k = j + 16 kk] *= W_512^(k par)
+        if (par)      // uniform per wave
+            mul_base_step16(v, unit_root((float)(j * par), 2.0f / (256.0f * F), false),
+                            unit_root((float)(16 * par), 2.0f / (256.0f * F), false));
+        // second exchange + the last radix-2 butterfly across the two images: X[k + 256 q] = Y_0[k] +- Y_1[k], q = par
+        float2 x[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) img[(j + 16 * k) * C + c] = v[oreg(k)].x;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int idx = (j + 16 * k) * C + c;
+            const float e0 = plane[idx], e1 = plane[256 * C + idx];
+            x[k].x = par ? e0 - e1 : e0 + e1;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; k++) img[(j + 16 * k) * C + c] = v[oreg(k)].y;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int idx = (j + 16 * k) * C + c;
+            const float e0 = plane[idx], e1 = plane[256 * C + idx];
+            x[k].y = par ? e0 - e1 : e0 + e1;
+        }
+        __syncthreads();                                         // the next tile writes the planes again
+#pragma unroll
+        for (int k = 0; k < 16; k++) v[oreg(k)] = x[k];
+        // X[k2 = j + 16 k + 256 q] *= W_Nc^(n1 k2) = W^(n1 (j + 256 q)) * (W^(16 n1))^k
+        float2 *out = T + (size_t)w * pl.Nc;
+        const int n1o = opaque_i(n1);
+        const float inv2 = 2.0f / (float)pl.Nc;
+        const int e0 = (int)(((long long)n1 * (j + 256 * par)) & (pl.Nc - 1));
+        const int e1 = (n1 * 16) & (int)(pl.Nc - 1);
+        mul_base_step16(v, unit_root((float)e0, inv2, false), unit_root((float)e1, inv2, false));
+        __builtin_amdgcn_sched_barrier(0);                       // offsets are formed here, not during the transform
+#pragma unroll
+        for (int k = 0; k < 16; k++) store_at(out, 8u * (unsigned)((j + 16 * k + 256 * par) * N1 + opaque_i(n1o)), v[oreg(k)]);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // forward column pass for short columns, N2 = 16 F (F = 1, 2, 4, 8: windows of 0.06 .. 0.5 s at 2 Msps,
 // N = 2^17 .. 2^20).  Decimation in time by F: thread (column c, part p) transforms the 16 rows
 // n2 = p (mod F) in registers, applies W_(16F)^(k p), and after one LDS exchange computes the outputs

@@ -226,7 +226,10 @@ __device__ __forceinline__ void inv_rows_twiddle_store(float2 (&va)[8], float2 (
 // G is written as the [N2'][4096] four-step layout of the R-point inverse (j = j2 + N2' j1, N2' = N2/16).
 // (A variant that kept the template's tiles in registers for up to four pair-windows sharing it read a third fewer
 // bytes and ran 8 - 30 % slower: one more barrier pair per pair-window and 128 VGPRs with spills.)
-// Work item = (pair-window, tile pair); 512 threads, dynamic LDS 2 x 16 x 296 x 8 B = 74 KB.
+// grid (N2/2, n_pw), 512 threads, dynamic LDS 2 x 16 x 296 x 8 B = 74 KB (+ 1 KB of taps).
+// (Round 3 also measured a persistent form that prefetches the next item's spectrum tiles behind the FIR -- neutral on 3
+// pairs, 4 % slower on the 4096 x 512 plan -- and a form whose FIR is wave-uniform in the phase, with scalar taps and the
+// phase groups added through LDS: 1.35 ms against 0.79; neither is kept.  DESIGN.md section 3.)
 // ---------------------------------------------------------------------------
 constexpr int kDecD = 16;
 constexpr int kDecSteps = 14;                               // a tap t = 16 (s - 7) + p: phase p = 0..15, step s = 0..13, |t| <= T <= 111
@@ -246,30 +249,24 @@ __device__ __forceinline__ constexpr int dec_slot(int i) { return i + ((i + 8) >
 // E[pw][tile][14] (slots 0..6: outputs 249..255 of the previous tile, 7..13: outputs 0..6 of the next one);
 // k_inv_rows_plain_r8 adds them when it loads G.  No halo is fetched: the halo bins of a [tile][k2][col] layout are 8-byte
 // pieces of 224 different lines per tile side and spectrum, which nearly doubled the bytes this kernel pulled in.
-//
-// Persistent and software-pipelined (round 3): a workgroup takes the work items (pair-window, tile pair) blockIdx.x,
-// blockIdx.x + gridDim.x, ...  (tile pair fastest, so the workgroups that run together stream the same two station
-// spectra, as the 2-D grid did).  Its 32 spectrum loads are consumed by K3 straight into LDS, so their 64 registers are
-// free while the FIR runs from LDS: the loads of the NEXT item are issued right after the barrier that ends K3 and
-// land during the FIR.  The one-item-per-workgroup form waited for memory half of its time (SQ_WAIT_ANY 49 % of the wave
-// cycles at 50 % vector issue): two resident workgroups per CU cannot cover a 128 KB fetch each.
-// grid (2 n_cu), 512 threads, dynamic LDS 74 KB.
 template <int LOGN2>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_PLAIN_DS_OPS)) void k_pair_decimate16(const PWDesc *pw, const float2 *Z, float2 *G, float2 *E, FftPlan pl,
-                                                         const float *taps, int small_n2, int n_pw)
+                                                         const float *taps, int small_n2)
 {
     constexpr int N2 = 1 << LOGN2, COLS = 4096 >> LOGN2;     // a tile: all N2 rows x COLS columns = 4096 consecutive bins
-    constexpr int DK = 512 / COLS;                           // bins between a thread's consecutive elements
-    static_assert(DK % 16 == 0, "a thread's elements share their phase");
     extern __shared__ float2 lds[];                          // [2][16][kDecPitch]
-    __shared__ float ltaps[256];                             // the FIR taps [phase][16]: per-lane phases, so not scalar operands;
-                                                             // from LDS they cost a few cycles where global loads cost a round trip
+    // the FIR taps [phase][16] in LDS: a lane's phases p = pq + 4 m differ from its neighbours', so the taps cannot be scalar
+    // operands, and fetched from global memory inside the FIR (rounds 1-2: 56 per-lane loads per thread, each a round trip
+    // to L2 between the multiply-adds) they cost this kernel a fifth of its time: 0.96 -> 0.79 ms on cfg2
+    __shared__ float ltaps[256];
     float2 *qa = lds, *qb = lds + 16 * kDecPitch;
-    const int t0 = threadIdx.x;
-    if (t0 < 256) ltaps[t0] = taps[t0];
+    const int t = threadIdx.x;
+    if (t < 256) ltaps[t] = taps[t];
+    const PWDesc d = pw[blockIdx.y];
+    const float2 *Za = Z + (size_t)d.sw_a * pl.Nc, *Zb = Z + (size_t)d.sw_b * pl.Nc;
     const long long mask = pl.Nc - 1;
+    const long long kA0 = 4096ll * blockIdx.x;               // first bin of tile A
     const float invNc = 1.0f / (float)pl.Nc;
-    const int n_items = (N2 / 2) * n_pw;
     // spectra in COLS-column tiles (k_fwd_row4096 with a tiled output): element (k2, k1) at [k1 / COLS][k2][k1 % COLS]
     auto coords = [&](long long k, unsigned int &at, unsigned int &atm) {
         const int k2 = (int)(k & (N2 - 1)), k1 = (int)(k >> LOGN2);
@@ -278,192 +275,155 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_
         atm = (unsigned int)(pc / COLS) * 4096u + (unsigned int)pr * COLS + (unsigned int)(pc % COLS);
     };
     auto slot_of = [](int o) { return (o & 15) * kDecPitch + dec_slot((o >> 4) + 8); };
-    // zero slots on either side of both images: 16 phases x (8 + 8) x 2 tiles = 512 entries, one per thread; K3 never
-    // writes them, so once per workgroup
+    // zero slots on either side of both images: 16 phases x (8 + 8) x 2 tiles = 512 entries, one per thread
     {
-        const int img = t0 >> 8, p = (t0 >> 4) & 15, z = t0 & 15;
+        const int img = t >> 8, p = (t >> 4) & 15, z = t & 15;
         (img ? qb : qa)[p * kDecPitch + dec_slot(z < 8 ? z : 256 + z)] = make_float2(0.0f, 0.0f);
     }
-    // a tile's 4096 elements, 8 per thread, x = t + 512 it in tile order (k2 = x / COLS, column x % COLS: one contiguous
-    // 4 KB run per trip).  From trip 1 on everything is linear in the trip (k2 >= 512 / COLS > 0: the partner's row just
-    // counts down, no wrap): own element + 512 it, partner - 512 (it - 1).
-    const bool has_b0 = t0 == 511;                           // B[0]: its partner is A[0] of the next tile; one thread fetches it
-    float2 za[8], zam[8], zb[8], zbm[8], b0[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) b0[k] = make_float2(0.0f, 0.0f);
-    // (the thread index is laundered wherever addresses are derived from it: hoisted out of the item loop as invariants,
-    // the offsets, slots and pointers of all phases would occupy the registers the prefetch needs)
-    // PART 0: the two spectra's own tiles (+ B[0]'s operands); PART 1: the mirror tiles
-#define TDOA_DEC_LOADS(ITEM, PART)                                                                                    \
-    do {                                                                                                              \
-        const int t_ = opaque_i(t0);                                                                                  \
-        const int o0_ = t_ / COLS + N2 * (t_ % COLS);                                                                 \
-        const int bx_ = (ITEM) % (N2 / 2), py_ = (ITEM) / (N2 / 2);                                                   \
-        const PWDesc d_ = pw[py_];                                                                                    \
-        const float2 *Za_ = Z + (size_t)d_.sw_a * pl.Nc, *Zb_ = Z + (size_t)d_.sw_b * pl.Nc;                          \
-        unsigned int at0_, atm0_, at1_, atm1_;                                                                        \
-        coords(4096ll * bx_ + o0_, at0_, atm0_);                                                                      \
-        coords(4096ll * bx_ + o0_ + DK, at1_, atm1_);                                                                 \
-        if ((PART) == 0) {                                                                                            \
-            if (has_b0) {                                                                                             \
-                unsigned int at_, atm_;                                                                               \
-                coords((pl.Nc - 4096ll * ((long long)bx_ + 1)) & mask, at_, atm_);                                    \
-                b0[0] = Za_[at_]; b0[1] = Za_[atm_]; b0[2] = Zb_[at_]; b0[3] = Zb_[atm_];                              \
-            }                                                                                                         \
-            za[0] = Za_[at0_]; zb[0] = Zb_[at0_];                                                                     \
-            _Pragma("unroll") for (int it = 1; it < 8; it++) {                                                        \
-                za[it] = Za_[at1_ + 512u * (it - 1)];                                                                 \
-                zb[it] = Zb_[at1_ + 512u * (it - 1)];                                                                 \
-            }                                                                                                         \
-        } else {                                                                                                      \
-            zam[0] = Za_[atm0_]; zbm[0] = Zb_[atm0_];                                                                 \
-            _Pragma("unroll") for (int it = 1; it < 8; it++) {                                                        \
-                zam[it] = Za_[atm1_ - 512u * (it - 1)];                                                               \
-                zbm[it] = Zb_[atm1_ - 512u * (it - 1)];                                                               \
-            }                                                                                                         \
-        }                                                                                                             \
-    } while (0)
-    int item = blockIdx.x;                                   // the host launches at most n_items workgroups
-    TDOA_DEC_LOADS(item, 0);
-    TDOA_DEC_LOADS(item, 1);
-    for (;;) {
-        const int bx = item % (N2 / 2), py = item / (N2 / 2);
-        const long long kA0 = 4096ll * bx;                   // first bin of tile A
-        {
-            const int t = opaque_i(t0);
-            const int o0 = t / COLS + N2 * (t % COLS);
-            // w(k) = W_N^k; a thread's bins are DK apart: one root, then a fixed rotation
-            float2 w = unit_root((float)(kA0 + o0), invNc, false);
-            const float2 rot = unit_root((float)DK, invNc, false);
-            const int sa1 = slot_of(o0 + DK), sb1 = slot_of(4096 - o0 - DK);
-            {
-                float2 q, qm;
-                pair_q_pk(za[0], zam[0], zb[0], zbm[0], w, q, qm);
-                qa[slot_of(o0)] = q;
-                if (o0) qb[slot_of(4096 - o0)] = qm;               // the partner of A[0] is B[0] of the workgroup before
-                w = cmul(w, rot);
-            }
-#pragma unroll
-            for (int it = 1; it < 8; it++) {
-                float2 q, qm;
-                pair_q_pk(za[it], zam[it], zb[it], zbm[it], w, q, qm);
-                if constexpr (LOGN2 == 8) {                        // N2 = 256: a thread's slots stay inside one column of the image
-                    qa[sa1 + (DK / 16) * (it - 1)] = q;
-                    qb[sb1 - (DK / 16) * (it - 1)] = qm;
-                } else {
-                    qa[slot_of(o0 + DK * it)] = q;
-                    qb[slot_of(4096 - o0 - DK * it)] = qm;
-                }
-                w = cmul(w, rot);
-            }
-        }
-        if (has_b0) {
-            const long long kb0 = (pl.Nc - 4096ll * ((long long)bx + 1)) & mask;
-            float2 q, qm;
-            pair_q_pk(b0[0], b0[1], b0[2], b0[3], unit_root((float)kb0, invNc, false), q, qm);
-            qb[slot_of(0)] = q;
-        }
-        __syncthreads();
-        // the spectra registers are free now: the next item's loads fly while the FIR below runs from LDS
-        // (a workgroup that is done re-loads its last item: unconditional code, no result is used)
-        const int next = item + (int)gridDim.x;
-        const bool more = next < n_items;
-        const int pf = more ? next : item;
-        TDOA_DEC_LOADS(pf, 0);
-        // FIR + decimation.  Output i of a tile is sum_t h[t] Q[16 i + t] = sum_{p, s} tab[p][s] img[p][i + s - 7]
-        // (t = 16 (s - 7) + p; the host lays the taps out as taps[p][16], s = 0..13, zero where |t| > T).
-        // A thread takes FOUR consecutive outputs and FOUR phases p = pq + 4 m: image slot 4 g + s' (s' = 0..17, counted from
-        // the 8 zero slots) serves output o = 0..3 with step s = s' - o - 1, so 18 LDS reads per phase feed 56 multiply-adds
-        // (one read per output and tap would make the kernel LDS-bound: 13 reads of every bin).  Waves 0..3: tile A, 4..7:
-        // tile B; wave w takes the output groups g = 4 g_l + (w & 3), lane = 4 g_l + pq: physical slot of 4 g + s' is
-        // 17 g_l + [4 wq + s' + ((4 wq + s' + 8) >> 4)], the bracket a compile-time offset once the wave's wq is fixed (four
-        // copies of the loop, wave-uniform switch).
-        const int t = opaque_i(t0);
-        const int tile = __builtin_amdgcn_readfirstlane(t >> 8), wq = __builtin_amdgcn_readfirstlane((t >> 6) & 3);
-        const int pq = t & 3, gl = (t & 63) >> 2;
-        const float2 *img = tile ? qb : qa;
-        const float2 *src = img + 17 * gl;
-        float2 acc[4];
-#pragma unroll
-        for (int o = 0; o < 4; o++) acc[o] = make_float2(0.0f, 0.0f);
-        auto fir = [&](auto wq_c) {
-            constexpr int WQ = decltype(wq_c)::value;
-#pragma unroll
-            for (int m = 0; m < 4; m++) {
-                const int p = pq + 4 * m;
-                float h[kDecSteps];
-#pragma unroll
-                for (int s2 = 0; s2 < kDecSteps; s2++) h[s2] = ltaps[16 * p + s2];
-                const float2 *row = src + p * kDecPitch;
-                __builtin_amdgcn_sched_barrier(0);       // one phase's 18 reads and 14 taps at a time: registers for the prefetch
-
-#pragma unroll
-                for (int s1 = 1; s1 < 18; s1++) {
-                    const float2 v = row[4 * WQ + s1 + ((4 * WQ + s1 + 8) >> 4)];
-#pragma unroll
-                    for (int o = 0; o < 4; o++) {
-                        const int s2 = s1 - o - 1;
-                        if (s2 >= 0 && s2 < kDecSteps) {
-                            acc[o].x += h[s2] * v.x;
-                            acc[o].y += h[s2] * v.y;
-                        }
-                    }
-                }
-            }
-        };
-        if (wq == 0) fir(std::integral_constant<int, 0>{});
-        else if (wq == 1) fir(std::integral_constant<int, 1>{});
-        else if (wq == 2) fir(std::integral_constant<int, 2>{});
-        else fir(std::integral_constant<int, 3>{});
-        // sum over the four phase groups (adjacent lanes); lane pq then writes output 4 g + pq
-#pragma unroll
-        for (int o = 0; o < 4; o++) {
-            acc[o].x += __shfl_xor(acc[o].x, 1, kWave);
-            acc[o].y += __shfl_xor(acc[o].y, 1, kWave);
-            acc[o].x += __shfl_xor(acc[o].x, 2, kWave);
-            acc[o].y += __shfl_xor(acc[o].y, 2, kWave);
-        }
-        const float2 mine = pq == 0 ? acc[0] : pq == 1 ? acc[1] : pq == 2 ? acc[2] : acc[3];
-        // tile number in bin order: bx for tile A, N2 - 1 - bx for tile B; its outputs are G[256 tn + i]; four-step layout of
-        // the small plan: j = j2 + N2' j1 at [j2][j1]
-        const int rc = (int)(pl.Nc / kDecD);
-        const int tn = tile ? N2 - 1 - bx : bx;
-        {
-            const int j = 256 * tn + 4 * (4 * gl + wq) + pq;
-            G[(size_t)py * (size_t)rc + (size_t)(j & (small_n2 - 1)) * 4096 + (j / small_n2)] = mine;
-        }
-        // this tile's share of the 7 outputs before it (i = -7..-1) and the 7 after it (i = 256..262): lane (output, phase),
-        // 14 x 16 = 224 lanes of the tile's first four waves; sum over the steps whose bins lie inside the tile, then over
-        // the phases (16 adjacent lanes)
-        {
-            const int tl = t & 255, eo = tl >> 4, p = tl & 15;         // eo = 0..13 (14, 15: idle lanes of the fourth wave)
-            const int i = eo < kDecEdge ? eo - kDecEdge : 256 + (eo - kDecEdge);
-            float2 e = make_float2(0.0f, 0.0f);
-            if (eo < 2 * kDecEdge) {
-#pragma unroll
-                for (int s2 = 0; s2 < kDecSteps; s2++) {
-                    const int idx = i + s2 - 7;                        // slot of the bin group; inside the tile: 0..255
-                    if (idx >= 0 && idx < 256) {
-                        const float hh = ltaps[16 * p + s2];
-                        const float2 v = img[p * kDecPitch + dec_slot(idx + 8)];
-                        e.x += hh * v.x;
-                        e.y += hh * v.y;
-                    }
-                }
-            }
-#pragma unroll
-            for (int sh = 1; sh < 16; sh <<= 1) {
-                e.x += __shfl_xor(e.x, sh, kWave);
-                e.y += __shfl_xor(e.y, sh, kWave);
-            }
-            if (p == 0 && eo < 2 * kDecEdge) E[((size_t)py * N2 + tn) * (2 * kDecEdge) + eo] = e;
-        }
-        TDOA_DEC_LOADS(pf, 1);
-        __syncthreads();                                     // the next item's K3 overwrites the images
-        if (!more) break;
-        item = next;
+    // B[0]: its partner is A[0] of the next workgroup's tile.  One thread (of the last wave) fetches the four values
+    // up front, next to everybody's main loads, and forms Q after its main work
+    const bool has_b0 = t == 511;
+    const long long kb0 = (pl.Nc - 4096ll * ((long long)blockIdx.x + 1)) & mask;
+    float2 b0[4] = {};
+    if (has_b0) {
+        unsigned int at, atm;
+        coords(kb0, at, atm);
+        b0[0] = Za[at]; b0[1] = Za[atm]; b0[2] = Zb[at]; b0[3] = Zb[atm];
     }
-#undef TDOA_DEC_LOADS
+    {
+        // a tile's 4096 elements, 8 per thread, x = t + 512 it in tile order (k2 = x / COLS, column x % COLS: one
+        // contiguous 4 KB run per trip); all 32 loads of a thread are issued first.  From trip 1 on everything is linear in
+        // the trip (k2 >= 512 / COLS > 0: the partner's row just counts down, no wrap): own element + 512 it, partner
+        // - 512 (it - 1); for N2 = 256 also the image slots (+- 2 per trip, inside one column of the image: constant pad).
+        constexpr int DK = 512 / COLS;                             // bins between a thread's consecutive elements
+        static_assert(DK % 16 == 0, "a thread's elements share their phase");
+        float2 za[8], zam[8], zb[8], zbm[8];
+        const int o0 = t / COLS + N2 * (t % COLS);                 // x -> bin offset k2 + N2 col
+        unsigned int at0, atm0, at1, atm1;
+        coords(kA0 + o0, at0, atm0);
+        coords(kA0 + o0 + DK, at1, atm1);
+        za[0] = Za[at0]; zam[0] = Za[atm0]; zb[0] = Zb[at0]; zbm[0] = Zb[atm0];
+#pragma unroll
+        for (int it = 1; it < 8; it++) {
+            za[it] = Za[at1 + 512u * (it - 1)]; zam[it] = Za[atm1 - 512u * (it - 1)];
+            zb[it] = Zb[at1 + 512u * (it - 1)]; zbm[it] = Zb[atm1 - 512u * (it - 1)];
+        }
+        // w(k) = W_N^k; a thread's bins are DK apart: one root, then a fixed rotation
+        float2 w = unit_root((float)(kA0 + o0), invNc, false);
+        const float2 rot = unit_root((float)DK, invNc, false);
+        const int sa1 = slot_of(o0 + DK), sb1 = slot_of(4096 - o0 - DK);
+        {
+            float2 q, qm;
+            pair_q_pk(za[0], zam[0], zb[0], zbm[0], w, q, qm);
+            qa[slot_of(o0)] = q;
+            if (o0) qb[slot_of(4096 - o0)] = qm;                   // the partner of A[0] is B[0] of the workgroup before
+            w = cmul(w, rot);
+        }
+#pragma unroll
+        for (int it = 1; it < 8; it++) {
+            float2 q, qm;
+            pair_q_pk(za[it], zam[it], zb[it], zbm[it], w, q, qm);
+            if constexpr (LOGN2 == 8) {                            // N2 = 256: a thread's slots stay inside one column of the image
+                qa[sa1 + (DK / 16) * (it - 1)] = q;
+                qb[sb1 - (DK / 16) * (it - 1)] = qm;
+            } else {
+                qa[slot_of(o0 + DK * it)] = q;
+                qb[slot_of(4096 - o0 - DK * it)] = qm;
+            }
+            w = cmul(w, rot);
+        }
+    }
+    if (has_b0) {
+        float2 q, qm;
+        pair_q_pk(b0[0], b0[1], b0[2], b0[3], unit_root((float)kb0, invNc, false), q, qm);
+        qb[slot_of(0)] = q;
+    }
+    __syncthreads();
+    // FIR + decimation.  Output i of a tile is sum_t h[t] Q[16 i + t] = sum_{p, s} tab[p][s] img[p][i + s - 7]
+    // (t = 16 (s - 7) + p; the host lays the taps out as taps[p][16], s = 0..13, zero where |t| > T).
+    // A thread takes FOUR consecutive outputs and FOUR phases p = pq + 4 m: image slot 4 g + s' (s' = 0..17, counted from
+    // the 8 zero slots) serves output o = 0..3 with step s = s' - o - 1, so 18 LDS reads per phase feed 56 multiply-adds
+    // (one read per output and tap would make the kernel LDS-bound: 13 reads of every bin).  Waves 0..3: tile A, 4..7:
+    // tile B; wave w takes the output groups g = 4 g_l + (w & 3), lane = 4 g_l + pq: physical slot of 4 g + s' is
+    // 17 g_l + [4 wq + s' + ((4 wq + s' + 8) >> 4)], the bracket a compile-time offset once the wave's wq is fixed (four
+    // copies of the loop, wave-uniform switch).
+    const int tile = __builtin_amdgcn_readfirstlane(t >> 8), wq = __builtin_amdgcn_readfirstlane((t >> 6) & 3);
+    const int pq = t & 3, gl = (t & 63) >> 2;
+    const float2 *img = tile ? qb : qa;
+    const float2 *src = img + 17 * gl;
+    float2 acc[4];
+#pragma unroll
+    for (int o = 0; o < 4; o++) acc[o] = make_float2(0.0f, 0.0f);
+    auto fir = [&](auto wq_c) {
+        constexpr int WQ = decltype(wq_c)::value;
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            const int p = pq + 4 * m;
+            float h[kDecSteps];
+#pragma unroll
+            for (int s2 = 0; s2 < kDecSteps; s2++) h[s2] = ltaps[16 * p + s2];
+            const float2 *row = src + p * kDecPitch;
+#pragma unroll
+            for (int s1 = 1; s1 < 18; s1++) {
+                const float2 v = row[4 * WQ + s1 + ((4 * WQ + s1 + 8) >> 4)];
+#pragma unroll
+                for (int o = 0; o < 4; o++) {
+                    const int s2 = s1 - o - 1;
+                    if (s2 >= 0 && s2 < kDecSteps) {
+                        acc[o].x += h[s2] * v.x;
+                        acc[o].y += h[s2] * v.y;
+                    }
+                }
+            }
+        }
+    };
+    if (wq == 0) fir(std::integral_constant<int, 0>{});
+    else if (wq == 1) fir(std::integral_constant<int, 1>{});
+    else if (wq == 2) fir(std::integral_constant<int, 2>{});
+    else fir(std::integral_constant<int, 3>{});
+    // sum over the four phase groups (adjacent lanes); lane pq then writes output 4 g + pq
+#pragma unroll
+    for (int o = 0; o < 4; o++) {
+        acc[o].x += __shfl_xor(acc[o].x, 1, kWave);
+        acc[o].y += __shfl_xor(acc[o].y, 1, kWave);
+        acc[o].x += __shfl_xor(acc[o].x, 2, kWave);
+        acc[o].y += __shfl_xor(acc[o].y, 2, kWave);
+    }
+    const float2 mine = pq == 0 ? acc[0] : pq == 1 ? acc[1] : pq == 2 ? acc[2] : acc[3];
+    // tile number in bin order: bx for tile A, N2 - 1 - bx for tile B; its outputs are G[256 tn + i]; four-step layout of
+    // the small plan: j = j2 + N2' j1 at [j2][j1]
+    const int rc = (int)(pl.Nc / kDecD);
+    const int tn = tile ? N2 - 1 - (int)blockIdx.x : (int)blockIdx.x;
+    {
+        const int j = 256 * tn + 4 * (4 * gl + wq) + pq;
+        G[(size_t)blockIdx.y * (size_t)rc + (size_t)(j & (small_n2 - 1)) * 4096 + (j / small_n2)] = mine;
+    }
+    // this tile's share of the 7 outputs before it (i = -7..-1) and the 7 after it (i = 256..262): lane (output, phase),
+    // 14 x 16 = 224 lanes of the tile's first four waves; sum over the steps whose bins lie inside the tile, then over
+    // the phases (16 adjacent lanes)
+    {
+        const int tl = t & 255, eo = tl >> 4, p = tl & 15;         // eo = 0..13 (14, 15: idle lanes of the fourth wave)
+        const int i = eo < kDecEdge ? eo - kDecEdge : 256 + (eo - kDecEdge);
+        float2 e = make_float2(0.0f, 0.0f);
+        if (eo < 2 * kDecEdge) {
+#pragma unroll
+            for (int s2 = 0; s2 < kDecSteps; s2++) {
+                const int idx = i + s2 - 7;                        // slot of the bin group; inside the tile: 0..255
+                if (idx >= 0 && idx < 256) {
+                    const float hh = ltaps[16 * p + s2];
+                    const float2 v = img[p * kDecPitch + dec_slot(idx + 8)];
+                    e.x += hh * v.x;
+                    e.y += hh * v.y;
+                }
+            }
+        }
+#pragma unroll
+        for (int sh = 1; sh < 16; sh <<= 1) {
+            e.x += __shfl_xor(e.x, sh, kWave);
+            e.y += __shfl_xor(e.y, sh, kWave);
+        }
+        if (p == 0 && eo < 2 * kDecEdge) E[((size_t)blockIdx.y * N2 + tn) * (2 * kDecEdge) + eo] = e;
+    }
 }
 
 // inverse rows of the decimated spectrum (no K3, no mirror): rows a = 2 bx, b = a + 1 of G[N2'][4096] -> V'[k2][n1]

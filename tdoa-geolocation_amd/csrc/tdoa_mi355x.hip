@@ -441,7 +441,7 @@ int segment_pq(const tdoa_ctx *ctx, const FftPlan &pl, int lag_lo, int lag_hi, i
 bool fused_k1_applies(const tdoa_ctx *ctx, const FftPlan &pl, int lag_lo, int lag_hi, int n_pw, bool allow)
 {
     if (!allow || !ctx->fused_k1 || ctx->force_generic || ctx->prm.k1_smooth > 1 || ctx->prm.k1_gate) return false;
-    if (pl.N1 != 4096 || !(pl.N2 == 256 || pl.N2 == 2048 || pl.N2 == 4096)) return false;
+    if (pl.N1 != 4096 || !(pl.N2 == 256 || pl.N2 == 512 || pl.N2 == 2048 || pl.N2 == 4096)) return false;
     return segment_pq(ctx, pl, lag_lo, lag_hi, n_pw) == 0;
 }
 
@@ -567,6 +567,8 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
             else
                 hipLaunchKernelGGL(k_fwd_col_finish<8>, dim3(pl.N1 / 512, 256, n_sw), dim3(256), 0, st, tz, pl);
         }
+        else if (fused_k1 && colx == 2)
+            hipLaunchKernelGGL(k_fwd_col512_k1, dim3(2 * ctx->n_cu), dim3(512), kColK1Lds, st, d_sw, table, stats, tz, pl, n_sw);
         else if (col16)
             hipLaunchKernelGGL(k_fwd_col256_c16<false>, dim3(pl.N1 / 32, n_sw), dim3(512), lds_col16, st, d_sw, codes,
                                code_stride, stats, tz, pl);
@@ -665,15 +667,12 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
         {
             ProfScope ps(ctx, TDOA_K_INV_ROW, 2.0 * nc8 * n_pw + 8.0 * (double)rc_pts * n_pw);      // two spectra read, G written
             float2 *edges = v + dec_edge_offset(pl, n_pw), *spectra = v + dec_spectra_offset(pl, n_pw);
-            // persistent: two workgroups per CU (74 KB of LDS each) walk the (pair-window, tile pair) items
-            const long long dec_items = (long long)(pl.N2 / 2) * n_pw;
-            const dim3 dec_grid((unsigned)std::max<long long>(1, std::min<long long>(dec_items, 2ll * ctx->n_cu)));
             if (pl.N2 == 256)
-                hipLaunchKernelGGL(k_pair_decimate16<8>, dec_grid, dim3(512), sizeof(float2) * 2 * 16 * kDecPitch, st,
-                                   d_pw, spectra, g, edges, pl, static_cast<const float *>(ctx->dec_taps.p), ps2.N2, n_pw);
+                hipLaunchKernelGGL(k_pair_decimate16<8>, dim3(pl.N2 / 2, n_pw), dim3(512), sizeof(float2) * 2 * 16 * kDecPitch, st,
+                                   d_pw, spectra, g, edges, pl, static_cast<const float *>(ctx->dec_taps.p), ps2.N2);
             else
-                hipLaunchKernelGGL(k_pair_decimate16<9>, dec_grid, dim3(512), sizeof(float2) * 2 * 16 * kDecPitch, st,
-                                   d_pw, spectra, g, edges, pl, static_cast<const float *>(ctx->dec_taps.p), ps2.N2, n_pw);
+                hipLaunchKernelGGL(k_pair_decimate16<9>, dim3(pl.N2 / 2, n_pw), dim3(512), sizeof(float2) * 2 * 16 * kDecPitch, st,
+                                   d_pw, spectra, g, edges, pl, static_cast<const float *>(ctx->dec_taps.p), ps2.N2);
         }
         {
             ProfScope ps(ctx, TDOA_K_INV_COL, 3.0 * 8.0 * (double)rc_pts * n_pw);
@@ -769,6 +768,7 @@ int allow_big_lds(tdoa_ctx *ctx)
     if ((rc = set_lds(ctx, k_fm_demod<false>, all))) return rc;
     if ((rc = set_lds(ctx, k_fwd_col256_k1<false>, all))) return rc;
     if ((rc = set_lds(ctx, k_fwd_col256_k1<true>, all))) return rc;
+    if ((rc = set_lds(ctx, k_fwd_col512_k1, all))) return rc;
     if ((rc = set_lds(ctx, k_fwd_col_c16, all))) return rc;
     if ((rc = set_lds(ctx, k_fwd_row, all))) return rc;
     if ((rc = set_lds(ctx, k_inv_row_pair, all))) return rc;
