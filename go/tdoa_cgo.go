@@ -24,10 +24,15 @@ import (
 // gpuCorrelator owns one tdoa_ctx (one GPU). Not safe for concurrent use (the reference is single-goroutine).
 type gpuCorrelator struct{ ctx *C.tdoa_ctx }
 
-func newGPUCorrelator(device int) (*gpuCorrelator, error) {
+// goLagSet: search the lags timeDomainCorrelation searches (processor.go:650-678: shorter input = template, lags
+// [0, max(1, min(maxLag, Ls-Lt))), first strict maximum) instead of the signed range -maxLag < lag < maxLag.
+func newGPUCorrelator(device int, goLagSet bool) (*gpuCorrelator, error) {
 	var p C.tdoa_params
 	C.tdoa_default_params(&p) // 2e6 Hz, maxLag 20000, block 1000, gate 0.001, window 2 000 000
 	p.device = C.int32_t(device)
+	if goLagSet {
+		p.lag_mode = C.TDOA_LAGS_GO
+	}
 	var ctx *C.tdoa_ctx
 	if rc := C.tdoa_create(&p, &ctx); rc != C.TDOA_OK {
 		return nil, fmt.Errorf("tdoa_create: %s", C.GoString(C.tdoa_strerror(rc)))
