@@ -26,9 +26,7 @@ __device__ __forceinline__ void fft16(float2 (&v)[16])
 #pragma unroll
     for (int n1 = 0; n1 < 4; n1++) bfly4<INV>(v[n1], v[n1 + 4], v[n1 + 8], v[n1 + 12]);
     // v[n1 + 4*k2] *= W16^(n1*k2)   (forward: e^{-2 pi i m/16}; inverse: conjugate)
-    auto tw = [](float2 a, float c, float s) {
-        return INV ? make_float2(a.x * c - a.y * s, a.x * s + a.y * c) : make_float2(a.x * c + a.y * s, a.y * c - a.x * s);
-    };
+    auto tw = [](float2 a, float c, float s) { return cmul(a, make_float2(c, INV ? s : -s)); };      // a e^{-+i phi}: two packed ops
     v[1 + 4] = tw(v[1 + 4], c1, s1);      // m = 1
     v[1 + 8] = tw(v[1 + 8], h, h);        // m = 2
     v[1 + 12] = tw(v[1 + 12], s1, c1);    // m = 3

@@ -35,12 +35,10 @@ __device__ __forceinline__ void fft8(float2 (&v)[8])
     }
     // v[4 + n2] *= W8^n2   (forward e^{-2 pi i n2/8}; inverse: conjugate)
     {
-        const float2 a = v[5];   // W8^1 = h (1 -+ i)
-        v[5] = INV ? make_float2(h * (a.x - a.y), h * (a.x + a.y)) : make_float2(h * (a.x + a.y), h * (a.y - a.x));
-        const float2 b = v[6];   // W8^2 = -+ i
+        v[5] = cmul(v[5], make_float2(h, INV ? h : -h));      // W8^1 = h (1 -+ i)
+        const float2 b = v[6];                                 // W8^2 = -+ i
         v[6] = INV ? make_float2(-b.y, b.x) : make_float2(b.y, -b.x);
-        const float2 c = v[7];   // W8^3 = h (-1 -+ i)
-        v[7] = INV ? make_float2(-h * (c.x + c.y), h * (c.x - c.y)) : make_float2(h * (c.y - c.x), -h * (c.x + c.y));
+        v[7] = cmul(v[7], make_float2(-h, INV ? h : -h));     // W8^3 = h (-1 -+ i)
     }
     bfly4<INV>(v[0], v[1], v[2], v[3]);
     bfly4<INV>(v[4], v[5], v[6], v[7]);
