@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void k_fwd_row4096(float2 *TZ, FftPlan pl, int
 {
     __shared__ float2 lds[kRowLds];
     const int k2 = blockIdx.x * row_mul;
-    float2 *row = TZ + (size_t)blockIdx.y * pl.Nc + (size_t)k2 * 4096;
+    float2 *row = TZ + (size_t)blockIdx.y * pl.Zs + (size_t)k2 * 4096 + (size_t)(k2 >> 8) * pl.zpad;
     const int j = threadIdx.x;
     float2 v[16];
 #pragma unroll
@@ -185,13 +185,13 @@ __global__ __launch_bounds__(512) void k_fwd_col256_c16(const SWDesc *sw, const 
     for (int r = 0; r < 16; r++) v[r] = lds[((j + 16 * r) << 5) + c];
     mul_powers16(v, unit_root((float)j, 2.0f / 256.0f, false));
     fft16<false>(v);
-    float2 *out = T + (size_t)blockIdx.y * pl.Nc;
+    float2 *out = T + (size_t)blockIdx.y * pl.Zs;
     if (SUB) {
         // Y_a[kb = j + 16k] *= W_(256G)^(a kb) = W^(a j) * (W^(16 a))^k
         const float invg = 2.0f / (float)pl.N2;
         if (a) mul_base_step16(v, unit_root((float)(a * j), invg, false), unit_root((float)(16 * a), invg, false));
 #pragma unroll
-        for (int k = 0; k < 16; k++) out[(size_t)(a * 256 + j + 16 * k) * N1 + n1] = v[oreg(k)];
+        for (int k = 0; k < 16; k++) out[(size_t)(a * 256 + j + 16 * k) * N1 + (size_t)a * pl.zpad + n1] = v[oreg(k)];
     } else {
         // Y[k2 = j + 16k] *= W_Nc^(n1*k2) = W^(n1*j) * (W^(16*n1))^k
         const float inv2 = 2.0f / (float)pl.Nc;
@@ -231,14 +231,11 @@ __device__ __forceinline__ void store_at(float2 *base, unsigned int byte_off, fl
     *reinterpret_cast<float2 *>(reinterpret_cast<char *>(base) + byte_off) = v;      // (non-temporal stores here: 12 % slower)
 }
 
-// One element from the dword `w` its thread fetched at sample index min(2m, len - 2) (never beyond the window) and the
-// angle code `ap` of sample 2m - 1.  Returns the normalised pair; `a1` = angle of the element's LAST valid sample (what
+// One element from the angle codes (a0, a1) of the dword its thread fetched at sample index min(2m, len - 2) (never beyond
+// the window) and the angle code `ap` of sample 2m - 1.  Returns the normalised pair; `a1` = angle of the element's LAST valid sample (what
 // the lane to the right needs).  head: m may be 0 (code_0 := code_1).  len >= 2.
-__device__ __forceinline__ float2 k1_element(unsigned int w, int ap, int i0, int len, float mean, float scale, const int *lut,
-                                             bool head)
+__device__ __forceinline__ float2 k1_element_from(int a0, int a1, int ap, int i0, int len, float mean, float scale, bool head)
 {
-    int a0, a1;
-    k1_angle2(w, lut, a0, a1);
     if (len & 1) {                       // wave-uniform: only then can a last element hold ONE sample (2m + 1 = len);
         if (i0 + 1 == len) {             // its dword was fetched one sample early: (2m - 1, 2m)
             ap = a0;
@@ -251,110 +248,180 @@ __device__ __forceinline__ float2 k1_element(unsigned int w, int ap, int i0, int
     return make_float2(i0 < len ? v0 : 0.0f, i0 + 1 < len ? v1 : 0.0f);
 }
 
+// WIDE: the same transform with ONE 1024-thread workgroup per CU (the occupancy of two 512-thread ones: 4 waves per
+// SIMD): the LDS of the CU then holds the QUADRANT table (64 KB, k1_angle_quadrant: 11 instructions per sample instead of
+// 17) next to a plane of 64 columns.  A wave is then one item j with 64 adjacent elements of every row r: the left
+// neighbour's angle comes by one whole-wave DPP shift and only lane 0 has none -- the 16 boundary samples of a wave (one
+// per r) are looked up by its lanes 0..15 and enter the shift as its `old` operand (v_readlane + v_mov: no permute, no
+// select).  grid (n_cu), 1024 threads (c = t & 63, j = t >> 6), dynamic LDS 64 KB (table) + 64 KB (plane [256][64]).
+//
+// Both forms fetch the capture bytes of their NEXT tile before they store the current one.  The memory counter of a wave
+// retires in order, so a tile whose first act is to wait for its loads also waits for every store of the tile before it
+// to be acknowledged -- with the stores at the end of the trip that was 0.3 of the kernel's 1.08 ms (measured by leaving
+// the stores out: 0.77 ms); with the loads ahead of them in the queue the stores have a whole trip to drain.
+constexpr size_t kColK1wLds = kK1QuadrantBytes + sizeof(float) * 256 * 64;
+
+struct ColK1Tile {        // what a trip needs to know about its tile (all wave-uniform)
+    int bx, a, w, len;
+    gptr16 p;
+};
+
 template <bool SUB>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_fwd_col256_k1(const SWDesc *sw, const int *table, const FmStats *stats, float2 *T,
+__device__ __forceinline__ ColK1Tile col_k1_tile(const SWDesc *__restrict__ sw, int tile, int nbx, int G)
+{
+    ColK1Tile t;
+    t.bx = tile % nbx;
+    const int wa = tile / nbx;
+    t.a = SUB ? wa % G : 0;
+    t.w = SUB ? wa / G : wa;
+    const SWDesc d = sw[t.w];
+    t.len = d.len;
+    t.p = k1_global(d.base);
+    return t;
+}
+
+// the 16 dwords of a thread (rows j + 16 r of column n1) and the boundary sample its lane looks up (row rb of item jb)
+template <int LOGW>
+__device__ __forceinline__ void col_k1_fetch(const ColK1Tile &t, int G, int N1, int j, int c, int jb, int rb, unsigned int (&raw)[16],
+                                             unsigned int &sb)
+{
+    const int n1 = (t.bx << LOGW) + c, last = t.len - 2;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int i0 = 2 * ((t.a + G * (j + 16 * r)) * N1 + n1);        // sample index 2 (row N1 + n1) < 2^25 (Nc <= 2^24)
+        raw[r] = k1_fetch2(t.p, i0 < last ? i0 : last);
+    }
+    const int ib = 2 * ((t.a + G * (jb + 16 * rb)) * N1 + (t.bx << LOGW)) - 1;      // the sample before that row of the tile,
+    sb = t.p[ib >= 0 && ib < t.len ? ib : 0];                                        // if the window has one
+}
+
+template <bool SUB, bool WIDE>
+__global__ __launch_bounds__(WIDE ? 1024 : 512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_fwd_col256_k1(const SWDesc *__restrict__ sw, const int *__restrict__ table, const FmStats *__restrict__ stats, float2 *__restrict__ T,
                                                        FftPlan pl, int n_sw)
 {
-    extern __shared__ int lds_k1[];                             // the table at offset 0 (immediate offsets), then the plane
+    constexpr int LOGW = WIDE ? 6 : 5, W = 1 << LOGW;
+    extern __shared__ int lds_k1[];                             // the table at offset 0 (the offset IS the address), then the plane
     int *lut = lds_k1;
-    float *plane = reinterpret_cast<float *>(lds_k1 + kK1TableEntries);      // [256][32]
-    k1_load_table(lut, table);
+    float *plane = reinterpret_cast<float *>(lds_k1 + (WIDE ? kK1QuadrantEntries : kK1TableEntries));      // [256][W]
+    k1_assert_lds0(lut);
     const int G = SUB ? pl.N2 >> 8 : 1;
-    const int N1 = pl.N1, nbx = N1 >> 5;
+    const int N1 = pl.N1, nbx = N1 >> LOGW;
     const int n_tiles = n_sw * G * nbx;
+    // the first tile's bytes, ahead of the table load
+    unsigned int raw_next[16], sb_next = 0;
+    if ((int)blockIdx.x < n_tiles) {
+        const int tid = threadIdx.x, lane = tid & 63, j = tid >> LOGW;
+        col_k1_fetch<LOGW>(col_k1_tile<SUB>(sw, blockIdx.x, nbx, G), G, N1, j, tid & (W - 1),
+                           WIDE ? j : (j & ~1) + (lane & 1), WIDE ? lane & 15 : (lane & 31) >> 1, raw_next, sb_next);
+    }
+    for (int k = threadIdx.x; k < (WIDE ? kK1QuadrantEntries : kK1TableEntries); k += blockDim.x) lut[k] = table[k];
+    __syncthreads();
+    float2 v[16];                                                // the previous tile's outputs until they are stored (below)
+#pragma unroll
+    for (int r = 0; r < 16; r++) v[r] = make_float2(0.0f, 0.0f);
+    int prev = -1;
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         // (laundered per tile: the row / plane / output addresses derived from the thread index are rebuilt inside the
         // trip -- hoisted out of this loop as ~80 invariants they spilled 112 VGPRs)
         const int tid = opaque_i((int)threadIdx.x);
         const int lane = tid & 63;
-        const int c = tid & 31, j = tid >> 5;                    // column, item (0..15)
-        const int bx = tile % nbx, wa = tile / nbx, a = SUB ? wa % G : 0, w = SUB ? wa / G : wa;
-        const SWDesc d = sw[w];
-        const int len = d.len;
-        const gptr16 p = k1_global(d.base);
+        const int c = tid & (W - 1), j = tid >> LOGW;          // column, item (0..15)
+        const ColK1Tile t = col_k1_tile<SUB>(sw, tile, nbx, G);
+        const int a = t.a, w = t.w, len = t.len;
         const float mean = stats[w].mean, scale = stats[w].scale;
-        const int n1 = (bx << 5) + c;
-        // sample index of element (row, n1): 2 (row N1 + n1) < 2^25 (Nc <= 2^24)
-        const int last = len - 2;
-        float2 v[16];
+        const int n1 = (t.bx << LOGW) + c;
+        // where the previous tile's outputs go: output k of thread j is row (a 256 +) j + 16 k, column n1; it sits in v[oreg(k)]
+        const ColK1Tile tp = col_k1_tile<SUB>(sw, prev >= 0 ? prev : tile, nbx, G);
+        float2 *outp = T + (size_t)tp.w * pl.Zs + (SUB ? (size_t)tp.a * ((size_t)256 * N1 + pl.zpad) : 0);
+        const unsigned int offp = 8u * (unsigned)(j * N1 + (tp.bx << LOGW) + c);
         {
             unsigned int raw[16];
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int i0 = 2 * ((a + G * (j + 16 * r)) * N1 + n1);
-                raw[r] = k1_fetch2(p, i0 < last ? i0 : last);
-            }
-            // boundary samples: lane L < 32 takes row r = L >> 1 of half-wave h = L & 1 (item j_b = (j & ~1) + h, column
-            // 32 bx): the sample before that element, if there is one inside the window
-            int ab;
-            {
-                const int jb = (j & ~1) + (lane & 1), rb = (lane & 31) >> 1;
-                const int ib = 2 * ((a + G * (jb + 16 * rb)) * N1 + (bx << 5)) - 1;
-                const unsigned int sb = p[ib >= 0 && ib < len ? ib : 0];
-                ab = k1_angle(sb, lut);
-            }
-            // rows are classified per wave (its two half-waves hold items jw and jw + 1 of every r): entirely inside the
-            // window -- no bounds selects, the common case --, entirely beyond it -- zero padding, nothing to look up
+            for (int r = 0; r < 16; r++) raw[r] = raw_next[r];
+            // boundary samples.  Narrow: lane L < 32 took row r = L >> 1 of half-wave h = L & 1 (item (j & ~1) + h);
+            // wide: lane L took row r = L & 15 of the wave's item
+            const int ab = WIDE ? k1_angle_quadrant<false, true>(k1_index_bytes(sb_next), ~sb_next, lut) : k1_angle<true>(sb_next, lut);
+            // rows are classified per wave (narrow: its two half-waves hold items jw and jw + 1 of every r): entirely inside
+            // the window -- no bounds selects, the common case --, entirely beyond it -- zero padding, nothing to look up
             // (40 % of the rows of a 10 s window in N = 2^25) --, or general
-            const int jw = __builtin_amdgcn_readfirstlane(j & ~1);
+            const int jw = __builtin_amdgcn_readfirstlane(WIDE ? j : j & ~1);
 #pragma unroll
             for (int r = 0; r < 16; r++) {
+                // The previous tile's output in v[r] leaves just before the register is needed again: the 16 stores of a
+                // thread go out one per ~60 instructions of discriminator work instead of as a burst at the end of a trip.
+                // (A burst from every wave of the CU at once fills the store queue and then holds all of them at the
+                // store instructions while it drains: leaving the stores out made the kernel 0.31 ms of 1.08 faster,
+                // although the memory system takes the same bytes in 0.43 ms as a plain fill.)
+                if (prev >= 0) store_at(outp + (size_t)(16 * oreg(r)) * N1, offp, v[r]);
                 const int i0 = 2 * ((a + G * (j + 16 * r)) * N1 + n1);
-                const int i_first = 2 * ((a + G * (jw + 16 * r)) * N1 + (bx << 5));
-                const int i_end = 2 * ((a + G * (jw + 1 + 16 * r)) * N1 + (bx << 5) + 32);      // one past the wave's last sample of this r
+                const int i_first = 2 * ((a + G * (jw + 16 * r)) * N1 + (t.bx << LOGW));
+                const int i_end = 2 * ((a + G * (jw + (WIDE ? 0 : 1) + 16 * r)) * N1 + (t.bx << LOGW) + W);      // one past the wave's last sample of this r
                 if (i_first >= len) {
                     v[r] = make_float2(0.0f, 0.0f);
                     continue;
                 }
-                int a0, a1;
-                k1_angle2(raw[r], lut, a0, a1);
-                const int left = wave_shift_right1(a1);        // the angle of sample 2m - 1 is the left lane's second angle
-                const int bnd = __shfl(ab, 2 * r + (lane >> 5), kWave);
-                const int ap = c ? left : bnd;
+                int a0, a1, ap;
+                if (WIDE) {
+                    k1_angle2_quadrant<true>(raw[r], lut, a0, a1);
+                    const int bnd = __builtin_amdgcn_readlane(ab, r);
+                    ap = __builtin_amdgcn_update_dpp(bnd, a1, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);      // lane 0 keeps bnd
+                } else {
+                    k1_angle2<true>(raw[r], lut, a0, a1);
+                    const int left = wave_shift_right1(a1);        // the angle of sample 2m - 1 is the left lane's second angle
+                    const int bnd = __shfl(ab, 2 * r + (lane >> 5), kWave);
+                    ap = c ? left : bnd;
+                }
                 if (i_first > 0 && i_end <= len) {
                     v[r] = make_float2(k1_normalise(k1_stored_code(a0, ap), mean, scale), k1_normalise(k1_stored_code(a1, a0), mean, scale));
                 } else {
-                    v[r] = k1_element(raw[r], ap, i0, len, mean, scale, lut, r == 0);     // (its two lookups are the ones above)
+                    v[r] = k1_element_from(a0, a1, ap, i0, len, mean, scale, r == 0);
                 }
             }
         }
+        // the capture bytes of the next tile: asked for now, used a whole transform later
+        __builtin_amdgcn_sched_barrier(0);
+        if (tile + (int)gridDim.x < n_tiles) {
+            const int tid2 = opaque_i((int)threadIdx.x), lane2 = tid2 & 63, j2 = tid2 >> LOGW;
+            col_k1_fetch<LOGW>(col_k1_tile<SUB>(sw, tile + gridDim.x, nbx, G), G, N1, j2, tid2 & (W - 1),
+                               WIDE ? j2 : (j2 & ~1) + (lane2 & 1), WIDE ? lane2 & 15 : (lane2 & 31) >> 1, raw_next, sb_next);
+        }
+        __builtin_amdgcn_sched_barrier(0);
         fft16<false>(v);
         // exchange through one float plane: real parts, then imaginary parts
 #pragma unroll
-        for (int k = 0; k < 16; k++) plane[((16 * j + k) << 5) + c] = v[oreg(k)].x;
+        for (int k = 0; k < 16; k++) plane[((16 * j + k) << LOGW) + c] = v[oreg(k)].x;
         __syncthreads();
 #pragma unroll
-        for (int r = 0; r < 16; r++) v[r].x = plane[((j + 16 * r) << 5) + c];      // .y still holds stage-1 outputs (oreg order)
+        for (int r = 0; r < 16; r++) v[r].x = plane[((j + 16 * r) << LOGW) + c];      // .y still holds stage-1 outputs (oreg order)
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < 16; k++) plane[((16 * j + k) << 5) + c] = v[oreg(k)].y;
+        for (int k = 0; k < 16; k++) plane[((16 * j + k) << LOGW) + c] = v[oreg(k)].y;
         __syncthreads();
 #pragma unroll
-        for (int r = 0; r < 16; r++) v[r].y = plane[((j + 16 * r) << 5) + c];
+        for (int r = 0; r < 16; r++) v[r].y = plane[((j + 16 * r) << LOGW) + c];
         __syncthreads();                                         // the next tile writes the plane again
         mul_powers16(v, unit_root((float)j, 2.0f / 256.0f, false));
         fft16<false>(v);
-        float2 *out = T + (size_t)w * pl.Nc;
-        // (the output offsets are 4 x the input sample indices of the same rows: rebuilt from a laundered n1 here, or the
-        // 16 load offsets stay alive through both transforms for the sake of one shift each -- and spill)
-        const int n1o = opaque_i(n1);
         if (SUB) {
             // Y_a[kb = j + 16k] *= W_(256G)^(a kb) = W^(a j) * (W^(16 a))^k
             const float invg = 2.0f / (float)pl.N2;
             if (a) mul_base_step16(v, unit_root((float)(a * j), invg, false), unit_root((float)(16 * a), invg, false));
-            __builtin_amdgcn_sched_barrier(0);                   // offsets are formed here, not during the transform
-#pragma unroll
-            for (int k = 0; k < 16; k++) store_at(out, 8u * (unsigned)((a * 256 + j + 16 * k) * N1 + opaque_i(n1o)), v[oreg(k)]);
         } else {
             // Y[k2 = j + 16k] *= W_Nc^(n1*k2) = W^(n1*j) * (W^(16*n1))^k
             const float inv2 = 2.0f / (float)pl.Nc;
             const int e0 = (n1 * j) & (int)(pl.Nc - 1);              // n1 j < 2^16, Nc <= 2^24
             const int e1 = (n1 * 16) & (int)(pl.Nc - 1);
             mul_base_step16(v, unit_root((float)e0, inv2, false), unit_root((float)e1, inv2, false));
-            __builtin_amdgcn_sched_barrier(0);                   // offsets are formed here, not during the transform
-#pragma unroll
-            for (int k = 0; k < 16; k++) store_at(out, 8u * (unsigned)((j + 16 * k) * N1 + opaque_i(n1o)), v[oreg(k)]);
         }
+        prev = tile;
+    }
+    if (prev >= 0) {                                             // the last tile of this workgroup
+        const int tid = opaque_i((int)threadIdx.x);
+        const ColK1Tile tp = col_k1_tile<SUB>(sw, prev, nbx, G);
+        float2 *outp = T + (size_t)tp.w * pl.Zs + (SUB ? (size_t)tp.a * ((size_t)256 * N1 + pl.zpad) : 0);
+        const unsigned int offp = 8u * (unsigned)((tid >> LOGW) * N1 + (tp.bx << LOGW) + (tid & (W - 1)));
+#pragma unroll
+        for (int r = 0; r < 16; r++) store_at(outp + (size_t)(16 * oreg(r)) * N1, offp, v[r]);
     }
 }
 
@@ -368,8 +435,8 @@ __global__ __launch_bounds__(256) void k_fwd_col_finish(float2 *T, FftPlan pl)
     static_assert(G == 8 || G == 16, "two-sweep column pass: N2 = 2048 or 4096");
     // a thread takes TWO adjacent columns (one 16-byte access per row): a workgroup moves 4 KB runs of each of its 16 rows
     const int n1 = ((blockIdx.x << 8) + threadIdx.x) * 2, kb = blockIdx.y;
-    float2 *base = T + (size_t)blockIdx.z * pl.Nc + (size_t)kb * pl.N1 + n1;
-    const size_t stride = (size_t)256 * pl.N1;
+    float2 *base = T + (size_t)blockIdx.z * pl.Zs + (size_t)kb * pl.N1 + n1;
+    const size_t stride = (size_t)256 * pl.N1 + pl.zpad;      // (zpad = 0: 27 % slower -- every row of the sum on one channel)
     typedef float f4v __attribute__((ext_vector_type(4)));
     float2 v[16], u[16];
 #pragma unroll
@@ -485,6 +552,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     extern __shared__ int lds_k1[];                             // the table at offset 0 (immediate offsets), then the planes
     int *lut = lds_k1;
     float *plane = reinterpret_cast<float *>(lds_k1 + kK1TableEntries);      // [F][256][C]
+    k1_assert_lds0(lut);
     k1_load_table(lut, table);
     const int N1 = pl.N1, nbx = N1 / C;
     const int n_tiles = n_sw * nbx;
@@ -514,7 +582,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             {
                 const int jb = (j & ~3) + (lane & 3), rb = lane >> 2;
                 const int ib = 2 * ((F * (jb + 16 * rb) + par) * N1 + bx * C) - 1;
-                ab = k1_angle(p[ib >= 0 && ib < len ? ib : 0], lut);
+                ab = k1_angle<true>(p[ib >= 0 && ib < len ? ib : 0], lut);
             }
             const int jw = __builtin_amdgcn_readfirstlane(j & ~3), pw = __builtin_amdgcn_readfirstlane(par);
 #pragma unroll
@@ -527,14 +595,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                     continue;
                 }
                 int a0, a1;
-                k1_angle2(raw[r], lut, a0, a1);
+                k1_angle2<true>(raw[r], lut, a0, a1);
                 const int left = wave_shift_right1(a1);
                 const int bnd = __shfl(ab, 4 * r + ((lane >> LOGC) & 3), kWave);
                 const int ap = c ? left : bnd;
                 if (i_first > 0 && i_end <= len)
                     v[r] = make_float2(k1_normalise(k1_stored_code(a0, ap), mean, scale), k1_normalise(k1_stored_code(a1, a0), mean, scale));
                 else
-                    v[r] = k1_element(raw[r], ap, i0, len, mean, scale, lut, r == 0);
+                    v[r] = k1_element_from(a0, a1, ap, i0, len, mean, scale, r == 0);
             }
         }
         fft16<false>(v);
@@ -781,10 +849,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SELF ? 1 : 
     }
     const PWDesc d = pw[pw_index];
     const int b = self ? N2 / 2 : N2 - a;
-    const float2 *ZaA = Z + (size_t)d.sw_a * pl.Nc + (size_t)a * 4096;
-    const float2 *ZaB = Z + (size_t)d.sw_a * pl.Nc + (size_t)b * 4096;
-    const float2 *ZbA = Z + (size_t)d.sw_b * pl.Nc + (size_t)a * 4096;
-    const float2 *ZbB = Z + (size_t)d.sw_b * pl.Nc + (size_t)b * 4096;
+    const float2 *ZaA = Z + (size_t)d.sw_a * pl.Zs + (size_t)a * 4096 + (size_t)(a >> 8) * pl.zpad;
+    const float2 *ZaB = Z + (size_t)d.sw_a * pl.Zs + (size_t)b * 4096 + (size_t)(b >> 8) * pl.zpad;
+    const float2 *ZbA = Z + (size_t)d.sw_b * pl.Zs + (size_t)a * 4096 + (size_t)(a >> 8) * pl.zpad;
+    const float2 *ZbB = Z + (size_t)d.sw_b * pl.Zs + (size_t)b * 4096 + (size_t)(b >> 8) * pl.zpad;
     const int t = threadIdx.x;
     const float invNc = 1.0f / (float)pl.Nc;
     float2 va[16], vb[16];

@@ -100,6 +100,11 @@ struct FftPlan {
     int N1, N2, logN1, logN2;   // Nc = N1*N2
     int C, logC;                // columns per tile in the column passes
     long long Nc;
+    // TZ layout of the radix-16 kernels: row k2 of a station-window starts at k2 N1 + (k2 >> 8) zpad, station-windows are Zs
+    // apart.  zpad > 0 only for the two-sweep column pass (N2 = 2048, 4096), whose second sweep combines rows that would
+    // otherwise lie exactly 256 N1 elements = 8 MB apart (k_fwd_col_finish); everywhere else zpad = 0 and Zs = Nc.
+    int zpad;
+    long long Zs;
 };
 
 // ---------------------------------------------------------------------------

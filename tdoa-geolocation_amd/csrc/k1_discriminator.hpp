@@ -36,6 +36,23 @@ constexpr int kK1Half = 1 << 23;                 // code units per half turn (pi
 constexpr int kK1TableEntries = 128 * 129 / 2;   // first-octant directions, mn <= mx
 constexpr size_t kK1TableBytes = sizeof(int) * kK1TableEntries;      // 33 024
 
+// Table read at byte offset `off`.  ABS0: the table is known to start at LDS address 0 (a kernel whose only LDS is its
+// dynamic segment; checked once per workgroup by k1_assert_lds0) -- the offset IS the address.  Otherwise the address is
+// lut + off, and since the base of a dynamic LDS segment is a link-time symbol that costs a `v_add_u32 v, 0, v` per read.
+template <bool ABS0>
+__device__ __forceinline__ int k1_table_read(const int *lut, unsigned int off)
+{
+#if defined(__HIP_DEVICE_COMPILE__)      // (an LDS pointer is 32 bits wide in the device pass only)
+    if (ABS0) return *__builtin_bit_cast(const __attribute__((address_space(3))) int *, off);
+#endif
+    return *reinterpret_cast<const int *>(reinterpret_cast<const char *>(lut) + off);
+}
+
+__device__ __forceinline__ void k1_assert_lds0(const int *lut)
+{
+    if ((unsigned int)(uintptr_t)(const __attribute__((address_space(3))) int *)lut != 0u) __builtin_trap();
+}
+
 // Angle code of an IQ sample (I = 2 b_I - 255, Q = 2 b_Q - 255) from the first-octant table, |code| < 2^23.
 // This runs once per sample of the capture inside kernels that are bound by vector-instruction issue (SQ counters:
 // 80 % VALU-busy), so the sequence is pinned in inline assembly: 17 instructions per sample, no compare, no select
@@ -47,7 +64,7 @@ constexpr size_t kK1TableBytes = sizeof(int) * kK1TableEntries;      // 33 024
 //   each placement step is  c -> K - c  under a condition, written  (c ^ m) + (m & (K + 1))  with m = 0 or -1:
 //   |Q| > |I|: K = 2^22;  I < 0: K = 2^23;  Q < 0: K = 0.
 // HI = false: the sample in the low half of the dword, true: the high half.
-template <bool HI>
+template <bool HI, bool ABS0 = false>
 __device__ __forceinline__ int k1_angle_from(unsigned int x, unsigned int neg, const int *lut)
 {
     unsigned int mx, mn, p, off;
@@ -64,7 +81,7 @@ __device__ __forceinline__ int k1_angle_from(unsigned int x, unsigned int neg, c
     asm("v_mad_u32_u24 %0, %1, %1, %1" : "=v"(p) : "v"(mx));                    // mx^2 + mx
     asm("v_lshlrev_b32 %0, 2, %1" : "=v"(mn) : "v"(mn));
     asm("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(off) : "v"(p), "v"(mn));         // byte offset 2 (mx^2 + mx) + 4 mn
-    c = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(lut) + off);
+    c = k1_table_read<ABS0>(lut, off);
     asm("v_ashrrev_i32 %0, 31, %1" : "=v"(msw) : "v"(d));                       // -1: |Q| > |I|
     asm("v_and_b32 %0, 0x400001, %1" : "=v"(k) : "v"(msw));
     asm("v_xad_u32 %0, %1, %2, %3" : "=v"(c) : "v"(c), "v"(msw), "v"(k));      // (c ^ m) + k
@@ -79,20 +96,58 @@ __device__ __forceinline__ int k1_angle_from(unsigned int x, unsigned int neg, c
     return c;
 }
 
+// The same from the QUADRANT table (128 x 128 entries, Tq[iq][ia] = angle of (2 ia + 1, 2 iq + 1), 64 KB): no min / max,
+// no |Q| > |I| reflection -- 11 instructions per sample instead of 17.  For kernels that can afford the 64 KB
+// (k_fwd_col256_k1w: one 1024-thread workgroup per CU).
+template <bool HI, bool ABS0 = false>
+__device__ __forceinline__ int k1_angle_quadrant(unsigned int x, unsigned int neg, const int *qlut)
+{
+    unsigned int oa, oq, off;
+    int k, mi, mq, c;
+    if (!HI) {
+        asm("v_lshlrev_b32_sdwa %0, 2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(oa) : "v"(x));
+        asm("v_lshlrev_b32_sdwa %0, 9, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(oq) : "v"(x));
+    } else {
+        asm("v_lshlrev_b32_sdwa %0, 2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(oa) : "v"(x));
+        asm("v_lshlrev_b32_sdwa %0, 9, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(oq) : "v"(x));
+    }
+    asm("v_or_b32 %0, %1, %2" : "=v"(off) : "v"(oa), "v"(oq));                    // byte offset 4 (128 iq + ia)
+    c = k1_table_read<ABS0>(qlut, off);
+    if (!HI) asm("v_bfe_i32 %0, %1, 7, 1" : "=v"(mi) : "v"(neg));               // -1: I < 0
+    else asm("v_bfe_i32 %0, %1, 23, 1" : "=v"(mi) : "v"(neg));
+    asm("v_and_b32 %0, 0x800001, %1" : "=v"(k) : "v"(mi));
+    asm("v_xad_u32 %0, %1, %2, %3" : "=v"(c) : "v"(c), "v"(mi), "v"(k));       // c -> 2^23 - c
+    if (!HI) asm("v_bfe_i32 %0, %1, 15, 1" : "=v"(mq) : "v"(neg));              // -1: Q < 0
+    else asm("v_ashrrev_i32 %0, 31, %1" : "=v"(mq) : "v"(neg));
+    asm("v_xor_b32 %0, %1, %2" : "=v"(c) : "v"(c), "v"(mq));
+    asm("v_sub_u32 %0, %1, %2" : "=v"(c) : "v"(c), "v"(mq));                    // c -> -c
+    return c;
+}
+
 __device__ __forceinline__ unsigned int k1_index_bytes(unsigned int w) { return w ^ (0x7f7f7f7fu + ((w >> 7) & 0x01010101u)); }
 
 // the two samples of a dword w = b_I0 | b_Q0 << 8 | b_I1 << 16 | b_Q1 << 24
+template <bool ABS0 = false>
 __device__ __forceinline__ void k1_angle2(unsigned int w, const int *lut, int &a0, int &a1)
 {
     const unsigned int x = k1_index_bytes(w), neg = ~w;
-    a0 = k1_angle_from<false>(x, neg, lut);
-    a1 = k1_angle_from<true>(x, neg, lut);
+    a0 = k1_angle_from<false, ABS0>(x, neg, lut);
+    a1 = k1_angle_from<true, ABS0>(x, neg, lut);
 }
 
 // one sample s = b_I | b_Q << 8
+template <bool ABS0 = false>
 __device__ __forceinline__ int k1_angle(unsigned int s, const int *lut)
 {
-    return k1_angle_from<false>(k1_index_bytes(s), ~s, lut);
+    return k1_angle_from<false, ABS0>(k1_index_bytes(s), ~s, lut);
+}
+
+template <bool ABS0 = false>
+__device__ __forceinline__ void k1_angle2_quadrant(unsigned int w, const int *qlut, int &a0, int &a1)
+{
+    const unsigned int x = k1_index_bytes(w), neg = ~w;
+    a0 = k1_angle_quadrant<false, ABS0>(x, neg, qlut);
+    a1 = k1_angle_quadrant<true, ABS0>(x, neg, qlut);
 }
 
 // The streaming K1 kernel (k_fm_demod) has the LDS to itself and keeps a DIRECT table instead: the point reflection
@@ -100,6 +155,8 @@ __device__ __forceinline__ int k1_angle(unsigned int s, const int *lut)
 // cover the half plane Q > 0: D[b_I | (b_Q & 0x7f) << 8] = a(I, Q) in (0, 2^23), b_Q >= 128  (128 KB, built by the host
 // from the same first-octant codes).  Lookup of the two samples of a dword: 11 instructions, against 2 x 17 above.
 // Returns the angle modulo 2^24 (in [0, 2^24)); only differences of angles are ever used.
+constexpr int kK1QuadrantEntries = 128 * 128;
+constexpr size_t kK1QuadrantBytes = sizeof(int) * kK1QuadrantEntries;     // 65 536
 constexpr int kK1DirectEntries = 32768;
 constexpr size_t kK1DirectBytes = sizeof(int) * kK1DirectEntries;      // 131 072
 

@@ -62,6 +62,8 @@ struct tdoa_ctx {
 
     DevBuf k1_table;                        // kK1TableEntries first-octant angle codes (k1_build_table_host)
     DevBuf k1_direct;                       // kK1DirectEntries half-plane angle codes of the streaming K1 kernel
+    DevBuf k1_quad;                         // kK1QuadrantEntries first-quadrant angle codes (k_fwd_col256_k1w)
+    bool col_k1w = true;                  // one 1024-thread workgroup per CU in the fused column pass (TDOA_COL_K1W=1)
     DevBuf sw_desc, pw_desc, partials, stats, codes, codes_lp, k1_power, tz, v, keys, scales, peaks, scratch_a, scratch_b, lagdump;
     DevBuf ex_a, ex_b, ex_c, ex_d, ex_part;
 
@@ -175,6 +177,9 @@ long long next_pow2(long long n)   // processor.go:502-512
 constexpr size_t kLdsCap = 128 * 1024;
 
 // factor Nc = N1 * N2 for the four-step FFT; rows (N1) live whole in LDS
+// elements of padding after every 256 rows of a two-sweep plan's TZ (4 KB)
+int g_zpad = [] { const char *e = std::getenv("TDOA_ZPAD"); return e ? std::atoi(e) : 512; }();
+
 int make_plan(long long n_real, bool packed, FftPlan *pl)
 {
     long long nc = packed ? n_real / 2 : n_real;
@@ -199,6 +204,8 @@ int make_plan(long long n_real, bool packed, FftPlan *pl)
     pl->C = (int)c;
     pl->logC = ilog2(c);
     pl->Nc = nc;
+    pl->zpad = n1 == 4096 && (n2 == 4096 || n2 == 2048) ? g_zpad : 0;      // two-sweep column pass (fft_stockham.hpp, FftPlan)
+    pl->Zs = nc + (long long)(n2 / 256) * pl->zpad;
     return TDOA_OK;
 }
 
@@ -267,7 +274,7 @@ void prof_collect(tdoa_ctx *ctx)
 // The K1 angle table (k1_discriminator.hpp): first-octant directions (mn, mx), index mx (mx + 1) / 2 + mn over the
 // indices of the odd magnitudes 2 idx + 1; entry = llround(atan2(mn', mx') 2^23 / pi) of the gcd-reduced pair, float64.
 // (oracle/tdoa_oracle.c: ob_octant_code states the same expression; tests compare the device's codes with it bit for bit)
-void k1_build_table_host(std::vector<int32_t> &tab, std::vector<int32_t> &direct)
+void k1_build_table_host(std::vector<int32_t> &tab, std::vector<int32_t> &direct, std::vector<int32_t> &quad)
 {
     tab.resize(kK1TableEntries);
     for (int mx = 0; mx < 128; mx++)
@@ -290,6 +297,14 @@ void k1_build_table_host(std::vector<int32_t> &tab, std::vector<int32_t> &direct
             if (iq > ia) c = (kK1Half >> 1) - c;
             if (bi < 128) c = kK1Half - c;
             direct[(size_t)bi | ((size_t)(bq & 0x7f) << 8)] = c;
+        }
+    // the first-quadrant table Q[iq][ia] = a(2 ia + 1, 2 iq + 1): the |Q| > |I| reflection done here instead of per sample
+    quad.resize(kK1QuadrantEntries);
+    for (int iq = 0; iq < 128; iq++)
+        for (int ia = 0; ia < 128; ia++) {
+            const int mx = std::max(ia, iq), mn = std::min(ia, iq);
+            const int c = tab[(size_t)mx * (mx + 1) / 2 + mn];
+            quad[(size_t)iq * 128 + ia] = iq > ia ? (kK1Half >> 1) - c : c;
         }
 }
 
@@ -457,7 +472,7 @@ int reserve_fm_batch(tdoa_ctx *ctx, int n_sw, int maxlen, int n_pw, const FftPla
         if (ctx->prm.k1_smooth > 1 && (rc = ensure(ctx, ctx->codes_lp, sizeof(int) * (size_t)code_stride * n_sw))) return rc;
     }
     if (ctx->prm.k1_gate && (rc = ensure(ctx, ctx->k1_power, sizeof(unsigned long long) * (size_t)n_sw))) return rc;
-    if ((rc = ensure(ctx, ctx->tz, sizeof(float2) * (size_t)pl.Nc * n_sw))) return rc;
+    if ((rc = ensure(ctx, ctx->tz, sizeof(float2) * (size_t)pl.Zs * n_sw))) return rc;
     if (n_pw && decimation_applies(ctx, pl, lag_lo, lag_hi) && (rc = ensure_decimation(ctx, pl, lag_lo, lag_hi))) return rc;
     size_t v_elems = (size_t)pl.Nc * n_pw;
     if (n_pw && decimation_applies(ctx, pl, lag_lo, lag_hi))      // G + V' of the pairs, then the tiled spectra of the stations
@@ -480,7 +495,7 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
     const long long code_stride = ((long long)maxlen + 15) / 8 * 8;      // rows stay 16-byte aligned
     if ((rc = ensure(ctx, ctx->partials, sizeof(StatsPartial) * (size_t)n_sw))) return rc;
     if ((rc = ensure(ctx, ctx->stats, sizeof(FmStats) * (size_t)n_sw))) return rc;
-    if ((rc = ensure(ctx, ctx->tz, sizeof(float2) * (size_t)pl.Nc * n_sw))) return rc;
+    if ((rc = ensure(ctx, ctx->tz, sizeof(float2) * (size_t)pl.Zs * n_sw))) return rc;
     if ((rc = reserve_fm_batch(ctx, n_sw, maxlen, n_pw, pl, lag_lo, lag_hi, allow_fused_k1))) return rc;
     auto *stats = static_cast<FmStats *>(ctx->stats.p);
     const int *codes = nullptr;
@@ -556,11 +571,23 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
         // two-sweep column pass (N2 = 2048, 4096): 8 Nc written, read and written again -- SURVEY's third pass
         ProfScope ps(ctx, TDOA_K_FWD_COL, (fused_k1 ? 2.0 : 4.0) * sum_len + (col2pass ? 3.0 : 1.0) * nc8 * n_sw);
         const auto *table = static_cast<const int *>(ctx->k1_table.p);
-        if (fused_k1 && col16)
-            hipLaunchKernelGGL(k_fwd_col256_k1<false>, dim3(2 * ctx->n_cu), dim3(512), kColK1Lds, st, d_sw, table, stats, tz, pl,
+        const auto *qtable = static_cast<const int *>(ctx->k1_quad.p);
+        if (fused_k1 && col16 && ctx->col_k1w)
+            hipLaunchKernelGGL((k_fwd_col256_k1<false, true>), dim3(ctx->n_cu), dim3(1024), kColK1wLds, st, d_sw, qtable, stats, tz, pl,
+                               n_sw);
+        else if (fused_k1 && col2pass && ctx->col_k1w) {
+            hipLaunchKernelGGL((k_fwd_col256_k1<true, true>), dim3(ctx->n_cu), dim3(1024), kColK1wLds, st, d_sw, qtable, stats, tz, pl,
+                               n_sw);
+            if (pl.N2 == 4096)
+                hipLaunchKernelGGL(k_fwd_col_finish<16>, dim3(pl.N1 / 512, 256, n_sw), dim3(256), 0, st, tz, pl);
+            else
+                hipLaunchKernelGGL(k_fwd_col_finish<8>, dim3(pl.N1 / 512, 256, n_sw), dim3(256), 0, st, tz, pl);
+        }
+        else if (fused_k1 && col16)
+            hipLaunchKernelGGL((k_fwd_col256_k1<false, false>), dim3(2 * ctx->n_cu), dim3(512), kColK1Lds, st, d_sw, table, stats, tz, pl,
                                n_sw);
         else if (fused_k1 && col2pass) {
-            hipLaunchKernelGGL(k_fwd_col256_k1<true>, dim3(2 * ctx->n_cu), dim3(512), kColK1Lds, st, d_sw, table, stats, tz, pl,
+            hipLaunchKernelGGL((k_fwd_col256_k1<true, false>), dim3(2 * ctx->n_cu), dim3(512), kColK1Lds, st, d_sw, table, stats, tz, pl,
                                n_sw);
             if (pl.N2 == 4096)
                 hipLaunchKernelGGL(k_fwd_col_finish<16>, dim3(pl.N1 / 512, 256, n_sw), dim3(256), 0, st, tz, pl);
@@ -766,9 +793,11 @@ int allow_big_lds(tdoa_ctx *ctx)
     const size_t all = 136 * 1024;   // largest dynamic request: 128 KiB (kLdsCap tiles, generic row pair); static LDS comes on top
     if ((rc = set_lds(ctx, k_fm_demod<true>, all))) return rc;
     if ((rc = set_lds(ctx, k_fm_demod<false>, all))) return rc;
-    if ((rc = set_lds(ctx, k_fwd_col256_k1<false>, all))) return rc;
-    if ((rc = set_lds(ctx, k_fwd_col256_k1<true>, all))) return rc;
+    if ((rc = set_lds(ctx, (k_fwd_col256_k1<false, false>), all))) return rc;
+    if ((rc = set_lds(ctx, (k_fwd_col256_k1<true, false>), all))) return rc;
     if ((rc = set_lds(ctx, k_fwd_col512_k1, all))) return rc;
+    if ((rc = set_lds(ctx, (k_fwd_col256_k1<false, true>), all))) return rc;
+    if ((rc = set_lds(ctx, (k_fwd_col256_k1<true, true>), all))) return rc;
     if ((rc = set_lds(ctx, k_fwd_col_c16, all))) return rc;
     if ((rc = set_lds(ctx, k_fwd_row, all))) return rc;
     if ((rc = set_lds(ctx, k_inv_row_pair, all))) return rc;
@@ -1029,16 +1058,23 @@ int tdoa_create(const tdoa_params *p, tdoa_ctx **out)
         }
         ctx->k1_table.p = t;
         ctx->k1_table.cap = kK1TableBytes;
-        std::vector<int32_t> tab, direct;
-        k1_build_table_host(tab, direct);
-        void *dt = nullptr;
+        std::vector<int32_t> tab, direct, quad;
+        k1_build_table_host(tab, direct, quad);
+        void *dt = nullptr, *dq = nullptr;
         if (hipMalloc(&dt, kK1DirectBytes) != hipSuccess) {
             tdoa_destroy(ctx);
             return TDOA_ERR_NOMEM;
         }
         ctx->k1_direct.p = dt;
         ctx->k1_direct.cap = kK1DirectBytes;
+        if (hipMalloc(&dq, kK1QuadrantBytes) != hipSuccess) {
+            tdoa_destroy(ctx);
+            return TDOA_ERR_NOMEM;
+        }
+        ctx->k1_quad.p = dq;
+        ctx->k1_quad.cap = kK1QuadrantBytes;
         if (hipMemcpy(t, tab.data(), kK1TableBytes, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(dq, quad.data(), kK1QuadrantBytes, hipMemcpyHostToDevice) != hipSuccess ||
             hipMemcpy(dt, direct.data(), kK1DirectBytes, hipMemcpyHostToDevice) != hipSuccess) {
             tdoa_destroy(ctx);
             return TDOA_ERR_HIP;
@@ -1046,6 +1082,7 @@ int tdoa_create(const tdoa_params *p, tdoa_ctx **out)
     }
     // run-time switches are read ONCE here (a captured graph must not depend on an environment that changes later)
     if (const char *e = std::getenv("TDOA_NO_GRAPH")) ctx->use_graph = !(e[0] == '1');
+    if (const char *e = std::getenv("TDOA_COL_K1W")) ctx->col_k1w = e[0] == '1';
     if (const char *e = std::getenv("TDOA_NO_SHORT_LAG")) ctx->short_lag = !(e[0] == '1');
     if (const char *e = std::getenv("TDOA_NO_SEGMENT_FORM")) ctx->segment_form = !(e[0] == '1');
     if (const char *e = std::getenv("TDOA_NO_SEGMENT_QUADS")) ctx->segment_quads = !(e[0] == '1');
@@ -1068,7 +1105,7 @@ void tdoa_destroy(tdoa_ctx *ctx)
     if (ctx->graph_exec) (void)hipGraphExecDestroy(ctx->graph_exec);
     if (ctx->graph) (void)hipGraphDestroy(ctx->graph);
     tdoa_capture_clear(ctx);
-    DevBuf *bufs[] = {&ctx->k1_table, &ctx->k1_direct, &ctx->sw_desc, &ctx->pw_desc, &ctx->partials, &ctx->stats, &ctx->codes, &ctx->codes_lp, &ctx->k1_power, &ctx->dec_taps, &ctx->dec_gain, &ctx->tz, &ctx->v, &ctx->keys,
+    DevBuf *bufs[] = {&ctx->k1_table, &ctx->k1_direct, &ctx->k1_quad, &ctx->sw_desc, &ctx->pw_desc, &ctx->partials, &ctx->stats, &ctx->codes, &ctx->codes_lp, &ctx->k1_power, &ctx->dec_taps, &ctx->dec_gain, &ctx->tz, &ctx->v, &ctx->keys,
                       &ctx->scales, &ctx->peaks, &ctx->scratch_a, &ctx->scratch_b, &ctx->lagdump,
                       &ctx->ex_a, &ctx->ex_b, &ctx->ex_c, &ctx->ex_d, &ctx->ex_part,
                       &ctx->g_sw_desc, &ctx->g_pw_desc, &ctx->g_quad_desc, &ctx->g_scales, &ctx->g_keys, &ctx->fine_raw, &ctx->fine, &ctx->qual};
