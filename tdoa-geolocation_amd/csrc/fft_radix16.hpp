@@ -234,6 +234,7 @@ __device__ __forceinline__ void store_at(float2 *base, unsigned int byte_off, fl
 // One element from the angle codes (a0, a1) of the dword its thread fetched at sample index min(2m, len - 2) (never beyond
 // the window) and the angle code `ap` of sample 2m - 1.  Returns the normalised pair; `a1` = angle of the element's LAST valid sample (what
 // the lane to the right needs).  head: m may be 0 (code_0 := code_1).  len >= 2.
+template <bool SCALED = false>
 __device__ __forceinline__ float2 k1_element_from(int a0, int a1, int ap, int i0, int len, float mean, float scale, bool head)
 {
     if (len & 1) {                       // wave-uniform: only then can a last element hold ONE sample (2m + 1 = len);
@@ -242,8 +243,8 @@ __device__ __forceinline__ float2 k1_element_from(int a0, int a1, int ap, int i0
             a0 = a1;
         }
     }
-    const int st1 = k1_stored_code(a1, a0);
-    const int st0 = head && i0 == 0 ? st1 : k1_stored_code(a0, ap);
+    const int st1 = SCALED ? k1_stored_code_scaled(a1, a0) : k1_stored_code(a1, a0);
+    const int st0 = head && i0 == 0 ? st1 : SCALED ? k1_stored_code_scaled(a0, ap) : k1_stored_code(a0, ap);
     const float v0 = k1_normalise(st0, mean, scale), v1 = k1_normalise(st1, mean, scale);
     return make_float2(i0 < len ? v0 : 0.0f, i0 + 1 < len ? v1 : 0.0f);
 }
@@ -260,6 +261,18 @@ __device__ __forceinline__ float2 k1_element_from(int a0, int a1, int ap, int i0
 // to be acknowledged -- with the stores at the end of the trip that was 0.3 of the kernel's 1.08 ms (measured by leaving
 // the stores out: 0.77 ms); with the loads ahead of them in the queue the stores have a whole trip to drain.
 constexpr size_t kColK1wLds = kK1QuadrantBytes + sizeof(float) * 256 * 64;
+
+// Which tile a workgroup takes as its seq-th: workgroups go to the XCDs round-robin (seq % 8, the grid is a multiple of 8).
+// A window may start on any 2-byte boundary, in which case the 256-byte row pieces of adjacent column blocks share a cache
+// line at either end (and the boundary sample always is the last one of the block before): dealt out in sequence,
+// adjacent blocks would always meet in DIFFERENT L2s.  Instead XCD x takes the blocks [x nbx/8, (x + 1) nbx/8) of a row
+// group, its 32 workgroups neighbouring blocks at the same time.  (Line-aligned windows -- cfg2 -- are indifferent to
+// the order.)  nbx = 64 here; a bijection of [0, n_tiles) for any grid.
+__device__ __forceinline__ int col_k1_order(int seq, int nbx)
+{
+    const int per = nbx >> 3, x = seq & 7, q = seq >> 3;
+    return (q / per) * nbx + x * per + q % per;
+}
 
 struct ColK1Tile {        // what a trip needs to know about its tile (all wave-uniform)
     int bx, a, w, len;
@@ -295,14 +308,14 @@ __device__ __forceinline__ void col_k1_fetch(const ColK1Tile &t, int G, int N1, 
     sb = t.p[ib >= 0 && ib < t.len ? ib : 0];                                        // if the window has one
 }
 
-template <bool SUB, bool WIDE>
-__global__ __launch_bounds__(WIDE ? 1024 : 512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_fwd_col256_k1(const SWDesc *__restrict__ sw, const int *__restrict__ table, const FmStats *__restrict__ stats, float2 *__restrict__ T,
+template <bool SUB>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_fwd_col256_k1(const SWDesc *__restrict__ sw, const int *__restrict__ table, const FmStats *__restrict__ stats, float2 *__restrict__ T,
                                                        FftPlan pl, int n_sw)
 {
-    constexpr int LOGW = WIDE ? 6 : 5, W = 1 << LOGW;
+    constexpr int LOGW = 6, W = 1 << LOGW;                      // 64 columns per tile
     extern __shared__ int lds_k1[];                             // the table at offset 0 (the offset IS the address), then the plane
     int *lut = lds_k1;
-    float *plane = reinterpret_cast<float *>(lds_k1 + (WIDE ? kK1QuadrantEntries : kK1TableEntries));      // [256][W]
+    float *plane = reinterpret_cast<float *>(lds_k1 + kK1QuadrantEntries);      // [256][W]
     k1_assert_lds0(lut);
     const int G = SUB ? pl.N2 >> 8 : 1;
     const int N1 = pl.N1, nbx = N1 >> LOGW;
@@ -311,24 +324,26 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512) __attribute__((amdgpu_waves_per_
     unsigned int raw_next[16], sb_next = 0;
     if ((int)blockIdx.x < n_tiles) {
         const int tid = threadIdx.x, lane = tid & 63, j = tid >> LOGW;
-        col_k1_fetch<LOGW>(col_k1_tile<SUB>(sw, blockIdx.x, nbx, G), G, N1, j, tid & (W - 1),
-                           WIDE ? j : (j & ~1) + (lane & 1), WIDE ? lane & 15 : (lane & 31) >> 1, raw_next, sb_next);
+        col_k1_fetch<LOGW>(col_k1_tile<SUB>(sw, col_k1_order(blockIdx.x, nbx), nbx, G), G, N1, j, tid & (W - 1),
+                           j, lane & 15, raw_next, sb_next);
     }
-    for (int k = threadIdx.x; k < (WIDE ? kK1QuadrantEntries : kK1TableEntries); k += blockDim.x) lut[k] = table[k];
+    for (int k = threadIdx.x; k < kK1QuadrantEntries; k += blockDim.x) lut[k] = table[k];
     __syncthreads();
+    const float2 wj = unit_root((float)(threadIdx.x >> LOGW), 2.0f / 256.0f, false);      // W_256^j: the thread's item never changes
     float2 v[16];                                                // the previous tile's outputs until they are stored (below)
 #pragma unroll
     for (int r = 0; r < 16; r++) v[r] = make_float2(0.0f, 0.0f);
     int prev = -1;
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    for (int seq = blockIdx.x; seq < n_tiles; seq += gridDim.x) {
+        const int tile = col_k1_order(seq, nbx);
         // (laundered per tile: the row / plane / output addresses derived from the thread index are rebuilt inside the
         // trip -- hoisted out of this loop as ~80 invariants they spilled 112 VGPRs)
         const int tid = opaque_i((int)threadIdx.x);
-        const int lane = tid & 63;
         const int c = tid & (W - 1), j = tid >> LOGW;          // column, item (0..15)
         const ColK1Tile t = col_k1_tile<SUB>(sw, tile, nbx, G);
         const int a = t.a, w = t.w, len = t.len;
-        const float mean = stats[w].mean, scale = stats[w].scale;
+        // (the quadrant table's angle codes are scaled by 256 -- so are the mean and, inversely, the scale: exact)
+        const float mean = stats[w].mean * 256.0f, scale = stats[w].scale * 0.00390625f;
         const int n1 = (t.bx << LOGW) + c;
         // where the previous tile's outputs go: output k of thread j is row (a 256 +) j + 16 k, column n1; it sits in v[oreg(k)]
         const ColK1Tile tp = col_k1_tile<SUB>(sw, prev >= 0 ? prev : tile, nbx, G);
@@ -338,13 +353,12 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512) __attribute__((amdgpu_waves_per_
             unsigned int raw[16];
 #pragma unroll
             for (int r = 0; r < 16; r++) raw[r] = raw_next[r];
-            // boundary samples.  Narrow: lane L < 32 took row r = L >> 1 of half-wave h = L & 1 (item (j & ~1) + h);
-            // wide: lane L took row r = L & 15 of the wave's item
-            const int ab = WIDE ? k1_angle_quadrant<false, true>(k1_index_bytes(sb_next), ~sb_next, lut) : k1_angle<true>(sb_next, lut);
-            // rows are classified per wave (narrow: its two half-waves hold items jw and jw + 1 of every r): entirely inside
-            // the window -- no bounds selects, the common case --, entirely beyond it -- zero padding, nothing to look up
-            // (40 % of the rows of a 10 s window in N = 2^25) --, or general
-            const int jw = __builtin_amdgcn_readfirstlane(WIDE ? j : j & ~1);
+            // boundary samples: lane L took row r = L & 15 of the wave's item
+            const int ab = k1_angle_quadrant<false, true>(k1_index_bytes(sb_next), ~sb_next, lut);
+            // rows are classified per wave (it holds item j of every r): entirely inside the window -- no bounds selects,
+            // the common case --, entirely beyond it -- zero padding, nothing to look up (40 % of the rows of a 10 s window
+            // in N = 2^25) --, or general
+            const int jw = __builtin_amdgcn_readfirstlane(j);
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 // The previous tile's output in v[r] leaves just before the register is needed again: the 16 stores of a
@@ -355,35 +369,30 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512) __attribute__((amdgpu_waves_per_
                 if (prev >= 0) store_at(outp + (size_t)(16 * oreg(r)) * N1, offp, v[r]);
                 const int i0 = 2 * ((a + G * (j + 16 * r)) * N1 + n1);
                 const int i_first = 2 * ((a + G * (jw + 16 * r)) * N1 + (t.bx << LOGW));
-                const int i_end = 2 * ((a + G * (jw + (WIDE ? 0 : 1) + 16 * r)) * N1 + (t.bx << LOGW) + W);      // one past the wave's last sample of this r
+                const int i_end = i_first + 2 * W;                                                   // one past the wave's last sample of this r
                 if (i_first >= len) {
                     v[r] = make_float2(0.0f, 0.0f);
                     continue;
                 }
-                int a0, a1, ap;
-                if (WIDE) {
-                    k1_angle2_quadrant<true>(raw[r], lut, a0, a1);
-                    const int bnd = __builtin_amdgcn_readlane(ab, r);
-                    ap = __builtin_amdgcn_update_dpp(bnd, a1, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);      // lane 0 keeps bnd
-                } else {
-                    k1_angle2<true>(raw[r], lut, a0, a1);
-                    const int left = wave_shift_right1(a1);        // the angle of sample 2m - 1 is the left lane's second angle
-                    const int bnd = __shfl(ab, 2 * r + (lane >> 5), kWave);
-                    ap = c ? left : bnd;
-                }
+                int a0, a1;
+                k1_angle2_quadrant<true>(raw[r], lut, a0, a1);
+                // the angle of sample 2m - 1 is the left lane's second angle; lane 0 keeps `old` = the boundary sample's
+                const int bnd = __builtin_amdgcn_readlane(ab, r);
+                const int ap = __builtin_amdgcn_update_dpp(bnd, a1, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
                 if (i_first > 0 && i_end <= len) {
-                    v[r] = make_float2(k1_normalise(k1_stored_code(a0, ap), mean, scale), k1_normalise(k1_stored_code(a1, a0), mean, scale));
+                    const int st0 = k1_stored_code_scaled(a0, ap), st1 = k1_stored_code_scaled(a1, a0);
+                    v[r] = make_float2(k1_normalise(st0, mean, scale), k1_normalise(st1, mean, scale));
                 } else {
-                    v[r] = k1_element_from(a0, a1, ap, i0, len, mean, scale, r == 0);
+                    v[r] = k1_element_from<true>(a0, a1, ap, i0, len, mean, scale, r == 0);
                 }
             }
         }
         // the capture bytes of the next tile: asked for now, used a whole transform later
         __builtin_amdgcn_sched_barrier(0);
-        if (tile + (int)gridDim.x < n_tiles) {
+        if (seq + (int)gridDim.x < n_tiles) {
             const int tid2 = opaque_i((int)threadIdx.x), lane2 = tid2 & 63, j2 = tid2 >> LOGW;
-            col_k1_fetch<LOGW>(col_k1_tile<SUB>(sw, tile + gridDim.x, nbx, G), G, N1, j2, tid2 & (W - 1),
-                               WIDE ? j2 : (j2 & ~1) + (lane2 & 1), WIDE ? lane2 & 15 : (lane2 & 31) >> 1, raw_next, sb_next);
+            col_k1_fetch<LOGW>(col_k1_tile<SUB>(sw, col_k1_order(seq + gridDim.x, nbx), nbx, G), G, N1, j2, tid2 & (W - 1),
+                               j2, lane2 & 15, raw_next, sb_next);
         }
         __builtin_amdgcn_sched_barrier(0);
         fft16<false>(v);
@@ -400,7 +409,7 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512) __attribute__((amdgpu_waves_per_
 #pragma unroll
         for (int r = 0; r < 16; r++) v[r].y = plane[((j + 16 * r) << LOGW) + c];
         __syncthreads();                                         // the next tile writes the plane again
-        mul_powers16(v, unit_root((float)j, 2.0f / 256.0f, false));
+        mul_powers16(v, opaque(wj));                             // (laundered: its 15 powers are rebuilt per tile, not kept)
         fft16<false>(v);
         if (SUB) {
             // Y_a[kb = j + 16k] *= W_(256G)^(a kb) = W^(a j) * (W^(16 a))^k

@@ -98,7 +98,10 @@ __device__ __forceinline__ int k1_angle_from(unsigned int x, unsigned int neg, c
 
 // The same from the QUADRANT table (128 x 128 entries, Tq[iq][ia] = angle of (2 ia + 1, 2 iq + 1), 64 KB): no min / max,
 // no |Q| > |I| reflection -- 11 instructions per sample instead of 17.  For kernels that can afford the 64 KB
-// (k_fwd_col256_k1w: one 1024-thread workgroup per CU).
+// (k_fwd_col256_k1: one 1024-thread workgroup per CU).  The quadrant table holds the angle codes SCALED BY 256 (a full
+// turn = 2^32): a difference of two scaled angles wraps in the 32-bit subtraction itself, so k1_stored_code's sign
+// extension of 24 bits disappears (k1_stored_code_scaled); 256 x code is still exact in a float32 and the factor is
+// divided out with the window's scale (k1_normalise_scaled: bit-identical results).
 template <bool HI, bool ABS0 = false>
 __device__ __forceinline__ int k1_angle_quadrant(unsigned int x, unsigned int neg, const int *qlut)
 {
@@ -115,8 +118,8 @@ __device__ __forceinline__ int k1_angle_quadrant(unsigned int x, unsigned int ne
     c = k1_table_read<ABS0>(qlut, off);
     if (!HI) asm("v_bfe_i32 %0, %1, 7, 1" : "=v"(mi) : "v"(neg));               // -1: I < 0
     else asm("v_bfe_i32 %0, %1, 23, 1" : "=v"(mi) : "v"(neg));
-    asm("v_and_b32 %0, 0x800001, %1" : "=v"(k) : "v"(mi));
-    asm("v_xad_u32 %0, %1, %2, %3" : "=v"(c) : "v"(c), "v"(mi), "v"(k));       // c -> 2^23 - c
+    asm("v_and_b32 %0, 0x80000001, %1" : "=v"(k) : "v"(mi));
+    asm("v_xad_u32 %0, %1, %2, %3" : "=v"(c) : "v"(c), "v"(mi), "v"(k));       // c -> 2^31 - c (half a turn of the scaled code)
     if (!HI) asm("v_bfe_i32 %0, %1, 15, 1" : "=v"(mq) : "v"(neg));              // -1: Q < 0
     else asm("v_ashrrev_i32 %0, 31, %1" : "=v"(mq) : "v"(neg));
     asm("v_xor_b32 %0, %1, %2" : "=v"(c) : "v"(c), "v"(mq));
@@ -190,6 +193,9 @@ __device__ __forceinline__ int k1_stored_code(int a_cur, int a_prev)
 {
     return (int)((unsigned int)(a_prev - a_cur) << 8) >> 8;        // v_bfe_i32: sign-extend the low 24 bits
 }
+
+// the same from angle codes scaled by 256 (quadrant table): 256 x stored, by the wrap of the subtraction
+__device__ __forceinline__ int k1_stored_code_scaled(int a_cur, int a_prev) { return (int)((unsigned int)a_prev - (unsigned int)a_cur); }
 
 // normalised discriminator sample from a STORED code: (float(code) - mean) * scale with code = -stored
 __device__ __forceinline__ float k1_normalise(int stored, float mean, float scale)

@@ -62,8 +62,7 @@ struct tdoa_ctx {
 
     DevBuf k1_table;                        // kK1TableEntries first-octant angle codes (k1_build_table_host)
     DevBuf k1_direct;                       // kK1DirectEntries half-plane angle codes of the streaming K1 kernel
-    DevBuf k1_quad;                         // kK1QuadrantEntries first-quadrant angle codes (k_fwd_col256_k1w)
-    bool col_k1w = true;                  // one 1024-thread workgroup per CU in the fused column pass (TDOA_COL_K1W=1)
+    DevBuf k1_quad;                         // kK1QuadrantEntries first-quadrant angle codes (k_fwd_col256_k1)
     DevBuf sw_desc, pw_desc, partials, stats, codes, codes_lp, k1_power, tz, v, keys, scales, peaks, scratch_a, scratch_b, lagdump;
     DevBuf ex_a, ex_b, ex_c, ex_d, ex_part;
 
@@ -304,7 +303,7 @@ void k1_build_table_host(std::vector<int32_t> &tab, std::vector<int32_t> &direct
         for (int ia = 0; ia < 128; ia++) {
             const int mx = std::max(ia, iq), mn = std::min(ia, iq);
             const int c = tab[(size_t)mx * (mx + 1) / 2 + mn];
-            quad[(size_t)iq * 128 + ia] = iq > ia ? (kK1Half >> 1) - c : c;
+            quad[(size_t)iq * 128 + ia] = (iq > ia ? (kK1Half >> 1) - c : c) * 256;      // scaled: a full turn = 2^32
         }
 }
 
@@ -572,22 +571,11 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
         ProfScope ps(ctx, TDOA_K_FWD_COL, (fused_k1 ? 2.0 : 4.0) * sum_len + (col2pass ? 3.0 : 1.0) * nc8 * n_sw);
         const auto *table = static_cast<const int *>(ctx->k1_table.p);
         const auto *qtable = static_cast<const int *>(ctx->k1_quad.p);
-        if (fused_k1 && col16 && ctx->col_k1w)
-            hipLaunchKernelGGL((k_fwd_col256_k1<false, true>), dim3(ctx->n_cu), dim3(1024), kColK1wLds, st, d_sw, qtable, stats, tz, pl,
-                               n_sw);
-        else if (fused_k1 && col2pass && ctx->col_k1w) {
-            hipLaunchKernelGGL((k_fwd_col256_k1<true, true>), dim3(ctx->n_cu), dim3(1024), kColK1wLds, st, d_sw, qtable, stats, tz, pl,
-                               n_sw);
-            if (pl.N2 == 4096)
-                hipLaunchKernelGGL(k_fwd_col_finish<16>, dim3(pl.N1 / 512, 256, n_sw), dim3(256), 0, st, tz, pl);
-            else
-                hipLaunchKernelGGL(k_fwd_col_finish<8>, dim3(pl.N1 / 512, 256, n_sw), dim3(256), 0, st, tz, pl);
-        }
-        else if (fused_k1 && col16)
-            hipLaunchKernelGGL((k_fwd_col256_k1<false, false>), dim3(2 * ctx->n_cu), dim3(512), kColK1Lds, st, d_sw, table, stats, tz, pl,
+        if (fused_k1 && col16)
+            hipLaunchKernelGGL(k_fwd_col256_k1<false>, dim3(ctx->n_cu), dim3(1024), kColK1wLds, st, d_sw, qtable, stats, tz, pl,
                                n_sw);
         else if (fused_k1 && col2pass) {
-            hipLaunchKernelGGL((k_fwd_col256_k1<true, false>), dim3(2 * ctx->n_cu), dim3(512), kColK1Lds, st, d_sw, table, stats, tz, pl,
+            hipLaunchKernelGGL(k_fwd_col256_k1<true>, dim3(ctx->n_cu), dim3(1024), kColK1wLds, st, d_sw, qtable, stats, tz, pl,
                                n_sw);
             if (pl.N2 == 4096)
                 hipLaunchKernelGGL(k_fwd_col_finish<16>, dim3(pl.N1 / 512, 256, n_sw), dim3(256), 0, st, tz, pl);
@@ -793,11 +781,9 @@ int allow_big_lds(tdoa_ctx *ctx)
     const size_t all = 136 * 1024;   // largest dynamic request: 128 KiB (kLdsCap tiles, generic row pair); static LDS comes on top
     if ((rc = set_lds(ctx, k_fm_demod<true>, all))) return rc;
     if ((rc = set_lds(ctx, k_fm_demod<false>, all))) return rc;
-    if ((rc = set_lds(ctx, (k_fwd_col256_k1<false, false>), all))) return rc;
-    if ((rc = set_lds(ctx, (k_fwd_col256_k1<true, false>), all))) return rc;
     if ((rc = set_lds(ctx, k_fwd_col512_k1, all))) return rc;
-    if ((rc = set_lds(ctx, (k_fwd_col256_k1<false, true>), all))) return rc;
-    if ((rc = set_lds(ctx, (k_fwd_col256_k1<true, true>), all))) return rc;
+    if ((rc = set_lds(ctx, k_fwd_col256_k1<false>, all))) return rc;
+    if ((rc = set_lds(ctx, k_fwd_col256_k1<true>, all))) return rc;
     if ((rc = set_lds(ctx, k_fwd_col_c16, all))) return rc;
     if ((rc = set_lds(ctx, k_fwd_row, all))) return rc;
     if ((rc = set_lds(ctx, k_inv_row_pair, all))) return rc;
@@ -1082,7 +1068,6 @@ int tdoa_create(const tdoa_params *p, tdoa_ctx **out)
     }
     // run-time switches are read ONCE here (a captured graph must not depend on an environment that changes later)
     if (const char *e = std::getenv("TDOA_NO_GRAPH")) ctx->use_graph = !(e[0] == '1');
-    if (const char *e = std::getenv("TDOA_COL_K1W")) ctx->col_k1w = e[0] == '1';
     if (const char *e = std::getenv("TDOA_NO_SHORT_LAG")) ctx->short_lag = !(e[0] == '1');
     if (const char *e = std::getenv("TDOA_NO_SEGMENT_FORM")) ctx->segment_form = !(e[0] == '1');
     if (const char *e = std::getenv("TDOA_NO_SEGMENT_QUADS")) ctx->segment_quads = !(e[0] == '1');

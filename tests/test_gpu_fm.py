@@ -222,6 +222,28 @@ def test_long_windows_vs_f64_fft(oracle, n, delay, label):
             _assert_lags_close(c.fm_xcorr_lags(a, b, 20000), hot)
 
 
+def test_two_sweep_plan_padded_rows_in_every_form(oracle):
+    """N = 2^24 (4096 x 2048): TZ rows of a two-sweep plan are padded after every 256 rows (FftPlan.zpad); every kernel
+    family that reads them -- general inverse, short-lag rows (3000 lags), the same from materialised codes -- must agree
+    with the f64 oracle and with each other"""
+    import tdoa_amd
+    n, delay = 9_000_000, 1234
+    a = oracle.simulate_delayed_fm(n, 0, 77, 1)
+    b = oracle.simulate_delayed_fm(n, delay, 77, 2)
+    ta, _ = oracle.b_preprocess(a)
+    tb, _ = oracle.b_preprocess(b)
+    olag, ocorr, want = oracle.b_xcorr_peak_fft(ta, tb, 3000)
+    assert olag == delay
+    with tdoa_amd.Context() as c:
+        lags = c.fm_xcorr_lags(a, b, 3000)                   # short-lag form (k_inv_row_pair4096<*, 8>)
+        assert tuple(c.plan_info())[1:] == (4096, 2048)
+        _assert_lags_close(lags, want)
+        c.debug_flags(no_short_lag=True)                      # general inverse + pruned column pass
+        _assert_lags_close(c.fm_xcorr_lags(a, b, 3000), lags)
+        c.debug_flags(no_fused_k1=True)                       # k_fwd_col256_c16<true> writes the padded rows
+        _assert_lags_close(c.fm_xcorr_lags(a, b, 3000), lags)
+
+
 def test_eight_stations_28_pairs(oracle):
     """BASELINE config 4 geometry in miniature: 8 collectors, 28 pairs ordered i<j."""
     import tdoa_amd
