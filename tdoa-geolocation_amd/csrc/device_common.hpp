@@ -52,6 +52,19 @@ __device__ __forceinline__ float2 cmulc(float2 a, float2 b)   // conj(a) * b
 }
 __device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
 
+// x + (x of another lane of the same 16-lane row) by a DPP move -- no LDS permute, no address register (__shfl_xor goes
+// through ds_bpermute).  CTRL: 0xB1 = quad_perm [1,0,3,2] (lane ^ 1), 0x4E = quad_perm [2,3,0,1] (lane ^ 2), 0x141 =
+// row_half_mirror (the other quad of an 8-lane half row once the quads agree), 0x140 = row_mirror (the other half row).
+// (Spelled as one v_add_f32_dpp in inline assembly the pair kernel's FIR spilled: the separate result registers.)
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float x)
+{
+    return x + __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+// sum over aligned groups of 4 / of 16 lanes, the result in every lane of the group
+__device__ __forceinline__ float quad_sum(float x) { return dpp_add<0x4E>(dpp_add<0xB1>(x)); }
+__device__ __forceinline__ float row16_sum(float x) { return dpp_add<0x140>(dpp_add<0x141>(quad_sum(x))); }
+
 // exp(sign * 2*pi*i * num / den), den a power of two, 0 <= num < 2^24 (exact in f32).
 // x = 2*num/den is an exact dyadic number, so the quadrant reduction x = q/2 + u/2, |u| <= 1/2, is
 // exact; sin and cos of (pi/2)u are degree-9 / degree-8 Taylor polynomials (truncation < 3e-8),

@@ -300,11 +300,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_
         unsigned int at0, atm0, at1, atm1;
         coords(kA0 + o0, at0, atm0);
         coords(kA0 + o0 + DK, at1, atm1);
-        za[0] = Za[at0]; zam[0] = Za[atm0]; zb[0] = Zb[at0]; zbm[0] = Zb[atm0];
+        // (32-bit byte offsets from the two wave-uniform bases instead of 32 64-bit addresses)
+        auto at = [](const float2 *base, unsigned int byte_off) {
+            return *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(base) + byte_off);
+        };
+        za[0] = at(Za, 8u * at0); zam[0] = at(Za, 8u * atm0); zb[0] = at(Zb, 8u * at0); zbm[0] = at(Zb, 8u * atm0);
 #pragma unroll
         for (int it = 1; it < 8; it++) {
-            za[it] = Za[at1 + 512u * (it - 1)]; zam[it] = Za[atm1 - 512u * (it - 1)];
-            zb[it] = Zb[at1 + 512u * (it - 1)]; zbm[it] = Zb[atm1 - 512u * (it - 1)];
+            za[it] = at(Za, 8u * at1 + 4096u * (it - 1)); zam[it] = at(Za, 8u * atm1 - 4096u * (it - 1));
+            zb[it] = at(Zb, 8u * at1 + 4096u * (it - 1)); zbm[it] = at(Zb, 8u * atm1 - 4096u * (it - 1));
         }
         // w(k) = W_N^k; a thread's bins are DK apart: one root, then a fixed rotation
         float2 w = unit_root((float)(kA0 + o0), invNc, false);
@@ -382,10 +386,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_
     // sum over the four phase groups (adjacent lanes); lane pq then writes output 4 g + pq
 #pragma unroll
     for (int o = 0; o < 4; o++) {
-        acc[o].x += __shfl_xor(acc[o].x, 1, kWave);
-        acc[o].y += __shfl_xor(acc[o].y, 1, kWave);
-        acc[o].x += __shfl_xor(acc[o].x, 2, kWave);
-        acc[o].y += __shfl_xor(acc[o].y, 2, kWave);
+        acc[o].x = quad_sum(acc[o].x);
+        acc[o].y = quad_sum(acc[o].y);
     }
     const float2 mine = pq == 0 ? acc[0] : pq == 1 ? acc[1] : pq == 2 ? acc[2] : acc[3];
     // tile number in bin order: bx for tile A, N2 - 1 - bx for tile B; its outputs are G[256 tn + i]; four-step layout of
@@ -415,11 +417,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_
                 }
             }
         }
-#pragma unroll
-        for (int sh = 1; sh < 16; sh <<= 1) {
-            e.x += __shfl_xor(e.x, sh, kWave);
-            e.y += __shfl_xor(e.y, sh, kWave);
-        }
+        e.x = row16_sum(e.x);
+        e.y = row16_sum(e.y);
         if (p == 0 && eo < 2 * kDecEdge) E[((size_t)blockIdx.y * N2 + tn) * (2 * kDecEdge) + eo] = e;
     }
 }

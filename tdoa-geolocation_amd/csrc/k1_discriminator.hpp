@@ -436,6 +436,9 @@ __global__ __launch_bounds__(kDemodThreads) void k_fm_demod(const SWDesc *sw, in
                 for (int h = 0; h < kDemodChunks; h++) qs[h] = k1_fetch8(p, start + h * 512 + lane * 8);
                 int carry = k1_direct_angle(before, dlut);
                 int t1 = 0;                      // 32 stored codes of |.| <= 2^23: fits
+                // code^2 <= 2^46 and a lane adds 32 of them per piece: below 2^53, so a float64 accumulator is EXACT here
+                // (v_cvt_f64_i32 + v_fma_f64: two instructions per sample against four for the 64-bit integer square-add)
+                double t2 = 0.0;
 #pragma unroll
                 for (int h = 0; h < kDemodChunks; h++) {
                     int a[9], c[8];
@@ -450,11 +453,13 @@ __global__ __launch_bounds__(kDemodThreads) void k_fm_demod(const SWDesc *sw, in
                     for (int k = 0; k < 8; k++) {
                         c[k] = k1_stored_code(a[k + 1], a[k]);
                         t1 -= c[k];
-                        s2 += (unsigned long long)((long long)c[k] * c[k]);      // v_mul_i32_i24 / v_mul_hi_i32_i24 + 64-bit add
+                        const double cd = (double)c[k];
+                        t2 = __builtin_fma(cd, cd, t2);
                     }
                     if (WRITE) k1_store8(out + start + h * 512 + lane * 8, c);
                 }
                 s1 += t1;
+                s2 += (unsigned long long)t2;
             } else {
                 // window head (code_0 := code_1) and tail, sample by sample; samples beyond len carry code 0 in memory and
                 // do not enter the sums

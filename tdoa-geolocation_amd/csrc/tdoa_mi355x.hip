@@ -176,8 +176,8 @@ long long next_pow2(long long n)   // processor.go:502-512
 constexpr size_t kLdsCap = 128 * 1024;
 
 // factor Nc = N1 * N2 for the four-step FFT; rows (N1) live whole in LDS
-// elements of padding after every 256 rows of a two-sweep plan's TZ (4 KB)
-int g_zpad = [] { const char *e = std::getenv("TDOA_ZPAD"); return e ? std::atoi(e) : 512; }();
+// elements of padding after every 256 rows of a two-sweep plan's TZ (2 KB; measured on cfg3: 0 -> 107 ms column pass, 128 -> 91, 256 -> 87, 512 -> 89)
+int g_zpad = [] { const char *e = std::getenv("TDOA_ZPAD"); return e ? std::atoi(e) : 256; }();
 
 int make_plan(long long n_real, bool packed, FftPlan *pl)
 {
