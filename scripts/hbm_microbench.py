@@ -1,3 +1,6 @@
+"""What the memory system of this box sustains for plain streams (torch elementwise kernels over 2.49 GB, the size of one
+cfg2 spectrum pass): the practical ceiling the kernels' GB/s are read against next to the 8 TB/s peak.
+usage (GPU box): python3 scripts/hbm_microbench.py > gpurun_out/<tag>_hbm_microbench.txt"""
 import torch, time
 x = torch.empty(2_490_000_000 // 4, dtype=torch.float32, device="cuda")
 y = torch.empty_like(x)
