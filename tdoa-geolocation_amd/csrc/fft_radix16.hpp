@@ -150,6 +150,62 @@ __global__ __launch_bounds__(256) void k_fwd_row4096(float2 *TZ, FftPlan pl, int
 }
 
 // ---------------------------------------------------------------------------
+// forward row pass for the decimated inverse: rows k2 = a and N2 - a of one station-window together (a = 0: the two
+// self-mirrored rows 0 and N2/2), and the HALF OF K3 THAT BELONGS TO THE STATION done here, once, instead of in
+// k_pair_decimate16 once per pair the station is in.  With z = Z[k], zm = Z[Nc - k] (k = k2 + N2 k1, the mirror of (k2, k1)
+// is (N2 - k2, 4095 - k1); in row 0: (0, 4096 - k1)) and w = W_N^k, N = 2 Nc:
+//   U[k] = (z + conj(zm)) - i w (z - conj(zm))        = A+ of pair_q (fft_stockham.hpp), twice the real window's spectrum
+// and A-[k] = conj(U[Nc - k]) for every k != 0, so U is all the pair step needs:  G = conj(Ua[k]) Ub[k],
+// H = Ua[Nc-k] conj(Ub[Nc-k]).  Bin 0 pairs with itself and carries two real numbers: U[0] := (A+[0], A-[0]) = 2 (Re z + Im z,
+// Re z - Im z), the DC and Nyquist terms.
+// This pass is HBM-bound with more than half of its issue slots free; the pair step is not.
+// Output: only the tiled layout k_pair_decimate16 streams (element (k2, k1) at [k1 / COLS][k2][k1 % COLS], COLS = 4096/N2);
+// TZ keeps the column-pass output.
+// grid (N2/2, n_sw), 512 threads (t >> 8: which row of the pair), dynamic LDS 2 x 34 KB.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void k_fwd_row4096_unpack(const float2 *TZ, FftPlan pl, float2 *tiled)
+{
+    extern __shared__ float2 lds2[];                             // [2][kRowLds]
+    const int a = blockIdx.x, g = threadIdx.x >> 8, j = threadIdx.x & 255;
+    const int k2 = a == 0 ? (g ? pl.N2 >> 1 : 0) : (g ? pl.N2 - a : a);
+    float2 *lds = lds2 + g * kRowLds;
+    const float2 *row = TZ + (size_t)blockIdx.y * pl.Zs + (size_t)k2 * 4096 + (size_t)(k2 >> 8) * pl.zpad;
+    float2 v[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) v[r] = load_nt(row + j + 256 * r);      // the column pass's output: read once
+    fft16<false>(v);
+    row4096_finish<false>(v, lds, j);                            // Y[k1 = j + 256 k] in v[oreg(k)]
+    __syncthreads();                                             // everybody has read its last stage inputs
+#pragma unroll
+    for (int k = 0; k < 16; k++) lds[pad16(j + 256 * k)] = v[oreg(k)];
+    __syncthreads();
+    // the mirror elements: the other row of the pair at 4095 - k1; the self-mirrored rows (a = 0) pair inside themselves,
+    // row 0 at 4096 - k1.  k1 = j + 256 k: pad16(4095 - j - 256 k) = pad16(4095 - j) - 272 k, one base per thread.
+    // (row 0, j = 0, k = 0 reads one element past its image -- the other image's first -- and does not use it: bin 0)
+    const bool row0 = a == 0 && g == 0;
+    const float2 *mirror = lds2 + (a == 0 ? g : g ^ 1) * kRowLds + pad16(row0 ? 4096 - j : 4095 - j);
+    // w = W_N^(k2 + N2 k1) = W_N^(k2 + N2 j) * W_32^k   (N2 * 256 / N = 1 / 32)
+    const float2 wb = unit_root((float)(k2 + pl.N2 * j), 1.0f / (float)pl.Nc, false);
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const float2 z = v[oreg(k)];
+        const float2 zm = mirror[-272 * k];
+        constexpr float kPi = 3.14159265358979323846f;
+        const float2 w = cmul(wb, make_float2(__builtin_cosf(kPi * (float)k / 16.0f), -__builtin_sinf(kPi * (float)k / 16.0f)));
+        float2 u = unpack_u_pk(z, zm, w);
+        if (k == 0 && row0 && j == 0) u = make_float2(2.0f * (z.x + z.y), 2.0f * (z.x - z.y));
+        v[oreg(k)] = u;
+    }
+    {
+        // tiles of COLS = 4096 / N2 columns x N2 rows = 4096 elements: column k1 = j + 256 k -> tile k1 / COLS
+        const int cols = 4096 / pl.N2;
+        float2 *out = tiled + (size_t)blockIdx.y * pl.Nc + (size_t)(j / cols) * 4096 + (size_t)k2 * cols + (j % cols);
+#pragma unroll
+        for (int k = 0; k < 16; k++) out[(size_t)(256 / cols) * k * 4096] = v[oreg(k)];
+    }
+}
+
+// ---------------------------------------------------------------------------
 // forward column pass, N2 = 256, 32 columns per workgroup: phase codes -> normalise -> pack ->
 // two radix-16 stages down the columns -> twiddle -> T[k2][n1].
 // grid (N1/32, n_sw), 512 threads (c = t & 31 column, j = t >> 5 item), dynamic LDS 64 KB

@@ -316,7 +316,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_
         const int sa1 = slot_of(o0 + DK), sb1 = slot_of(4096 - o0 - DK);
         {
             float2 q, qm;
-            pair_q_pk(za[0], zam[0], zb[0], zbm[0], w, q, qm);
+            pair_u_pk(za[0], zam[0], zb[0], zbm[0], w, kA0 + o0 == 0, q, qm);
             qa[slot_of(o0)] = q;
             if (o0) qb[slot_of(4096 - o0)] = qm;                   // the partner of A[0] is B[0] of the workgroup before
             w = cmul(w, rot);
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_
 #pragma unroll
         for (int it = 1; it < 8; it++) {
             float2 q, qm;
-            pair_q_pk(za[it], zam[it], zb[it], zbm[it], w, q, qm);
+            pair_u_pk(za[it], zam[it], zb[it], zbm[it], w, false, q, qm);
             if constexpr (LOGN2 == 8) {                            // N2 = 256: a thread's slots stay inside one column of the image
                 qa[sa1 + (DK / 16) * (it - 1)] = q;
                 qb[sb1 - (DK / 16) * (it - 1)] = qm;
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_
     }
     if (has_b0) {
         float2 q, qm;
-        pair_q_pk(b0[0], b0[1], b0[2], b0[3], unit_root((float)kb0, invNc, false), q, qm);
+        pair_u_pk(b0[0], b0[1], b0[2], b0[3], unit_root((float)kb0, invNc, false), false, q, qm);
         qb[slot_of(0)] = q;
     }
     __syncthreads();

@@ -247,6 +247,38 @@ __device__ __forceinline__ void pair_q_pk(float2 za_, float2 zam_, float2 zb_, f
     q_ = make_float2(q.x, q.y);
     qm_ = make_float2(qm.x, qm.y);
 }
+// The pair's half of K3 when the stations' spectra arrive unpacked (U of k_fwd_row4096_unpack, fft_radix16.hpp):
+// G = conj(Ua[k]) Ub[k], conj(H) = conj(Ua[Nc-k]) Ub[Nc-k], then as above: 10 instructions.
+// dc: this is bin 0, whose U holds the two real numbers (A+[0], A-[0]): G = Ua.x Ub.x, H = Ua.y Ub.y.
+__device__ __forceinline__ void pair_u_pk(float2 ua_, float2 uam_, float2 ub_, float2 ubm_, float2 w_, bool dc,
+                                          float2 &q_, float2 &qm_)
+{
+    const v2f ua = {ua_.x, ua_.y}, uam = {uam_.x, uam_.y}, ub = {ub_.x, ub_.y}, ubm = {ubm_.x, ubm_.y}, w = {w_.x, w_.y};
+    v2f qe, gh, q, qm;
+    v2f g = pk_cmulc(ua, ub), hc = pk_cmulc(uam, ubm);
+    if (dc) {
+        g = v2f{ua_.x * ub_.x, 0.0f};
+        hc = v2f{ua_.y * ub_.y, 0.0f};
+    }
+    TDOA_PK2("v_pk_add_f32", qe, g, hc, "neg_hi:[0,1]");                                     // G + H,  H = conj(hc)
+    TDOA_PK2("v_pk_add_f32", gh, g, hc, "neg_lo:[0,1]");                                     // G - H
+    const v2f qo = pk_cmulc(w, gh);                                                          // (G - H) conj(w)
+    TDOA_PK2("v_pk_add_f32", q, qe, qo, "op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]");        // qe + i qo
+    TDOA_PK2("v_pk_add_f32", qm, qe, qo, "op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[1,0]");       // conj(qe) + i conj(qo)
+    q_ = make_float2(q.x, q.y);
+    qm_ = make_float2(qm.x, qm.y);
+}
+// the station's half: U = (z + conj(zm)) - i w (z - conj(zm)), five instructions
+__device__ __forceinline__ float2 unpack_u_pk(float2 z_, float2 zm_, float2 w_)
+{
+    const v2f z = {z_.x, z_.y}, zm = {zm_.x, zm_.y}, w = {w_.x, w_.y};
+    v2f e2, d, u;
+    TDOA_PK2("v_pk_add_f32", e2, z, zm, "neg_hi:[0,1]");                                     // z + conj(zm)
+    TDOA_PK2("v_pk_add_f32", d, z, zm, "neg_lo:[0,1]");                                      // z - conj(zm)
+    const v2f wd = pk_cmul(w, d);
+    TDOA_PK2("v_pk_add_f32", u, e2, wd, "op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]");        // E2 - i (w d)
+    return make_float2(u.x, u.y);
+}
 #undef TDOA_PK2
 
 // grid: (N2 / 2, n_pair_windows), dynamic LDS: 2 * (2*N1) * 8 bytes

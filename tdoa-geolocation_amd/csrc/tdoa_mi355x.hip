@@ -629,8 +629,9 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
     }
     if (!seg_chunks) {
         ProfScope ps(ctx, TDOA_K_FWD_ROW, 2.0 * nc8 * n_sw);
-        if (row16 && decim)     // spectra in 16-column tiles behind G and V' in the V workspace (k_pair_decimate16 streams them)
-            hipLaunchKernelGGL(k_fwd_row4096, dim3(pl.N2, n_sw), dim3(256), 0, st, tz, pl, 1, v + dec_spectra_offset(pl, n_pw));
+        if (row16 && decim)     // unpacked spectra in COLS-column tiles behind G and V' in the V workspace (k_pair_decimate16 streams them)
+            hipLaunchKernelGGL(k_fwd_row4096_unpack, dim3(pl.N2 / 2, n_sw), dim3(512), sizeof(float2) * 2 * kRowLds, st, tz, pl,
+                               v + dec_spectra_offset(pl, n_pw));
         else if (row16)
             hipLaunchKernelGGL(k_fwd_row4096, dim3(pl.N2, n_sw), dim3(256), 0, st, tz, pl, 1, static_cast<float2 *>(nullptr));
         else
@@ -782,6 +783,7 @@ int allow_big_lds(tdoa_ctx *ctx)
     if ((rc = set_lds(ctx, k_fm_demod<true>, all))) return rc;
     if ((rc = set_lds(ctx, k_fm_demod<false>, all))) return rc;
     if ((rc = set_lds(ctx, k_fwd_col512_k1, all))) return rc;
+    if ((rc = set_lds(ctx, k_fwd_row4096_unpack, all))) return rc;
     if ((rc = set_lds(ctx, k_fwd_col256_k1<false>, all))) return rc;
     if ((rc = set_lds(ctx, k_fwd_col256_k1<true>, all))) return rc;
     if ((rc = set_lds(ctx, k_fwd_col_c16, all))) return rc;
