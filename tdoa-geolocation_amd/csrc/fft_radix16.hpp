@@ -76,6 +76,31 @@ __device__ __forceinline__ void mul_base_step16(float2 (&v)[16], float2 base, fl
     }
 }
 
+// the same on values in natural order: v[r] *= base * step^r
+__device__ __forceinline__ void mul_base_step16_nat(float2 (&v)[16], float2 base, float2 step)
+{
+    const float2 s2 = cmul(step, step), s3 = cmul(s2, step), s4 = cmul(s2, s2);
+    float2 g = base;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        v[4 * q] = cmul(v[4 * q], g);
+        v[4 * q + 1] = cmul(v[4 * q + 1], cmul(g, step));
+        v[4 * q + 2] = cmul(v[4 * q + 2], cmul(g, s2));
+        v[4 * q + 3] = cmul(v[4 * q + 3], cmul(g, s3));
+        g = cmul(g, s4);
+    }
+}
+
+// The four-step twiddle W_Nc^(n1 k2) applied by the ROW pass to its inputs (thread j holds columns n1 = j + 256 r of row
+// k2): W^(k2 j) * (W^(256 k2))^r.  The fused column kernel k_fwd_col256_k1<false> leaves it out: that kernel is the one
+// short of issue slots, the row passes are HBM-bound with half of theirs free.
+__device__ __forceinline__ void row_pre_twiddle(float2 (&v)[16], int k2, int j, const FftPlan &pl)
+{
+    const float inv2 = 2.0f / (float)pl.Nc;
+    const int e0 = (k2 * j) & (int)(pl.Nc - 1), e1 = (k2 * 256) & (int)(pl.Nc - 1);      // k2 j < 2^20
+    mul_base_step16_nat(v, unit_root((float)e0, inv2, false), unit_root((float)e1, inv2, false));
+}
+
 __device__ __forceinline__ int pad16(int i) { return i + (i >> 4); }
 
 // a fetched code pair rides in the registers of the float2 it will become
@@ -121,32 +146,21 @@ __device__ __forceinline__ void row4096_finish(float2 (&v)[16], float2 *lds, int
 // ---------------------------------------------------------------------------
 // forward row pass, N1 = 4096, in place.  grid (N2, n_sw), 256 threads, static LDS 34 KB
 // ---------------------------------------------------------------------------
-// row_mul: row index = blockIdx.x * row_mul (1: every row, grid.x = N2; N2/2: only the two self-mirrored rows 0 and
-// N2/2, grid.x = 2 -- the rest of the rows are then transformed inside k_pair_rows_fused_r8, fft_radix8.hpp)
-// tiled != nullptr: the spectrum goes there in tiles of COLS = 4096/N2 columns, element (k2, k1) at
-// [k1 / COLS][k2][k1 % COLS] -- the layout k_pair_decimate16 streams (a tile of all N2 rows x COLS columns = 4096
-// consecutive bins is one contiguous run); TZ keeps the column-pass output.
-__global__ __launch_bounds__(256) void k_fwd_row4096(float2 *TZ, FftPlan pl, int row_mul, float2 *tiled = nullptr)
+// pre_tw: the column pass left the four-step twiddle to this kernel (row_pre_twiddle).
+__global__ __launch_bounds__(256) void k_fwd_row4096(float2 *TZ, FftPlan pl, bool pre_tw)
 {
     __shared__ float2 lds[kRowLds];
-    const int k2 = blockIdx.x * row_mul;
+    const int k2 = blockIdx.x;
     float2 *row = TZ + (size_t)blockIdx.y * pl.Zs + (size_t)k2 * 4096 + (size_t)(k2 >> 8) * pl.zpad;
     const int j = threadIdx.x;
     float2 v[16];
 #pragma unroll
     for (int r = 0; r < 16; r++) v[r] = load_nt(row + j + 256 * r);      // the column pass's output: read once
+    if (pre_tw) row_pre_twiddle(v, k2, j, pl);
     fft16<false>(v);
     row4096_finish<false>(v, lds, j);
-    if (tiled) {
-        // tiles of COLS = 4096 / N2 columns x N2 rows = 4096 elements: column k1 = j + 256 k -> tile k1 / COLS
-        const int cols = 4096 / pl.N2;
-        float2 *out = tiled + (size_t)blockIdx.y * pl.Nc + (size_t)(j / cols) * 4096 + (size_t)k2 * cols + (j % cols);
 #pragma unroll
-        for (int k = 0; k < 16; k++) out[(size_t)(256 / cols) * k * 4096] = v[oreg(k)];
-    } else {
-#pragma unroll
-        for (int k = 0; k < 16; k++) row[j + 256 * k] = v[oreg(k)];
-    }
+    for (int k = 0; k < 16; k++) row[j + 256 * k] = v[oreg(k)];
 }
 
 // ---------------------------------------------------------------------------
@@ -163,7 +177,7 @@ __global__ __launch_bounds__(256) void k_fwd_row4096(float2 *TZ, FftPlan pl, int
 // TZ keeps the column-pass output.
 // grid (N2/2, n_sw), 512 threads (t >> 8: which row of the pair), dynamic LDS 2 x 34 KB.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void k_fwd_row4096_unpack(const float2 *TZ, FftPlan pl, float2 *tiled)
+__global__ __launch_bounds__(512) void k_fwd_row4096_unpack(const float2 *TZ, FftPlan pl, float2 *tiled, bool pre_tw)
 {
     extern __shared__ float2 lds2[];                             // [2][kRowLds]
     const int a = blockIdx.x, g = threadIdx.x >> 8, j = threadIdx.x & 255;
@@ -173,6 +187,7 @@ __global__ __launch_bounds__(512) void k_fwd_row4096_unpack(const float2 *TZ, Ff
     float2 v[16];
 #pragma unroll
     for (int r = 0; r < 16; r++) v[r] = load_nt(row + j + 256 * r);      // the column pass's output: read once
+    if (pre_tw) row_pre_twiddle(v, k2, j, pl);
     fft16<false>(v);
     row4096_finish<false>(v, lds, j);                            // Y[k1 = j + 256 k] in v[oreg(k)]
     __syncthreads();                                             // everybody has read its last stage inputs
@@ -471,13 +486,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
             // Y_a[kb = j + 16k] *= W_(256G)^(a kb) = W^(a j) * (W^(16 a))^k
             const float invg = 2.0f / (float)pl.N2;
             if (a) mul_base_step16(v, unit_root((float)(a * j), invg, false), unit_root((float)(16 * a), invg, false));
-        } else {
-            // Y[k2 = j + 16k] *= W_Nc^(n1*k2) = W^(n1*j) * (W^(16*n1))^k
-            const float inv2 = 2.0f / (float)pl.Nc;
-            const int e0 = (n1 * j) & (int)(pl.Nc - 1);              // n1 j < 2^16, Nc <= 2^24
-            const int e1 = (n1 * 16) & (int)(pl.Nc - 1);
-            mul_base_step16(v, unit_root((float)e0, inv2, false), unit_root((float)e1, inv2, false));
         }
+        // (one-sweep plans: the four-step twiddle W_Nc^(n1 k2) is applied by the row pass to its inputs, row_pre_twiddle)
         prev = tile;
     }
     if (prev >= 0) {                                             // the last tile of this workgroup
