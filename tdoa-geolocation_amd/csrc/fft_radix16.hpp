@@ -283,17 +283,12 @@ __global__ __launch_bounds__(512) void k_fwd_col256_c16(const SWDesc *sw, const 
 //
 // Element m of the packed window (samples 2m, 2m+1) needs the angle codes of samples 2m-1, 2m, 2m+1.  A thread loads
 // the dword of its two samples and looks both up; the angle of sample 2m-1 is the second angle of the lane to its
-// LEFT (the 32 lanes of a half-wave hold 32 adjacent elements): one DPP move instead of a third load and lookup.  Only
-// the first column of the tile has no left neighbour: those 16 rows x 2 half-waves = 32 "boundary" samples of a wave
-// are loaded and looked up by its lanes 0..31 in one go and handed out by lane permutes.
-// LDS: the angle table (33 KB) has to sit next to the tile, and two workgroups must still fit a CU: the exchange between
-// the two radix-16 stages therefore goes through ONE float plane [256][32] (32 KB), real parts first, then imaginary
-// parts (the tile of the code-reading kernel is 64 KB).  The workgroups are persistent -- grid = 2 per CU, tiles dealt
-// round-robin -- so the table is loaded once per workgroup, not once per tile.
-// Tile t = (w A + a) (N1/32) + bx: consecutive workgroups take adjacent 32-column blocks of the same rows.
-// grid (2 n_cu), 512 threads (c = t & 31 column, j = t >> 5 item), dynamic LDS 33 KB (table) + 32 KB (plane).
+// LEFT: one DPP move instead of a third load and lookup.  Only the first column of the tile has no left neighbour:
+// those "boundary" samples of a wave are loaded and looked up by its first lanes in one go.
+// LDS: the angle table (64 KB quadrant table) sits next to ONE float plane [256][64] (64 KB) through which the exchange
+// between the two radix-16 stages goes twice, real parts first, then imaginary parts.  The workgroup is persistent --
+// one per CU, tiles dealt by col_k1_order -- so the table is loaded once per workgroup, not once per tile.
 // ---------------------------------------------------------------------------
-constexpr size_t kColK1Lds = kK1TableBytes + sizeof(float) * 256 * 32;
 
 // store at a 32-bit unsigned byte offset from a wave-uniform base (global_store v_off, v[data], s[base]): one offset
 // register per store instead of a 64-bit address pair (a window's transform is at most 2^27 bytes)
@@ -614,72 +609,117 @@ __global__ __launch_bounds__(512) void k_fwd_colx_c16(const SWDesc *sw, const in
 
 // ---------------------------------------------------------------------------
 // K1 fused into the forward column pass for N2 = 512 (1 s windows at 4 Msps, N = 2^22: BASELINE config 5): k_fwd_colx_c16<2>
-// with the capture bytes as its input, built like k_fwd_col256_k1 -- persistent workgroups, angle table in LDS, the angle
-// of the sample before an element taken from the lane to the left, rows classified per wave, both exchanges through float
-// planes.  16 columns per workgroup; thread (c = t & 15, j = (t >> 4) & 15, par = t >> 8) transforms the rows
-// n2 = 2 (j + 16 r) + par; a wave holds 4 consecutive items j of one parity.
-// grid (2 n_cu), 512 threads, dynamic LDS kColK1Lds (table + plane [2][256][16]).
+// with the capture bytes as its input, built like k_fwd_col256_k1 -- one persistent 1024-thread workgroup per CU, the
+// quadrant table of scaled angle codes at LDS address 0, next tile's bytes prefetched, previous tile's stores spread over
+// the lookups, four-step twiddle left to the row pass.  32 columns per workgroup; thread (c = t & 31, j = (t >> 5) & 15,
+// par = t >> 9) transforms the rows n2 = 2 (j + 16 r) + par; a wave holds two consecutive items j of one parity (one per
+// half-wave), so the left-lane angle sharing runs inside a half-wave and the 32 boundary samples of a wave (16 rows x 2
+// items) are looked up by its lanes 0..31 and handed out by a lane permute.
+// grid (n_cu), 1024 threads, dynamic LDS 64 KB (table) + 64 KB (planes [2][256][32]).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_fwd_col512_k1(const SWDesc *sw, const int *table, const FmStats *stats, float2 *T,
-                                                       FftPlan pl, int n_sw)
+constexpr size_t kCol512Lds = kK1QuadrantBytes + sizeof(float) * 2 * 256 * 32;
+
+struct Col512Tile {
+    int bx, w, len;
+    gptr16 p;
+};
+
+__device__ __forceinline__ Col512Tile col512_tile(const SWDesc *__restrict__ sw, int tile, int nbx)
 {
-    constexpr int F = 2, C = 16, LOGC = 4;
-    extern __shared__ int lds_k1[];                             // the table at offset 0 (immediate offsets), then the planes
+    Col512Tile t;
+    t.bx = tile % nbx;
+    t.w = tile / nbx;
+    const SWDesc d = sw[t.w];
+    t.len = d.len;
+    t.p = k1_global(d.base);
+    return t;
+}
+
+__device__ __forceinline__ void col512_fetch(const Col512Tile &t, int N1, int tid, unsigned int (&raw)[16], unsigned int &sb)
+{
+    const int lane = tid & 63, c = tid & 31, j = (tid >> 5) & 15, par = tid >> 9;
+    const int n1 = t.bx * 32 + c, last = t.len - 2;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int i0 = 2 * ((2 * (j + 16 * r) + par) * N1 + n1);
+        raw[r] = k1_fetch2(t.p, i0 < last ? i0 : last);
+    }
+    // boundary samples (first column of the tile): lane L < 32 takes row r = L >> 1 of the wave's item (j & ~1) + (L & 1)
+    const int jb = (j & ~1) + (lane & 1), rb = (lane & 31) >> 1;
+    const int ib = 2 * ((2 * (jb + 16 * rb) + par) * N1 + t.bx * 32) - 1;
+    sb = t.p[ib >= 0 && ib < t.len ? ib : 0];
+}
+
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_fwd_col512_k1(const SWDesc *__restrict__ sw, const int *__restrict__ qtable, const FmStats *__restrict__ stats,
+                                                       float2 *__restrict__ T, FftPlan pl, int n_sw)
+{
+    constexpr int F = 2, C = 32, LOGC = 5;
+    extern __shared__ int lds_k1[];                             // the table at offset 0 (the offset IS the address), then the planes
     int *lut = lds_k1;
-    float *plane = reinterpret_cast<float *>(lds_k1 + kK1TableEntries);      // [F][256][C]
+    float *plane = reinterpret_cast<float *>(lds_k1 + kK1QuadrantEntries);      // [F][256][C]
     k1_assert_lds0(lut);
-    k1_load_table(lut, table);
     const int N1 = pl.N1, nbx = N1 / C;
     const int n_tiles = n_sw * nbx;
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    unsigned int raw_next[16], sb_next = 0;
+    if ((int)blockIdx.x < n_tiles) col512_fetch(col512_tile(sw, col_k1_order(blockIdx.x, nbx), nbx), N1, threadIdx.x, raw_next, sb_next);
+    for (int k = threadIdx.x; k < kK1QuadrantEntries; k += blockDim.x) lut[k] = qtable[k];
+    __builtin_amdgcn_s_waitcnt(0x0f70);                          // vmcnt(0): the loop is entered with nothing pending
+    __syncthreads();
+    // thread constants: the item's stage twiddle W_256^j and the parity twiddle W_512^j (odd rows only)
+    const float2 wj = unit_root((float)((threadIdx.x >> LOGC) & 15), 2.0f / 256.0f, false);
+    const float2 wp = unit_root((float)((threadIdx.x >> LOGC) & 15), 2.0f / (256.0f * F), false);
+    float2 v[16];                                                // the previous tile's outputs until they are stored
+#pragma unroll
+    for (int r = 0; r < 16; r++) v[r] = make_float2(0.0f, 0.0f);
+    int prev = -1;
+    for (int seq = blockIdx.x; seq < n_tiles; seq += gridDim.x) {
+        const int tile = col_k1_order(seq, nbx);
         const int tid = opaque_i((int)threadIdx.x);              // (laundered per tile: see k_fwd_col256_k1)
         const int lane = tid & 63;
         const int c = tid & (C - 1), j = (tid >> LOGC) & 15, par = tid >> (LOGC + 4);
-        const int bx = tile % nbx, w = tile / nbx;
-        const SWDesc d = sw[w];
-        const int len = d.len;
-        const gptr16 p = k1_global(d.base);
-        const float mean = stats[w].mean, scale = stats[w].scale;
-        const int n1 = bx * C + c;
-        const int last = len - 2;
+        const Col512Tile t = col512_tile(sw, tile, nbx);
+        const int w = t.w, len = t.len;
+        const float mean = stats[w].mean * 256.0f, scale = stats[w].scale * 0.00390625f;      // scaled codes: k_fwd_col256_k1
+        const int n1 = t.bx * C + c;
         float *img = plane + par * 256 * C;
-        float2 v[16];
+        // where the previous tile's outputs go: output k of thread (j, par) is row j + 16 k + 256 par, column n1, in v[oreg(k)]
+        const Col512Tile tp = col512_tile(sw, prev >= 0 ? prev : tile, nbx);
+        float2 *outp = T + (size_t)tp.w * pl.Zs;
+        const unsigned int offp = 8u * (unsigned)((j + 256 * par) * N1 + tp.bx * C + c);
         {
             unsigned int raw[16];
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int i0 = 2 * ((F * (j + 16 * r) + par) * N1 + n1);
-                raw[r] = k1_fetch2(p, i0 < last ? i0 : last);
-            }
-            // boundary samples (first column of the tile): 16 rows x 4 items of the wave = 64, one per lane:
-            // lane L takes row r = L >> 2 of the wave's item (j & ~3) + (L & 3)
-            int ab;
-            {
-                const int jb = (j & ~3) + (lane & 3), rb = lane >> 2;
-                const int ib = 2 * ((F * (jb + 16 * rb) + par) * N1 + bx * C) - 1;
-                ab = k1_angle<true>(p[ib >= 0 && ib < len ? ib : 0], lut);
-            }
-            const int jw = __builtin_amdgcn_readfirstlane(j & ~3), pw = __builtin_amdgcn_readfirstlane(par);
+            for (int r = 0; r < 16; r++) raw[r] = raw_next[r];
+            const int ab = k1_angle_quadrant<false, true>(k1_index_bytes(sb_next), ~sb_next, lut);
+            const int jw = __builtin_amdgcn_readfirstlane(j & ~1), pw = __builtin_amdgcn_readfirstlane(par);
 #pragma unroll
             for (int r = 0; r < 16; r++) {
+                if (prev >= 0) store_at(outp + (size_t)(16 * oreg(r)) * N1, offp, v[r]);
                 const int i0 = 2 * ((F * (j + 16 * r) + par) * N1 + n1);
-                const int i_first = 2 * ((F * (jw + 16 * r) + pw) * N1 + bx * C);
-                const int i_end = 2 * ((F * (jw + 3 + 16 * r) + pw) * N1 + bx * C + C);      // one past the wave's last sample of this r
+                const int i_first = 2 * ((F * (jw + 16 * r) + pw) * N1 + t.bx * C);
+                const int i_end = 2 * ((F * (jw + 1 + 16 * r) + pw) * N1 + t.bx * C + C);      // one past the wave's last sample of this r
                 if (i_first >= len) {
                     v[r] = make_float2(0.0f, 0.0f);
                     continue;
                 }
                 int a0, a1;
-                k1_angle2<true>(raw[r], lut, a0, a1);
+                k1_angle2_quadrant<true>(raw[r], lut, a0, a1);
                 const int left = wave_shift_right1(a1);
-                const int bnd = __shfl(ab, 4 * r + ((lane >> LOGC) & 3), kWave);
+                const int bnd = __shfl(ab, 2 * r + (lane >> LOGC), kWave);
                 const int ap = c ? left : bnd;
-                if (i_first > 0 && i_end <= len)
-                    v[r] = make_float2(k1_normalise(k1_stored_code(a0, ap), mean, scale), k1_normalise(k1_stored_code(a1, a0), mean, scale));
-                else
-                    v[r] = k1_element_from(a0, a1, ap, i0, len, mean, scale, r == 0);
+                if (i_first > 0 && i_end <= len) {
+                    const int st0 = k1_stored_code_scaled(a0, ap), st1 = k1_stored_code_scaled(a1, a0);
+                    v[r] = make_float2(k1_normalise(st0, mean, scale), k1_normalise(st1, mean, scale));
+                } else {
+                    v[r] = k1_element_from<true>(a0, a1, ap, i0, len, mean, scale, r == 0);
+                }
             }
         }
+        // the capture bytes of the next tile: asked for now, used a whole transform later
+        __builtin_amdgcn_sched_barrier(0);
+        if (seq + (int)gridDim.x < n_tiles)
+            col512_fetch(col512_tile(sw, col_k1_order(seq + gridDim.x, nbx), nbx), N1, opaque_i((int)threadIdx.x), raw_next, sb_next);
+        __builtin_amdgcn_sched_barrier(0);
         fft16<false>(v);
         // first exchange (inside the image of this parity), real parts then imaginary parts
 #pragma unroll
@@ -694,14 +734,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
         for (int r = 0; r < 16; r++) v[r].y = img[(j + 16 * r) * C + c];
         __syncthreads();
-        mul_powers16(v, unit_root((float)j, 2.0f / 256.0f, false));
+        mul_powers16(v, opaque(wj));
         fft16<false>(v);
-        // Y_par[k = j + 16 kk] *= W_512^(k par)
+        // Y_par[k = j + 16 kk] *= W_512^(k par) = W_512^j * (W_32)^kk
         if (par)      // uniform per wave
-            mul_base_step16(v, unit_root((float)(j * par), 2.0f / (256.0f * F), false),
-                            unit_root((float)(16 * par), 2.0f / (256.0f * F), false));
+            mul_base_step16(v, opaque(wp), make_float2(0.98078528040323043f, -0.19509032201612825f));
         // second exchange + the last radix-2 butterfly across the two images: X[k + 256 q] = Y_0[k] +- Y_1[k], q = par
-        float2 x[16];
 #pragma unroll
         for (int k = 0; k < 16; k++) img[(j + 16 * k) * C + c] = v[oreg(k)].x;
         __syncthreads();
@@ -709,7 +747,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         for (int k = 0; k < 16; k++) {
             const int idx = (j + 16 * k) * C + c;
             const float e0 = plane[idx], e1 = plane[256 * C + idx];
-            x[k].x = par ? e0 - e1 : e0 + e1;
+            v[oreg(k)].x = par ? e0 - e1 : e0 + e1;
         }
         __syncthreads();
 #pragma unroll
@@ -719,21 +757,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         for (int k = 0; k < 16; k++) {
             const int idx = (j + 16 * k) * C + c;
             const float e0 = plane[idx], e1 = plane[256 * C + idx];
-            x[k].y = par ? e0 - e1 : e0 + e1;
+            v[oreg(k)].y = par ? e0 - e1 : e0 + e1;
         }
         __syncthreads();                                         // the next tile writes the planes again
+        // (the four-step twiddle W_Nc^(n1 k2) is applied by the row pass to its inputs, row_pre_twiddle)
+        prev = tile;
+    }
+    if (prev >= 0) {                                             // the last tile of this workgroup
+        const int tid = opaque_i((int)threadIdx.x);
+        const Col512Tile tp = col512_tile(sw, prev, nbx);
+        float2 *outp = T + (size_t)tp.w * pl.Zs;
+        const unsigned int offp = 8u * (unsigned)((((tid >> LOGC) & 15) + 256 * (tid >> (LOGC + 4))) * N1 + tp.bx * C + (tid & (C - 1)));
 #pragma unroll
-        for (int k = 0; k < 16; k++) v[oreg(k)] = x[k];
-        // X[k2 = j + 16 k + 256 q] *= W_Nc^(n1 k2) = W^(n1 (j + 256 q)) * (W^(16 n1))^k
-        float2 *out = T + (size_t)w * pl.Nc;
-        const int n1o = opaque_i(n1);
-        const float inv2 = 2.0f / (float)pl.Nc;
-        const int e0 = (int)(((long long)n1 * (j + 256 * par)) & (pl.Nc - 1));
-        const int e1 = (n1 * 16) & (int)(pl.Nc - 1);
-        mul_base_step16(v, unit_root((float)e0, inv2, false), unit_root((float)e1, inv2, false));
-        __builtin_amdgcn_sched_barrier(0);                       // offsets are formed here, not during the transform
-#pragma unroll
-        for (int k = 0; k < 16; k++) store_at(out, 8u * (unsigned)((j + 16 * k + 256 * par) * N1 + opaque_i(n1o)), v[oreg(k)]);
+        for (int r = 0; r < 16; r++) store_at(outp + (size_t)(16 * oreg(r)) * N1, offp, v[r]);
     }
 }
 

@@ -17,11 +17,15 @@
 //
 // The table: T[mx (mx + 1) / 2 + mn] = llround(atan2(2 mn' + 1, 2 mx' + 1) 2^23/pi) over the gcd-reduced pair, for
 // 0 <= mn <= mx <= 127 (index of the odd magnitudes |2b - 255| = 2 idx + 1): 8256 int32, built by the HOST in float64
-// (tdoa_mi355x.hip, k1_build_table_host) and kept in LDS by every kernel that evaluates the discriminator.
+// (tdoa_mi355x.hip, k1_build_table_host).  The kernels keep tables DERIVED from it by the host with the integer placement
+// rules (|Q| > |I|: 2^22 - c; I < 0: 2^23 - c; Q < 0: -c) in LDS: the first-quadrant table of the column kernels (128 x 128
+// entries, scaled by 256, k1_angle_quadrant) and the half-plane table of the streaming pass (32768 entries,
+// k1_direct_angle2).  (Round 3 started with the 33 KB first-octant table itself in LDS and a 17-instruction lookup pinned
+// in inline assembly; the 11-instruction quadrant lookup replaced it once the column kernels became one workgroup per CU.)
 //
 // Two ways the codes reach the transforms:
 //   * fused (default on the hot plans): k_fm_demod<false> only adds up the window sums (one streaming read of the
-//     capture bytes, nothing written); the forward column kernels (fft_radix16.hpp, k_fwd_col256_k1 / k_fwd_colx_k1)
+//     capture bytes, nothing written); the forward column kernels (fft_radix16.hpp, k_fwd_col256_k1 / k_fwd_col512_k1)
 //     read the capture bytes themselves and evaluate the discriminator on the fly.  No code array exists.
 //   * materialised: k_fm_demod<true> also writes the codes (int32, held NEGATED: stored = -code in [-2^23, 2^23)) for
 //     the consumers that re-read samples many times or post-process them (segment form, k1_smooth, k1_gate, the
@@ -34,7 +38,6 @@ namespace tdoa {
 
 constexpr int kK1Half = 1 << 23;                 // code units per half turn (pi)
 constexpr int kK1TableEntries = 128 * 129 / 2;   // first-octant directions, mn <= mx
-constexpr size_t kK1TableBytes = sizeof(int) * kK1TableEntries;      // 33 024
 
 // Table read at byte offset `off`.  ABS0: the table is known to start at LDS address 0 (a kernel whose only LDS is its
 // dynamic segment; checked once per workgroup by k1_assert_lds0) -- the offset IS the address.  Otherwise the address is
@@ -53,52 +56,16 @@ __device__ __forceinline__ void k1_assert_lds0(const int *lut)
     if ((unsigned int)(uintptr_t)(const __attribute__((address_space(3))) int *)lut != 0u) __builtin_trap();
 }
 
-// Angle code of an IQ sample (I = 2 b_I - 255, Q = 2 b_Q - 255) from the first-octant table, |code| < 2^23.
-// This runs once per sample of the capture inside kernels that are bound by vector-instruction issue (SQ counters:
-// 80 % VALU-busy), so the sequence is pinned in inline assembly: 17 instructions per sample, no compare, no select
-// (left to itself the compiler turns the masks back into v_cmp + 2 v_cndmask per step -- plus their wait states on
-// gfx950 -- and came out at 30).
+// Angle code of an IQ sample (I = 2 b_I - 255, Q = 2 b_Q - 255) from the QUADRANT table (128 x 128 entries, Tq[iq][ia] =
+// angle of (2 ia + 1, 2 iq + 1), 64 KB; the column kernels: one 1024-thread workgroup per CU).  This runs once per sample
+// of the capture inside kernels that are short of vector-instruction issue slots, so the sequence is pinned in inline
+// assembly: 11 instructions per sample, no compare, no select (left to itself the compiler turns the masks back into
+// v_cmp + v_cndmask pairs plus their wait states on gfx950).
 //   x   = index bytes (|2 b - 255| - 1) / 2 = b ^ (b >= 128 ? 0x80 : 0x7f)          (formed per dword by the caller)
 //   neg = ~b: bit 7 set = the component is negative
-//   c   = table[mx (mx + 1) / 2 + mn]                                               first-octant angle
 //   each placement step is  c -> K - c  under a condition, written  (c ^ m) + (m & (K + 1))  with m = 0 or -1:
-//   |Q| > |I|: K = 2^22;  I < 0: K = 2^23;  Q < 0: K = 0.
-// HI = false: the sample in the low half of the dword, true: the high half.
-template <bool HI, bool ABS0 = false>
-__device__ __forceinline__ int k1_angle_from(unsigned int x, unsigned int neg, const int *lut)
-{
-    unsigned int mx, mn, p, off;
-    int d, msw, k, mi, mq, c;
-    if (!HI) {
-        asm("v_max_u32_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_1" : "=v"(mx) : "v"(x));
-        asm("v_min_u32_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_1" : "=v"(mn) : "v"(x));
-        asm("v_sub_u32_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_1" : "=v"(d) : "v"(x));
-    } else {
-        asm("v_max_u32_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:BYTE_3" : "=v"(mx) : "v"(x));
-        asm("v_min_u32_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:BYTE_3" : "=v"(mn) : "v"(x));
-        asm("v_sub_u32_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:BYTE_3" : "=v"(d) : "v"(x));
-    }
-    asm("v_mad_u32_u24 %0, %1, %1, %1" : "=v"(p) : "v"(mx));                    // mx^2 + mx
-    asm("v_lshlrev_b32 %0, 2, %1" : "=v"(mn) : "v"(mn));
-    asm("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(off) : "v"(p), "v"(mn));         // byte offset 2 (mx^2 + mx) + 4 mn
-    c = k1_table_read<ABS0>(lut, off);
-    asm("v_ashrrev_i32 %0, 31, %1" : "=v"(msw) : "v"(d));                       // -1: |Q| > |I|
-    asm("v_and_b32 %0, 0x400001, %1" : "=v"(k) : "v"(msw));
-    asm("v_xad_u32 %0, %1, %2, %3" : "=v"(c) : "v"(c), "v"(msw), "v"(k));      // (c ^ m) + k
-    if (!HI) asm("v_bfe_i32 %0, %1, 7, 1" : "=v"(mi) : "v"(neg));               // -1: I < 0
-    else asm("v_bfe_i32 %0, %1, 23, 1" : "=v"(mi) : "v"(neg));
-    asm("v_and_b32 %0, 0x800001, %1" : "=v"(k) : "v"(mi));
-    asm("v_xad_u32 %0, %1, %2, %3" : "=v"(c) : "v"(c), "v"(mi), "v"(k));
-    if (!HI) asm("v_bfe_i32 %0, %1, 15, 1" : "=v"(mq) : "v"(neg));              // -1: Q < 0
-    else asm("v_ashrrev_i32 %0, 31, %1" : "=v"(mq) : "v"(neg));
-    asm("v_xor_b32 %0, %1, %2" : "=v"(c) : "v"(c), "v"(mq));
-    asm("v_sub_u32 %0, %1, %2" : "=v"(c) : "v"(c), "v"(mq));                    // (c ^ m) - m
-    return c;
-}
-
-// The same from the QUADRANT table (128 x 128 entries, Tq[iq][ia] = angle of (2 ia + 1, 2 iq + 1), 64 KB): no min / max,
-// no |Q| > |I| reflection -- 11 instructions per sample instead of 17.  For kernels that can afford the 64 KB
-// (k_fwd_col256_k1: one 1024-thread workgroup per CU).  The quadrant table holds the angle codes SCALED BY 256 (a full
+//   I < 0: K = half a turn;  Q < 0: K = 0.      HI = false: the sample in the low half of the dword, true: the high half.
+// The quadrant table holds the angle codes SCALED BY 256 (a full
 // turn = 2^32): a difference of two scaled angles wraps in the 32-bit subtraction itself, so k1_stored_code's sign
 // extension of 24 bits disappears (k1_stored_code_scaled); 256 x code is still exact in a float32 and the factor is
 // divided out with the window's scale (k1_normalise_scaled: bit-identical results).
@@ -131,21 +98,6 @@ __device__ __forceinline__ unsigned int k1_index_bytes(unsigned int w) { return 
 
 // the two samples of a dword w = b_I0 | b_Q0 << 8 | b_I1 << 16 | b_Q1 << 24
 template <bool ABS0 = false>
-__device__ __forceinline__ void k1_angle2(unsigned int w, const int *lut, int &a0, int &a1)
-{
-    const unsigned int x = k1_index_bytes(w), neg = ~w;
-    a0 = k1_angle_from<false, ABS0>(x, neg, lut);
-    a1 = k1_angle_from<true, ABS0>(x, neg, lut);
-}
-
-// one sample s = b_I | b_Q << 8
-template <bool ABS0 = false>
-__device__ __forceinline__ int k1_angle(unsigned int s, const int *lut)
-{
-    return k1_angle_from<false, ABS0>(k1_index_bytes(s), ~s, lut);
-}
-
-template <bool ABS0 = false>
 __device__ __forceinline__ void k1_angle2_quadrant(unsigned int w, const int *qlut, int &a0, int &a1)
 {
     const unsigned int x = k1_index_bytes(w), neg = ~w;
@@ -156,7 +108,7 @@ __device__ __forceinline__ void k1_angle2_quadrant(unsigned int w, const int *ql
 // The streaming K1 kernel (k_fm_demod) has the LDS to itself and keeps a DIRECT table instead: the point reflection
 // (I, Q) -> (-I, -Q) is b -> 255 - b = ~b on both bytes and changes the angle by exactly half a turn, so 32768 entries
 // cover the half plane Q > 0: D[b_I | (b_Q & 0x7f) << 8] = a(I, Q) in (0, 2^23), b_Q >= 128  (128 KB, built by the host
-// from the same first-octant codes).  Lookup of the two samples of a dword: 11 instructions, against 2 x 17 above.
+// from the same first-octant codes).  Lookup of the two samples of a dword: 11 instructions, against 2 x 11 above.
 // Returns the angle modulo 2^24 (in [0, 2^24)); only differences of angles are ever used.
 constexpr int kK1QuadrantEntries = 128 * 128;
 constexpr size_t kK1QuadrantBytes = sizeof(int) * kK1QuadrantEntries;     // 65 536
@@ -275,13 +227,6 @@ __device__ __forceinline__ void k1_unpack8(uint4 q, unsigned int (&s)[9])
 }
 
 __device__ __forceinline__ void k1_load8(gptr16 p, int i0, unsigned int (&s)[9]) { k1_unpack8(k1_fetch8(p, i0), s); }
-
-// the angle table into LDS (all threads of the workgroup; followed by a barrier)
-__device__ __forceinline__ void k1_load_table(int *lut, const int *table)
-{
-    for (int k = threadIdx.x; k < kK1TableEntries; k += blockDim.x) lut[k] = table[k];
-    __syncthreads();
-}
 
 // ---- optional power gate (tdoa_params.k1_gate; the prebuilt binary's preprocessSignal) -----
 // mean power p = mean |x|^2 of x = (b - 127.5)/127.5 is M / (65025 len) with the exact integer

@@ -60,7 +60,6 @@ struct tdoa_ctx {
     };
     std::vector<Capture> caps;
 
-    DevBuf k1_table;                        // kK1TableEntries first-octant angle codes (k1_build_table_host)
     DevBuf k1_direct;                       // kK1DirectEntries half-plane angle codes of the streaming K1 kernel
     DevBuf k1_quad;                         // kK1QuadrantEntries first-quadrant angle codes (k_fwd_col256_k1)
     DevBuf sw_desc, pw_desc, partials, stats, codes, codes_lp, k1_power, tz, v, keys, scales, peaks, scratch_a, scratch_b, lagdump;
@@ -286,7 +285,7 @@ void k1_build_table_host(std::vector<int32_t> &tab, std::vector<int32_t> &direct
             tab[(size_t)mx * (mx + 1) / 2 + mn] = (int32_t)std::llround(std::atan2((double)b, (double)a) * (8388608.0 / M_PI));
         }
     // the direct half-plane table of the streaming kernel: D[b_I | (b_Q & 0x7f) << 8] = a(I, Q) for b_Q >= 128 (Q > 0),
-    // placed from the first-octant codes by the integer rules of k1_angle_from
+    // placed from the first-octant codes by the integer rules of k1_discriminator.hpp
     direct.resize(kK1DirectEntries);
     for (int bq = 128; bq < 256; bq++)
         for (int bi = 0; bi < 256; bi++) {
@@ -569,7 +568,6 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
     if (!seg_chunks) {
         // two-sweep column pass (N2 = 2048, 4096): 8 Nc written, read and written again -- SURVEY's third pass
         ProfScope ps(ctx, TDOA_K_FWD_COL, (fused_k1 ? 2.0 : 4.0) * sum_len + (col2pass ? 3.0 : 1.0) * nc8 * n_sw);
-        const auto *table = static_cast<const int *>(ctx->k1_table.p);
         const auto *qtable = static_cast<const int *>(ctx->k1_quad.p);
         if (fused_k1 && col16)
             hipLaunchKernelGGL(k_fwd_col256_k1<false>, dim3(ctx->n_cu), dim3(1024), kColK1wLds, st, d_sw, qtable, stats, tz, pl,
@@ -583,7 +581,7 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
                 hipLaunchKernelGGL(k_fwd_col_finish<8>, dim3(pl.N1 / 512, 256, n_sw), dim3(256), 0, st, tz, pl);
         }
         else if (fused_k1 && colx == 2)
-            hipLaunchKernelGGL(k_fwd_col512_k1, dim3(2 * ctx->n_cu), dim3(512), kColK1Lds, st, d_sw, table, stats, tz, pl, n_sw);
+            hipLaunchKernelGGL(k_fwd_col512_k1, dim3(ctx->n_cu), dim3(1024), kCol512Lds, st, d_sw, qtable, stats, tz, pl, n_sw);
         else if (col16)
             hipLaunchKernelGGL(k_fwd_col256_c16<false>, dim3(pl.N1 / 32, n_sw), dim3(512), lds_col16, st, d_sw, codes,
                                code_stride, stats, tz, pl);
@@ -631,9 +629,9 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
         ProfScope ps(ctx, TDOA_K_FWD_ROW, 2.0 * nc8 * n_sw);
         if (row16 && decim)     // unpacked spectra in COLS-column tiles behind G and V' in the V workspace (k_pair_decimate16 streams them)
             hipLaunchKernelGGL(k_fwd_row4096_unpack, dim3(pl.N2 / 2, n_sw), dim3(512), sizeof(float2) * 2 * kRowLds, st, tz, pl,
-                               v + dec_spectra_offset(pl, n_pw), fused_k1 && col16);
+                               v + dec_spectra_offset(pl, n_pw), fused_k1 && (col16 || colx == 2));
         else if (row16)
-            hipLaunchKernelGGL(k_fwd_row4096, dim3(pl.N2, n_sw), dim3(256), 0, st, tz, pl, fused_k1 && col16);
+            hipLaunchKernelGGL(k_fwd_row4096, dim3(pl.N2, n_sw), dim3(256), 0, st, tz, pl, fused_k1 && (col16 || colx == 2));
         else
             hipLaunchKernelGGL(k_fwd_row, dim3(pl.N2, n_sw), dim3(256), lds_row, st, tz, pl);
     }
@@ -1037,20 +1035,13 @@ int tdoa_create(const tdoa_params *p, tdoa_ctx **out)
         delete ctx;
         return TDOA_ERR_HIP;
     }
-    {   // K1 angle table, once per context
-        void *t = nullptr;
-        if (hipMalloc(&t, kK1TableBytes) != hipSuccess) {
-            (void)hipStreamDestroy(ctx->stream);
-            delete ctx;
-            return TDOA_ERR_NOMEM;
-        }
-        ctx->k1_table.p = t;
-        ctx->k1_table.cap = kK1TableBytes;
+    {   // K1 angle tables, once per context (the first-octant table is the host's source for the two the kernels use)
         std::vector<int32_t> tab, direct, quad;
         k1_build_table_host(tab, direct, quad);
         void *dt = nullptr, *dq = nullptr;
         if (hipMalloc(&dt, kK1DirectBytes) != hipSuccess) {
-            tdoa_destroy(ctx);
+            (void)hipStreamDestroy(ctx->stream);
+            delete ctx;
             return TDOA_ERR_NOMEM;
         }
         ctx->k1_direct.p = dt;
@@ -1061,8 +1052,7 @@ int tdoa_create(const tdoa_params *p, tdoa_ctx **out)
         }
         ctx->k1_quad.p = dq;
         ctx->k1_quad.cap = kK1QuadrantBytes;
-        if (hipMemcpy(t, tab.data(), kK1TableBytes, hipMemcpyHostToDevice) != hipSuccess ||
-            hipMemcpy(dq, quad.data(), kK1QuadrantBytes, hipMemcpyHostToDevice) != hipSuccess ||
+        if (hipMemcpy(dq, quad.data(), kK1QuadrantBytes, hipMemcpyHostToDevice) != hipSuccess ||
             hipMemcpy(dt, direct.data(), kK1DirectBytes, hipMemcpyHostToDevice) != hipSuccess) {
             tdoa_destroy(ctx);
             return TDOA_ERR_HIP;
@@ -1092,7 +1082,7 @@ void tdoa_destroy(tdoa_ctx *ctx)
     if (ctx->graph_exec) (void)hipGraphExecDestroy(ctx->graph_exec);
     if (ctx->graph) (void)hipGraphDestroy(ctx->graph);
     tdoa_capture_clear(ctx);
-    DevBuf *bufs[] = {&ctx->k1_table, &ctx->k1_direct, &ctx->k1_quad, &ctx->sw_desc, &ctx->pw_desc, &ctx->partials, &ctx->stats, &ctx->codes, &ctx->codes_lp, &ctx->k1_power, &ctx->dec_taps, &ctx->dec_gain, &ctx->tz, &ctx->v, &ctx->keys,
+    DevBuf *bufs[] = {&ctx->k1_direct, &ctx->k1_quad, &ctx->sw_desc, &ctx->pw_desc, &ctx->partials, &ctx->stats, &ctx->codes, &ctx->codes_lp, &ctx->k1_power, &ctx->dec_taps, &ctx->dec_gain, &ctx->tz, &ctx->v, &ctx->keys,
                       &ctx->scales, &ctx->peaks, &ctx->scratch_a, &ctx->scratch_b, &ctx->lagdump,
                       &ctx->ex_a, &ctx->ex_b, &ctx->ex_c, &ctx->ex_d, &ctx->ex_part,
                       &ctx->g_sw_desc, &ctx->g_pw_desc, &ctx->g_quad_desc, &ctx->g_scales, &ctx->g_keys, &ctx->fine_raw, &ctx->fine, &ctx->qual};
