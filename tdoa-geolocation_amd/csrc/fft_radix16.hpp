@@ -945,7 +945,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SELF ? 1 : 
     // pair-windows of one window all read the same S station rows a and N2 - a; workgroups are dealt round-robin over
     // the 8 XCDs (b and b + 8 share an L2), so the workgroups of one (window, row pair) group are given consecutive
     // slots of ONE XCD: a station row then comes from HBM once and from that XCD's L2 for its other S - 2 pairs.
-    // (With 3 stations a row has two readers and the remap measured neutral: the plain 2-D grid stays for P <= S.)
+    // (With 3 stations a row has two readers and on cfg2 -- 8 MB spectra, the whole window waits in the Infinity Cache -- the
+    // remap measured neutral: the plain 2-D grid stays for P <= S unless a window's spectra exceed 64 MB, cfg3.)
     constexpr bool self = SELF;
     int pw_index = blockIdx.y, a = self ? 0 : blockIdx.x + 1;
     if (!self && group_pairs > 0) {

@@ -619,11 +619,17 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
     // (window-major sharding with more pairs than stations): see k_inv_row_pair4096
     int xcd_pairs = 0;
     unsigned int xcd_grid = 0;
-    if (row16 && ctx->xcd_rows && pairs_per_window > 0 && n_pw % pairs_per_window == 0 && n_sw > 0 &&
-        pairs_per_window > n_sw / (n_pw / pairs_per_window) && pl.N2 > 2) {
-        const long long groups = (long long)(n_pw / pairs_per_window) * (pl.N2 / 2 - 1);
-        const long long blocks = (groups + 7) / 8 * 8 * pairs_per_window;
-        if (blocks < (1ll << 31)) { xcd_pairs = pairs_per_window; xcd_grid = (unsigned int)blocks; }
+    // ... or when a window's spectra are too large to wait in the Infinity Cache for their second reader (cfg3: 3 x 134 MB per
+    // window, and the plain grid runs ALL rows of one pair-window before the next: 62 ms against 73-75 for its pair-row pass;
+    // one workgroup running a group's pair-windows one after the other measured 67)
+    if (row16 && ctx->xcd_rows && pairs_per_window > 0 && n_pw % pairs_per_window == 0 && n_sw > 0 && pl.N2 > 2) {
+        const int stations = n_sw / (n_pw / pairs_per_window);
+        if (pairs_per_window > stations ||
+            (pairs_per_window > 1 && (size_t)stations * (size_t)pl.Nc * sizeof(float2) > ((size_t)64 << 20))) {
+            const long long groups = (long long)(n_pw / pairs_per_window) * (pl.N2 / 2 - 1);
+            const long long blocks = (groups + 7) / 8 * 8 * pairs_per_window;
+            if (blocks < (1ll << 31)) { xcd_pairs = pairs_per_window; xcd_grid = (unsigned int)blocks; }
+        }
     }
     if (!seg_chunks) {
         ProfScope ps(ctx, TDOA_K_FWD_ROW, 2.0 * nc8 * n_sw);
