@@ -40,6 +40,7 @@ STATIONS = [
 TX = (41.20, -96.00, 400.0)
 SEED_BASE = 0x5D0A0000
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured achievable)
+HBM_FILL_GBS = 5800.0       # what a plain fill / out-of-place add sustains on the pool's boxes (profiles/r03_hbm_microbench.txt)
 
 CONFIGS = {
     "cfg2": dict(stations=3, fs=2e6, block=66_666_666, wlen=2_000_000, sim="simulator", steps=10,
@@ -470,7 +471,8 @@ def main():
         decimated = (n1 == 4096 and n2 in (256, 512) and reach > 4095 and os.environ.get("TDOA_NO_DECIMATE") != "1"
                      and decimation_fits(n1 * n2, max_lag))
         if decimated:     # K3 + 16:1 FIR decimation of the pair spectrum, then an Nc/16-point inverse
-            hot = dict(hot, k_inv_row_pair=["k_pair_decimate16"], k_inv_col_peak=["k_inv_rows_plain_r8", "k_small_col_peak"])
+            hot = dict(hot, k_fwd_row=["k_fwd_row4096_unpack"], k_inv_row_pair=["k_pair_decimate16"],
+                       k_inv_col_peak=["k_inv_rows_plain_r8", "k_small_col_peak"])
         if max_lag <= 1024 and n1 == 4096:
             # segment form; with 3+ pairs per window the station transforms are shared (quads)
             hot = dict(hot, k_inv_row_pair=["k_xcorr_segments_quad" if n_pairs >= 3 and os.environ.get("TDOA_NO_SEGMENT_QUADS") != "1"
@@ -492,13 +494,16 @@ def main():
             # what limits the kernel, from the evidence at hand: its vector-instruction issue share (SQ counters) against
             # its share of the HBM peak
             hbm_frac = None if traffic is None else traffic / avg_s / 1e9 / HBM_PEAK_GBS
+            # ("hbm": its memory-side bytes per second are a larger share of what a plain fill sustains than its issue share)
             limiter = None
             if sq is not None:
-                limiter = "valu_issue" if sq["valu_issue_frac"] > max(0.6, hbm_frac or 0.0) else "hbm"
+                hbm_of_fill = (hbm_frac or 0.0) * HBM_PEAK_GBS / HBM_FILL_GBS
+                limiter = "valu_issue" if sq["valu_issue_frac"] > max(0.6, hbm_of_fill) else "hbm"
             roof = {"bound": "hbm", "kernel": " + ".join(kernels),
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                     "frac_of_measured_achievable": round(achieved / 6290.0, 4),   # guide: 6.29 TB/s achievable
+                    "frac_of_fill_rate": round(achieved / HBM_FILL_GBS, 4),
                     "traffic": traffic, "traffic_source": src,
                     # HBM side: bytes the memory-side counters saw per launch / launch time / 8 TB/s
                     "hbm_frac": None if hbm_frac is None else round(hbm_frac, 4),
