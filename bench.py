@@ -4,17 +4,19 @@
 A step = one pass of the hot path (u8 IQ -> FM discriminator -> FFT -> conj-multiply -> inverse FFT -> peak pick)
 over one synthetic capture set already resident in HBM; peaks end on the host.
 
-  --config cfg2 (default at --gpus 1)  3 stations x 2 Msps x 100 s, 99 windows x 3 pairs, L = 2 000 000, N = 2^21
+  --config cfg2 (default)              3 stations x 2 Msps x 100 s, 99 windows x 3 pairs, L = 2 000 000, N = 2^21
   --config cfg3                        weak_signal_simulator.go captures, 10 s windows (L = 2e7, N = 2^25), 342 windows
                                        x 3 pairs = 1026 pair-windows streamed in launch groups
-  --config cfg4 (default at --gpus >1) 8 stations (28 pairs) x 2 Msps x 100 s
+  --config cfg4                        8 stations (28 pairs) x 2 Msps x 100 s
   --config cfg5                        16 stations (120 pairs) x 4 Msps x 300 s, 1 s windows (L = 4e6, N = 2^22)
 
-Multi-GPU (one rank per GPU, torch.distributed over RCCL):
-  --scaling strong (default for --gpus > 1): ONE capture set; rank r runs tdoa_process(ctx, r, world) on the windows it
-      owns (window-major, wid % world == r), one all-gather of the per-pair peak records, merge, N-station least-squares
-      solve on rank 0 -- all inside the timed region.  value = the job's station-samples / time.
-  --scaling weak: every rank owns its own capture set (replicas + the same all-gather); value = sum over ranks.
+Multi-GPU (one rank per GPU, torch.distributed over RCCL; no collective on the data path):
+  --scaling weak (default): one job of N x (the config's windows), window-major -- rank r holds and processes capture
+      set r, ONE all-gather of the per-pair peak records per step, rank 0 decodes all of them and solves every set -- all
+      inside the timed region.  Per-GPU work is fixed; value = the station-samples all ranks processed / time.
+  --scaling strong (BASELINE config 4 as written: `--config cfg4 --scaling strong`): ONE capture set; rank r runs
+      tdoa_process(ctx, r, world) on the windows it owns (wid % world == r), one all-gather, byte-wise owner merge and the
+      N-station least-squares solve on rank 0 -- all inside the timed region.  value = the job's station-samples / time.
 
 Prints ONE JSON line on rank 0 (see the contract in the task description).
 """
@@ -302,9 +304,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
-    cfg_name = args.config or ("cfg2" if world == 1 else "cfg4")
+    # The default at every N is BASELINE config 2, WEAK-scaled: one job of N x 99 windows, window-major -- rank r holds and
+    # processes its own 99 windows (its own capture set, different seeds), the peak records are all-gathered over RCCL and
+    # rank 0 decodes all of them and solves every set.  Per-GPU work is fixed, so value(N) / (N value(1)) is the scaling
+    # efficiency.  `--config cfg4 --scaling strong` is BASELINE config 4 as written: ONE 8-station capture set, its windows
+    # dealt wid % N to the ranks.
+    cfg_name = args.config or "cfg2"
     cfg = dict(CONFIGS[cfg_name])
-    scaling = args.scaling or ("strong" if (world > 1 or args.force_dist) else "weak")
+    scaling = args.scaling or "weak"
     steps = args.steps if args.steps is not None else cfg["steps"]
     # one rank per GPU; TDOA_BENCH_BACKEND=gloo is a rehearsal mode (several ranks may then share
     # a GPU and the peak records travel through host memory) -- the driver always runs nccl (= RCCL)
@@ -400,6 +407,14 @@ def main():
             merged = gathered.view(world, -1).amax(dim=0).cpu().numpy()
             state["peaks"] = sharding.bytes_as_peaks(merged, n_windows, n_pairs)
             state["fix"] = solve(state["peaks"])
+        elif scaling == "weak" and rank == 0:
+            # rank r's part is capture set r (windows r n_windows ... of the job): decode all, solve every set
+            parts = gathered.cpu().numpy().reshape(world, -1)
+            fixes = [solve(sharding.bytes_as_peaks(parts[r], n_windows, n_pairs)) for r in range(world)]
+            state["peaks"] = sharding.bytes_as_peaks(parts[0], n_windows, n_pairs)
+            state["fix"] = fixes[0]
+        elif scaling == "weak":
+            state["peaks"] = sharding.bytes_as_peaks(dev_peaks.cpu().numpy(), n_windows, n_pairs)
 
     def fence():
         if use_dist:
@@ -535,8 +550,10 @@ def main():
         if use_dist and scaling == "strong":
             par = ("one capture set, windows dealt wid %% %d to the ranks, %s all-gather of the peak records, owner merge + "
                    "least-squares solve on rank 0, all inside the timed region" % (world, "RCCL" if backend == "nccl" else backend))
-        elif world > 1:
-            par = "independent capture set per GPU x%d + RCCL all-gather of the peak records" % world
+        elif use_dist:
+            par = ("one job of %d x %d windows, window-major: rank r holds and processes capture set r (%d windows), %s all-gather of "
+                   "the peak records, rank 0 decodes all of them and solves every set, all inside the timed region"
+                   % (world, n_windows, n_windows, "RCCL" if backend == "nccl" else backend))
         else:
             par = "single GPU"
         out = {
