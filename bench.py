@@ -413,8 +413,6 @@ def main():
             fixes = [solve(sharding.bytes_as_peaks(parts[r], n_windows, n_pairs)) for r in range(world)]
             state["peaks"] = sharding.bytes_as_peaks(parts[0], n_windows, n_pairs)
             state["fix"] = fixes[0]
-        elif scaling == "weak":
-            state["peaks"] = sharding.bytes_as_peaks(dev_peaks.cpu().numpy(), n_windows, n_pairs)
 
     def fence():
         if use_dist:
