@@ -176,7 +176,11 @@ constexpr size_t kLdsCap = 128 * 1024;
 
 // factor Nc = N1 * N2 for the four-step FFT; rows (N1) live whole in LDS
 // elements of padding after every 256 rows of a two-sweep plan's TZ (2 KB; measured on cfg3: 0 -> 107 ms column pass, 128 -> 91, 256 -> 87, 512 -> 89)
-int g_zpad = [] { const char *e = std::getenv("TDOA_ZPAD"); return e ? std::atoi(e) : 256; }();
+int g_zpad = [] {
+    const char *e = std::getenv("TDOA_ZPAD");
+    const int v = e ? std::atoi(e) : 256;
+    return v < 0 ? 0 : v > 4096 ? 4096 : v & ~15;      // rows stay 128-byte aligned (the finish sweep reads 16-byte pairs)
+}();
 
 int make_plan(long long n_real, bool packed, FftPlan *pl)
 {
