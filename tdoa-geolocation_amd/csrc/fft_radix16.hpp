@@ -410,7 +410,6 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         const int a = t.a, w = t.w, len = t.len;
         // (the quadrant table's angle codes are scaled by 256 -- so are the mean and, inversely, the scale: exact)
         const float mean = stats[w].mean * 256.0f, scale = stats[w].scale * 0.00390625f;
-        const int n1 = (t.bx << LOGW) + c;
         // where the previous tile's outputs go: output k of thread j is row (a 256 +) j + 16 k, column n1; it sits in v[oreg(k)]
         const ColK1Tile tp = col_k1_tile<SUB>(sw, prev >= 0 ? prev : tile, nbx, G);
         float2 *outp = T + (size_t)tp.w * pl.Zs + (SUB ? (size_t)tp.a * ((size_t)256 * N1 + pl.zpad) : 0);
@@ -428,15 +427,14 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 // The previous tile's output in v[r] leaves just before the register is needed again: the 16 stores of a
-                // thread go out one per ~60 instructions of discriminator work instead of as a burst at the end of a trip.
-                // (A burst from every wave of the CU at once fills the store queue and then holds all of them at the
-                // store instructions while it drains: leaving the stores out made the kernel 0.31 ms of 1.08 faster,
-                // although the memory system takes the same bytes in 0.43 ms as a plain fill.)
-                if (prev >= 0) store_at(outp + (size_t)(16 * oreg(r)) * N1, offp, v[r]);
-                const int i0 = 2 * ((a + G * (j + 16 * r)) * N1 + n1);
+                // thread go out one per ~35 instructions of discriminator work instead of as a burst of 256 store
+                // instructions from the sixteen waves of the CU at the end of a trip (0.98 -> 0.96 ms).  Unconditional: on
+                // a workgroup's first trip v[] is zero and goes to the place of THIS tile, which the same thread
+                // overwrites with the real values one trip later (one wave's stores to an address stay in order).
+                store_at(outp + (size_t)(16 * oreg(r)) * N1, offp, v[r]);
                 const int i_first = 2 * ((a + G * (jw + 16 * r)) * N1 + (t.bx << LOGW));
                 const int i_end = i_first + 2 * W;                                                   // one past the wave's last sample of this r
-                if (i_first >= len) {
+                if (__builtin_expect(i_first >= len, 0)) {
                     v[r] = make_float2(0.0f, 0.0f);
                     continue;
                 }
@@ -449,7 +447,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
                     const int st0 = k1_stored_code_scaled(a0, ap), st1 = k1_stored_code_scaled(a1, a0);
                     v[r] = make_float2(k1_normalise(st0, mean, scale), k1_normalise(st1, mean, scale));
                 } else {
-                    v[r] = k1_element_from<true>(a0, a1, ap, i0, len, mean, scale, r == 0);
+                    v[r] = k1_element_from<true>(a0, a1, ap, i_first + 2 * c, len, mean, scale, r == 0);
                 }
             }
         }
@@ -680,7 +678,6 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         const Col512Tile t = col512_tile(sw, tile, nbx);
         const int w = t.w, len = t.len;
         const float mean = stats[w].mean * 256.0f, scale = stats[w].scale * 0.00390625f;      // scaled codes: k_fwd_col256_k1
-        const int n1 = t.bx * C + c;
         float *img = plane + par * 256 * C;
         // where the previous tile's outputs go: output k of thread (j, par) is row j + 16 k + 256 par, column n1, in v[oreg(k)]
         const Col512Tile tp = col512_tile(sw, prev >= 0 ? prev : tile, nbx);
@@ -694,11 +691,10 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
             const int jw = __builtin_amdgcn_readfirstlane(j & ~1), pw = __builtin_amdgcn_readfirstlane(par);
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                if (prev >= 0) store_at(outp + (size_t)(16 * oreg(r)) * N1, offp, v[r]);
-                const int i0 = 2 * ((F * (j + 16 * r) + par) * N1 + n1);
+                store_at(outp + (size_t)(16 * oreg(r)) * N1, offp, v[r]);      // (unconditional: see k_fwd_col256_k1)
                 const int i_first = 2 * ((F * (jw + 16 * r) + pw) * N1 + t.bx * C);
                 const int i_end = 2 * ((F * (jw + 1 + 16 * r) + pw) * N1 + t.bx * C + C);      // one past the wave's last sample of this r
-                if (i_first >= len) {
+                if (__builtin_expect(i_first >= len, 0)) {
                     v[r] = make_float2(0.0f, 0.0f);
                     continue;
                 }
@@ -711,7 +707,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
                     const int st0 = k1_stored_code_scaled(a0, ap), st1 = k1_stored_code_scaled(a1, a0);
                     v[r] = make_float2(k1_normalise(st0, mean, scale), k1_normalise(st1, mean, scale));
                 } else {
-                    v[r] = k1_element_from<true>(a0, a1, ap, i0, len, mean, scale, r == 0);
+                    v[r] = k1_element_from<true>(a0, a1, ap, i_first + 2 * (F * (j - jw) * N1 + c), len, mean, scale, r == 0);
                 }
             }
         }
