@@ -311,6 +311,10 @@ enum {
     TDOA_K_PEAK, TDOA_K_COUNT
 };
 int         tdoa_profile_enable(tdoa_ctx *ctx, int on);
+/* which scopes of the profiling path record events: bit k = TDOA_K_* scope k (default: all).  A measurement that needs
+ * one kernel's launch durations (bench.py: the dominant kernel's, for the roofline) selects that scope alone, so that the
+ * timed steps carry two event records instead of one per kernel boundary. */
+int         tdoa_profile_select(tdoa_ctx *ctx, unsigned int scope_mask);
 int         tdoa_profile_reset(tdoa_ctx *ctx);
 int         tdoa_profile_get(tdoa_ctx *ctx, int kernel, double *total_ms, int64_t *launches,
                              double *algorithmic_bytes);

@@ -66,6 +66,7 @@ struct tdoa_ctx {
     DevBuf ex_a, ex_b, ex_c, ex_d, ex_part;
 
     bool profiling = false;
+    unsigned int prof_mask = ~0u;           // scopes that record events (tdoa_profile_select)
     bool force_generic = false;   // tests: run the any-size kernels even at the hot sizes
     std::vector<ProfRec> recs;
     std::vector<hipEvent_t> prof_pool;      // events of the profiling path, reused from call to call
@@ -242,6 +243,10 @@ struct ProfScope {
     bool on;
     ProfScope(tdoa_ctx *c, int kernel, double bytes) : ctx(c), on(c->profiling)
     {
+        if (on && !((c->prof_mask >> kernel) & 1u)) {      // not selected: its launches are unscoped work
+            on = false;
+            c->prof_last = -1;
+        }
         if (!on) return;
         rec.kernel = kernel;
         rec.bytes = bytes;
@@ -1823,6 +1828,13 @@ int tdoa_profile_enable(tdoa_ctx *ctx, int on)
 {
     if (!ctx) return TDOA_ERR_INVALID;
     ctx->profiling = on != 0;
+    return TDOA_OK;
+}
+
+int tdoa_profile_select(tdoa_ctx *ctx, unsigned int scope_mask)
+{
+    if (!ctx) return TDOA_ERR_INVALID;
+    ctx->prof_mask = scope_mask;
     return TDOA_OK;
 }
 

@@ -74,7 +74,7 @@ SYMBOLS = [
     "tdoa_fm_xcorr_u8", "tdoa_fm_preprocess_u8", "tdoa_fm_xcorr_lags_u8", "tdoa_debug_force_generic",
     "tdoa_debug_flags", "tdoa_debug_graph_info", "tdoa_debug_segment_quads", "tdoa_cross_correlate_batch_c64",
     "tdoa_latlon_to_ecef", "tdoa_ecef_to_latlon", "tdoa_solve_3station", "tdoa_solve_nstation",
-    "tdoa_profile_enable", "tdoa_profile_reset", "tdoa_profile_get", "tdoa_kernel_name",
+    "tdoa_profile_enable", "tdoa_profile_select", "tdoa_profile_reset", "tdoa_profile_get", "tdoa_kernel_name",
     "tdoa_plan_info",
 ]
 
@@ -151,6 +151,7 @@ def load(build_if_missing=True):
     L.tdoa_solve_3station.argtypes = [dp, dp, dp, C.POINTER(C.c_int)]
     L.tdoa_solve_nstation.argtypes = [dp, C.c_int, dp, dp, C.c_int, dp, C.POINTER(C.c_int)]
     L.tdoa_profile_enable.argtypes = [vp, C.c_int]
+    L.tdoa_profile_select.argtypes = [vp, C.c_uint]
     L.tdoa_profile_reset.argtypes = [vp]
     L.tdoa_profile_get.argtypes = [vp, C.c_int, dp, C.POINTER(C.c_int64), dp]
     L.tdoa_plan_info.argtypes = [vp, C.POINTER(C.c_int64), i32p, i32p]
@@ -454,6 +455,17 @@ class Context:
     # ---- measurement -------------------------------------------------------
     def profile_enable(self, on=True):
         self._chk(self._L.tdoa_profile_enable(self._h, 1 if on else 0))
+
+    def profile_select(self, names=None):
+        """record events only for the named scopes (tdoa_kernel_name); None = all"""
+        if names is None:
+            mask = 0xffffffff
+        else:
+            all_names = [self._L.tdoa_kernel_name(k).decode() for k in range(len(KERNELS))]
+            mask = 0
+            for n in names:
+                mask |= 1 << all_names.index(n)
+        self._chk(self._L.tdoa_profile_select(self._h, mask))
 
     def profile_reset(self):
         self._chk(self._L.tdoa_profile_reset(self._h))
