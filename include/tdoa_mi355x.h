@@ -310,6 +310,9 @@ enum {
     TDOA_K_STATS = 0, TDOA_K_FWD_COL, TDOA_K_FWD_ROW, TDOA_K_INV_ROW, TDOA_K_INV_COL,
     TDOA_K_PEAK, TDOA_K_COUNT
 };
+/* on = 1: tdoa_process launches its kernels one by one with HIP events at the boundaries of the selected scopes.
+ * on = 2: tdoa_process keeps replaying the whole step as one hipGraph (the default path); the selected scopes are timed by
+ *         event-record nodes spliced into the captured graph.  on = 0: off. */
 int         tdoa_profile_enable(tdoa_ctx *ctx, int on);
 /* which scopes of the profiling path record events: bit k = TDOA_K_* scope k (default: all).  A measurement that needs
  * one kernel's launch durations (bench.py: the dominant kernel's, for the roofline) selects that scope alone, so that the

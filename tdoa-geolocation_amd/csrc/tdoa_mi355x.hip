@@ -67,6 +67,14 @@ struct tdoa_ctx {
 
     bool profiling = false;
     unsigned int prof_mask = ~0u;           // scopes that record events (tdoa_profile_select)
+    // profiling INSIDE the replayed step graph (tdoa_profile_enable(ctx, 2)): while the step is captured the selected scopes
+    // note the capture's last node before their first and after their last kernel; after the capture an event-record NODE
+    // goes in at either place (events recorded on a capturing stream are dropped by this ROCm; explicit nodes are timed
+    // correctly: scripts/microbench/graph_event_nodes.hip)
+    bool graph_prof = false;
+    bool capturing = false;
+    struct GraphMark { int kernel; double bytes; hipGraphNode_t before, last; hipEvent_t e0, e1; };
+    std::vector<GraphMark> graph_marks;
     bool force_generic = false;   // tests: run the any-size kernels even at the hot sizes
     std::vector<ProfRec> recs;
     std::vector<hipEvent_t> prof_pool;      // events of the profiling path, reused from call to call
@@ -221,6 +229,15 @@ int set_lds(tdoa_ctx *ctx, K kernel, size_t bytes)
     return TDOA_OK;
 }
 
+void clear_graph_marks(tdoa_ctx *ctx)
+{
+    for (auto &m : ctx->graph_marks) {
+        if (m.e0) (void)hipEventDestroy(m.e0);
+        if (m.e1) (void)hipEventDestroy(m.e1);
+    }
+    ctx->graph_marks.clear();
+}
+
 // next free event of the pool, recorded on the context's stream; -1 on failure
 int prof_mark(tdoa_ctx *ctx)
 {
@@ -241,8 +258,24 @@ struct ProfScope {
     tdoa_ctx *ctx;
     ProfRec rec{};
     bool on;
+    int mark = -1;                           // graph mode: index into ctx->graph_marks
+    static hipGraphNode_t capture_tail(tdoa_ctx *c)
+    {
+        hipStreamCaptureStatus stt;
+        const hipGraphNode_t *deps = nullptr;
+        size_t nd = 0;
+        if (hipStreamGetCaptureInfo_v2(c->stream, &stt, nullptr, nullptr, &deps, &nd) != hipSuccess || nd != 1) return nullptr;
+        return deps[0];
+    }
     ProfScope(tdoa_ctx *c, int kernel, double bytes) : ctx(c), on(c->profiling)
     {
+        if (c->graph_prof && c->capturing && ((c->prof_mask >> kernel) & 1u)) {
+            tdoa_ctx::GraphMark m{kernel, bytes, capture_tail(c), nullptr, nullptr, nullptr};
+            if (m.before) {
+                mark = (int)c->graph_marks.size();
+                c->graph_marks.push_back(m);
+            }
+        }
         if (on && !((c->prof_mask >> kernel) & 1u)) {      // not selected: its launches are unscoped work
             on = false;
             c->prof_last = -1;
@@ -255,6 +288,7 @@ struct ProfScope {
     }
     ~ProfScope()
     {
+        if (mark >= 0) ctx->graph_marks[mark].last = capture_tail(ctx);
         if (!on) return;
         rec.e1 = prof_mark(ctx);
         ctx->prof_last = rec.e1;
@@ -1095,6 +1129,7 @@ void tdoa_destroy(tdoa_ctx *ctx)
     prof_collect(ctx);
     for (hipEvent_t e : ctx->prof_pool) (void)hipEventDestroy(e);
     if (ctx->graph_exec) (void)hipGraphExecDestroy(ctx->graph_exec);
+    clear_graph_marks(ctx);
     if (ctx->graph) (void)hipGraphDestroy(ctx->graph);
     tdoa_capture_clear(ctx);
     DevBuf *bufs[] = {&ctx->k1_direct, &ctx->k1_quad, &ctx->sw_desc, &ctx->pw_desc, &ctx->partials, &ctx->stats, &ctx->codes, &ctx->codes_lp, &ctx->k1_power, &ctx->dec_taps, &ctx->dec_gain, &ctx->tz, &ctx->v, &ctx->keys,
@@ -1499,6 +1534,7 @@ static int process_impl(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host,
         key.push_back((uint64_t)(uintptr_t)c.dev);
         key.push_back((uint64_t)c.n);
     }
+    key.push_back(ctx->graph_prof ? 0x100000000ull | ctx->prof_mask : 0ull);      // an instrumented step is a different graph
     const bool graph_ok = ctx->use_graph && !ctx->profiling;
     const bool replay = graph_ok && ctx->graph_exec && key == ctx->graph_key;
 
@@ -1555,7 +1591,10 @@ static int process_impl(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host,
         if (ctx->graph) { (void)hipGraphDestroy(ctx->graph); ctx->graph = nullptr; }
         ctx->graph_key.clear();
         HIPCHK(ctx, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        clear_graph_marks(ctx);
+        ctx->capturing = true;
         rc = enqueue();
+        ctx->capturing = false;
         hipGraph_t g = nullptr;
         hipError_t e = hipStreamEndCapture(st, &g);
         if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
@@ -1583,6 +1622,28 @@ static int process_impl(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host,
                 return fail(ctx, TDOA_ERR_STATE, "captured step is not one dependency chain");
             if (memsets && !ctx->memset_nodes) return fail(ctx, TDOA_ERR_STATE, "captured step holds a memset node");
         }
+        // graph-mode profiling: an event-record node before the first and after the last kernel of every marked scope
+        for (auto &m : ctx->graph_marks) {
+            if (!m.before || !m.last || m.last == m.before) { m.e0 = m.e1 = nullptr; continue; }
+            HIPCHK(ctx, hipEventCreate(&m.e0));
+            HIPCHK(ctx, hipEventCreate(&m.e1));
+            auto splice = [&](hipGraphNode_t after, hipEvent_t ev) -> hipError_t {      // after -> [record ev] -> after's successors
+                size_t nd = 0;
+                hipError_t r = hipGraphNodeGetDependentNodes(after, nullptr, &nd);
+                if (r != hipSuccess) return r;
+                std::vector<hipGraphNode_t> succ(nd);
+                if (nd && (r = hipGraphNodeGetDependentNodes(after, succ.data(), &nd)) != hipSuccess) return r;
+                hipGraphNode_t rec = nullptr;
+                for (hipGraphNode_t sn : succ)
+                    if ((r = hipGraphRemoveDependencies(g, &after, &sn, 1)) != hipSuccess) return r;
+                if ((r = hipGraphAddEventRecordNode(&rec, g, &after, 1, ev)) != hipSuccess) return r;
+                for (hipGraphNode_t sn : succ)
+                    if ((r = hipGraphAddDependencies(g, &rec, &sn, 1)) != hipSuccess) return r;
+                return hipSuccess;
+            };
+            HIPCHK(ctx, splice(m.last, m.e1));       // (the later place first: `before` keeps its successor until then)
+            HIPCHK(ctx, splice(m.before, m.e0));
+        }
         HIPCHK(ctx, hipGraphInstantiate(&ctx->graph_exec, g, nullptr, nullptr, 0));
         ctx->graph_key = key;
         HIPCHK(ctx, hipGraphLaunch(ctx->graph_exec, st));
@@ -1597,6 +1658,15 @@ static int process_impl(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host,
         HIPCHK(ctx, hipMemcpyAsync(fine_host, ctx->fine.p, sizeof(FineOut) * slots, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
     prof_collect(ctx);
+    if (graph_ok && ctx->graph_prof)            // the replay just finished: read the event-record nodes of this step
+        for (auto &m : ctx->graph_marks) {
+            float ms = 0;
+            if (m.e0 && m.e1 && hipEventElapsedTime(&ms, m.e0, m.e1) == hipSuccess) {
+                ctx->prof_ms[m.kernel] += ms;
+                ctx->prof_launches[m.kernel] += 1;
+                ctx->prof_bytes[m.kernel] += m.bytes;
+            }
+        }
     return TDOA_OK;
 }
 
@@ -1827,7 +1897,8 @@ int tdoa_debug_flags(tdoa_ctx *ctx, unsigned flags)
 int tdoa_profile_enable(tdoa_ctx *ctx, int on)
 {
     if (!ctx) return TDOA_ERR_INVALID;
-    ctx->profiling = on != 0;
+    ctx->profiling = on == 1;
+    ctx->graph_prof = on == 2;
     return TDOA_OK;
 }
 

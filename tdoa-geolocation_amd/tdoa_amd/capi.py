@@ -454,7 +454,8 @@ class Context:
 
     # ---- measurement -------------------------------------------------------
     def profile_enable(self, on=True):
-        self._chk(self._L.tdoa_profile_enable(self._h, 1 if on else 0))
+        """True / 1: launch by launch with events; 2: events as nodes of the replayed step graph; False / 0: off"""
+        self._chk(self._L.tdoa_profile_enable(self._h, int(on)))
 
     def profile_select(self, names=None):
         """record events only for the named scopes (tdoa_kernel_name); None = all"""

@@ -244,6 +244,33 @@ def test_two_sweep_plan_padded_rows_in_every_form(oracle):
         _assert_lags_close(c.fm_xcorr_lags(a, b, 3000), lags)
 
 
+def test_profiling_inside_the_replayed_graph(oracle):
+    """tdoa_profile_enable(2): the step keeps replaying as one hipGraph and the selected scope is timed by event-record
+    nodes spliced into the captured graph; the results must not change and only the selected scope may report launches"""
+    import tdoa_amd
+    blk, wl, ml = 30000, 10000, 300
+    caps = [oracle.simulate_delayed_fm(3 * blk, d, 5, 40 + i) for i, d in enumerate((0, 21, 8))]
+    with tdoa_amd.Context(max_lag=ml, window_len=wl) as c:
+        for s, cap in enumerate(caps):
+            c.capture_upload(s, cap)
+        plain = c.process()
+        base_nodes = c.graph_info()["nodes"]
+        c.profile_enable(2)
+        c.profile_select(["k_fwd_row"])
+        first = c.process()                                  # captures and instruments the step
+        c.profile_reset()
+        again = [c.process() for _ in range(3)]
+        prof = c.profile()
+        c.profile_enable(False)
+        c.profile_select(None)
+        after = c.process()                                  # back to the plain graph
+        assert c.graph_info()["nodes"] == base_nodes
+    for got in [first, after] + again:
+        assert np.array_equal(got, plain)
+    assert prof["k_fwd_row"]["launches"] == 3 and prof["k_fwd_row"]["ms"] > 0.0
+    assert all(v["launches"] == 0 for k, v in prof.items() if k != "k_fwd_row")
+
+
 def test_eight_stations_28_pairs(oracle):
     """BASELINE config 4 geometry in miniature: 8 collectors, 28 pairs ordered i<j."""
     import tdoa_amd
