@@ -471,6 +471,32 @@ def test_fused_k1_in_the_batched_path(oracle):
     assert np.abs(fused["corr"] - stored["corr"]).max() <= 1e-6 * np.abs(stored["corr"]).max()
 
 
+@pytest.mark.parametrize("block,plan", [(1_100_001, (4096, 256)), (2_200_001, (4096, 512))])
+def test_fused_column_kernel_on_odd_window_starts_at_the_timed_plan(oracle, block, plan):
+    """The kernels of the timed path (4096 x 256 plan; 4096 x 512: config 5's; decimated inverse) on windows that start on ODD samples: blocks of an
+    odd number of samples put every window of blocks 1 and 2 at a byte offset that is 2 modulo 4 -- the 1024-thread column
+    kernel reads them with 2-byte-aligned dword loads, takes its boundary samples from the tile to the left, and its tiles
+    are dealt XCD by XCD.  Against the f64 oracle on the same slices, and against the materialised-code path."""
+    import tdoa_amd
+    wl, ml = block, 20000
+    caps = [oracle.simulate_delayed_fm(3 * block, d, 314, 70 + i) for i, d in enumerate((0, 29))]
+    with tdoa_amd.Context(max_lag=ml, window_len=wl) as c:
+        fused = c.process_u8(caps)
+        assert tuple(c.plan_info())[1:] == plan
+        c.debug_flags(no_fused_k1=True)
+        stored = c.process()
+    assert fused.shape == (3, 1)
+    assert np.array_equal(fused["lag"], stored["lag"])
+    assert np.abs(fused["corr"] - stored["corr"]).max() <= 1e-6 * np.abs(stored["corr"]).max()
+    for wid in range(3):
+        off = wid * block
+        ta, _ = oracle.b_preprocess(caps[0][2 * off:2 * (off + wl)])
+        tb, _ = oracle.b_preprocess(caps[1][2 * off:2 * (off + wl)])
+        olag, ocorr, _ = oracle.b_xcorr_peak_fft(ta, tb, ml)
+        assert fused[wid, 0]["lag"] == olag == 29
+        assert abs(fused[wid, 0]["corr"] - ocorr) <= REL_TOL * abs(ocorr)
+
+
 @pytest.mark.parametrize("n1,n2,max_lag,delay", [(300_000, 300_000, 512, 77), (123_457, 99_991, 200, -150),
                                                  (50_001, 50_000, 1023, 1000), (2_000_000, 2_000_000, 512, -333)])
 def test_segment_form_ragged_and_full_size(oracle, n1, n2, max_lag, delay):
