@@ -315,18 +315,16 @@ __device__ __forceinline__ float2 k1_element_from(int a0, int a1, int ap, int i0
     return make_float2(i0 < len ? v0 : 0.0f, i0 + 1 < len ? v1 : 0.0f);
 }
 
-// WIDE: the same transform with ONE 1024-thread workgroup per CU (the occupancy of two 512-thread ones: 4 waves per
-// SIMD): the LDS of the CU then holds the QUADRANT table (64 KB, k1_angle_quadrant: 11 instructions per sample instead of
-// 17) next to a plane of 64 columns.  A wave is then one item j with 64 adjacent elements of every row r: the left
-// neighbour's angle comes by one whole-wave DPP shift and only lane 0 has none -- the 16 boundary samples of a wave (one
-// per r) are looked up by its lanes 0..15 and enter the shift as its `old` operand (v_readlane + v_mov: no permute, no
-// select).  grid (n_cu), 1024 threads (c = t & 63, j = t >> 6), dynamic LDS 64 KB (table) + 64 KB (plane [256][64]).
-//
-// Both forms fetch the capture bytes of their NEXT tile before they store the current one.  The memory counter of a wave
-// retires in order, so a tile whose first act is to wait for its loads also waits for every store of the tile before it
-// to be acknowledged -- with the stores at the end of the trip that was 0.3 of the kernel's 1.08 ms (measured by leaving
-// the stores out: 0.77 ms); with the loads ahead of them in the queue the stores have a whole trip to drain.
-constexpr size_t kColK1wLds = kK1QuadrantBytes + sizeof(float) * 256 * 64;
+// The workgroup: ONE of 1024 threads per CU (four waves per SIMD), c = t & 63 column, j = t >> 6 item.  A wave is one item j
+// with 64 adjacent elements of every row r: the left neighbour's angle comes by one whole-wave DPP shift and only lane 0
+// has none -- the 16 boundary samples of a wave (one per r) are looked up by its lanes 0..15 and enter the shift as its
+// `old` operand (v_readlane + v_mov: no permute, no select).
+// Memory order inside a trip: the capture bytes of the NEXT tile are asked for right after the lookups of the current one
+// (a whole transform ahead of their use), and the 16 stores of the PREVIOUS tile leave one by one between the lookups.
+// The memory counter of a wave retires in order: with the stores at the end of a trip and the loads at the top of the next,
+// the first lookup waited for every store before it to be acknowledged (and 256 store instructions left the CU at once).
+// grid (n_cu), 1024 threads, dynamic LDS 64 KB (table) + 64 KB (plane [256][64]).
+constexpr size_t kColK1Lds = kK1QuadrantBytes + sizeof(float) * 256 * 64;
 
 // Which tile a workgroup takes as its seq-th: workgroups go to the XCDs round-robin (seq % 8, the grid is a multiple of 8).
 // A window may start on any 2-byte boundary, in which case the 256-byte row pieces of adjacent column blocks share a cache

@@ -216,8 +216,9 @@ __device__ __forceinline__ void inv_rows_twiddle_store(float2 (&va)[8], float2 (
 // a 4096-point row transform, V shrinks 16 times, and the pair step is one streaming read of the two spectra.
 //
 // k = k2 + N2 k1: consecutive bins run down a column, so a workgroup takes a tile of all N2 rows x 4096/N2 columns
-// (4096 consecutive bins; the forward row pass writes the spectra tile by tile for this kernel, so a tile is one
-// contiguous 32 KB run instead of N2 row pieces) and, because K3 needs Z[k] and Z[Nc - k] together, the mirrored tile:
+// (4096 consecutive bins; the forward row pass k_fwd_row4096_unpack writes the stations' UNPACKED spectra U tile by tile
+// for this kernel -- the station's half of K3 is done there --, so a tile is one contiguous 32 KB run instead of N2 row
+// pieces) and, because K3 needs U[k] and U[Nc - k] together, the mirrored tile:
 //   tile A: bins [4096 bx - 112, 4096 (bx + 1) + 112), tile B: bins Nc - (those), both with their halos.
 // Q of both tiles goes to LDS phase-major (bin o of a tile at [o & 15][o >> 4]) so that thread i of the FIR reads
 // element i + const of one phase for every tap: conflict-free.  256 outputs per tile, one per thread.
@@ -265,7 +266,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_
     const long long mask = pl.Nc - 1;
     const long long kA0 = 4096ll * blockIdx.x;               // first bin of tile A
     const float invNc = 1.0f / (float)pl.Nc;
-    // spectra in COLS-column tiles (k_fwd_row4096 with a tiled output): element (k2, k1) at [k1 / COLS][k2][k1 % COLS]
+    // spectra in COLS-column tiles (k_fwd_row4096_unpack): element (k2, k1) at [k1 / COLS][k2][k1 % COLS]
     auto coords = [&](long long k, unsigned int &at, unsigned int &atm) {
         const int k2 = (int)(k & (N2 - 1)), k1 = (int)(k >> LOGN2);
         const int pr = (N2 - k2) & (N2 - 1), pc = ((k2 == 0 ? 4096 : 4095) - k1) & 4095;

@@ -206,8 +206,9 @@ __device__ __forceinline__ void pair_q(float2 za, float2 zam, float2 zb, float2 
 // lane, neg_lo / neg_hi negate per lane): a complex product is two instructions and a multiplication by +-i or a
 // conjugation costs nothing, where the compiler's version of the same arithmetic spent about 100 instructions per
 // call, a quarter of them moves that build swapped pairs (22 here).  scripts/microbench/pk_complex.hip checks the
-// modifier semantics on the device.  Used by k_pair_decimate16 (-2.4 % on cfg2, -4 % on cfg4); k_inv_row_pair4096 ran
-// 17 % SLOWER with it (the asm statements pin the schedule between its 64 loads), so the row kernels keep pair_q.
+// modifier semantics on the device.  Used by the decimated path (pair_u_pk in k_pair_decimate16, unpack_u_pk in
+// k_fwd_row4096_unpack); k_inv_row_pair4096 ran 17 % SLOWER with the packed form of pair_q (the asm statements pin the
+// schedule between its 64 loads), so the row kernels keep pair_q.
 typedef float v2f __attribute__((ext_vector_type(2)));
 #define TDOA_PK2(op, d, a, b, mods) asm(op " %0, %1, %2 " mods : "=v"(d) : "v"(a), "v"(b))
 __device__ __forceinline__ v2f pk_cmul(v2f a, v2f b)      // a * b
@@ -223,29 +224,6 @@ __device__ __forceinline__ v2f pk_cmulc(v2f a, v2f b)     // conj(a) * b
     TDOA_PK2("v_pk_mul_f32", t, a, b, "op_sel:[0,0] op_sel_hi:[0,1]");
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
     return r;                                                                               // (+ a.y b.y, - a.y b.x) added
-}
-__device__ __forceinline__ void pair_q_pk(float2 za_, float2 zam_, float2 zb_, float2 zbm_, float2 w_,
-                                          float2 &q_, float2 &qm_)
-{
-    const v2f za = {za_.x, za_.y}, zam = {zam_.x, zam_.y}, zb = {zb_.x, zb_.y}, zbm = {zbm_.x, zbm_.y}, w = {w_.x, w_.y};
-    v2f e2a, da, e2b, db, ap, am, bp, bm, qe, gh, q, qm;
-    TDOA_PK2("v_pk_add_f32", e2a, za, zam, "neg_hi:[0,1]");                                  // z + conj(zm)
-    TDOA_PK2("v_pk_add_f32", da, za, zam, "neg_lo:[0,1]");                                   // z - conj(zm)
-    TDOA_PK2("v_pk_add_f32", e2b, zb, zbm, "neg_hi:[0,1]");
-    TDOA_PK2("v_pk_add_f32", db, zb, zbm, "neg_lo:[0,1]");
-    const v2f wda = pk_cmul(w, da), wdb = pk_cmul(w, db);                                    // w O2 = -i (w d)
-    TDOA_PK2("v_pk_add_f32", ap, e2a, wda, "op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]");     // E2 - i (w d)
-    TDOA_PK2("v_pk_add_f32", am, e2a, wda, "op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]");     // E2 + i (w d)
-    TDOA_PK2("v_pk_add_f32", bp, e2b, wdb, "op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]");
-    TDOA_PK2("v_pk_add_f32", bm, e2b, wdb, "op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]");
-    const v2f g = pk_cmulc(ap, bp), h = pk_cmulc(am, bm);
-    TDOA_PK2("v_pk_add_f32", qe, g, h, "");
-    TDOA_PK2("v_pk_add_f32", gh, g, h, "neg_lo:[0,1] neg_hi:[0,1]");
-    const v2f qo = pk_cmulc(w, gh);                                                          // (G - H) conj(w)
-    TDOA_PK2("v_pk_add_f32", q, qe, qo, "op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]");        // qe + i qo
-    TDOA_PK2("v_pk_add_f32", qm, qe, qo, "op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[1,0]");       // conj(qe) + i conj(qo)
-    q_ = make_float2(q.x, q.y);
-    qm_ = make_float2(qm.x, qm.y);
 }
 // The pair's half of K3 when the stations' spectra arrive unpacked (U of k_fwd_row4096_unpack, fft_radix16.hpp):
 // G = conj(Ua[k]) Ub[k], conj(H) = conj(Ua[Nc-k]) Ub[Nc-k], then as above: 10 instructions.

@@ -613,10 +613,10 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
         ProfScope ps(ctx, TDOA_K_FWD_COL, (fused_k1 ? 2.0 : 4.0) * sum_len + (col2pass ? 3.0 : 1.0) * nc8 * n_sw);
         const auto *qtable = static_cast<const int *>(ctx->k1_quad.p);
         if (fused_k1 && col16)
-            hipLaunchKernelGGL(k_fwd_col256_k1<false>, dim3(ctx->n_cu), dim3(1024), kColK1wLds, st, d_sw, qtable, stats, tz, pl,
+            hipLaunchKernelGGL(k_fwd_col256_k1<false>, dim3(ctx->n_cu), dim3(1024), kColK1Lds, st, d_sw, qtable, stats, tz, pl,
                                n_sw);
         else if (fused_k1 && col2pass) {
-            hipLaunchKernelGGL(k_fwd_col256_k1<true>, dim3(ctx->n_cu), dim3(1024), kColK1wLds, st, d_sw, qtable, stats, tz, pl,
+            hipLaunchKernelGGL(k_fwd_col256_k1<true>, dim3(ctx->n_cu), dim3(1024), kColK1Lds, st, d_sw, qtable, stats, tz, pl,
                                n_sw);
             if (pl.N2 == 4096)
                 hipLaunchKernelGGL(k_fwd_col_finish<16>, dim3(pl.N1 / 512, 256, n_sw), dim3(256), 0, st, tz, pl);
