@@ -99,6 +99,8 @@ struct tdoa_ctx {
     int seg_chunks_override = 0;            // TDOA_SEG_CHUNKS=n at tdoa_create time: chunk count of the segment form
     int graph_nodes = 0, graph_edges = 0, graph_roots = 0, graph_memsets = 0;      // structure of the captured step (tdoa_debug_graph_info)
     bool fused_k1 = true;                   // TDOA_NO_FUSED_K1=1: K1 always materialises its codes (no discriminator inside the column kernels)
+    int zpad = 256;                         // TDOA_ZPAD=n at tdoa_create time: padding (elements) after every 256 rows of a two-sweep plan's TZ:
+                                            // 2 KB; measured on cfg3: 0 -> 107 ms column pass, 128 -> 91, 256 -> 87, 512 -> 89
     bool decimate = true;                   // TDOA_NO_DECIMATE=1: general form with the full inverse even where the decimated one applies
     // decimated inverse (k_pair_decimate16): FIR taps and window correction for (Nc, reach); small plan of the R-point inverse
     DevBuf dec_taps, dec_gain;
@@ -184,14 +186,8 @@ long long next_pow2(long long n)   // processor.go:502-512
 constexpr size_t kLdsCap = 128 * 1024;
 
 // factor Nc = N1 * N2 for the four-step FFT; rows (N1) live whole in LDS
-// elements of padding after every 256 rows of a two-sweep plan's TZ (2 KB; measured on cfg3: 0 -> 107 ms column pass, 128 -> 91, 256 -> 87, 512 -> 89)
-int g_zpad = [] {
-    const char *e = std::getenv("TDOA_ZPAD");
-    const int v = e ? std::atoi(e) : 256;
-    return v < 0 ? 0 : v > 4096 ? 4096 : v & ~15;      // rows stay 128-byte aligned (the finish sweep reads 16-byte pairs)
-}();
-
-int make_plan(long long n_real, bool packed, FftPlan *pl)
+// zpad: elements of padding after every 256 rows of a two-sweep plan's TZ (tdoa_ctx::zpad; 0 for the small plans)
+int make_plan(long long n_real, bool packed, FftPlan *pl, int zpad = 0)
 {
     long long nc = packed ? n_real / 2 : n_real;
     if (nc < 32 || nc > (1ll << 24) || (nc & (nc - 1))) return TDOA_ERR_UNSUPPORTED;
@@ -215,7 +211,7 @@ int make_plan(long long n_real, bool packed, FftPlan *pl)
     pl->C = (int)c;
     pl->logC = ilog2(c);
     pl->Nc = nc;
-    pl->zpad = n1 == 4096 && (n2 == 4096 || n2 == 2048) ? g_zpad : 0;      // two-sweep column pass (fft_stockham.hpp, FftPlan)
+    pl->zpad = n1 == 4096 && (n2 == 4096 || n2 == 2048) ? zpad : 0;      // two-sweep column pass (fft_stockham.hpp, FftPlan)
     pl->Zs = nc + (long long)(n2 / 256) * pl->zpad;
     return TDOA_OK;
 }
@@ -935,7 +931,7 @@ int fm_pair(tdoa_ctx *ctx, const uint8_t *iq1, size_t n1, const uint8_t *iq2, si
     }
     long long n = std::max<long long>(next_pow2((long long)std::max(n1, n2) + max_lag), 64);
     FftPlan pl;
-    if ((rc = make_plan(n, true, &pl))) return fail(ctx, rc, "FFT size unsupported");
+    if ((rc = make_plan(n, true, &pl, ctx->zpad))) return fail(ctx, rc, "FFT size unsupported");
     ctx->plan = pl;            // tdoa_plan_info reports the plan of the last call, pair calls included
     ctx->plan_n = n;
     SWDesc *d_sw;
@@ -1113,6 +1109,10 @@ int tdoa_create(const tdoa_params *p, tdoa_ctx **out)
     if (const char *e = std::getenv("TDOA_NO_SEGMENT_FORM")) ctx->segment_form = !(e[0] == '1');
     if (const char *e = std::getenv("TDOA_NO_SEGMENT_QUADS")) ctx->segment_quads = !(e[0] == '1');
     if (const char *e = std::getenv("TDOA_NO_DECIMATE")) ctx->decimate = !(e[0] == '1');
+    if (const char *e = std::getenv("TDOA_ZPAD")) {
+        const int v = std::atoi(e);
+        ctx->zpad = v < 0 ? 0 : v > 4096 ? 4096 : v & ~15;      // rows stay 128-byte aligned (the finish sweep reads 16-byte pairs)
+    }
     if (const char *e = std::getenv("TDOA_NO_FUSED_K1")) ctx->fused_k1 = !(e[0] == '1');
     if (const char *e = std::getenv("TDOA_SEG_CHUNKS")) ctx->seg_chunks_override = std::max(0, std::atoi(e));
     if (const char *e = std::getenv("TDOA_DEBUG_MEMSET_NODES")) ctx->memset_nodes = e[0] == '1';
@@ -1415,7 +1415,7 @@ static int process_impl(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host,
     const int W = 3 * wpb;
     const long long n = std::max<long long>(next_pow2(wlen + ctx->prm.max_lag), 64);
     FftPlan pl;
-    if ((rc = make_plan(n, true, &pl))) return fail(ctx, rc, "FFT size unsupported");
+    if ((rc = make_plan(n, true, &pl, ctx->zpad))) return fail(ctx, rc, "FFT size unsupported");
     ctx->plan = pl;
     ctx->plan_n = n;
     // TDOA_LAGS_GO: every window has the same length, so timeDomainCorrelation evaluates lag 0 only (processor.go:668-678)
