@@ -250,8 +250,23 @@ __device__ __forceinline__ constexpr int dec_slot(int i) { return i + ((i + 8) >
 // pieces of 224 different lines per tile side and spectrum, which nearly doubled the bytes this kernel pulled in.
 template <int LOGN2>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_PLAIN_DS_OPS)) void k_pair_decimate16(const PWDesc *pw, const float2 *Z, float2 *G, float2 *E, FftPlan pl,
-                                                         const float *taps, int small_n2)
+                                                         const float *taps, int small_n2, int group_pairs, int n_pw)
 {
+    // group_pairs = 0: grid (N2/2, n_pw), workgroup (bx, pw).  group_pairs = P > 0 (every window of the batch carries the same P
+    // pair-windows): 1-D grid; the P pair-windows of one (window, tile pair) all read the same station tiles, so they are given
+    // consecutive slots of ONE XCD (workgroups go to the XCDs round-robin: L and L + 8 share an L2) -- a station's tile then
+    // comes from memory for its first pair and from that XCD's L2 for the others (k_inv_row_pair4096 has the same scheme).
+    unsigned int bxu = blockIdx.x, pwu = blockIdx.y;
+    if (group_pairs > 0) {
+        const unsigned int L = blockIdx.x, xcd = L & 7u, slot = L >> 3;
+        const unsigned int g = slot / (unsigned int)group_pairs, p = slot % (unsigned int)group_pairs;
+        const unsigned int Gi = g * 8u + xcd, tiles = (unsigned int)(pl.N2 >> 1);
+        const unsigned int w = Gi / tiles;
+        if (w * (unsigned int)group_pairs >= (unsigned int)n_pw) return;      // padding of the last round of 8 groups
+        bxu = Gi % tiles;
+        pwu = w * (unsigned int)group_pairs + p;
+    }
+    const unsigned int bx_ = bxu, pw_ = pwu;
     constexpr int N2 = 1 << LOGN2, COLS = 4096 >> LOGN2;     // a tile: all N2 rows x COLS columns = 4096 consecutive bins
     extern __shared__ float2 lds[];                          // [2][16][kDecPitch]
     // the FIR taps [phase][16] in LDS: a lane's phases p = pq + 4 m differ from its neighbours', so the taps cannot be scalar
@@ -261,10 +276,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_
     float2 *qa = lds, *qb = lds + 16 * kDecPitch;
     const int t = threadIdx.x;
     if (t < 256) ltaps[t] = taps[t];
-    const PWDesc d = pw[blockIdx.y];
+    const PWDesc d = pw[pw_];
     const float2 *Za = Z + (size_t)d.sw_a * pl.Nc, *Zb = Z + (size_t)d.sw_b * pl.Nc;
     const long long mask = pl.Nc - 1;
-    const long long kA0 = 4096ll * blockIdx.x;               // first bin of tile A
+    const long long kA0 = 4096ll * bx_;               // first bin of tile A
     const float invNc = 1.0f / (float)pl.Nc;
     // spectra in COLS-column tiles (k_fwd_row4096_unpack): element (k2, k1) at [k1 / COLS][k2][k1 % COLS]
     auto coords = [&](long long k, unsigned int &at, unsigned int &atm) {
@@ -282,7 +297,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_
     // B[0]: its partner is A[0] of the next workgroup's tile.  One thread (of the last wave) fetches the four values
     // up front, next to everybody's main loads, and forms Q after its main work
     const bool has_b0 = t == 511;
-    const long long kb0 = (pl.Nc - 4096ll * ((long long)blockIdx.x + 1)) & mask;
+    const long long kb0 = (pl.Nc - 4096ll * ((long long)bx_ + 1)) & mask;
     float2 b0[4] = {};
     if (has_b0) {
         unsigned int at, atm;
@@ -399,10 +414,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_
     // tile number in bin order: bx for tile A, N2 - 1 - bx for tile B; its outputs are G[256 tn + i]; four-step layout of
     // the small plan: j = j2 + N2' j1 at [j2][j1]
     const int rc = (int)(pl.Nc / kDecD);
-    const int tn = tile ? N2 - 1 - (int)blockIdx.x : (int)blockIdx.x;
+    const int tn = tile ? N2 - 1 - (int)bx_ : (int)bx_;
     {
         const int j = 256 * tn + 4 * (4 * gl + wq) + pq;
-        G[(size_t)blockIdx.y * (size_t)rc + (size_t)(j & (small_n2 - 1)) * 4096 + (j / small_n2)] = mine;
+        G[(size_t)pw_ * (size_t)rc + (size_t)(j & (small_n2 - 1)) * 4096 + (j / small_n2)] = mine;
     }
     // this tile's share of the 7 outputs before it (i = -7..-1) and the 7 after it (i = 256..262): lane (output, phase),
     // 14 x 16 = 224 lanes of the tile's first four waves; sum over the steps whose bins lie inside the tile, then over
@@ -425,7 +440,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_
         }
         e.x = row16_sum(e.x);
         e.y = row16_sum(e.y);
-        if (p == 0 && eo < 2 * kDecEdge) E[((size_t)blockIdx.y * N2 + tn) * (2 * kDecEdge) + eo] = e;
+        if (p == 0 && eo < 2 * kDecEdge) E[((size_t)pw_ * N2 + tn) * (2 * kDecEdge) + eo] = e;
     }
 }
 

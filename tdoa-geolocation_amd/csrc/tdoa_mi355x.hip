@@ -726,12 +726,23 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
         {
             ProfScope ps(ctx, TDOA_K_INV_ROW, 2.0 * nc8 * n_pw + 8.0 * (double)rc_pts * n_pw);      // two spectra read, G written
             float2 *edges = v + dec_edge_offset(pl, n_pw), *spectra = v + dec_spectra_offset(pl, n_pw);
+            // pair-windows of a window that share station tiles on one XCD (k_pair_decimate16): when the batch is uniform and
+            // a window's spectra are too many to wait in the Infinity Cache for their other readers (cfg5: 16 stations x 16.8
+            // MB; its step 258 -> 237 ms.  cfg4, 8 x 8.4 MB: neutral; cfg2, 3 x 8.4 MB: the plain grid is 4 % faster)
+            int gp = 0;
+            dim3 grid(pl.N2 / 2, n_pw);
+            if (ctx->xcd_rows && pairs_per_window > 1 && n_pw % pairs_per_window == 0 && n_sw > 0 &&
+                (size_t)(n_sw / (n_pw / pairs_per_window)) * (size_t)pl.Nc * sizeof(float2) > ((size_t)128 << 20)) {
+                const long long groups = (long long)(n_pw / pairs_per_window) * (pl.N2 / 2);
+                const long long blocks = (groups + 7) / 8 * 8 * pairs_per_window;
+                if (blocks < (1ll << 31)) { gp = pairs_per_window; grid = dim3((unsigned int)blocks); }
+            }
             if (pl.N2 == 256)
-                hipLaunchKernelGGL(k_pair_decimate16<8>, dim3(pl.N2 / 2, n_pw), dim3(512), sizeof(float2) * 2 * 16 * kDecPitch, st,
-                                   d_pw, spectra, g, edges, pl, static_cast<const float *>(ctx->dec_taps.p), ps2.N2);
+                hipLaunchKernelGGL(k_pair_decimate16<8>, grid, dim3(512), sizeof(float2) * 2 * 16 * kDecPitch, st,
+                                   d_pw, spectra, g, edges, pl, static_cast<const float *>(ctx->dec_taps.p), ps2.N2, gp, n_pw);
             else
-                hipLaunchKernelGGL(k_pair_decimate16<9>, dim3(pl.N2 / 2, n_pw), dim3(512), sizeof(float2) * 2 * 16 * kDecPitch, st,
-                                   d_pw, spectra, g, edges, pl, static_cast<const float *>(ctx->dec_taps.p), ps2.N2);
+                hipLaunchKernelGGL(k_pair_decimate16<9>, grid, dim3(512), sizeof(float2) * 2 * 16 * kDecPitch, st,
+                                   d_pw, spectra, g, edges, pl, static_cast<const float *>(ctx->dec_taps.p), ps2.N2, gp, n_pw);
         }
         {
             ProfScope ps(ctx, TDOA_K_INV_COL, 3.0 * 8.0 * (double)rc_pts * n_pw);
