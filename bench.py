@@ -449,16 +449,28 @@ def main():
     # event-record nodes spliced into the captured graph around the DOMINANT kernel (the roofline's launch durations,
     # measured live on the library's stream inside the timed steps).  The same steps without any event are timed right
     # after (graph_replay).
-    ctx.profile_enable(2)
+    timed_mode = 2
     ctx.profile_select([dominant])
-    step()                                                                # captures and instruments the graph (untimed)
+    try:
+        ctx.profile_enable(2)
+        step()                                                            # captures and instruments the graph (untimed)
+        ctx.profile_reset()
+        step()
+        if not ctx.profile()[dominant]["launches"]:
+            raise tdoa_amd.TdoaError("no event-record node fired")
+    except tdoa_amd.TdoaError as e:
+        # a runtime without working event-record nodes: the launch-by-launch path with events around the same kernel
+        print("bench: graph-mode profiling unavailable (%s); timing the launch-by-launch path" % e, file=sys.stderr)
+        timed_mode = 1
+        ctx.profile_enable(1)
+        step()
     ctx.profile_reset()
     dt = timed(steps)
     ctx.profile_enable(False)
     ctx.profile_select(None)
     prof_timed = ctx.profile()
     if not prof_timed[dominant]["launches"]:
-        raise SystemExit("graph-mode profiling recorded nothing for %s" % dominant)
+        raise SystemExit("profiling recorded nothing for %s" % dominant)
     prof = {k: {"ms": v["ms"] * steps / table_steps, "launches": v["launches"] * steps // table_steps, "bytes": v["bytes"] * steps / table_steps}
             for k, v in table.items()}                                   # the table, scaled to `steps` steps
     prof[dominant] = prof_timed[dominant]                               # the dominant kernel: measured inside the timed region
@@ -584,10 +596,11 @@ def main():
                                       n_fft, n1, n2, max_lag),
                        "name": cfg_name, "capture_bytes": args.sim, "stations": S, "pairs": n_pairs, "windows": n_windows, "window_len": wl,
                        "fft_n": n_fft, "sample_rate": fs, "parallelism": par},
-            "timed_path": "the whole step replayed as one hipGraph (the library's default path) with event-record nodes around the "
-                          "dominant kernel (the roofline's source); the other kernels' times come from %d untimed steps launched "
-                          "kernel by kernel with an event at every boundary; graph_replay: the same replay without any event"
-                          % table_steps,
+            "timed_path": ("the whole step replayed as one hipGraph (the library's default path) with event-record nodes around the "
+                           "dominant kernel (the roofline's source)" if timed_mode == 2 else
+                           "kernels launched one by one, HIP events around the dominant kernel's launches (the roofline's source)")
+                          + "; the other kernels' times come from %d untimed steps launched kernel by kernel with an event at every "
+                            "boundary; graph_replay: the whole step replayed as one hipGraph without any event" % table_steps,
             "graph_replay": graph_leg,
             # SURVEY.md 8d byte model (a fixed price list per sample, NOT what this pipeline moves: the decimated inverse and
             # the fused K1 move less) -- kept under its own name
