@@ -427,8 +427,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_
         const int i = eo < kDecEdge ? eo - kDecEdge : 256 + (eo - kDecEdge);
         float2 e = make_float2(0.0f, 0.0f);
         if (eo < 2 * kDecEdge) {
+            // (the 16 lanes of an output differ in the phase only, and a phase is 16 banks on: every lane starts the sum at
+            // another step -- p >> 2 steps on -- so that the lanes of one read fall into different banks)
 #pragma unroll
-            for (int s2 = 0; s2 < kDecSteps; s2++) {
+            for (int it = 0; it < kDecSteps; it++) {
+                int s2 = it + (p >> 2);
+                s2 = s2 >= kDecSteps ? s2 - kDecSteps : s2;
                 const int idx = i + s2 - 7;                        // slot of the bin group; inside the tile: 0..255
                 if (idx >= 0 && idx < 256) {
                     const float hh = ltaps[16 * p + s2];
