@@ -345,8 +345,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_
                 qa[sa1 + (DK / 16) * (it - 1)] = q;
                 qb[sb1 - (DK / 16) * (it - 1)] = qm;
             } else {
-                qa[slot_of(o0 + DK * it)] = q;
-                qb[slot_of(4096 - o0 - DK * it)] = qm;
+                // (DK is a multiple of 16: the phase stays, the slot index moves by DK / 16 per trip; only the pad term is
+                // rebuilt -- slot_of from scratch cost 7 instructions per store in a kernel that issues 82 % of its time)
+                const int ia = (o0 >> 4) + 8 + (DK / 16) * it, ib = ((4096 - o0) >> 4) + 8 - (DK / 16) * it;
+                qa[(o0 & 15) * kDecPitch + ia + ((ia + 8) >> 4)] = q;
+                qb[((4096 - o0) & 15) * kDecPitch + ib + ((ib + 8) >> 4)] = qm;
             }
             w = cmul(w, rot);
         }
