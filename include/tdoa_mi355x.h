@@ -278,9 +278,15 @@ enum {
     TDOA_DEBUG_NO_SEGMENT_FORM = 8,  /* no LDS-resident overlap-save correlation for search ranges up to 1024 lags    */
     TDOA_DEBUG_NO_XCD_ROWS     = 16, /* plain 2-D grid of the pair kernel even with more pairs than stations          */
     TDOA_DEBUG_NO_SEGMENT_QUADS = 64, /* segment form one pair-window at a time: no station transforms shared by pairs */
-    TDOA_DEBUG_NO_DECIMATE     = 256 /* full inverse transform even where the decimated one applies (4096 x 256 / x 512 plans, search ranges above 4095 lags) */
+    TDOA_DEBUG_NO_DECIMATE     = 256, /* full inverse transform even where the decimated one applies (4096 x 256 / x 512 plans, search ranges above 4095 lags) */
+    TDOA_DEBUG_NO_K1_ONCE      = 512 /* the K1 statistics pre-pass everywhere: no single-look K1 (every capture byte read once,
+                                        the mean's residual removed where the lags come out; csrc/k1_single_look.hpp)      */
 };
 int tdoa_debug_flags(tdoa_ctx *ctx, unsigned flags);
+/* inspection: the K1 statistics of station-window `sw_index` of the last batch (the order of the batch's descriptors:
+ * pair calls 0 = first input, 1 = second; tdoa_process: window-major, stations in the order of first use), and whether
+ * that batch took the single-look path (every capture byte read once; statistics from the column kernels' tile sums). */
+int tdoa_debug_last_k1(tdoa_ctx *ctx, int sw_index, tdoa_fm_stats *stats, int32_t *single_look);
 /* tests only: structure of the hipGraph the last tdoa_process captured -- info = {nodes, edges, root nodes, memset nodes};
  * dot_path (may be NULL): also writes the graph in Graphviz form (hipGraphDebugDotPrint).  The library itself refuses a
  * captured step that is not ONE dependency chain of kernel nodes (TDOA_ERR_STATE), see DESIGN.md section 7. */

@@ -12,6 +12,7 @@
 
 #include "device_common.hpp"
 #include "fft_stockham.hpp"
+#include "k1_single_look.hpp"
 #include "k1_discriminator.hpp"
 
 namespace tdoa {
@@ -300,8 +301,9 @@ __device__ __forceinline__ void store_at(float2 *base, unsigned int byte_off, fl
 // One element from the angle codes (a0, a1) of the dword its thread fetched at sample index min(2m, len - 2) (never beyond
 // the window) and the angle code `ap` of sample 2m - 1.  Returns the normalised pair; `a1` = angle of the element's LAST valid sample (what
 // the lane to the right needs).  head: m may be 0 (code_0 := code_1).  len >= 2.
-template <bool SCALED = false>
-__device__ __forceinline__ float2 k1_element_from(int a0, int a1, int ap, int i0, int len, float mean, float scale, bool head)
+template <bool SCALED = false, bool ONCE = false>
+__device__ __forceinline__ float2 k1_element_from(int a0, int a1, int ap, int i0, int len, float mean, float scale, bool head,
+                                                  double *t1 = nullptr, double *t2 = nullptr)
 {
     if (len & 1) {                       // wave-uniform: only then can a last element hold ONE sample (2m + 1 = len);
         if (i0 + 1 == len) {             // its dword was fetched one sample early: (2m - 1, 2m)
@@ -312,6 +314,10 @@ __device__ __forceinline__ float2 k1_element_from(int a0, int a1, int ap, int i0
     const int st1 = SCALED ? k1_stored_code_scaled(a1, a0) : k1_stored_code(a1, a0);
     const int st0 = head && i0 == 0 ? st1 : SCALED ? k1_stored_code_scaled(a0, ap) : k1_stored_code(a0, ap);
     const float v0 = k1_normalise(st0, mean, scale), v1 = k1_normalise(st1, mean, scale);
+    if (ONCE) {                          // single-look K1: the window sums of exactly the samples that are transformed
+        if (i0 < len) col_once_accumulate(st0, *t1, *t2);
+        if (i0 + 1 < len) col_once_accumulate(st1, *t1, *t2);
+    }
     return make_float2(i0 < len ? v0 : 0.0f, i0 + 1 < len ? v1 : 0.0f);
 }
 
@@ -324,7 +330,7 @@ __device__ __forceinline__ float2 k1_element_from(int a0, int a1, int ap, int i0
 // The memory counter of a wave retires in order: with the stores at the end of a trip and the loads at the top of the next,
 // the first lookup waited for every store before it to be acknowledged (and 256 store instructions left the CU at once).
 // grid (n_cu), 1024 threads, dynamic LDS 64 KB (table) + 64 KB (plane [256][64]).
-constexpr size_t kColK1Lds = kK1QuadrantBytes + sizeof(float) * 256 * 64;
+constexpr size_t kColK1Lds = kK1QuadrantBytes + sizeof(float) * 256 * 64 + sizeof(double) * 3 * 16;      // + the waves' sums (ONCE)
 
 // Which tile a workgroup takes as its seq-th: workgroups go to the XCDs round-robin (seq % 8, the grid is a multiple of 8).
 // A window may start on any 2-byte boundary, in which case the 256-byte row pieces of adjacent column blocks share a cache
@@ -372,14 +378,17 @@ __device__ __forceinline__ void col_k1_fetch(const ColK1Tile &t, int G, int N1, 
     sb = t.p[ib >= 0 && ib < t.len ? ib : 0];                                        // if the window has one
 }
 
-template <bool SUB>
+// ONCE (k1_single_look.hpp): `stats` holds the estimates (m0, s0) of k_once_edges, and every tile leaves the exact sums of
+// its stored codes in once_tiles[tile].
+template <bool SUB, bool ONCE = false>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_fwd_col256_k1(const SWDesc *__restrict__ sw, const int *__restrict__ table, const FmStats *__restrict__ stats, float2 *__restrict__ T,
-                                                       FftPlan pl, int n_sw)
+                                                       FftPlan pl, int n_sw, OnceTile *__restrict__ once_tiles)
 {
     constexpr int LOGW = 6, W = 1 << LOGW;                      // 64 columns per tile
     extern __shared__ int lds_k1[];                             // the table at offset 0 (the offset IS the address), then the plane
     int *lut = lds_k1;
     float *plane = reinterpret_cast<float *>(lds_k1 + kK1QuadrantEntries);      // [256][W]
+    double *once_red = reinterpret_cast<double *>(plane + 256 * W);             // [16 waves][3] (ONCE)
     k1_assert_lds0(lut);
     const int G = SUB ? pl.N2 >> 8 : 1;
     const int N1 = pl.N1, nbx = N1 >> LOGW;
@@ -422,6 +431,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
             // the common case --, entirely beyond it -- zero padding, nothing to look up (40 % of the rows of a 10 s window
             // in N = 2^25) --, or general
             const int jw = __builtin_amdgcn_readfirstlane(j);
+            double t1 = 0.0, t2 = 0.0;                            // ONCE: exact sums of this thread's stored codes
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 // The previous tile's output in v[r] leaves just before the register is needed again: the 16 stores of a
@@ -443,11 +453,16 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
                 const int ap = __builtin_amdgcn_update_dpp(bnd, a1, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
                 if (i_first > 0 && i_end <= len) {
                     const int st0 = k1_stored_code_scaled(a0, ap), st1 = k1_stored_code_scaled(a1, a0);
+                    if (ONCE) {
+                        col_once_accumulate(st0, t1, t2);
+                        col_once_accumulate(st1, t1, t2);
+                    }
                     v[r] = make_float2(k1_normalise(st0, mean, scale), k1_normalise(st1, mean, scale));
                 } else {
-                    v[r] = k1_element_from<true>(a0, a1, ap, i_first + 2 * c, len, mean, scale, r == 0);
+                    v[r] = k1_element_from<true, ONCE>(a0, a1, ap, i_first + 2 * c, len, mean, scale, r == 0, &t1, &t2);
                 }
             }
+            if (ONCE) col_once_wave_reduce(t1, t2, once_red, tid >> 6);
         }
         // the capture bytes of the next tile: asked for now, used a whole transform later
         __builtin_amdgcn_sched_barrier(0);
@@ -462,6 +477,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
 #pragma unroll
         for (int k = 0; k < 16; k++) plane[((16 * j + k) << LOGW) + c] = v[oreg(k)].x;
         __syncthreads();
+        if (ONCE) col_once_store_tile(once_red, 16, once_tiles + tile);      // (the waves wrote their sums before this barrier)
 #pragma unroll
         for (int r = 0; r < 16; r++) v[r].x = plane[((j + 16 * r) << LOGW) + c];      // .y still holds stage-1 outputs (oreg order)
         __syncthreads();
@@ -613,7 +629,7 @@ __global__ __launch_bounds__(512) void k_fwd_colx_c16(const SWDesc *sw, const in
 // items) are looked up by its lanes 0..31 and handed out by a lane permute.
 // grid (n_cu), 1024 threads, dynamic LDS 64 KB (table) + 64 KB (planes [2][256][32]).
 // ---------------------------------------------------------------------------
-constexpr size_t kCol512Lds = kK1QuadrantBytes + sizeof(float) * 2 * 256 * 32;
+constexpr size_t kCol512Lds = kK1QuadrantBytes + sizeof(float) * 2 * 256 * 32 + sizeof(double) * 3 * 16;      // + the waves' sums (ONCE)
 
 struct Col512Tile {
     int bx, w, len;
@@ -646,13 +662,15 @@ __device__ __forceinline__ void col512_fetch(const Col512Tile &t, int N1, int ti
     sb = t.p[ib >= 0 && ib < t.len ? ib : 0];
 }
 
+template <bool ONCE = false>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_fwd_col512_k1(const SWDesc *__restrict__ sw, const int *__restrict__ qtable, const FmStats *__restrict__ stats,
-                                                       float2 *__restrict__ T, FftPlan pl, int n_sw)
+                                                       float2 *__restrict__ T, FftPlan pl, int n_sw, OnceTile *__restrict__ once_tiles)
 {
     constexpr int F = 2, C = 32, LOGC = 5;
     extern __shared__ int lds_k1[];                             // the table at offset 0 (the offset IS the address), then the planes
     int *lut = lds_k1;
     float *plane = reinterpret_cast<float *>(lds_k1 + kK1QuadrantEntries);      // [F][256][C]
+    double *once_red = reinterpret_cast<double *>(plane + F * 256 * C);         // [16 waves][3] (ONCE)
     k1_assert_lds0(lut);
     const int N1 = pl.N1, nbx = N1 / C;
     const int n_tiles = n_sw * nbx;
@@ -687,6 +705,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
             for (int r = 0; r < 16; r++) raw[r] = raw_next[r];
             const int ab = k1_angle_quadrant<false, true>(k1_index_bytes(sb_next), ~sb_next, lut);
             const int jw = __builtin_amdgcn_readfirstlane(j & ~1), pw = __builtin_amdgcn_readfirstlane(par);
+            double t1 = 0.0, t2 = 0.0;                            // ONCE: exact sums of this thread's stored codes
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 store_at(outp + (size_t)(16 * oreg(r)) * N1, offp, v[r]);      // (unconditional: see k_fwd_col256_k1)
@@ -703,11 +722,17 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
                 const int ap = c ? left : bnd;
                 if (i_first > 0 && i_end <= len) {
                     const int st0 = k1_stored_code_scaled(a0, ap), st1 = k1_stored_code_scaled(a1, a0);
+                    if (ONCE) {
+                        col_once_accumulate(st0, t1, t2);
+                        col_once_accumulate(st1, t1, t2);
+                    }
                     v[r] = make_float2(k1_normalise(st0, mean, scale), k1_normalise(st1, mean, scale));
                 } else {
-                    v[r] = k1_element_from<true>(a0, a1, ap, i_first + 2 * (F * (j - jw) * N1 + c), len, mean, scale, r == 0);
+                    v[r] = k1_element_from<true, ONCE>(a0, a1, ap, i_first + 2 * (F * (j - jw) * N1 + c), len, mean, scale, r == 0,
+                                                       &t1, &t2);
                 }
             }
+            if (ONCE) col_once_wave_reduce(t1, t2, once_red, tid >> 6);
         }
         // the capture bytes of the next tile: asked for now, used a whole transform later
         __builtin_amdgcn_sched_barrier(0);
@@ -719,6 +744,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
 #pragma unroll
         for (int k = 0; k < 16; k++) img[(16 * j + k) * C + c] = v[oreg(k)].x;
         __syncthreads();
+        if (ONCE) col_once_store_tile(once_red, 16, once_tiles + tile);
 #pragma unroll
         for (int r = 0; r < 16; r++) v[r].x = img[(j + 16 * r) * C + c];
         __syncthreads();
@@ -1081,9 +1107,10 @@ constexpr int kPruneMax = 8;
 
 // grid (N1/128, n_pw), 256 threads: cp = t & 63 (column PAIR: n1 = 128*bx + 2cp, +1), g = t >> 6
 // (row group: rows g, g+4, ...); 16-byte loads -> 1 KB contiguous per row, 8 rows in flight per thread
+// oc (single-look K1, k1_single_look.hpp): the residual-mean terms added to every candidate before the argmax
 __global__ __launch_bounds__(256) void k_inv_col_pruned_any(const float2 *V, unsigned long long *keys, const PWDesc *pw,
                                                        FftPlan pl, int lag_lo, int lag_hi, int np, int nn,
-                                                       float *lag_dump, float dump_scale)
+                                                       float *lag_dump, float dump_scale, OnceCorr oc)
 {
     extern __shared__ float2 wtab[];               // e^{+2 pi i k/N2}, N2 entries (dynamic LDS)
     __shared__ float4 part[4][kPruneMax][64];
@@ -1093,6 +1120,10 @@ __global__ __launch_bounds__(256) void k_inv_col_pruned_any(const float2 *V, uns
     __syncthreads();
     const int cp = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int n1 = (blockIdx.x << 7) + 2 * cp;
+    const PWDesc pwd = pw[blockIdx.y];
+    if (oc.fin && blockIdx.x == 0 && threadIdx.x == 0) once_publish_gain(oc, pwd);
+    OncePair op{};
+    if (oc.fin) op = once_pair(oc, pwd);
     const float4 *in = reinterpret_cast<const float4 *>(V + (size_t)blockIdx.y * pl.Nc + n1);
     const size_t row_stride = (size_t)N1 / 2;      // in float4 units
     float4 acc[kPruneMax];
@@ -1136,12 +1167,13 @@ __global__ __launch_bounds__(256) void k_inv_col_pruned_any(const float2 *V, uns
             s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
         }
         const int n2 = o < np ? o : N2 - nn + (o - np);
-        const float vals[4] = {s.x, s.y, s.z, s.w};   // lags 2m .. 2m+3 with m = n2*N1 + n1
+        float vals[4] = {s.x, s.y, s.z, s.w};   // lags 2m .. 2m+3 with m = n2*N1 + n1
         long long d = 2 * ((long long)n2 * N1 + (blockIdx.x << 7) + 2 * c);
         if (d >= pl.Nc) d -= 2 * pl.Nc;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const long long dq = d + q;
+            if (oc.fin && dq >= lag_lo && dq <= lag_hi) vals[q] += once_correction(op, dq);
             if (dq >= lag_lo && dq <= lag_hi && vals[q] == vals[q]) {
                 const unsigned long long k = peak_key(vals[q], (int)dq);
                 best = k > best ? k : best;
@@ -1155,7 +1187,7 @@ __global__ __launch_bounds__(256) void k_inv_col_pruned_any(const float2 *V, uns
     if (threadIdx.x == 0) {
         unsigned long long bb = red[0];
         for (int w = 1; w < 4; w++) bb = red[w] > bb ? red[w] : bb;
-        if (bb) atomicMax(&keys[pw[blockIdx.y].out_index], bb);
+        if (bb) atomicMax(&keys[pwd.out_index], bb);
     }
 }
 
@@ -1166,7 +1198,7 @@ __global__ __launch_bounds__(256) void k_inv_col_pruned_any(const float2 *V, uns
 template <int NP, int NN>
 __global__ __launch_bounds__(256) void k_inv_col_pruned(const float2 *V, unsigned long long *keys, const PWDesc *pw,
                                                        FftPlan pl, int lag_lo, int lag_hi, float *lag_dump,
-                                                       float dump_scale)
+                                                       float dump_scale, OnceCorr oc)
 {
     constexpr int NOUT = NP + NN;
     constexpr int NPW = (NP - 1 > NN ? NP - 1 : NN) + 1;     // powers w^0 .. w^(NPW-1)
@@ -1178,6 +1210,10 @@ __global__ __launch_bounds__(256) void k_inv_col_pruned(const float2 *V, unsigne
     __syncthreads();
     const int cp = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int n1 = (blockIdx.x << 7) + 2 * cp;
+    const PWDesc pwd = pw[blockIdx.y];
+    if (oc.fin && blockIdx.x == 0 && threadIdx.x == 0) once_publish_gain(oc, pwd);
+    OncePair op{};
+    if (oc.fin) op = once_pair(oc, pwd);
     const float4 *in = reinterpret_cast<const float4 *>(V + (size_t)blockIdx.y * pl.Nc + n1);
     const size_t row_stride = (size_t)N1 / 2;      // in float4 units
     float4 acc[NOUT];
@@ -1228,12 +1264,13 @@ __global__ __launch_bounds__(256) void k_inv_col_pruned(const float2 *V, unsigne
             s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
         }
         const int n2 = o < NP ? o : N2 - NN + (o - NP);
-        const float vals[4] = {s.x, s.y, s.z, s.w};   // lags 2m .. 2m+3 with m = n2*N1 + n1
+        float vals[4] = {s.x, s.y, s.z, s.w};   // lags 2m .. 2m+3 with m = n2*N1 + n1
         long long d = 2 * ((long long)n2 * N1 + (blockIdx.x << 7) + 2 * c);
         if (d >= pl.Nc) d -= 2 * pl.Nc;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const long long dq = d + q;
+            if (oc.fin && dq >= lag_lo && dq <= lag_hi) vals[q] += once_correction(op, dq);
             if (dq >= lag_lo && dq <= lag_hi && vals[q] == vals[q]) {
                 const unsigned long long k = peak_key(vals[q], (int)dq);
                 best = k > best ? k : best;
@@ -1247,7 +1284,7 @@ __global__ __launch_bounds__(256) void k_inv_col_pruned(const float2 *V, unsigne
     if (threadIdx.x == 0) {
         unsigned long long bb = red[0];
         for (int w = 1; w < 4; w++) bb = red[w] > bb ? red[w] : bb;
-        if (bb) atomicMax(&keys[pw[blockIdx.y].out_index], bb);
+        if (bb) atomicMax(&keys[pwd.out_index], bb);
     }
 }
 

@@ -496,9 +496,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_
 // window out (gain[|m|] = 1 / w[m], m = packed lag index) and keeps the best peak key.  Same lag bookkeeping as
 // k_inv_col_pruned_any, which spends most of its time setting up for long columns.
 // grid (N1 / 256, n_pw), 256 threads.
+// oc (single-look K1, k1_single_look.hpp): the residual-mean terms added to every candidate before the argmax.
 __global__ __launch_bounds__(256) void k_small_col_peak(const float2 *V, unsigned long long *keys, const PWDesc *pw, FftPlan pl,
                                                         int lag_lo, int lag_hi, int np, int nn, float *lag_dump,
-                                                        float dump_scale, const float *gain)
+                                                        float dump_scale, const float *gain, OnceCorr oc)
 {
     __shared__ float2 wtab[32];                    // e^{+2 pi i k / N2'}
     __shared__ unsigned long long red[4];
@@ -507,6 +508,10 @@ __global__ __launch_bounds__(256) void k_small_col_peak(const float2 *V, unsigne
     __syncthreads();
     const int n1 = blockIdx.x * 256 + threadIdx.x;
     const float2 *in = V + (size_t)blockIdx.y * pl.Nc + n1;
+    const PWDesc pwd = pw[blockIdx.y];
+    if (oc.fin && n1 == 0) once_publish_gain(oc, pwd);
+    OncePair op{};
+    if (oc.fin) op = once_pair(oc, pwd);
     float2 acc[kPruneMax];
 #pragma unroll
     for (int o = 0; o < kPruneMax; o++) acc[o] = make_float2(0.0f, 0.0f);
@@ -538,10 +543,11 @@ __global__ __launch_bounds__(256) void k_small_col_peak(const float2 *V, unsigne
             if (d + 1 >= lag_lo && d <= lag_hi) {
                 const long long m = d >> 1;
                 const float gg = gain[m < 0 ? -m : m];
-                const float vals[2] = {acc[o].x * gg, acc[o].y * gg};
+                float vals[2] = {acc[o].x * gg, acc[o].y * gg};
 #pragma unroll
                 for (int q = 0; q < 2; q++) {
                     const long long dq = d + q;
+                    if (oc.fin && dq >= lag_lo && dq <= lag_hi) vals[q] += once_correction(op, dq);
                     if (dq >= lag_lo && dq <= lag_hi && vals[q] == vals[q]) {
                         const unsigned long long k = peak_key(vals[q], (int)dq);
                         best = k > best ? k : best;
@@ -557,7 +563,7 @@ __global__ __launch_bounds__(256) void k_small_col_peak(const float2 *V, unsigne
     if (threadIdx.x == 0) {
         unsigned long long bb = red[0];
         for (int w = 1; w < 4; w++) bb = red[w] > bb ? red[w] : bb;
-        if (bb) atomicMax(&keys[pw[blockIdx.y].out_index], bb);
+        if (bb) atomicMax(&keys[pwd.out_index], bb);
     }
 }
 

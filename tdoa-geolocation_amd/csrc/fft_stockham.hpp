@@ -19,6 +19,7 @@
 
 #include "device_common.hpp"
 #include "k1_discriminator.hpp"
+#include "k1_single_look.hpp"
 
 namespace tdoa {
 
@@ -368,8 +369,10 @@ struct PeakOut {      // mirrors tdoa_peak
     double corr;
 };
 
-// decode keys -> peaks; scale = 1 / (4 N sqrt(len_a))
-__global__ void k_decode_peaks(const unsigned long long *keys, const double *scales, PeakOut *out, int n)
+// decode keys -> peaks; scale = 1 / (4 N sqrt(len_a)); slot_gain (single-look K1, k1_single_look.hpp): the pair-window's
+// g_t g_s, published by the K5 kernel that built the key (nullptr: the values were normalised before the transforms)
+__global__ void k_decode_peaks(const unsigned long long *keys, const double *scales, PeakOut *out, int n,
+                               const double *slot_gain = nullptr)
 {
     int id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= n) return;
@@ -384,6 +387,7 @@ __global__ void k_decode_peaks(const unsigned long long *keys, const double *sca
         unsigned int rank = 0x7fffffffu - (low >> 1);
         int lag = rank == 0 ? 0 : ((rank & 1u) ? (int)((rank + 1u) >> 1) : -(int)(rank >> 1));
         double v = (double)__uint_as_float(mag) * scales[id];
+        if (slot_gain) v *= slot_gain[id];
         if (low & 1u) v = -v;
         p.lag = lag;
         p.corr = v;
@@ -402,8 +406,10 @@ __global__ void k_decode_peaks(const unsigned long long *keys, const double *sca
 // ---------------------------------------------------------------------------
 // gain (decimated inverse): V is then the row-pass output of the small plan and value (lag l) is multiplied by
 // gain[|floor(l / 2)|], the window of the decimation divided out.
+// oc (single-look K1): the same additive term the K5 kernel gave the candidates.
 __global__ __launch_bounds__(64) void k_refine_peaks(const float2 *V, const unsigned long long *keys,
-                                                    const PWDesc *pw, FftPlan pl, float *raw, const float *gain = nullptr)
+                                                    const PWDesc *pw, FftPlan pl, float *raw, const float *gain = nullptr,
+                                                    OnceCorr oc = OnceCorr{})
 {
     const int slot = pw[blockIdx.x].out_index;
     const unsigned long long k = keys[slot];
@@ -430,7 +436,9 @@ __global__ __launch_bounds__(64) void k_refine_peaks(const float2 *V, const unsi
         for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, kWave);
         if (threadIdx.x == 0) {
             const long long ms = ((long long)lag - 1 + q) >> 1;        // signed packed index (arithmetic shift = floor)
-            raw[3 * (size_t)slot + q] = gain ? acc * gain[ms < 0 ? -ms : ms] : acc;
+            float val = gain ? acc * gain[ms < 0 ? -ms : ms] : acc;
+            if (oc.fin) val += once_correction(once_pair(oc, pw[blockIdx.x]), (long long)lag - 1 + q);
+            raw[3 * (size_t)slot + q] = val;
         }
     }
 }
@@ -445,7 +453,7 @@ struct FineOut {      // mirrors tdoa_fine_peak
 
 // raw neighbours -> parabola vertex (f64), delay = lag + frac, plausibility gate
 __global__ void k_decode_fine(const unsigned long long *keys, const double *scales, const float *raw, FineOut *out,
-                              double gate, int n)
+                              double gate, int n, const double *slot_gain = nullptr)
 {
     int id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= n) return;
@@ -460,7 +468,8 @@ __global__ void k_decode_fine(const unsigned long long *keys, const double *scal
         const unsigned int low = (unsigned int)k;
         const unsigned int rank = 0x7fffffffu - (low >> 1);
         lag = rank == 0 ? 0 : ((rank & 1u) ? (int)((rank + 1u) >> 1) : -(int)(rank >> 1));
-        const double sc = (low & 1u) ? -scales[id] : scales[id];
+        const double sc0 = slot_gain ? scales[id] * slot_gain[id] : scales[id];
+        const double sc = (low & 1u) ? -sc0 : sc0;
         const double ym = (double)raw[3 * (size_t)id] * sc, y0 = (double)raw[3 * (size_t)id + 1] * sc,
                      yp = (double)raw[3 * (size_t)id + 2] * sc;
         const double den = ym - 2.0 * y0 + yp;

@@ -1,0 +1,402 @@
+// k1_single_look.hpp -- K1 with every capture byte read ONCE (round 4): no statistics pre-pass.
+//
+// The fused column kernels (fft_radix16.hpp) used to need the window's mean and scale BEFORE they could transform
+// v_i = (code_i - mean) scale, which is what k_fm_demod<false> was for: a second look-up of every sample (9 % of a cfg2
+// step's HBM traffic, 12.7 % of its time).  Correlation is bilinear, so the exact mean and scale can come afterwards:
+//   * k_once_edges looks at a few thousand samples of every station-window (1024 evenly spaced runs of 32) and fixes an
+//     INTEGER estimate m0 of the mean code and a power of two s0 ~ 1/sigma; it also leaves the prefix sums of the first
+//     and the last K samples of  w_i = (code_i - m0) s0  (head[k] = sum_{i<k} w_i, tail[k] = sum_{i>=L-k} w_i, k <= K =
+//     the largest |lag| searched);
+//   * the column kernels transform w (same code path as before: their `mean` is m0, their `scale` s0) and add up the
+//     EXACT integer window sums S1 = sum code, S2 = sum code^2 of the samples they look up anyway (float64 accumulators
+//     that cannot round: see col_once_accumulate), one record per tile -- no atomics, no zeroing;
+//   * k_once_final adds the tile records in integers and evaluates mean and scale with the formulas of k_fm_stats_final
+//     (the statistics are bit-identical to the pre-pass's), plus eps = (mean - m0) s0, the mean of w, and g = scale / s0;
+//   * with v = g (w - eps) the correlation of two windows of equal length L at lag d is
+//       sum_i v^t_i v^s_{i+d} = g_t g_s [ C_w(d) - eps_t eps_s (L + |d|) + eps_s X_t(|d|) + eps_t Y_s(|d|) ],
+//     (X, Y) = (tail_t, head_s) for d >= 0 and (head_t, tail_s) for d < 0  (once_correction; derivation in DESIGN.md
+//     section 3): the K5 kernels add the bracket's last three terms to every candidate before it enters the argmax, and
+//     k_decode_peaks multiplies the winner by g_t g_s next to the slot's scale.
+// Nothing here is approximate: m0 and s0 only decide how large the removed terms are (|eps| ~ 1/200 on noise-like codes).
+// Applies when every pair-window has two windows of the same length (always true for tdoa_process; pair calls with
+// n1 = n2), K < L/2, and the peak is picked by k_small_col_peak or the pruned column kernels; every other case keeps the
+// pre-pass.  TDOA_NO_K1_ONCE=1 / TDOA_DEBUG_NO_K1_ONCE: pre-pass everywhere.
+#pragma once
+
+#include "k1_discriminator.hpp"
+
+namespace tdoa {
+
+constexpr int kOnceRuns = 256;         // sampled runs per window (k_once_estimate: one per thread)
+constexpr int kOnceRun = 16;           // samples per run
+constexpr int kOncePieceLog = 11;      // k_once_edges: a wave takes 2048 consecutive positions of a region
+constexpr int kOncePiece = 1 << kOncePieceLog;
+constexpr int kOnceMaxPieces = 16;     // K + 1 <= 16 x 2048 (host checks)
+
+struct OnceFin {           // per station-window, written by k_once_final
+    double eps;            // mean of w = (code - m0) s0 over the window
+    double gain;           // true scale / s0
+    float off[2][kOnceMaxPieces];      // running-sum offsets of the head / tail region's pieces (w units), k_once_final
+};
+
+struct OnceCorr {          // what a K5 kernel needs to correct its candidates (by value; fin == nullptr: no correction)
+    const float *edges;    // [n_sw][2][k1]: piece-local running sums of w over the first K + 1 and the last K (+ 1) samples
+    const OnceFin *fin;    // [n_sw]
+    double *slot_gain;     // [slots]: g_t g_s of the pair-window, published for k_decode_peaks / k_decode_fine
+    int k1;                // entries per array (K + 1 rounded up to a multiple of 4)
+    int k_max;             // K
+    float raw_per_unit;    // raw units of the kernel's values per unit of sum w w  (4 N for every inverse here)
+};
+
+// A pair-window's constants, loaded once per thread.  The term is small against what it is added to (|eps| ~ 1/60: a few
+// hundred units where the noise floor of C_w is ~1400 and its peak >= 7000), so float32 evaluates it to ~1e-7 of ITSELF.
+struct OncePair {
+    float a, b, c, len, tail_all_t, tail_all_s;      // a = -eps_t eps_s raw, b = eps_s raw, c = eps_t raw
+    const float *head_t, *tail_t, *head_s, *tail_s;
+    const float *off_t, *off_s;                      // fin[.].off[0]; [1] follows kOnceMaxPieces later
+    int k_max;
+};
+
+// running sum of a region up to (not including) position i:  local[i] + offset of its piece
+__device__ __forceinline__ float once_run(const float *local, const float *off, int i)
+{
+    return local[i] + off[i >> kOncePieceLog];
+}
+
+__device__ __forceinline__ OncePair once_pair(const OnceCorr &oc, const PWDesc &p)
+{
+    OncePair r;
+    const OnceFin *ft = oc.fin + p.sw_a, *fs = oc.fin + p.sw_b;
+    const double et = ft->eps, es = fs->eps, raw = (double)oc.raw_per_unit;
+    r.a = (float)(-et * es * raw);
+    r.b = (float)(es * raw);
+    r.c = (float)(et * raw);
+    r.len = (float)p.len_a;
+    r.k_max = oc.k_max;
+    r.off_t = &ft->off[0][0];
+    r.off_s = &fs->off[0][0];
+    r.head_t = oc.edges + (size_t)p.sw_a * 2 * oc.k1;
+    r.tail_t = r.head_t + oc.k1;
+    r.head_s = oc.edges + (size_t)p.sw_b * 2 * oc.k1;
+    r.tail_s = r.head_s + oc.k1;
+    r.tail_all_t = once_run(r.tail_t, r.off_t + kOnceMaxPieces, oc.k_max);      // sum of w over the last K samples
+    r.tail_all_s = once_run(r.tail_s, r.off_s + kOnceMaxPieces, oc.k_max);
+    return r;
+}
+
+// the additive term of a candidate at lag d, in the kernel's raw units:
+//   raw_per_unit [ -eps_t eps_s (L + |d|) + eps_s X_t(|d|) + eps_t Y_s(|d|) ],  (X, Y) = (tail_t, head_s) for d >= 0, (head_t, tail_s) for d < 0
+// head(k) = sum of the first k samples' w = the head region's running sum at k; tail(k) = sum of the last k = the tail
+// region's (K samples from len - K on) running sum at K minus the one at K - k.
+__device__ __forceinline__ float once_correction(const OncePair &r, long long d)
+{
+    const int k = (int)(d < 0 ? -d : d);
+    float x, y;
+    if (d >= 0) {
+        x = r.tail_all_t - once_run(r.tail_t, r.off_t + kOnceMaxPieces, r.k_max - k);
+        y = once_run(r.head_s, r.off_s, k);
+    } else {
+        x = once_run(r.head_t, r.off_t, k);
+        y = r.tail_all_s - once_run(r.tail_s, r.off_s + kOnceMaxPieces, r.k_max - k);
+    }
+    return __builtin_fmaf(r.c, y, __builtin_fmaf(r.b, x, r.a * (r.len + (float)k)));
+}
+
+// the block that handles a pair-window's first columns publishes g_t g_s for the decode kernels
+__device__ __forceinline__ void once_publish_gain(const OnceCorr &oc, const PWDesc &p)
+{
+    oc.slot_gain[p.out_index] = oc.fin[p.sw_a].gain * oc.fin[p.sw_b].gain;
+}
+
+// ---- column-kernel side ---------------------------------------------------------------------------------------------
+// A thread adds the stored codes it forms (st = -256 code, |st| <= 2^31) into two float64 accumulators per tile:
+// t1 = sum st (|.| <= 32 x 2^31: exact) and t2 = sum st^2 = 2^16 sum code^2 (code^2 < 2^46 has 46 significant bits, 32 of
+// them < 2^51: exact).  v_cvt_f64_i32 + v_add_f64 + v_fma_f64: three instructions per sample, none of them rounds.
+__device__ __forceinline__ void col_once_accumulate(int st, double &t1, double &t2)
+{
+    const double c = (double)st;
+    t1 += c;
+    t2 = __builtin_fma(c, c, t2);
+}
+
+// x + (x of another lane), both halves moved by DPP; lanes outside ROW_MASK add 0
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ double dpp_add_f64(double x)
+{
+    const int lo = __double2loint(x), hi = __double2hiint(x);
+    const int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+    const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+    return x + __hiloint2double(hi2, lo2);
+}
+
+// sum over the 64 lanes of a wave, valid in lane 63: four steps inside the rows of 16, then row_bcast:15 into rows 1 and
+// 3 and row_bcast:31 into rows 2 and 3.  Exact as long as the wave's sum is (every caller splits its values so that it is).
+__device__ __forceinline__ double wave_sum_f64_lane63(double x)
+{
+    x = dpp_add_f64<0xB1>(x);                // quad_perm [1,0,3,2]
+    x = dpp_add_f64<0x4E>(x);                // quad_perm [2,3,0,1]
+    x = dpp_add_f64<0x141>(x);               // row_half_mirror
+    x = dpp_add_f64<0x140>(x);               // row_mirror
+    x = dpp_add_f64<0x142, 0xa>(x);          // row_bcast:15 -> rows 1, 3
+    x = dpp_add_f64<0x143, 0xc>(x);          // row_bcast:31 -> rows 2, 3
+    return x;
+}
+
+// A tile's record: three float64 that hold exact integers.  A lane's t2 = 2^16 q with q < 2^51 an integer, and 1024 such
+// lanes would exceed 2^53, so q is split first: hi = floor(q / 2^26) < 2^25, lo = q - 2^26 hi < 2^26; over a workgroup's
+// 1024 lanes the parts stay below 2^35 and 2^36.  t1 = -256 x (a lane's sum of codes), |sum over the tile| <= 1024 x 2^36.
+struct OnceTile {
+    double s1;             // sum st over the tile           (= -256 x sum code)
+    double q_hi, q_lo;     // sum of floor(q / 2^26) and of q mod 2^26, q = sum code^2 of a lane
+    double pad;
+};
+
+__device__ __forceinline__ void col_once_split(double t2, double &q_hi, double &q_lo)
+{
+    const double q = t2 * 0x1p-16;                       // exact
+    q_hi = __builtin_floor(q * 0x1p-26);
+    q_lo = __builtin_fma(q_hi, -0x1p26, q);              // exact
+}
+
+// the wave's three sums -> red[wave][3] in LDS (lane 63 writes); after the workgroup's next barrier thread q < 3 adds the
+// waves' entries and writes the tile's record
+__device__ __forceinline__ void col_once_wave_reduce(double t1, double t2, double *red, int wave)
+{
+    double hi, lo;
+    col_once_split(t2, hi, lo);
+    t1 = wave_sum_f64_lane63(t1);
+    hi = wave_sum_f64_lane63(hi);
+    lo = wave_sum_f64_lane63(lo);
+    if ((threadIdx.x & 63) == 63) {
+        red[3 * wave + 0] = t1;
+        red[3 * wave + 1] = hi;
+        red[3 * wave + 2] = lo;
+    }
+}
+
+__device__ __forceinline__ void col_once_store_tile(const double *red, int n_waves, OnceTile *rec)
+{
+    if (threadIdx.x < 3) {
+        double s = 0.0;
+        for (int w = 0; w < n_waves; w++) s += red[3 * w + threadIdx.x];
+        reinterpret_cast<double *>(rec)[threadIdx.x] = s;
+    }
+}
+
+// ---- k_once_estimate ------------------------------------------------------------------------------------------------
+// (m0, s0) of every station-window from 256 evenly spaced runs of 16 samples: one 256-thread workgroup per window, a
+// thread per run, angle look-ups in the direct half-plane table in global memory (17 independent gathers per thread, L2).
+// m0 = the nearest integer to the sampled mean code, s0 = 2^-e with 2^e within sqrt(2) of the sampled sigma.
+// Writes stats[w].mean = m0, stats[w].scale = s0 (what the column kernels normalise with).  len >= 64.
+__global__ __launch_bounds__(256) void k_once_estimate(const SWDesc *sw, const int *dtable, FmStats *stats)
+{
+    __shared__ long long red[2][4];
+    const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const SWDesc d = sw[w];
+    const int len = d.len;
+    const gptr16 p = k1_global(d.base);
+    const long long start = 1 + (long long)tid * (long long)(len - 1 - kOnceRun) / (kOnceRuns - 1);      // samples [start - 1, start + 16)
+    unsigned int raw[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) raw[k] = k < 8 ? k1_fetch2(p, start - 1 + 2 * k) : (unsigned int)p[start + 15];
+    int ang[18];
+#pragma unroll
+    for (int k = 0; k < 9; k++) k1_direct_angle2(raw[k] | (k == 8 ? 0x80000000u : 0u), dtable, ang[2 * k], ang[2 * k + 1]);
+    long long a1 = 0, a2 = 0;
+#pragma unroll
+    for (int k = 1; k <= kOnceRun; k++) {
+        const int c = -k1_stored_code(ang[k], ang[k - 1]);
+        a1 += c;
+        a2 += (long long)c * c;                        // < 2^46 x 16
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        a1 += __shfl_xor(a1, off, kWave);
+        a2 += __shfl_xor(a2, off, kWave);
+    }
+    if (lane == 0) { red[0][wv] = a1; red[1][wv] = a2; }
+    __syncthreads();
+    if (tid == 0) {
+        const long long sum1 = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        const long long sum2 = red[1][0] + red[1][1] + red[1][2] + red[1][3];      // < 2^46 x 4096
+        const double n_s = (double)(kOnceRuns * kOnceRun);
+        const double mean = (double)sum1 / n_s;
+        const double var = (double)sum2 / n_s - mean * mean;
+        int e = 0;
+        if (var > 1.0) {                                  // s0 = 2^-e with 2^e within a factor sqrt(2) of sigma
+            const int ex = (int)((__double_as_longlong(var) >> 52) & 0x7ff) - 1023;      // floor(log2(var))
+            e = (ex + 1) >> 1;
+            e = e < 0 ? 0 : e > 24 ? 24 : e;
+        }
+        FmStats out;
+        out.s1 = 0;
+        out.s2_lo = 0;
+        out.s2_hi = 0;
+        out.mean = (float)(int)llrint(mean);               // |m0| <= 2^23: exact
+        out.scale = __int_as_float((127 - e) << 23);
+        stats[w] = out;
+    }
+}
+
+// ---- k_once_edges ---------------------------------------------------------------------------------------------------
+// Running sums of w = (code - m0) s0 over the head region (samples 0 .. K) and the tail region (samples len - K .. len) of
+// every station-window, in the streaming style of k_fm_demod: persistent 1024-thread workgroups keep the direct angle
+// table in LDS (128 KB), their 16 waves run independently, and a wave takes one PIECE of 2048 consecutive positions of a
+// region: a lane owns 32 consecutive samples (four 16-byte loads, issued before any is used), looks each sample up once
+// (the angle before its run is the last angle of the lane to its left), adds its 32 values of (code - m0) up, and a scan
+// over the lanes' totals gives every position its running sum INSIDE the piece:
+//   edges[w][side][i] = s0 * sum of (code - m0) over the positions [piece start, i)     (float32)
+//   piece_tot[w][side][piece] = the piece's whole sum (exact integer)
+// k_once_final turns the piece totals into per-piece offsets; once_run() adds them where the values are used.
+// Position K of a region has no code (it only closes the last running sum).  items = n_sw x 2 x pieces.
+__global__ __launch_bounds__(kDemodThreads) void k_once_edges(const SWDesc *sw, int n_sw, const int *dtable, const FmStats *stats,
+                                                              float *edges, long long *piece_tot, int k_max, int k1, int pieces)
+{
+    extern __shared__ int dlut[];                // kK1DirectEntries angles (128 KB: one workgroup per CU)
+    for (int k = threadIdx.x; k < kK1DirectEntries / 4; k += kDemodThreads)
+        reinterpret_cast<int4 *>(dlut)[k] = reinterpret_cast<const int4 *>(dtable)[k];
+    __syncthreads();
+    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+    const int n_items = n_sw * 2 * pieces, waves = gridDim.x * (kDemodThreads / kWave);
+    for (int item = blockIdx.x * (kDemodThreads / kWave) + wv; item < n_items; item += waves) {
+        const int piece = item % pieces, ws = item / pieces, side = ws & 1, w = ws >> 1;
+        const SWDesc d = sw[w];
+        const int len = d.len;
+        const gptr16 p = k1_global(d.base);
+        const int m0 = (int)stats[w].mean;
+        const double s0 = (double)stats[w].scale;
+        const int region = side ? len - k_max : 0;          // first sample of the region
+        const int pos0 = piece * kOncePiece + lane * 32;     // the lane's first position
+        const int i0 = region + pos0;                        // ... and sample
+        int c[32];
+        if (region + piece * kOncePiece >= 1 && (piece + 1) * kOncePiece <= k_max) {
+            // every position of the piece has a code and a predecessor inside the window
+            uint4 qs[4];
+#pragma unroll
+            for (int h = 0; h < 4; h++) qs[h] = k1_fetch8(p, i0 + 8 * h);
+            const unsigned int before = p[region + piece * kOncePiece - 1];
+            int a[33];
+#pragma unroll
+            for (int h = 0; h < 4; h++) {
+                k1_direct_angle2(qs[h].x, dlut, a[8 * h + 1], a[8 * h + 2]);
+                k1_direct_angle2(qs[h].y, dlut, a[8 * h + 3], a[8 * h + 4]);
+                k1_direct_angle2(qs[h].z, dlut, a[8 * h + 5], a[8 * h + 6]);
+                k1_direct_angle2(qs[h].w, dlut, a[8 * h + 7], a[8 * h + 8]);
+            }
+            const int left = wave_shift_right1(a[32]);
+            a[0] = lane ? left : k1_direct_angle(before, dlut);
+#pragma unroll
+            for (int k = 0; k < 32; k++) c[k] = -k1_stored_code(a[k + 1], a[k]) - m0;
+        } else {
+            // first piece of the head region (code_0 := code_1), last piece of a region: sample by sample
+#pragma unroll
+            for (int k = 0; k < 32; k++) {
+                const int pos = pos0 + k, i = i0 + k;
+                int v = 0;
+                if (pos < k_max && i < len) {
+                    const int ii = i == 0 ? 1 : i;
+                    v = -k1_stored_code(k1_direct_angle(p[ii], dlut), k1_direct_angle(p[ii - 1], dlut)) - m0;
+                }
+                c[k] = v;
+            }
+        }
+        // running sums inside the lane (|code - m0| < 2^24, 32 of them: int32), then over the lanes (exact in float64)
+        int tot = 0;
+#pragma unroll
+        for (int k = 0; k < 32; k++) {
+            const int v = c[k];
+            c[k] = tot;                                        // exclusive
+            tot += v;
+        }
+        double incl = (double)tot;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const double t = __shfl_up(incl, off, kWave);
+            if (lane >= off) incl += t;
+        }
+        const double base = incl - (double)tot;
+        float *out = edges + ((size_t)w * 2 + side) * k1 + pos0;
+        if (pos0 + 32 <= k1) {
+#pragma unroll
+            for (int h = 0; h < 8; h++) {
+                float4 o;
+                o.x = (float)((base + (double)c[4 * h]) * s0);
+                o.y = (float)((base + (double)c[4 * h + 1]) * s0);
+                o.z = (float)((base + (double)c[4 * h + 2]) * s0);
+                o.w = (float)((base + (double)c[4 * h + 3]) * s0);
+                reinterpret_cast<float4 *>(out)[h] = o;
+            }
+        } else {
+            for (int k = 0; k < 32; k++)
+                if (pos0 + k < k1) out[k] = (float)((base + (double)c[k]) * s0);
+        }
+        if (lane == 63) piece_tot[((size_t)w * 2 + side) * kOnceMaxPieces + piece] = (long long)incl;
+    }
+}
+
+// ---- k_once_final ---------------------------------------------------------------------------------------------------
+// One wave per station-window adds its tiles' records (integers; any order gives the same bits) and evaluates the
+// statistics with the expressions of k_fm_stats_final, then eps and g against the (m0, s0) the column kernel used.
+// tiles: record of tile (w, a, bx) at index (w G + a) nbx + bx, i.e. tiles_per_sw consecutive records per window.
+__global__ __launch_bounds__(64) void k_once_final(const SWDesc *sw, const OnceTile *tiles, int tiles_per_sw, FmStats *stats,
+                                                   OnceFin *fin, int n_sw, const long long *piece_tot, int pieces)
+{
+#pragma clang fp contract(off)
+    const int w = blockIdx.x, lane = threadIdx.x;
+    if (w >= n_sw) return;
+    const OnceTile *t = tiles + (size_t)w * tiles_per_sw;
+    long long s1 = 0;
+    unsigned long long hi = 0, lo = 0;
+    for (int k = lane; k < tiles_per_sw; k += kWave) {
+        s1 += (long long)t[k].s1;
+        hi += (unsigned long long)t[k].q_hi;
+        lo += (unsigned long long)t[k].q_lo;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        s1 += __shfl_xor(s1, off, kWave);
+        hi += __shfl_xor(hi, off, kWave);
+        lo += __shfl_xor(lo, off, kWave);
+    }
+    if (lane) return;
+    // S1 = -(sum st) / 256; S2 = hi 2^26 + lo as a 128-bit integer
+    const long long S1 = -(s1 / 256);
+    const unsigned long long h_lo = hi << 26, h_hi = hi >> 38;
+    const unsigned long long s2_lo = h_lo + lo;
+    const unsigned long long s2_hi = h_hi + (s2_lo < h_lo ? 1ull : 0ull);
+    const int len = sw[w].len;
+    const double m0 = (double)stats[w].mean, s0 = (double)stats[w].scale;      // what k_once_edges chose
+    FmStats out;
+    out.s1 = S1;
+    out.s2_lo = s2_lo;
+    out.s2_hi = s2_hi;
+    OnceFin f;
+    if (len == 0) {
+        out.mean = 0.0f;
+        out.scale = 1.0f;
+        f.eps = 0.0;
+        f.gain = 1.0;
+    } else {
+        const double dn = (double)len;
+        out.mean = (float)((double)S1 / dn);
+        const double m2 = ((double)S1 * (double)S1) / dn;
+        const double s2d = (double)((s2_hi << 32) | (s2_lo >> 32)) * 4294967296.0 + (double)(s2_lo & 0xffffffffull);
+        const double var = (s2d - m2) / dn;
+        out.scale = var > 0 ? (float)(1.0 / sqrt(var)) : 1.0f;
+        // the pre-pass path transforms (f32(code) - mean) scale with the float32 mean and scale: the same two numbers here
+        f.eps = ((double)out.mean - m0) * s0;
+        f.gain = (double)out.scale / s0;
+    }
+    // offsets of the regions' pieces: the running sum at the start of piece q = the pieces before it (w units)
+    for (int side = 0; side < 2; side++) {
+        long long run = 0;
+        for (int q = 0; q < kOnceMaxPieces; q++) {
+            f.off[side][q] = (float)((double)run * s0);
+            if (q < pieces) run += piece_tot[((size_t)w * 2 + side) * kOnceMaxPieces + q];
+        }
+    }
+    stats[w] = out;
+    fin[w] = f;
+}
+
+}  // namespace tdoa

@@ -19,6 +19,7 @@
 
 #include "device_common.hpp"
 #include "k1_discriminator.hpp"
+#include "k1_single_look.hpp"
 #include "fft_stockham.hpp"
 #include "fft_radix16.hpp"
 #include "fft_radix8.hpp"
@@ -102,6 +103,9 @@ struct tdoa_ctx {
     int zpad = 256;                         // TDOA_ZPAD=n at tdoa_create time: padding (elements) after every 256 rows of a two-sweep plan's TZ:
                                             // 2 KB; measured on cfg3: 0 -> 107 ms column pass, 128 -> 91, 256 -> 87, 512 -> 89
     bool decimate = true;                   // TDOA_NO_DECIMATE=1: general form with the full inverse even where the decimated one applies
+    bool k1_once = true;                    // TDOA_NO_K1_ONCE=1: the statistics pre-pass everywhere (no single-look K1, k1_single_look.hpp)
+    bool once_active = false;               // the last run_fm_batch took the single-look path: decode multiplies by slot_gain
+    DevBuf once_edges, once_tiles, once_fin, once_pieces, slot_gain;
     // decimated inverse (k_pair_decimate16): FIR taps and window correction for (Nc, reach); small plan of the R-point inverse
     DevBuf dec_taps, dec_gain;
     long long dec_nc = 0;
@@ -497,6 +501,12 @@ bool fused_k1_applies(const tdoa_ctx *ctx, const FftPlan &pl, int lag_lo, int la
     return segment_pq(ctx, pl, lag_lo, lag_hi, n_pw) == 0;
 }
 
+// single-look K1 (k1_single_look.hpp): largest |lag| a K5 kernel or the refinement looks at, entries per edge array,
+// tile records per station-window of the fused column kernels
+int once_k_max(int lag_lo, int lag_hi) { return std::max(lag_hi + 1, -(lag_lo - 1)); }
+int once_k1(int lag_lo, int lag_hi) { return (once_k_max(lag_lo, lag_hi) + 1 + 3) & ~3; }
+int once_tiles_per_sw(const FftPlan &pl) { return pl.N2 == 512 ? pl.N1 / 32 : (pl.N1 / 64) * std::max(1, pl.N2 / 256); }
+
 int reserve_fm_batch(tdoa_ctx *ctx, int n_sw, int maxlen, int n_pw, const FftPlan &pl, int lag_lo, int lag_hi,
                      bool allow_fused_k1)
 {
@@ -509,6 +519,12 @@ int reserve_fm_batch(tdoa_ctx *ctx, int n_sw, int maxlen, int n_pw, const FftPla
         if (ctx->prm.k1_smooth > 1 && (rc = ensure(ctx, ctx->codes_lp, sizeof(int) * (size_t)code_stride * n_sw))) return rc;
     }
     if (ctx->prm.k1_gate && (rc = ensure(ctx, ctx->k1_power, sizeof(unsigned long long) * (size_t)n_sw))) return rc;
+    if (ctx->k1_once && n_pw && fused_k1_applies(ctx, pl, lag_lo, lag_hi, n_pw, allow_fused_k1)) {      // single-look K1
+        if ((rc = ensure(ctx, ctx->once_edges, sizeof(float) * 2 * (size_t)once_k1(lag_lo, lag_hi) * n_sw))) return rc;
+        if ((rc = ensure(ctx, ctx->once_tiles, sizeof(OnceTile) * (size_t)once_tiles_per_sw(pl) * n_sw))) return rc;
+        if ((rc = ensure(ctx, ctx->once_fin, sizeof(OnceFin) * (size_t)n_sw))) return rc;
+        if ((rc = ensure(ctx, ctx->once_pieces, sizeof(long long) * 2 * kOnceMaxPieces * (size_t)n_sw))) return rc;
+    }
     if ((rc = ensure(ctx, ctx->tz, sizeof(float2) * (size_t)pl.Zs * n_sw))) return rc;
     if (n_pw && decimation_applies(ctx, pl, lag_lo, lag_hi) && (rc = ensure_decimation(ctx, pl, lag_lo, lag_hi))) return rc;
     size_t v_elems = (size_t)pl.Nc * n_pw;
@@ -524,8 +540,9 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
                  unsigned long long *d_keys, const FftPlan &pl, int lag_lo, int lag_hi, float *lag_dump,
                  float dump_scale, double sum_len, float *fine_raw = nullptr, int pairs_per_window = 0,
                  const QuadDesc *d_quads = nullptr, int n_quads = 0, bool allow_fused_k1 = true,
-                 const SWDesc *d_sw_stats = nullptr)      // d_sw_stats: the windows K1 and its statistics run over when the
+                 const SWDesc *d_sw_stats = nullptr,      // d_sw_stats: the windows K1 and its statistics run over when the
                                                           // transforms see truncated ones (TDOA_LAGS_GO); default: d_sw
+                 bool equal_len = false)                  // every station-window of the batch has `maxlen` samples
 {
     int rc;
     const int pieces = std::max(1, (maxlen + kDemodPiece - 1) / kDemodPiece);
@@ -593,7 +610,32 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
         if (ctx->seg_chunks_override > 0) seg_chunks = std::max(1, std::min({ctx->seg_chunks_override, trips, pl.N2 / 2 - 1}));
     }
     const bool fused_k1 = fused_k1_applies(ctx, pl, lag_lo, lag_hi, n_pw, allow_fused_k1);
-    {
+    // single-look K1 (k1_single_look.hpp): no statistics pre-pass.  Needs windows of one length, the peak picked by
+    // k_small_col_peak or a pruned column kernel, and head / tail runs of K samples that do not meet.
+    const int once_kmax = once_k_max(lag_lo, lag_hi), once_n1 = once_k1(lag_lo, lag_hi);
+    const bool once = ctx->k1_once && fused_k1 && equal_len && !d_sw_stats && n_pw > 0 && !seg_chunks && fk == 0 && pruned &&
+                      once_kmax < maxlen / 2 && once_kmax + 1 <= kOncePiece * kOnceMaxPieces;
+    ctx->once_active = once;
+    OnceCorr oc{};
+    auto *once_tiles = static_cast<OnceTile *>(ctx->once_tiles.p);
+    if (once) {
+        oc.edges = static_cast<const float *>(ctx->once_edges.p);
+        oc.fin = static_cast<const OnceFin *>(ctx->once_fin.p);
+        oc.slot_gain = static_cast<double *>(ctx->slot_gain.p);
+        oc.k1 = once_n1;
+        oc.raw_per_unit = (float)(8.0 * (double)pl.Nc);          // raw = 4 N sum w w, N = 2 Nc
+        oc.k_max = once_kmax;
+        // 4096 samples per window -> the estimates (m0, s0) the column kernels normalise with; then the running sums of the
+        // first and the last K samples of every window (streamed like k_fm_demod, 2 x (K + 1) samples per window)
+        const int pieces = (once_kmax + 1 + kOncePiece - 1) / kOncePiece;
+        ProfScope ps(ctx, TDOA_K_STATS, (2.0 * (2.0 * (once_kmax + 1) + (double)kOnceRuns * (kOnceRun + 1)) + 8.0 * (once_kmax + 1)) * n_sw);
+        hipLaunchKernelGGL(k_once_estimate, dim3(n_sw), dim3(kOnceRuns), 0, st, d_sw, static_cast<const int *>(ctx->k1_direct.p), stats);
+        const long long items = (long long)n_sw * 2 * pieces;
+        const int blocks = (int)std::max<long long>(1, std::min<long long>((items + 15) / 16, ctx->n_cu));
+        hipLaunchKernelGGL(k_once_edges, dim3(blocks), dim3(kDemodThreads), kK1DirectBytes, st, d_sw, n_sw,
+                           static_cast<const int *>(ctx->k1_direct.p), stats, static_cast<float *>(ctx->once_edges.p),
+                           static_cast<long long *>(ctx->once_pieces.p), once_kmax, once_n1, pieces);
+    } else {
         // K1: capture bytes -> exact window statistics (fused: nothing else; the column pass evaluates the discriminator
         // itself) and, materialised, the 24-bit phase codes as int32
         ProfScope ps(ctx, TDOA_K_STATS, (fused_k1 ? 2.0 : 6.0) * sum_len);
@@ -608,19 +650,34 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
         // two-sweep column pass (N2 = 2048, 4096): 8 Nc written, read and written again -- SURVEY's third pass
         ProfScope ps(ctx, TDOA_K_FWD_COL, (fused_k1 ? 2.0 : 4.0) * sum_len + (col2pass ? 3.0 : 1.0) * nc8 * n_sw);
         const auto *qtable = static_cast<const int *>(ctx->k1_quad.p);
-        if (fused_k1 && col16)
-            hipLaunchKernelGGL(k_fwd_col256_k1<false>, dim3(ctx->n_cu), dim3(1024), kColK1Lds, st, d_sw, qtable, stats, tz, pl,
-                               n_sw);
+        if (fused_k1 && col16) {
+            if (once)
+                hipLaunchKernelGGL((k_fwd_col256_k1<false, true>), dim3(ctx->n_cu), dim3(1024), kColK1Lds, st, d_sw, qtable, stats,
+                                   tz, pl, n_sw, once_tiles);
+            else
+                hipLaunchKernelGGL((k_fwd_col256_k1<false, false>), dim3(ctx->n_cu), dim3(1024), kColK1Lds, st, d_sw, qtable, stats,
+                                   tz, pl, n_sw, static_cast<OnceTile *>(nullptr));
+        }
         else if (fused_k1 && col2pass) {
-            hipLaunchKernelGGL(k_fwd_col256_k1<true>, dim3(ctx->n_cu), dim3(1024), kColK1Lds, st, d_sw, qtable, stats, tz, pl,
-                               n_sw);
+            if (once)
+                hipLaunchKernelGGL((k_fwd_col256_k1<true, true>), dim3(ctx->n_cu), dim3(1024), kColK1Lds, st, d_sw, qtable, stats,
+                                   tz, pl, n_sw, once_tiles);
+            else
+                hipLaunchKernelGGL((k_fwd_col256_k1<true, false>), dim3(ctx->n_cu), dim3(1024), kColK1Lds, st, d_sw, qtable, stats,
+                                   tz, pl, n_sw, static_cast<OnceTile *>(nullptr));
             if (pl.N2 == 4096)
                 hipLaunchKernelGGL(k_fwd_col_finish<16>, dim3(pl.N1 / 512, 256, n_sw), dim3(256), 0, st, tz, pl);
             else
                 hipLaunchKernelGGL(k_fwd_col_finish<8>, dim3(pl.N1 / 512, 256, n_sw), dim3(256), 0, st, tz, pl);
         }
-        else if (fused_k1 && colx == 2)
-            hipLaunchKernelGGL(k_fwd_col512_k1, dim3(ctx->n_cu), dim3(1024), kCol512Lds, st, d_sw, qtable, stats, tz, pl, n_sw);
+        else if (fused_k1 && colx == 2) {
+            if (once)
+                hipLaunchKernelGGL(k_fwd_col512_k1<true>, dim3(ctx->n_cu), dim3(1024), kCol512Lds, st, d_sw, qtable, stats, tz, pl,
+                                   n_sw, once_tiles);
+            else
+                hipLaunchKernelGGL(k_fwd_col512_k1<false>, dim3(ctx->n_cu), dim3(1024), kCol512Lds, st, d_sw, qtable, stats, tz, pl,
+                                   n_sw, static_cast<OnceTile *>(nullptr));
+        }
         else if (col16)
             hipLaunchKernelGGL(k_fwd_col256_c16<false>, dim3(pl.N1 / 32, n_sw), dim3(512), lds_col16, st, d_sw, codes,
                                code_stride, stats, tz, pl);
@@ -653,6 +710,13 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
         else
             hipLaunchKernelGGL(k_fwd_col_c16, dim3(pl.N1 / pl.C, n_sw), dim3(256), lds_col, st, d_sw, codes,
                                code_stride, stats, tz, pl);
+    }
+    if (once) {
+        // the tiles' exact sums -> the window statistics (bit-identical to the pre-pass's), eps and g of every station-window
+        ProfScope ps(ctx, TDOA_K_STATS, sizeof(OnceTile) * (double)once_tiles_per_sw(pl) * n_sw);
+        hipLaunchKernelGGL(k_once_final, dim3(n_sw), dim3(64), 0, st, d_sw, once_tiles, once_tiles_per_sw(pl), stats,
+                           static_cast<OnceFin *>(ctx->once_fin.p), n_sw, static_cast<const long long *>(ctx->once_pieces.p),
+                           (once_kmax + 1 + kOncePiece - 1) / kOncePiece);
     }
     // XCD-aware 1-D grid of the pair kernel when every window of the group carries the same `pairs_per_window` > S pairs
     // (window-major sharding with more pairs than stations): see k_inv_row_pair4096
@@ -749,7 +813,7 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
             hipLaunchKernelGGL(k_inv_rows_plain_r8, dim3(ps2.N2 / 2, n_pw), dim3(512), sizeof(float2) * 2 * kRow8Lds, st, g,
                                v + dec_edge_offset(pl, n_pw), vs, ps2, pl.N2);
             hipLaunchKernelGGL(k_small_col_peak, dim3(ps2.N1 / 256, n_pw), dim3(256), 0, st, vs, d_keys, d_pw, ps2, lag_lo, lag_hi,
-                               np2, nn2, lag_dump, dump_scale, static_cast<const float *>(ctx->dec_gain.p));
+                               np2, nn2, lag_dump, dump_scale, static_cast<const float *>(ctx->dec_gain.p), oc);
         }
     } else if (n_pw) {
         {
@@ -793,7 +857,7 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
                 const size_t lds_wtab = sizeof(float2) * (size_t)pl.N2;
 #define TDOA_PRUNED(NP, NN)                                                                                      \
     hipLaunchKernelGGL((k_inv_col_pruned<NP, NN>), grid, blk, lds_wtab, st, v, d_keys, d_pw, pl, lag_lo, lag_hi, \
-                       lag_dump, dump_scale)
+                       lag_dump, dump_scale, oc)
                 const bool fixed = (pl.N2 & 31) == 0;     // the compile-time forms read 32 rows per trip unguarded
                 if (fixed && np == 3 && nn == 3) TDOA_PRUNED(3, 3);
                 else if (fixed && np == 1 && nn == 1) TDOA_PRUNED(1, 1);
@@ -801,7 +865,7 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
                 else if (fixed && np == 4 && nn == 4) TDOA_PRUNED(4, 4);
                 else
                     hipLaunchKernelGGL(k_inv_col_pruned_any, grid, blk, lds_wtab, st, v, d_keys, d_pw, pl, lag_lo, lag_hi, np,
-                                       nn, lag_dump, dump_scale);
+                                       nn, lag_dump, dump_scale, oc);
 #undef TDOA_PRUNED
             }
             else
@@ -821,9 +885,9 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
             FftPlan ps2;
             if ((rc = make_plan(2 * (pl.Nc / kDecD), true, &ps2))) return fail(ctx, rc, "decimated plan");
             hipLaunchKernelGGL(k_refine_peaks, dim3(n_pw), dim3(64), 0, st, v + (size_t)(pl.Nc / kDecD) * (size_t)n_pw, d_keys, d_pw,
-                               ps2, fine_raw, static_cast<const float *>(ctx->dec_gain.p));
+                               ps2, fine_raw, static_cast<const float *>(ctx->dec_gain.p), oc);
         }
-        else hipLaunchKernelGGL(k_refine_peaks, dim3(n_pw), dim3(64), 0, st, v, d_keys, d_pw, pl, fine_raw, static_cast<const float *>(nullptr));
+        else hipLaunchKernelGGL(k_refine_peaks, dim3(n_pw), dim3(64), 0, st, v, d_keys, d_pw, pl, fine_raw, static_cast<const float *>(nullptr), oc);
     }
     HIPCHK(ctx, hipGetLastError());
     return TDOA_OK;
@@ -834,12 +898,16 @@ int allow_big_lds(tdoa_ctx *ctx)
 {
     int rc;
     const size_t all = 136 * 1024;   // largest dynamic request: 128 KiB (kLdsCap tiles, generic row pair); static LDS comes on top
+    if ((rc = set_lds(ctx, k_once_edges, all))) return rc;
     if ((rc = set_lds(ctx, k_fm_demod<true>, all))) return rc;
     if ((rc = set_lds(ctx, k_fm_demod<false>, all))) return rc;
-    if ((rc = set_lds(ctx, k_fwd_col512_k1, all))) return rc;
+    if ((rc = set_lds(ctx, k_fwd_col512_k1<false>, all))) return rc;
+    if ((rc = set_lds(ctx, k_fwd_col512_k1<true>, all))) return rc;
     if ((rc = set_lds(ctx, k_fwd_row4096_unpack, all))) return rc;
-    if ((rc = set_lds(ctx, k_fwd_col256_k1<false>, all))) return rc;
-    if ((rc = set_lds(ctx, k_fwd_col256_k1<true>, all))) return rc;
+    if ((rc = set_lds(ctx, (k_fwd_col256_k1<false, false>), all))) return rc;
+    if ((rc = set_lds(ctx, (k_fwd_col256_k1<true, false>), all))) return rc;
+    if ((rc = set_lds(ctx, (k_fwd_col256_k1<false, true>), all))) return rc;
+    if ((rc = set_lds(ctx, (k_fwd_col256_k1<true, true>), all))) return rc;
     if ((rc = set_lds(ctx, k_fwd_col_c16, all))) return rc;
     if ((rc = set_lds(ctx, k_fwd_row, all))) return rc;
     if ((rc = set_lds(ctx, k_inv_row_pair, all))) return rc;
@@ -951,6 +1019,7 @@ int fm_pair(tdoa_ctx *ctx, const uint8_t *iq1, size_t n1, const uint8_t *iq2, si
     if ((rc = ensure(ctx, ctx->keys, sizeof(unsigned long long)))) return rc;
     if ((rc = ensure(ctx, ctx->scales, sizeof(double)))) return rc;
     if ((rc = ensure(ctx, ctx->peaks, sizeof(PeakOut)))) return rc;
+    if ((rc = ensure(ctx, ctx->slot_gain, sizeof(double)))) return rc;
     if (fine) {
         if ((rc = ensure(ctx, ctx->fine_raw, 3 * sizeof(float)))) return rc;
         if ((rc = ensure(ctx, ctx->fine, sizeof(FineOut)))) return rc;
@@ -969,20 +1038,24 @@ int fm_pair(tdoa_ctx *ctx, const uint8_t *iq1, size_t n1, const uint8_t *iq2, si
     rc = run_fm_batch(ctx, d_sw, 2, (int)std::max(n1, n2), d_pw, 1, static_cast<unsigned long long *>(ctx->keys.p),
                       pl, lag_lo, lag_hi, dump, 1.0f, (double)(n1 + n2),
                       fine ? static_cast<float *>(ctx->fine_raw.p) : nullptr, 0, nullptr, 0, n1 >= 2 && n2 >= 2 && corr_len >= 2,
-                      corr_len != n1 ? d_sw + 2 : nullptr);
+                      corr_len != n1 ? d_sw + 2 : nullptr, n1 == n2 && corr_len == n1);
     if (rc) return rc;
+    const double *slot_gain = ctx->once_active ? static_cast<const double *>(ctx->slot_gain.p) : nullptr;
     hipLaunchKernelGGL(k_decode_peaks, dim3(1), dim3(64), 0, ctx->stream,
                        static_cast<unsigned long long *>(ctx->keys.p), static_cast<double *>(ctx->scales.p),
-                       static_cast<PeakOut *>(ctx->peaks.p), 1);
+                       static_cast<PeakOut *>(ctx->peaks.p), 1, slot_gain);
     tdoa_peak pk;
     HIPCHK(ctx, hipMemcpyAsync(&pk, ctx->peaks.p, sizeof(pk), hipMemcpyDeviceToHost, ctx->stream));
     tdoa_fine_peak fk;
     if (fine) {
         hipLaunchKernelGGL(k_decode_fine, dim3(1), dim3(64), 0, ctx->stream,
                            static_cast<unsigned long long *>(ctx->keys.p), static_cast<double *>(ctx->scales.p),
-                           static_cast<float *>(ctx->fine_raw.p), static_cast<FineOut *>(ctx->fine.p), gate, 1);
+                           static_cast<float *>(ctx->fine_raw.p), static_cast<FineOut *>(ctx->fine.p), gate, 1, slot_gain);
         HIPCHK(ctx, hipMemcpyAsync(&fk, ctx->fine.p, sizeof(fk), hipMemcpyDeviceToHost, ctx->stream));
     }
+    double pair_gain = 1.0;                                   // single-look K1: the lag array lacks g_t g_s like the key does
+    if (lags_out && slot_gain)
+        HIPCHK(ctx, hipMemcpyAsync(&pair_gain, slot_gain, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     std::vector<float> hl;
     if (lags_out) {
         hl.resize(n_dump);
@@ -994,7 +1067,7 @@ int fm_pair(tdoa_ctx *ctx, const uint8_t *iq1, size_t n1, const uint8_t *iq2, si
     if (fine) *fine = fk;
     if (lags_out) {                                           // layout [2 max_lag - 1]: lag d at d + max_lag - 1
         std::fill(lags_out, lags_out + nl, 0.0);
-        for (int i = 0; i < n_dump; i++) lags_out[i + lag_lo + (max_lag - 1)] = (double)hl[i] * scale;
+        for (int i = 0; i < n_dump; i++) lags_out[i + lag_lo + (max_lag - 1)] = (double)hl[i] * scale * pair_gain;
     }
     return TDOA_OK;
 }
@@ -1120,6 +1193,7 @@ int tdoa_create(const tdoa_params *p, tdoa_ctx **out)
     if (const char *e = std::getenv("TDOA_NO_SEGMENT_FORM")) ctx->segment_form = !(e[0] == '1');
     if (const char *e = std::getenv("TDOA_NO_SEGMENT_QUADS")) ctx->segment_quads = !(e[0] == '1');
     if (const char *e = std::getenv("TDOA_NO_DECIMATE")) ctx->decimate = !(e[0] == '1');
+    if (const char *e = std::getenv("TDOA_NO_K1_ONCE")) ctx->k1_once = !(e[0] == '1');
     if (const char *e = std::getenv("TDOA_ZPAD")) {
         const int v = std::atoi(e);
         ctx->zpad = v < 0 ? 0 : v > 4096 ? 4096 : v & ~15;      // rows stay 128-byte aligned (the finish sweep reads 16-byte pairs)
@@ -1146,7 +1220,8 @@ void tdoa_destroy(tdoa_ctx *ctx)
     DevBuf *bufs[] = {&ctx->k1_direct, &ctx->k1_quad, &ctx->sw_desc, &ctx->pw_desc, &ctx->partials, &ctx->stats, &ctx->codes, &ctx->codes_lp, &ctx->k1_power, &ctx->dec_taps, &ctx->dec_gain, &ctx->tz, &ctx->v, &ctx->keys,
                       &ctx->scales, &ctx->peaks, &ctx->scratch_a, &ctx->scratch_b, &ctx->lagdump,
                       &ctx->ex_a, &ctx->ex_b, &ctx->ex_c, &ctx->ex_d, &ctx->ex_part,
-                      &ctx->g_sw_desc, &ctx->g_pw_desc, &ctx->g_quad_desc, &ctx->g_scales, &ctx->g_keys, &ctx->fine_raw, &ctx->fine, &ctx->qual};
+                      &ctx->g_sw_desc, &ctx->g_pw_desc, &ctx->g_quad_desc, &ctx->g_scales, &ctx->g_keys, &ctx->fine_raw, &ctx->fine, &ctx->qual,
+                      &ctx->once_edges, &ctx->once_tiles, &ctx->once_fin, &ctx->once_pieces, &ctx->slot_gain};
     for (DevBuf *b : bufs) release(*b);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -1514,6 +1589,7 @@ static int process_impl(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host,
     if ((rc = ensure(ctx, ctx->peaks, sizeof(PeakOut) * slots))) return rc;
     if ((rc = ensure(ctx, ctx->g_keys, sizeof(unsigned long long) * slots))) return rc;
     if ((rc = ensure(ctx, ctx->g_scales, sizeof(double) * slots))) return rc;
+    if ((rc = ensure(ctx, ctx->slot_gain, sizeof(double) * slots))) return rc;
     // TDOA_LAGS_GO: a second copy of the station-window descriptors with the full window length follows the first
     if ((rc = ensure(ctx, ctx->g_sw_desc, sizeof(SWDesc) * std::max<size_t>(2 * sw.size(), 1)))) return rc;
     if ((rc = ensure(ctx, ctx->g_pw_desc, sizeof(PWDesc) * std::max<size_t>(pw.size(), 1)))) return rc;
@@ -1537,7 +1613,7 @@ static int process_impl(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host,
                                  (uint64_t)ctx->force_generic | ((uint64_t)ctx->short_lag << 1) |
                                      ((uint64_t)ctx->segment_form << 3) | ((uint64_t)ctx->xcd_rows << 4) |
                                      ((uint64_t)ctx->segment_quads << 6) |
-                                     ((uint64_t)ctx->decimate << 8) | ((uint64_t)ctx->fused_k1 << 9) |
+                                     ((uint64_t)ctx->decimate << 8) | ((uint64_t)ctx->fused_k1 << 9) | ((uint64_t)ctx->k1_once << 11) |
                                      ((uint64_t)ctx->memset_nodes << 10) | ((uint64_t)ctx->seg_chunks_override << 16),
                                  ctx->alloc_gen, (uint64_t)(fine_host != nullptr), 0};
     std::memcpy(&key.back(), &gate, sizeof(double));
@@ -1582,16 +1658,18 @@ static int process_impl(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host,
                                        lag_lo, lag_hi, nullptr, 1.0f,
                                        (double)wlen * n_sw, fine_raw, pair_major ? 0 : P, d_quads + q_off[w0],
                                        (int)(q_off[w0 + nw] - q_off[w0]), corr_len >= 2,
-                                       go ? d_sw + sw.size() + sw_off[w0] : nullptr);
+                                       go ? d_sw + sw.size() + sw_off[w0] : nullptr, !go);      // every window has wlen samples
             if (r) return r;
         }
+        // (every batch of a step takes the same path: same plan, same lag range, same lengths)
+        const double *slot_gain = ctx->once_active ? static_cast<const double *>(ctx->slot_gain.p) : nullptr;
         if (fine_raw) ctx->prof_last = -1;
         if (fine_raw)
             hipLaunchKernelGGL(k_decode_fine, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, st, d_keys, d_scales,
-                               fine_raw, static_cast<FineOut *>(ctx->fine.p), gate, (int)slots);
+                               fine_raw, static_cast<FineOut *>(ctx->fine.p), gate, (int)slots, slot_gain);
         ProfScope ps(ctx, TDOA_K_PEAK, 32.0 * (double)slots);
         hipLaunchKernelGGL(k_decode_peaks, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, st, d_keys, d_scales,
-                           static_cast<PeakOut *>(ctx->peaks.p), (int)slots);
+                           static_cast<PeakOut *>(ctx->peaks.p), (int)slots, slot_gain);
         return TDOA_OK;
     };
 
@@ -1902,6 +1980,17 @@ int tdoa_debug_flags(tdoa_ctx *ctx, unsigned flags)
     ctx->segment_quads = !(flags & TDOA_DEBUG_NO_SEGMENT_QUADS);
     ctx->decimate = !(flags & TDOA_DEBUG_NO_DECIMATE);
     ctx->fused_k1 = !(flags & TDOA_DEBUG_NO_FUSED_K1);
+    ctx->k1_once = !(flags & TDOA_DEBUG_NO_K1_ONCE);
+    return TDOA_OK;
+}
+
+int tdoa_debug_last_k1(tdoa_ctx *ctx, int sw_index, tdoa_fm_stats *stats, int32_t *single_look)
+{
+    int rc;
+    if ((rc = check_ctx(ctx))) return rc;
+    if (sw_index < 0 || (size_t)(sw_index + 1) * sizeof(FmStats) > ctx->stats.cap) return fail(ctx, TDOA_ERR_INVALID, "no such station-window");
+    if (stats) HIPCHK(ctx, hipMemcpy(stats, static_cast<FmStats *>(ctx->stats.p) + sw_index, sizeof(FmStats), hipMemcpyDeviceToHost));
+    if (single_look) *single_look = ctx->once_active ? 1 : 0;
     return TDOA_OK;
 }
 

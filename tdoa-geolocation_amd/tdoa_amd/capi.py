@@ -72,7 +72,7 @@ SYMBOLS = [
     "tdoa_num_windows", "tdoa_num_pairs", "tdoa_process", "tdoa_process_u8",
     "tdoa_process_fine", "tdoa_fm_xcorr_fine_u8", "tdoa_window_quality_all", "tdoa_window_quality_u8",
     "tdoa_fm_xcorr_u8", "tdoa_fm_preprocess_u8", "tdoa_fm_xcorr_lags_u8", "tdoa_debug_force_generic",
-    "tdoa_debug_flags", "tdoa_debug_graph_info", "tdoa_debug_segment_quads", "tdoa_cross_correlate_batch_c64",
+    "tdoa_debug_flags", "tdoa_debug_last_k1", "tdoa_debug_graph_info", "tdoa_debug_segment_quads", "tdoa_cross_correlate_batch_c64",
     "tdoa_latlon_to_ecef", "tdoa_ecef_to_latlon", "tdoa_solve_3station", "tdoa_solve_nstation",
     "tdoa_profile_enable", "tdoa_profile_select", "tdoa_profile_reset", "tdoa_profile_get", "tdoa_kernel_name",
     "tdoa_plan_info",
@@ -142,6 +142,7 @@ def load(build_if_missing=True):
     L.tdoa_fm_xcorr_lags_u8.argtypes = [vp, u8p, sz, u8p, sz, C.c_int, dp]
     L.tdoa_debug_force_generic.argtypes = [vp, C.c_int]
     L.tdoa_debug_flags.argtypes = [vp, C.c_uint]
+    L.tdoa_debug_last_k1.argtypes = [vp, C.c_int, C.POINTER(FmStats), C.POINTER(C.c_int32)]
     L.tdoa_debug_graph_info.argtypes = [vp, C.POINTER(C.c_int32), C.c_char_p]
     L.tdoa_debug_segment_quads.argtypes = [C.c_int, C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_int32), C.c_int]
     L.tdoa_latlon_to_ecef.argtypes = [C.c_double, C.c_double, C.c_double, dp]
@@ -444,13 +445,21 @@ class Context:
         self._chk(self._L.tdoa_debug_force_generic(self._h, 1 if on else 0))
 
     def debug_flags(self, generic=False, no_short_lag=False, no_fused_k1=False, no_segment_form=False, no_xcd_rows=False,
-                    no_segment_quads=False, no_decimate=False):
+                    no_segment_quads=False, no_decimate=False, no_k1_once=False):
         """pick kernel variants by hand (tests / measurements): include/tdoa_mi355x.h TDOA_DEBUG_*; no argument = the
         library's default path, every argument switches one specialised form off"""
         self._chk(self._L.tdoa_debug_flags(self._h, (1 if generic else 0) | (2 if no_short_lag else 0) |
                                            (4 if no_fused_k1 else 0) | (8 if no_segment_form else 0) |
                                            (16 if no_xcd_rows else 0) | (64 if no_segment_quads else 0) |
-                                           (256 if no_decimate else 0)))
+                                           (256 if no_decimate else 0) | (512 if no_k1_once else 0)))
+
+    def last_k1(self, sw_index=0):
+        """(statistics of station-window `sw_index` of the last batch, True if that batch read every capture byte once:
+        the single-look K1 of csrc/k1_single_look.hpp) -- tdoa_debug_last_k1"""
+        st = FmStats()
+        once = C.c_int32(0)
+        self._chk(self._L.tdoa_debug_last_k1(self._h, int(sw_index), C.byref(st), C.byref(once)))
+        return st, bool(once.value)
 
     # ---- measurement -------------------------------------------------------
     def profile_enable(self, on=True):

@@ -1,0 +1,155 @@
+"""GPU: single-look K1 (csrc/k1_single_look.hpp) -- every capture byte read once, no statistics pre-pass.
+
+The column kernels transform (code - m0) s0 with a sampled estimate (m0, s0), add up the exact window sums on the way,
+and the residual of the mean is removed where the lags come out.  Checked here:
+  * the window statistics the path ends up with are BIT-IDENTICAL to the pre-pass's (same integers, same f64 formulas);
+  * peak lag identical and corr within 2e-6 of the pre-pass path (TDOA_DEBUG_NO_K1_ONCE) on every kind of input, the whole
+    lag array included, in the decimated inverse, the full inverse and the two-sweep plan;
+  * against the oracle (ob_*, f64 time domain) inside the usual 1e-5;
+  * the cases that must NOT take it (unequal lengths, short search ranges, TDOA_LAGS_GO) still run the pre-pass.
+The float64 atan2 anchors (tests/test_gpu_anchors.py, test_gpu_configs.py) run through this path by default."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ML = 20000
+
+
+def _pairs(oracle, n):
+    out = [("delayed_fm", oracle.simulate_delayed_fm(n, 0, 4242, 1), oracle.simulate_delayed_fm(n, 37, 4242, 2))]
+    sim = [oracle.simulate_station(nm, n, oracle.SEED_BASE + i) for i, nm in enumerate(oracle.COLLECTORS)]
+    weak = [oracle.simulate_weak_station(nm, n, oracle.SEED_BASE + i) for i, nm in enumerate(oracle.COLLECTORS)]
+    out.append(("simulator.go ref 0-1", sim[0][:2 * n], sim[1][:2 * n]))
+    out.append(("simulator.go tgt 0-2", sim[0][2 * n:4 * n], sim[2][2 * n:4 * n]))
+    out.append(("weak tgt 1-2", weak[1][2 * n:4 * n], weak[2][2 * n:4 * n]))
+    out.append(("weak ref 0-1 (constant bytes)", weak[0][:2 * n], weak[1][:2 * n]))
+    return out
+
+
+def _stats_tuple(st):
+    return (st.s1, st.s2_lo, st.s2_hi, np.float32(st.mean).view(np.uint32), np.float32(st.scale).view(np.uint32))
+
+
+@pytest.mark.parametrize("n", [1_100_000, 1_999_999])
+def test_single_look_vs_prepass_and_exact_statistics(oracle, n, capsys):
+    import tdoa_amd
+    rows = []
+    with tdoa_amd.Context(max_lag=ML, window_len=n) as c, tdoa_amd.Context(max_lag=ML, window_len=n) as ref:
+        ref.debug_flags(no_k1_once=True)
+        for name, a, b in _pairs(oracle, n):
+            lag, corr = c.fm_xcorr(a, b, ML)
+            st0, once = c.last_k1(0)
+            st1, _ = c.last_k1(1)
+            assert once, name
+            rlag, rcorr = ref.fm_xcorr(a, b, ML)
+            assert not ref.last_k1(0)[1]
+            # the statistics of both windows: the pre-pass's integers and floats, bit for bit
+            assert _stats_tuple(st0) == _stats_tuple(ref.fm_stats(a)), name
+            assert _stats_tuple(st1) == _stats_tuple(ref.fm_stats(b)), name
+            assert lag == rlag, (name, lag, rlag)
+            if rcorr == 0.0:
+                assert corr == 0.0
+                rows.append((name, lag, corr, 0.0, 0.0))
+                continue
+            dev = abs(corr - rcorr) / abs(rcorr)
+            la = c.fm_xcorr_lags(a, b, ML)
+            lr = ref.fm_xcorr_lags(a, b, ML)
+            arr = np.abs(la - lr).max() / np.abs(lr).max()
+            rows.append((name, lag, corr, dev, arr))
+            assert dev < 2e-6 and arr < 2e-6, (name, dev, arr)
+    with capsys.disabled():
+        print("\n  single-look K1 vs pre-pass path, L = %d" % n)
+        for r in rows:
+            print("    %-32s lag %6d corr %13.6f  |dcorr|/|corr| %.2e  lag array %.2e of the peak" % r)
+
+
+def test_single_look_vs_oracle_all_lags(oracle):
+    """all 2 max_lag - 1 lags against the f64 time-domain oracle on the same codes"""
+    import tdoa_amd
+    n, ml = 1_050_000, 6000
+    a = oracle.simulate_delayed_fm(n, 0, 99, 1)
+    b = oracle.simulate_delayed_fm(n, -1234, 99, 2)
+    with tdoa_amd.Context(max_lag=ml, window_len=n) as c:
+        lags = c.fm_xcorr_lags(a, b, ml)
+        assert c.last_k1(0)[1]
+        lag, corr = c.fm_xcorr(a, b, ml)
+    ta, _ = oracle.b_preprocess(a)
+    tb, _ = oracle.b_preprocess(b)
+    olag, ocorr, olags = oracle.b_xcorr_peak_fft(ta, tb, ml)
+    assert lag == olag == -1234 and abs(corr - ocorr) <= 1e-5 * abs(ocorr)
+    assert np.abs(lags - olags).max() <= 1e-5 * np.abs(olags).max()
+
+
+def test_single_look_full_inverse_and_fine(oracle):
+    """the pruned column kernels and the refinement carry the same correction as k_small_col_peak"""
+    import tdoa_amd
+    n = 1_100_000
+    a = oracle.simulate_delayed_fm(n, 0, 5, 1)
+    b = oracle.simulate_delayed_fm(n, 19990, 5, 2)
+    with tdoa_amd.Context(max_lag=ML, window_len=n) as c, tdoa_amd.Context(max_lag=ML, window_len=n) as ref:
+        ref.debug_flags(no_k1_once=True)
+        c.debug_flags(no_decimate=True)
+        ref.debug_flags(no_decimate=True, no_k1_once=True)
+        got, want = c.fm_xcorr(a, b, ML), ref.fm_xcorr(a, b, ML)
+        assert c.last_k1(0)[1] and not ref.last_k1(0)[1]
+        assert got[0] == want[0] == 19990 and abs(got[1] - want[1]) <= 2e-6 * abs(want[1])
+        la, lr = c.fm_xcorr_lags(a, b, ML), ref.fm_xcorr_lags(a, b, ML)
+        assert np.abs(la - lr).max() <= 2e-6 * np.abs(lr).max()
+        for ctx in (c, ref):
+            ctx.debug_flags(no_k1_once=ctx is ref)
+        fa, fr = c.fm_xcorr_fine(a, b, ML, 25000.0), ref.fm_xcorr_fine(a, b, ML, 25000.0)
+        assert c.last_k1(0)[1] and not ref.last_k1(0)[1]
+        assert fa[0][0] == fr[0][0] == 19990 and abs(fa[0][1] - fr[0][1]) <= 2e-6 * abs(fr[0][1])
+        assert abs(fa[1]["delay"] - fr[1]["delay"]) < 1e-4
+        assert np.abs(np.array(fa[1]["y"]) - np.array(fr[1]["y"])).max() <= 2e-6 * abs(want[1])
+
+
+def test_single_look_batched_process_ragged_alignment(oracle):
+    """tdoa_process: windows that start on odd 2-byte boundaries and odd lengths, three stations, replayed graph"""
+    import tdoa_amd
+    blk, wl = 2_200_002, 1_100_001
+    caps = [np.concatenate([oracle.simulate_delayed_fm(blk + (k == 1), 100 + d, 310 + k, 10 * s + k) for k in range(3)])[:2 * (3 * blk + s)]
+            for s, d in enumerate((0, 41, -17))]
+    with tdoa_amd.Context(max_lag=ML, window_len=wl) as c, tdoa_amd.Context(max_lag=ML, window_len=wl) as ref:
+        ref.debug_flags(no_k1_once=True)
+        got = c.process_u8(caps)
+        assert c.last_k1(0)[1] and c.graph_info()["memsets"] == 0
+        again = c.process()
+        want = ref.process_u8(caps)
+        assert not ref.last_k1(0)[1]
+    assert np.array_equal(got, again)
+    assert np.array_equal(got["lag"], want["lag"])
+    assert np.abs(got["corr"] - want["corr"]).max() <= 2e-6 * np.abs(want["corr"]).max()
+    assert (np.abs(got["corr"] - want["corr"]) <= 2e-6 * np.abs(want["corr"]) + 1e-9).all()
+
+
+def test_single_look_is_not_taken_where_it_does_not_apply(oracle):
+    import tdoa_amd
+    n = 1_100_000
+    a = oracle.simulate_delayed_fm(n, 0, 8, 1)
+    b = oracle.simulate_delayed_fm(n - 1000, 300, 8, 2)
+    with tdoa_amd.Context(max_lag=ML, window_len=n) as c:
+        c.fm_xcorr(a, b, ML)                      # unequal lengths
+        assert not c.last_k1(0)[1]
+        c.fm_xcorr(a, a, 2000)                    # short search range: short-lag / segment forms
+        assert not c.last_k1(0)[1]
+        c.fm_xcorr(a, a, ML)
+        assert c.last_k1(0)[1]
+    with tdoa_amd.Context(max_lag=ML, window_len=n, lag_mode=tdoa_amd.capi.LAGS_GO) as c:
+        c.fm_xcorr(a, a, ML)                      # the Go lag set cuts the template: statistics over other windows
+        assert not c.last_k1(0)[1]
+
+
+def test_single_look_worst_case_codes(oracle):
+    """a tone at exactly fs/2 (every sample the reverse of the one before): every code is +2^23, the largest the
+    accumulators can meet; zero variance -> (0, 0.0) on both paths and exact sums"""
+    import tdoa_amd
+    n = 1_100_000
+    iq = np.empty(2 * n, np.uint8)
+    iq[0::4], iq[1::4], iq[2::4], iq[3::4] = 255, 255, 0, 0
+    with tdoa_amd.Context(max_lag=ML, window_len=n) as c:
+        assert c.fm_xcorr(iq, iq, ML) == (0, 0.0)
+        st, once = c.last_k1(0)
+        assert once and st.s1 == n * (1 << 23) and (st.s2_hi << 64 | st.s2_lo) == n * (1 << 46)
+        assert _stats_tuple(st) == _stats_tuple(c.fm_stats(iq))
