@@ -1173,7 +1173,7 @@ __global__ __launch_bounds__(256) void k_inv_col_pruned_any(const float2 *V, uns
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const long long dq = d + q;
-            if (oc.fin && dq >= lag_lo && dq <= lag_hi) vals[q] += once_correction(op, dq);
+            if (oc.fin) vals[q] += once_correction(oc, op, dq);
             if (dq >= lag_lo && dq <= lag_hi && vals[q] == vals[q]) {
                 const unsigned long long k = peak_key(vals[q], (int)dq);
                 best = k > best ? k : best;
@@ -1270,7 +1270,7 @@ __global__ __launch_bounds__(256) void k_inv_col_pruned(const float2 *V, unsigne
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const long long dq = d + q;
-            if (oc.fin && dq >= lag_lo && dq <= lag_hi) vals[q] += once_correction(op, dq);
+            if (oc.fin) vals[q] += once_correction(oc, op, dq);
             if (dq >= lag_lo && dq <= lag_hi && vals[q] == vals[q]) {
                 const unsigned long long k = peak_key(vals[q], (int)dq);
                 best = k > best ? k : best;

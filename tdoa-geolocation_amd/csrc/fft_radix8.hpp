@@ -516,6 +516,22 @@ __global__ __launch_bounds__(256) void k_small_col_peak(const float2 *V, unsigne
 #pragma unroll
     for (int o = 0; o < kPruneMax; o++) acc[o] = make_float2(0.0f, 0.0f);
     const int nout = np + nn;
+    // single-look K1: the additive terms of all candidates, asked for before the column sums (unconditional, clamped loads:
+    // all in flight together, and back long before they are used)
+    float term[kPruneMax][2];
+#pragma unroll
+    for (int o = 0; o < kPruneMax; o++) {
+        term[o][0] = term[o][1] = 0.0f;
+        if (oc.fin && o < nout) {
+            const int n2 = o < np ? o : N2 - nn + (o - np);
+            long long d = 2 * ((long long)n2 * N1 + n1);
+            if (d >= pl.Nc) d -= 2 * pl.Nc;
+            const int di = (int)(d < -oc.k_max ? -oc.k_max : d > oc.k_max ? oc.k_max - 1 : d);      // (d + 1 stays on d's side)
+            const OnceSide &sd = o < np ? op.pos : op.neg;                                          // rows of one sign: uniform
+            term[o][0] = once_term(oc.edges, sd, op.a, di, oc.k_max);
+            term[o][1] = once_term(oc.edges, sd, op.a, di + 1, oc.k_max);
+        }
+    }
     for (int k0 = 0; k0 < N2; k0 += 8) {
         float2 x[8];
 #pragma unroll
@@ -543,11 +559,10 @@ __global__ __launch_bounds__(256) void k_small_col_peak(const float2 *V, unsigne
             if (d + 1 >= lag_lo && d <= lag_hi) {
                 const long long m = d >> 1;
                 const float gg = gain[m < 0 ? -m : m];
-                float vals[2] = {acc[o].x * gg, acc[o].y * gg};
+                const float vals[2] = {acc[o].x * gg + term[o][0], acc[o].y * gg + term[o][1]};
 #pragma unroll
                 for (int q = 0; q < 2; q++) {
                     const long long dq = d + q;
-                    if (oc.fin && dq >= lag_lo && dq <= lag_hi) vals[q] += once_correction(op, dq);
                     if (dq >= lag_lo && dq <= lag_hi && vals[q] == vals[q]) {
                         const unsigned long long k = peak_key(vals[q], (int)dq);
                         best = k > best ? k : best;

@@ -437,7 +437,7 @@ __global__ __launch_bounds__(64) void k_refine_peaks(const float2 *V, const unsi
         if (threadIdx.x == 0) {
             const long long ms = ((long long)lag - 1 + q) >> 1;        // signed packed index (arithmetic shift = floor)
             float val = gain ? acc * gain[ms < 0 ? -ms : ms] : acc;
-            if (oc.fin) val += once_correction(once_pair(oc, pw[blockIdx.x]), (long long)lag - 1 + q);
+            if (oc.fin) val += once_correction(oc, once_pair(oc, pw[blockIdx.x]), (long long)lag - 1 + q);
             raw[3 * (size_t)slot + q] = val;
         }
     }

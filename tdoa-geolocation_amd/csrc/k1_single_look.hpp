@@ -36,11 +36,10 @@ constexpr int kOnceMaxPieces = 16;     // K + 1 <= 16 x 2048 (host checks)
 struct OnceFin {           // per station-window, written by k_once_final
     double eps;            // mean of w = (code - m0) s0 over the window
     double gain;           // true scale / s0
-    float off[2][kOnceMaxPieces];      // running-sum offsets of the head / tail region's pieces (w units), k_once_final
 };
 
 struct OnceCorr {          // what a K5 kernel needs to correct its candidates (by value; fin == nullptr: no correction)
-    const float *edges;    // [n_sw][2][k1]: piece-local running sums of w over the first K + 1 and the last K (+ 1) samples
+    const float *edges;    // [n_sw][2][k1]: running sums of w over the first K (+ 1) and over the last K (+ 1) samples
     const OnceFin *fin;    // [n_sw]
     double *slot_gain;     // [slots]: g_t g_s of the pair-window, published for k_decode_peaks / k_decode_fine
     int k1;                // entries per array (K + 1 rounded up to a multiple of 4)
@@ -48,58 +47,58 @@ struct OnceCorr {          // what a K5 kernel needs to correct its candidates (
     float raw_per_unit;    // raw units of the kernel's values per unit of sum w w  (4 N for every inverse here)
 };
 
-// A pair-window's constants, loaded once per thread.  The term is small against what it is added to (|eps| ~ 1/60: a few
-// hundred units where the noise floor of C_w is ~1400 and its peak >= 7000), so float32 evaluates it to ~1e-7 of ITSELF.
-struct OncePair {
-    float a, b, c, len, tail_all_t, tail_all_s;      // a = -eps_t eps_s raw, b = eps_s raw, c = eps_t raw
-    const float *head_t, *tail_t, *head_s, *tail_s;
-    const float *off_t, *off_s;                      // fin[.].off[0]; [1] follows kOnceMaxPieces later
-    int k_max;
+// A pair-window's constants, set up once per thread.  With head(k) = H[k], tail(k) = T[K] - T[K - k] (H, T the running
+// sums of the head and of the tail region) the term of lag d is, for either sign of d,
+//   t0 + a |d| + bx E[off_x - d] + cy E[off_y + d]          (E = the edges buffer)
+//   d >= 0:  off_x = T_t + K, bx = -b, off_y = H_s,     cy = +c, t0 = a L + b T_t[K]
+//   d <  0:  off_x = H_t,     bx = +b, off_y = T_s + K, cy = -c, t0 = a L + c T_s[K]
+// a = -eps_t eps_s raw, b = eps_s raw, c = eps_t raw: two loads and four arithmetic instructions per candidate.
+// The term is small against what it is added to (|eps| ~ 1/60: a few hundred units where the noise floor of C_w is
+// ~1400 and its peak >= 7000), so float32 evaluates it to ~1e-7 of ITSELF.
+struct OnceSide {
+    int off_x, off_y;
+    float t0, bx, cy;
 };
-
-// running sum of a region up to (not including) position i:  local[i] + offset of its piece
-__device__ __forceinline__ float once_run(const float *local, const float *off, int i)
-{
-    return local[i] + off[i >> kOncePieceLog];
-}
+struct OncePair {
+    OnceSide pos, neg;
+    float a;
+};
 
 __device__ __forceinline__ OncePair once_pair(const OnceCorr &oc, const PWDesc &p)
 {
     OncePair r;
-    const OnceFin *ft = oc.fin + p.sw_a, *fs = oc.fin + p.sw_b;
-    const double et = ft->eps, es = fs->eps, raw = (double)oc.raw_per_unit;
+    const double et = oc.fin[p.sw_a].eps, es = oc.fin[p.sw_b].eps, raw = (double)oc.raw_per_unit;
+    const float b = (float)(es * raw), c = (float)(et * raw);
     r.a = (float)(-et * es * raw);
-    r.b = (float)(es * raw);
-    r.c = (float)(et * raw);
-    r.len = (float)p.len_a;
-    r.k_max = oc.k_max;
-    r.off_t = &ft->off[0][0];
-    r.off_s = &fs->off[0][0];
-    r.head_t = oc.edges + (size_t)p.sw_a * 2 * oc.k1;
-    r.tail_t = r.head_t + oc.k1;
-    r.head_s = oc.edges + (size_t)p.sw_b * 2 * oc.k1;
-    r.tail_s = r.head_s + oc.k1;
-    r.tail_all_t = once_run(r.tail_t, r.off_t + kOnceMaxPieces, oc.k_max);      // sum of w over the last K samples
-    r.tail_all_s = once_run(r.tail_s, r.off_s + kOnceMaxPieces, oc.k_max);
+    const int head_t = p.sw_a * 2 * oc.k1, tail_t = head_t + oc.k1, head_s = p.sw_b * 2 * oc.k1, tail_s = head_s + oc.k1;
+    const float al = r.a * (float)p.len_a;
+    r.pos.off_x = tail_t + oc.k_max;
+    r.pos.bx = -b;
+    r.pos.off_y = head_s;
+    r.pos.cy = c;
+    r.pos.t0 = __builtin_fmaf(b, oc.edges[tail_t + oc.k_max], al);
+    r.neg.off_x = head_t;
+    r.neg.bx = b;
+    r.neg.off_y = tail_s + oc.k_max;
+    r.neg.cy = -c;
+    r.neg.t0 = __builtin_fmaf(c, oc.edges[tail_s + oc.k_max], al);
     return r;
 }
 
-// the additive term of a candidate at lag d, in the kernel's raw units:
-//   raw_per_unit [ -eps_t eps_s (L + |d|) + eps_s X_t(|d|) + eps_t Y_s(|d|) ],  (X, Y) = (tail_t, head_s) for d >= 0, (head_t, tail_s) for d < 0
-// head(k) = sum of the first k samples' w = the head region's running sum at k; tail(k) = sum of the last k = the tail
-// region's (K samples from len - K on) running sum at K minus the one at K - k.
-__device__ __forceinline__ float once_correction(const OncePair &r, long long d)
+// the additive term of a candidate at lag d on side sd (pos for d >= 0, neg for d < 0), in the kernel's raw units.
+// Safe for ANY d of that sign (it is clamped to +-K: the value is then unused): a kernel evaluates the terms of all its
+// candidates first -- every load in flight at once -- and only then filters the lags.
+__device__ __forceinline__ float once_term(const float *edges, const OnceSide &sd, float a, int d, int k_max)
 {
-    const int k = (int)(d < 0 ? -d : d);
-    float x, y;
-    if (d >= 0) {
-        x = r.tail_all_t - once_run(r.tail_t, r.off_t + kOnceMaxPieces, r.k_max - k);
-        y = once_run(r.head_s, r.off_s, k);
-    } else {
-        x = once_run(r.head_t, r.off_t, k);
-        y = r.tail_all_s - once_run(r.tail_s, r.off_s + kOnceMaxPieces, r.k_max - k);
-    }
-    return __builtin_fmaf(r.c, y, __builtin_fmaf(r.b, x, r.a * (r.len + (float)k)));
+    const int dc = d < -k_max ? -k_max : d > k_max ? k_max : d;      // v_med3_i32
+    const float xr = edges[sd.off_x - dc], yr = edges[sd.off_y + dc];
+    return __builtin_fmaf(sd.cy, yr, __builtin_fmaf(sd.bx, xr, __builtin_fmaf(a, __builtin_fabsf((float)dc), sd.t0)));
+}
+
+__device__ __forceinline__ float once_correction(const OnceCorr &oc, const OncePair &r, long long d)
+{
+    const int di = (int)(d < -oc.k_max ? -oc.k_max : d > oc.k_max ? oc.k_max : d);
+    return once_term(oc.edges, di >= 0 ? r.pos : r.neg, r.a, di, oc.k_max);
 }
 
 // the block that handles a pair-window's first columns publishes g_t g_s for the decode kernels
@@ -241,25 +240,23 @@ __global__ __launch_bounds__(256) void k_once_estimate(const SWDesc *sw, const i
 // ---- k_once_edges ---------------------------------------------------------------------------------------------------
 // Running sums of w = (code - m0) s0 over the head region (samples 0 .. K) and the tail region (samples len - K .. len) of
 // every station-window, in the streaming style of k_fm_demod: persistent 1024-thread workgroups keep the direct angle
-// table in LDS (128 KB), their 16 waves run independently, and a wave takes one PIECE of 2048 consecutive positions of a
-// region: a lane owns 32 consecutive samples (four 16-byte loads, issued before any is used), looks each sample up once
-// (the angle before its run is the last angle of the lane to its left), adds its 32 values of (code - m0) up, and a scan
-// over the lanes' totals gives every position its running sum INSIDE the piece:
-//   edges[w][side][i] = s0 * sum of (code - m0) over the positions [piece start, i)     (float32)
-//   piece_tot[w][side][piece] = the piece's whole sum (exact integer)
-// k_once_final turns the piece totals into per-piece offsets; once_run() adds them where the values are used.
-// Position K of a region has no code (it only closes the last running sum).  items = n_sw x 2 x pieces.
+// table in LDS (128 KB).  A workgroup takes one REGION at a time; wave q < pieces takes its q-th PIECE of 2048 consecutive
+// positions: a lane owns 32 consecutive samples (four 16-byte loads, issued before any is used), looks each sample up
+// once (the angle before its run is the last angle of the lane to its left), adds its 32 values of (code - m0) up, a scan
+// over the lanes' totals gives every position its running sum inside the piece, the pieces' totals meet in LDS, and
+//   edges[w][side][i] = s0 * sum of (code - m0) over the region's positions [0, i)     (float32, i = 0 .. K)
+// goes out.  Position K of a region has no code (it only closes the last running sum).  items = n_sw x 2.
 __global__ __launch_bounds__(kDemodThreads) void k_once_edges(const SWDesc *sw, int n_sw, const int *dtable, const FmStats *stats,
-                                                              float *edges, long long *piece_tot, int k_max, int k1, int pieces)
+                                                              float *edges, int k_max, int k1, int pieces)
 {
     extern __shared__ int dlut[];                // kK1DirectEntries angles (128 KB: one workgroup per CU)
+    __shared__ double piece_tot[kDemodThreads / kWave];
     for (int k = threadIdx.x; k < kK1DirectEntries / 4; k += kDemodThreads)
         reinterpret_cast<int4 *>(dlut)[k] = reinterpret_cast<const int4 *>(dtable)[k];
     __syncthreads();
-    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
-    const int n_items = n_sw * 2 * pieces, waves = gridDim.x * (kDemodThreads / kWave);
-    for (int item = blockIdx.x * (kDemodThreads / kWave) + wv; item < n_items; item += waves) {
-        const int piece = item % pieces, ws = item / pieces, side = ws & 1, w = ws >> 1;
+    const int lane = threadIdx.x & (kWave - 1), piece = threadIdx.x / kWave;
+    for (int item = blockIdx.x; item < 2 * n_sw; item += gridDim.x) {
+        const int side = item & 1, w = item >> 1;
         const SWDesc d = sw[w];
         const int len = d.len;
         const gptr16 p = k1_global(d.base);
@@ -269,68 +266,76 @@ __global__ __launch_bounds__(kDemodThreads) void k_once_edges(const SWDesc *sw, 
         const int pos0 = piece * kOncePiece + lane * 32;     // the lane's first position
         const int i0 = region + pos0;                        // ... and sample
         int c[32];
-        if (region + piece * kOncePiece >= 1 && (piece + 1) * kOncePiece <= k_max) {
-            // every position of the piece has a code and a predecessor inside the window
-            uint4 qs[4];
+        int tot = 0;
+        double incl = 0.0;
+        if (piece < pieces) {
+            if (region + piece * kOncePiece >= 1 && (piece + 1) * kOncePiece <= k_max) {
+                // every position of the piece has a code and a predecessor inside the window
+                uint4 qs[4];
 #pragma unroll
-            for (int h = 0; h < 4; h++) qs[h] = k1_fetch8(p, i0 + 8 * h);
-            const unsigned int before = p[region + piece * kOncePiece - 1];
-            int a[33];
+                for (int h = 0; h < 4; h++) qs[h] = k1_fetch8(p, i0 + 8 * h);
+                const unsigned int before = p[region + piece * kOncePiece - 1];
+                int a[33];
 #pragma unroll
-            for (int h = 0; h < 4; h++) {
-                k1_direct_angle2(qs[h].x, dlut, a[8 * h + 1], a[8 * h + 2]);
-                k1_direct_angle2(qs[h].y, dlut, a[8 * h + 3], a[8 * h + 4]);
-                k1_direct_angle2(qs[h].z, dlut, a[8 * h + 5], a[8 * h + 6]);
-                k1_direct_angle2(qs[h].w, dlut, a[8 * h + 7], a[8 * h + 8]);
+                for (int h = 0; h < 4; h++) {
+                    k1_direct_angle2(qs[h].x, dlut, a[8 * h + 1], a[8 * h + 2]);
+                    k1_direct_angle2(qs[h].y, dlut, a[8 * h + 3], a[8 * h + 4]);
+                    k1_direct_angle2(qs[h].z, dlut, a[8 * h + 5], a[8 * h + 6]);
+                    k1_direct_angle2(qs[h].w, dlut, a[8 * h + 7], a[8 * h + 8]);
+                }
+                const int left = wave_shift_right1(a[32]);
+                a[0] = lane ? left : k1_direct_angle(before, dlut);
+#pragma unroll
+                for (int k = 0; k < 32; k++) c[k] = -k1_stored_code(a[k + 1], a[k]) - m0;
+            } else {
+                // first piece of the head region (code_0 := code_1), last piece of a region: sample by sample
+#pragma unroll
+                for (int k = 0; k < 32; k++) {
+                    const int pos = pos0 + k, i = i0 + k;
+                    int v = 0;
+                    if (pos < k_max && i < len) {
+                        const int ii = i == 0 ? 1 : i;
+                        v = -k1_stored_code(k1_direct_angle(p[ii], dlut), k1_direct_angle(p[ii - 1], dlut)) - m0;
+                    }
+                    c[k] = v;
+                }
             }
-            const int left = wave_shift_right1(a[32]);
-            a[0] = lane ? left : k1_direct_angle(before, dlut);
-#pragma unroll
-            for (int k = 0; k < 32; k++) c[k] = -k1_stored_code(a[k + 1], a[k]) - m0;
-        } else {
-            // first piece of the head region (code_0 := code_1), last piece of a region: sample by sample
+            // running sums inside the lane (|code - m0| < 2^24, 32 of them: int32), then over the lanes (exact in float64)
 #pragma unroll
             for (int k = 0; k < 32; k++) {
-                const int pos = pos0 + k, i = i0 + k;
-                int v = 0;
-                if (pos < k_max && i < len) {
-                    const int ii = i == 0 ? 1 : i;
-                    v = -k1_stored_code(k1_direct_angle(p[ii], dlut), k1_direct_angle(p[ii - 1], dlut)) - m0;
+                const int v = c[k];
+                c[k] = tot;                                    // exclusive
+                tot += v;
+            }
+            incl = (double)tot;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const double t = __shfl_up(incl, off, kWave);
+                if (lane >= off) incl += t;
+            }
+        }
+        if (lane == 63) piece_tot[piece] = incl;               // (0 for the waves without a piece)
+        __syncthreads();
+        if (piece < pieces) {
+            double base = incl - (double)tot;
+            for (int q = 0; q < piece; q++) base += piece_tot[q];
+            float *out = edges + ((size_t)w * 2 + side) * k1 + pos0;
+            if (pos0 + 32 <= k1) {
+#pragma unroll
+                for (int h = 0; h < 8; h++) {
+                    float4 o;
+                    o.x = (float)((base + (double)c[4 * h]) * s0);
+                    o.y = (float)((base + (double)c[4 * h + 1]) * s0);
+                    o.z = (float)((base + (double)c[4 * h + 2]) * s0);
+                    o.w = (float)((base + (double)c[4 * h + 3]) * s0);
+                    reinterpret_cast<float4 *>(out)[h] = o;
                 }
-                c[k] = v;
+            } else {
+                for (int k = 0; k < 32; k++)
+                    if (pos0 + k < k1) out[k] = (float)((base + (double)c[k]) * s0);
             }
         }
-        // running sums inside the lane (|code - m0| < 2^24, 32 of them: int32), then over the lanes (exact in float64)
-        int tot = 0;
-#pragma unroll
-        for (int k = 0; k < 32; k++) {
-            const int v = c[k];
-            c[k] = tot;                                        // exclusive
-            tot += v;
-        }
-        double incl = (double)tot;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const double t = __shfl_up(incl, off, kWave);
-            if (lane >= off) incl += t;
-        }
-        const double base = incl - (double)tot;
-        float *out = edges + ((size_t)w * 2 + side) * k1 + pos0;
-        if (pos0 + 32 <= k1) {
-#pragma unroll
-            for (int h = 0; h < 8; h++) {
-                float4 o;
-                o.x = (float)((base + (double)c[4 * h]) * s0);
-                o.y = (float)((base + (double)c[4 * h + 1]) * s0);
-                o.z = (float)((base + (double)c[4 * h + 2]) * s0);
-                o.w = (float)((base + (double)c[4 * h + 3]) * s0);
-                reinterpret_cast<float4 *>(out)[h] = o;
-            }
-        } else {
-            for (int k = 0; k < 32; k++)
-                if (pos0 + k < k1) out[k] = (float)((base + (double)c[k]) * s0);
-        }
-        if (lane == 63) piece_tot[((size_t)w * 2 + side) * kOnceMaxPieces + piece] = (long long)incl;
+        __syncthreads();                                       // piece_tot is rewritten by the next item
     }
 }
 
@@ -339,7 +344,7 @@ __global__ __launch_bounds__(kDemodThreads) void k_once_edges(const SWDesc *sw, 
 // statistics with the expressions of k_fm_stats_final, then eps and g against the (m0, s0) the column kernel used.
 // tiles: record of tile (w, a, bx) at index (w G + a) nbx + bx, i.e. tiles_per_sw consecutive records per window.
 __global__ __launch_bounds__(64) void k_once_final(const SWDesc *sw, const OnceTile *tiles, int tiles_per_sw, FmStats *stats,
-                                                   OnceFin *fin, int n_sw, const long long *piece_tot, int pieces)
+                                                   OnceFin *fin, int n_sw)
 {
 #pragma clang fp contract(off)
     const int w = blockIdx.x, lane = threadIdx.x;
@@ -386,14 +391,6 @@ __global__ __launch_bounds__(64) void k_once_final(const SWDesc *sw, const OnceT
         // the pre-pass path transforms (f32(code) - mean) scale with the float32 mean and scale: the same two numbers here
         f.eps = ((double)out.mean - m0) * s0;
         f.gain = (double)out.scale / s0;
-    }
-    // offsets of the regions' pieces: the running sum at the start of piece q = the pieces before it (w units)
-    for (int side = 0; side < 2; side++) {
-        long long run = 0;
-        for (int q = 0; q < kOnceMaxPieces; q++) {
-            f.off[side][q] = (float)((double)run * s0);
-            if (q < pieces) run += piece_tot[((size_t)w * 2 + side) * kOnceMaxPieces + q];
-        }
     }
     stats[w] = out;
     fin[w] = f;

@@ -105,7 +105,7 @@ struct tdoa_ctx {
     bool decimate = true;                   // TDOA_NO_DECIMATE=1: general form with the full inverse even where the decimated one applies
     bool k1_once = true;                    // TDOA_NO_K1_ONCE=1: the statistics pre-pass everywhere (no single-look K1, k1_single_look.hpp)
     bool once_active = false;               // the last run_fm_batch took the single-look path: decode multiplies by slot_gain
-    DevBuf once_edges, once_tiles, once_fin, once_pieces, slot_gain;
+    DevBuf once_edges, once_tiles, once_fin, slot_gain;
     // decimated inverse (k_pair_decimate16): FIR taps and window correction for (Nc, reach); small plan of the R-point inverse
     DevBuf dec_taps, dec_gain;
     long long dec_nc = 0;
@@ -523,7 +523,6 @@ int reserve_fm_batch(tdoa_ctx *ctx, int n_sw, int maxlen, int n_pw, const FftPla
         if ((rc = ensure(ctx, ctx->once_edges, sizeof(float) * 2 * (size_t)once_k1(lag_lo, lag_hi) * n_sw))) return rc;
         if ((rc = ensure(ctx, ctx->once_tiles, sizeof(OnceTile) * (size_t)once_tiles_per_sw(pl) * n_sw))) return rc;
         if ((rc = ensure(ctx, ctx->once_fin, sizeof(OnceFin) * (size_t)n_sw))) return rc;
-        if ((rc = ensure(ctx, ctx->once_pieces, sizeof(long long) * 2 * kOnceMaxPieces * (size_t)n_sw))) return rc;
     }
     if ((rc = ensure(ctx, ctx->tz, sizeof(float2) * (size_t)pl.Zs * n_sw))) return rc;
     if (n_pw && decimation_applies(ctx, pl, lag_lo, lag_hi) && (rc = ensure_decimation(ctx, pl, lag_lo, lag_hi))) return rc;
@@ -630,11 +629,10 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
         const int pieces = (once_kmax + 1 + kOncePiece - 1) / kOncePiece;
         ProfScope ps(ctx, TDOA_K_STATS, (2.0 * (2.0 * (once_kmax + 1) + (double)kOnceRuns * (kOnceRun + 1)) + 8.0 * (once_kmax + 1)) * n_sw);
         hipLaunchKernelGGL(k_once_estimate, dim3(n_sw), dim3(kOnceRuns), 0, st, d_sw, static_cast<const int *>(ctx->k1_direct.p), stats);
-        const long long items = (long long)n_sw * 2 * pieces;
-        const int blocks = (int)std::max<long long>(1, std::min<long long>((items + 15) / 16, ctx->n_cu));
+        const int blocks = std::max(1, std::min(2 * n_sw, ctx->n_cu));
         hipLaunchKernelGGL(k_once_edges, dim3(blocks), dim3(kDemodThreads), kK1DirectBytes, st, d_sw, n_sw,
-                           static_cast<const int *>(ctx->k1_direct.p), stats, static_cast<float *>(ctx->once_edges.p),
-                           static_cast<long long *>(ctx->once_pieces.p), once_kmax, once_n1, pieces);
+                           static_cast<const int *>(ctx->k1_direct.p), stats, static_cast<float *>(ctx->once_edges.p), once_kmax,
+                           once_n1, pieces);
     } else {
         // K1: capture bytes -> exact window statistics (fused: nothing else; the column pass evaluates the discriminator
         // itself) and, materialised, the 24-bit phase codes as int32
@@ -715,8 +713,7 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
         // the tiles' exact sums -> the window statistics (bit-identical to the pre-pass's), eps and g of every station-window
         ProfScope ps(ctx, TDOA_K_STATS, sizeof(OnceTile) * (double)once_tiles_per_sw(pl) * n_sw);
         hipLaunchKernelGGL(k_once_final, dim3(n_sw), dim3(64), 0, st, d_sw, once_tiles, once_tiles_per_sw(pl), stats,
-                           static_cast<OnceFin *>(ctx->once_fin.p), n_sw, static_cast<const long long *>(ctx->once_pieces.p),
-                           (once_kmax + 1 + kOncePiece - 1) / kOncePiece);
+                           static_cast<OnceFin *>(ctx->once_fin.p), n_sw);
     }
     // XCD-aware 1-D grid of the pair kernel when every window of the group carries the same `pairs_per_window` > S pairs
     // (window-major sharding with more pairs than stations): see k_inv_row_pair4096
@@ -1221,7 +1218,7 @@ void tdoa_destroy(tdoa_ctx *ctx)
                       &ctx->scales, &ctx->peaks, &ctx->scratch_a, &ctx->scratch_b, &ctx->lagdump,
                       &ctx->ex_a, &ctx->ex_b, &ctx->ex_c, &ctx->ex_d, &ctx->ex_part,
                       &ctx->g_sw_desc, &ctx->g_pw_desc, &ctx->g_quad_desc, &ctx->g_scales, &ctx->g_keys, &ctx->fine_raw, &ctx->fine, &ctx->qual,
-                      &ctx->once_edges, &ctx->once_tiles, &ctx->once_fin, &ctx->once_pieces, &ctx->slot_gain};
+                      &ctx->once_edges, &ctx->once_tiles, &ctx->once_fin, &ctx->slot_gain};
     for (DevBuf *b : bufs) release(*b);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
