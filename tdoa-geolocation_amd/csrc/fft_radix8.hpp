@@ -231,8 +231,18 @@ __device__ __forceinline__ void inv_rows_twiddle_store(float2 (&va)[8], float2 (
 // phase groups added through LDS: 1.35 ms against 0.79; neither is kept.  DESIGN.md section 3.)
 // ---------------------------------------------------------------------------
 constexpr int kDecD = 16;
-constexpr int kDecSteps = 14;                               // a tap t = 16 (s - 7) + p: phase p = 0..15, step s = 0..13, |t| <= T <= 111
-constexpr int kDecEdge = 7;                                 // outputs on either side of a tile boundary that the other tile's bins reach
+// Taps per phase.  Rounds 2-3 ran 14 steps (213 taps, 140 dB on cfg2's transition band); 12 steps hold T <= 95, i.e. a
+// Kaiser design of 126 dB there (the host takes what the band allows, up to 140 dB: tdoa_mi355x.hip ensure_decimation):
+// the alias leakage on noise-level peaks goes from 1.5e-7 to 7e-7 of the peak (float64 restatement, tests/
+// test_mode_b_anchors.py) for a seventh fewer multiply-adds and LDS reads.  TDOA_DEC_STEPS=14 rebuilds the old filter.
+#ifndef TDOA_DEC_STEPS
+#define TDOA_DEC_STEPS 12
+#endif
+constexpr int kDecSteps = TDOA_DEC_STEPS;                   // a tap t = 16 (s - C) + p: phase p = 0..15, step s = 0..kDecSteps-1
+constexpr int kDecCentre = kDecSteps / 2;                   // C
+constexpr int kDecTmax = 16 * kDecCentre - 1;               // |t| <= T <= kDecTmax
+constexpr int kDecEdge = kDecCentre;                        // outputs on either side of a tile boundary that the other tile's bins reach
+static_assert(kDecSteps % 2 == 0 && kDecSteps >= 4 && kDecSteps <= 14, "FIR geometry: 8 zero slots per side, 16 taps per phase in LDS");
 // LDS image of a tile (4096 consecutive bins, no halo): bin o lives at [o & 15][dec_slot((o >> 4) + 8)],
 // dec_slot(i) = i + ((i + 8) >> 4).  8 zero slots on either side stand for the neighbouring tiles (their share of an
 // edge output is added by THEIR workgroup, see below); one pad slot per 16 (= per column of the tile) puts the 16 columns
@@ -244,8 +254,8 @@ __device__ __forceinline__ constexpr int dec_slot(int i) { return i + ((i + 8) >
 // Tile A = bins [4096 bx, 4096 (bx + 1)), tile B = bins [Nc - 4096 (bx + 1), Nc - 4096 bx): bin o >= 1 of A and bin
 // 4096 - o of B are partners (k, Nc - k); the partners of A[0] and B[0] lie in the neighbouring workgroups' tiles and
 // are only read.  An output whose 2T+1 taps cross a tile boundary gets the far side's share from the workgroup that owns
-// those bins: every tile also evaluates the 7 + 7 outputs just outside it over its own bins and leaves them in
-// E[pw][tile][14] (slots 0..6: outputs 249..255 of the previous tile, 7..13: outputs 0..6 of the next one);
+// those bins: every tile also evaluates the kDecEdge + kDecEdge outputs just outside it over its own bins and leaves them in
+// E[pw][tile][2 kDecEdge] (first half: the last outputs of the previous tile, second half: the first ones of the next);
 // k_inv_rows_plain_r8 adds them when it loads G.  No halo is fetched: the halo bins of a [tile][k2][col] layout are 8-byte
 // pieces of 224 different lines per tile side and spectrum, which nearly doubled the bytes this kernel pulled in.
 template <int LOGN2>
@@ -360,10 +370,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_
         qb[slot_of(0)] = q;
     }
     __syncthreads();
-    // FIR + decimation.  Output i of a tile is sum_t h[t] Q[16 i + t] = sum_{p, s} tab[p][s] img[p][i + s - 7]
-    // (t = 16 (s - 7) + p; the host lays the taps out as taps[p][16], s = 0..13, zero where |t| > T).
-    // A thread takes FOUR consecutive outputs and FOUR phases p = pq + 4 m: image slot 4 g + s' (s' = 0..17, counted from
-    // the 8 zero slots) serves output o = 0..3 with step s = s' - o - 1, so 18 LDS reads per phase feed 56 multiply-adds
+    // FIR + decimation.  Output i of a tile is sum_t h[t] Q[16 i + t] = sum_{p, s} tab[p][s] img[p][i + s - C]
+    // (t = 16 (s - C) + p, C = kDecCentre; the host lays the taps out as taps[p][16], s = 0..kDecSteps-1, zero where |t| > T).
+    // A thread takes FOUR consecutive outputs and FOUR phases p = pq + 4 m: image slot 4 g + s' (counted from the 8 zero
+    // slots) serves output o = 0..3 with step s = s' - o - (8 - C), so kDecSteps + 3 LDS reads per phase feed 4 kDecSteps multiply-adds
     // (one read per output and tap would make the kernel LDS-bound: 13 reads of every bin).  Waves 0..3: tile A, 4..7:
     // tile B; wave w takes the output groups g = 4 g_l + (w & 3), lane = 4 g_l + pq: physical slot of 4 g + s' is
     // 17 g_l + [4 wq + s' + ((4 wq + s' + 8) >> 4)], the bracket a compile-time offset once the wave's wq is fixed (four
@@ -390,11 +400,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_
             asm volatile("" : "+v"(zero));                        // (an offset, not the pointer: it must stay an LDS pointer)
             const float2 *row = src + p * kDecPitch, *row_odd = row + zero;
 #pragma unroll
-            for (int s1 = 1; s1 < 18; s1++) {
+            for (int s1 = 8 - kDecCentre; s1 < 8 - kDecCentre + kDecSteps + 3; s1++) {
                 const float2 v = ((s1 & 1) ? row_odd : row)[4 * WQ + s1 + ((4 * WQ + s1 + 8) >> 4)];
 #pragma unroll
                 for (int o = 0; o < 4; o++) {
-                    const int s2 = s1 - o - 1;
+                    const int s2 = s1 - o - (8 - kDecCentre);
                     if (s2 >= 0 && s2 < kDecSteps) {
                         acc[o].x += h[s2] * v.x;
                         acc[o].y += h[s2] * v.y;
@@ -422,11 +432,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_
         const int j = 256 * tn + 4 * (4 * gl + wq) + pq;
         G[(size_t)pw_ * (size_t)rc + (size_t)(j & (small_n2 - 1)) * 4096 + (j / small_n2)] = mine;
     }
-    // this tile's share of the 7 outputs before it (i = -7..-1) and the 7 after it (i = 256..262): lane (output, phase),
-    // 14 x 16 = 224 lanes of the tile's first four waves; sum over the steps whose bins lie inside the tile, then over
+    // this tile's share of the kDecEdge outputs before it (i = -kDecEdge..-1) and the kDecEdge after it (i = 256..): lane
+    // (output, phase), 2 kDecEdge x 16 lanes of the tile's first four waves; sum over the steps whose bins lie inside the tile, then over
     // the phases (16 adjacent lanes)
     {
-        const int tl = t & 255, eo = tl >> 4, p = tl & 15;         // eo = 0..13 (14, 15: idle lanes of the fourth wave)
+        const int tl = t & 255, eo = tl >> 4, p = tl & 15;         // eo = 0 .. 2 kDecEdge - 1 (the rest: idle lanes)
         const int i = eo < kDecEdge ? eo - kDecEdge : 256 + (eo - kDecEdge);
         float2 e = make_float2(0.0f, 0.0f);
         if (eo < 2 * kDecEdge) {
@@ -436,7 +446,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_
             for (int it = 0; it < kDecSteps; it++) {
                 int s2 = it + (p >> 2);
                 s2 = s2 >= kDecSteps ? s2 - kDecSteps : s2;
-                const int idx = i + s2 - 7;                        // slot of the bin group; inside the tile: 0..255
+                const int idx = i + s2 - kDecCentre;               // slot of the bin group; inside the tile: 0..255
                 if (idx >= 0 && idx < 256) {
                     const float hh = ltaps[16 * p + s2];
                     const float2 v = img[p * kDecPitch + dec_slot(idx + 8)];
@@ -453,7 +463,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_
 
 // inverse rows of the decimated spectrum (no K3, no mirror): rows a = 2 bx, b = a + 1 of G[N2'][4096] -> V'[k2][n1]
 // with the four-step twiddle of the small plan.  G[j], j = 256 tile + i, still lacks the neighbouring tiles' shares
-// near the tile boundaries (k_pair_decimate16): i < 7 gets E[tile - 1][7 + i], i >= 249 gets E[tile + 1][i - 249].
+// near the tile boundaries (k_pair_decimate16): i < kDecEdge gets E[tile - 1][kDecEdge + i], i >= 256 - kDecEdge gets
+// E[tile + 1][i - (256 - kDecEdge)].
 // grid (N2'/2, n_pw), 512 threads, dynamic LDS 64 KB.
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_PLAIN_DS_OPS)) void k_inv_rows_plain_r8(const float2 *G, const float2 *E, float2 *V, FftPlan pl, int big_n2)
 {

@@ -407,17 +407,32 @@ int *launch_k1(tdoa_ctx *ctx, hipStream_t st, const SWDesc *d_sw, int n_sw, int 
 // ---- decimated inverse (fft_radix8.hpp, k_pair_decimate16) ----------------------------------------------------------
 // applies to the general form on 4096 x 256 plans when the packed search range M = reach/2 + 2 leaves a transition band:
 // R = Nc/16 = 65536, pass band |m| <= M, stop band |m| >= R - M
-constexpr double kDecAttenuationDb = 140.0;
+// Filter design: Kaiser-windowed sinc with T taps a side, T = what 140 dB needs on the transition band, at most kDecTmax
+// (fft_radix8.hpp: 95 with 12 steps per phase); the attenuation is then what T buys there, A = 8 + 2.285 dw 2T, and the
+// form applies from 120 dB on (cfg2 / cfg4: 126 dB, T = 95; cfg5: 140 dB, T = 87).  Alias leakage measured in float64 on
+// noise-level simulator.go peaks: ~4 x 10^(-A/20) of the peak (7e-7 at 126 dB; scripts/dec_filter_sweep.py).
+constexpr double kDecAttenuationDb = 140.0, kDecMinAttenuationDb = 120.0;
+struct DecDesign { bool ok; int T; double att; };
+DecDesign decimation_design(const FftPlan &pl, int reach)
+{
+    const long long M = reach / 2 + 2, R = pl.Nc / kDecD;
+    if (R - 2 * M <= 0) return {false, 0, 0.0};
+    const double dw = 2.0 * M_PI * (double)(R - 2 * M) / (double)pl.Nc;
+    int T = (int)std::ceil((kDecAttenuationDb - 8.0) / (2.285 * dw) / 2.0);
+    double att = kDecAttenuationDb;
+    if (T > kDecTmax) {
+        T = kDecTmax;
+        att = 8.0 + 2.285 * dw * 2.0 * T;
+    }
+    return {att >= kDecMinAttenuationDb, T, att};
+}
+
 bool decimation_applies(const tdoa_ctx *ctx, const FftPlan &pl, int lag_lo, int lag_hi)
 {
     if (!ctx->decimate || ctx->force_generic || pl.N1 != 4096 || (pl.N2 != 256 && pl.N2 != 512)) return false;
     const int reach = std::max(lag_hi + 1, -(lag_lo - 1));
     if (reach <= 4095) return false;                       // the short-lag forms take those
-    const long long M = reach / 2 + 2, R = pl.Nc / kDecD;
-    const double dw = 2.0 * M_PI * (double)(R - 2 * M) / (double)pl.Nc;
-    if (R - 2 * M <= 0) return false;
-    const int T = (int)std::ceil((kDecAttenuationDb - 8.0) / (2.285 * dw) / 2.0);
-    return T <= 111;          // taps t = 16 (s - 7) + p, s = 0..13
+    return decimation_design(pl, reach).ok;
 }
 
 // modified Bessel function I0 (Kaiser window)
@@ -433,7 +448,7 @@ double bessel_i0(double x)
 }
 
 // layout of the decimated inverse inside the V workspace (float2 elements): G [n_pw][R], V' [n_pw][R], the tiles' edge
-// shares E [n_pw][N2][14], then the stations' spectra in tiles [n_sw][Nc]
+// shares E [n_pw][N2][2 kDecEdge], then the stations' spectra in tiles [n_sw][Nc]
 size_t dec_edge_offset(const FftPlan &pl, int n_pw) { return 2 * (size_t)(pl.Nc / kDecD) * (size_t)n_pw; }
 size_t dec_spectra_offset(const FftPlan &pl, int n_pw)
 {
@@ -446,10 +461,10 @@ int ensure_decimation(tdoa_ctx *ctx, const FftPlan &pl, int lag_lo, int lag_hi)
 {
     const int reach = std::max(lag_hi + 1, -(lag_lo - 1));
     if (ctx->dec_nc == pl.Nc && ctx->dec_reach == reach) return TDOA_OK;
-    const long long M = reach / 2 + 2, R = pl.Nc / kDecD;
-    const double dw = 2.0 * M_PI * (double)(R - 2 * M) / (double)pl.Nc;
-    const int T = (int)std::ceil((kDecAttenuationDb - 8.0) / (2.285 * dw) / 2.0);
-    const double beta = 0.1102 * (kDecAttenuationDb - 8.7), i0b = bessel_i0(beta);
+    const long long M = reach / 2 + 2;
+    const DecDesign dd = decimation_design(pl, reach);
+    const int T = dd.T;
+    const double beta = 0.1102 * (dd.att - 8.7), i0b = bessel_i0(beta);
     std::vector<float> taps(2 * T + 1);
     for (int t = -T; t <= T; t++) {
         const double x = (double)t / kDecD, r = (double)t / T;
@@ -462,10 +477,10 @@ int ensure_decimation(tdoa_ctx *ctx, const FftPlan &pl, int lag_lo, int lag_hi)
         for (int t = -T; t <= T; t++) w += (double)taps[t + T] * std::cos(2.0 * M_PI * (double)t * (double)m / (double)pl.Nc);
         gain[m] = (float)((double)kDecD / w);
     }
-    // the kernel's layout: phase p x step s, the tap t = 16 (s - 7) + p (zero where |t| > T)
+    // the kernel's layout: phase p x step s, the tap t = 16 (s - kDecCentre) + p (zero where |t| > T)
     std::vector<float> tab(256, 0.0f);
     for (int t = -T; t <= T; t++) {
-        const int p = ((t % 16) + 16) % 16, sidx = (t - p) / 16 + 7;
+        const int p = ((t % 16) + 16) % 16, sidx = (t - p) / 16 + kDecCentre;
         tab[16 * p + sidx] = taps[t + T];
     }
     int rc;

@@ -5,7 +5,10 @@ import subprocess
 
 PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(PKG_ROOT, "csrc")
-LIB = os.path.join(PKG_ROOT, "libtdoa_mi355x.so")
+# TDOA_LIB_VARIANT=<name>: load libtdoa_mi355x_<name>.so instead -- a build of the same sources with other -D switches
+# (build_variant below), for same-box A/B measurements of compile-time choices; never set by tests, bench.py or the driver
+_VARIANT = os.environ.get("TDOA_LIB_VARIANT", "")
+LIB = os.path.join(PKG_ROOT, "libtdoa_mi355x%s.so" % ("_" + _VARIANT if _VARIANT else ""))
 CLI = os.path.join(PKG_ROOT, "tdoa_processor")
 CLI_SRC = os.path.join(CSRC, "host", "tdoa_processor.cpp")
 HEADER = os.path.join(os.path.dirname(PKG_ROOT), "include", "tdoa_mi355x.h")
@@ -27,6 +30,10 @@ def hipcc():
 
 
 def needs_build():
+    if _VARIANT:
+        if not os.path.exists(LIB):
+            raise RuntimeError("TDOA_LIB_VARIANT=%s: %s has not been built (tdoa_amd.build.build_variant)" % (_VARIANT, LIB))
+        return False
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
@@ -46,6 +53,17 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def build_variant(name, defines, verbose=False):
+    """libtdoa_mi355x_<name>.so from the same sources with extra -D switches (measurement builds, see TDOA_LIB_VARIANT)"""
+    out = os.path.join(PKG_ROOT, "libtdoa_mi355x_%s.so" % name)
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
+           "-pthread", "-Xarch_host", "-ffp-contract=off"] + ["-D" + d for d in defines] + ["-o", out, os.path.join(CSRC, "tdoa_mi355x.hip")]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return out
+
+
 def build_cli(force=False, verbose=False):
     """tdoa_processor: C++ host harness with the reference processor's command line, linked
     against the C-ABI library only (no HIP headers)."""
@@ -60,4 +78,8 @@ def build_cli(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    import sys
+    if len(sys.argv) > 2 and sys.argv[1] == "--variant":      # build.py --variant dec14 TDOA_DEC_STEPS=14
+        print(build_variant(sys.argv[2], sys.argv[3:], verbose=True))
+    else:
+        print(build(force=True, verbose=True))
