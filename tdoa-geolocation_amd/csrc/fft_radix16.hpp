@@ -313,7 +313,9 @@ __device__ __forceinline__ float2 k1_element_from(int a0, int a1, int ap, int i0
     }
     const int st1 = SCALED ? k1_stored_code_scaled(a1, a0) : k1_stored_code(a1, a0);
     const int st0 = head && i0 == 0 ? st1 : SCALED ? k1_stored_code_scaled(a0, ap) : k1_stored_code(a0, ap);
-    const float v0 = k1_normalise(st0, mean, scale), v1 = k1_normalise(st1, mean, scale);
+    // (ONCE: mean = m0, scale = s0 -- k1_normalise_fma(stored, -scale, -mean * scale), see there)
+    const float v0 = ONCE ? k1_normalise_fma(st0, -scale, -mean * scale) : k1_normalise(st0, mean, scale);
+    const float v1 = ONCE ? k1_normalise_fma(st1, -scale, -mean * scale) : k1_normalise(st1, mean, scale);
     if (ONCE) {                          // single-look K1: the window sums of exactly the samples that are transformed
         if (i0 < len) col_once_accumulate(st0, *t1, *t2);
         if (i0 + 1 < len) col_once_accumulate(st1, *t1, *t2);
@@ -417,6 +419,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         const int a = t.a, w = t.w, len = t.len;
         // (the quadrant table's angle codes are scaled by 256 -- so are the mean and, inversely, the scale: exact)
         const float mean = stats[w].mean * 256.0f, scale = stats[w].scale * 0.00390625f;
+        const float nscale = -scale, noff = -mean * scale;         // (ONCE: both products are exact)
         // where the previous tile's outputs go: output k of thread j is row (a 256 +) j + 16 k, column n1; it sits in v[oreg(k)]
         const ColK1Tile tp = col_k1_tile<SUB>(sw, prev >= 0 ? prev : tile, nbx, G);
         float2 *outp = T + (size_t)tp.w * pl.Zs + (SUB ? (size_t)tp.a * ((size_t)256 * N1 + pl.zpad) : 0);
@@ -457,7 +460,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
                         col_once_accumulate(st0, t1, t2);
                         col_once_accumulate(st1, t1, t2);
                     }
-                    v[r] = make_float2(k1_normalise(st0, mean, scale), k1_normalise(st1, mean, scale));
+                    v[r] = ONCE ? make_float2(k1_normalise_fma(st0, nscale, noff), k1_normalise_fma(st1, nscale, noff))
+                                : make_float2(k1_normalise(st0, mean, scale), k1_normalise(st1, mean, scale));
                 } else {
                     v[r] = k1_element_from<true, ONCE>(a0, a1, ap, i_first + 2 * c, len, mean, scale, r == 0, &t1, &t2);
                 }
@@ -694,6 +698,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         const Col512Tile t = col512_tile(sw, tile, nbx);
         const int w = t.w, len = t.len;
         const float mean = stats[w].mean * 256.0f, scale = stats[w].scale * 0.00390625f;      // scaled codes: k_fwd_col256_k1
+        const float nscale = -scale, noff = -mean * scale;
         float *img = plane + par * 256 * C;
         // where the previous tile's outputs go: output k of thread (j, par) is row j + 16 k + 256 par, column n1, in v[oreg(k)]
         const Col512Tile tp = col512_tile(sw, prev >= 0 ? prev : tile, nbx);
@@ -726,7 +731,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
                         col_once_accumulate(st0, t1, t2);
                         col_once_accumulate(st1, t1, t2);
                     }
-                    v[r] = make_float2(k1_normalise(st0, mean, scale), k1_normalise(st1, mean, scale));
+                    v[r] = ONCE ? make_float2(k1_normalise_fma(st0, nscale, noff), k1_normalise_fma(st1, nscale, noff))
+                                : make_float2(k1_normalise(st0, mean, scale), k1_normalise(st1, mean, scale));
                 } else {
                     v[r] = k1_element_from<true, ONCE>(a0, a1, ap, i_first + 2 * (F * (j - jw) * N1 + c), len, mean, scale, r == 0,
                                                        &t1, &t2);

@@ -260,7 +260,7 @@ __device__ __forceinline__ constexpr int dec_slot(int i) { return i + ((i + 8) >
 // pieces of 224 different lines per tile side and spectrum, which nearly doubled the bytes this kernel pulled in.
 template <int LOGN2>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_PLAIN_DS_OPS)) void k_pair_decimate16(const PWDesc *pw, const float2 *Z, float2 *G, float2 *E, FftPlan pl,
-                                                         const float *taps, int small_n2, int group_pairs, int n_pw)
+                                                         const float *taps, int small_n2, int group_pairs, int n_pw, float2 rot)
 {
     // group_pairs = 0: grid (N2/2, n_pw), workgroup (bx, pw).  group_pairs = P > 0 (every window of the batch carries the same P
     // pair-windows): 1-D grid; the P pair-windows of one (window, tile pair) all read the same station tiles, so they are given
@@ -336,9 +336,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_
             za[it] = at(Za, 8u * at1 + 4096u * (it - 1)); zam[it] = at(Za, 8u * atm1 - 4096u * (it - 1));
             zb[it] = at(Zb, 8u * at1 + 4096u * (it - 1)); zbm[it] = at(Zb, 8u * atm1 - 4096u * (it - 1));
         }
-        // w(k) = W_N^k; a thread's bins are DK apart: one root, then a fixed rotation
+        // w(k) = W_N^k; a thread's bins are DK apart: one root, then a fixed rotation (rot = W_N^DK, the same for every
+        // thread of every workgroup: a kernel argument from the host)
         float2 w = unit_root((float)(kA0 + o0), invNc, false);
-        const float2 rot = unit_root((float)DK, invNc, false);
         const int sa1 = slot_of(o0 + DK), sb1 = slot_of(4096 - o0 - DK);
         {
             float2 q, qm;
@@ -437,22 +437,31 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_
     // the phases (16 adjacent lanes)
     {
         const int tl = t & 255, eo = tl >> 4, p = tl & 15;         // eo = 0 .. 2 kDecEdge - 1 (the rest: idle lanes)
-        const int i = eo < kDecEdge ? eo - kDecEdge : 256 + (eo - kDecEdge);
         float2 e = make_float2(0.0f, 0.0f);
         if (eo < 2 * kDecEdge) {
-            // (the 16 lanes of an output differ in the phase only, and a phase is 16 banks on: every lane starts the sum at
-            // another step -- p >> 2 steps on -- so that the lanes of one read fall into different banks)
+            // Of an edge output's kDecSteps steps only those whose bin group lies inside this tile count: for the output k
+            // places before the tile (i = -k) the steps s >= C + k -- C - k of them, a run that ends at the last step --, for
+            // the output j places after it (i = 256 + j) the steps s <= C - 1 - j.  So a lane walks C steps, not 2 C, and
+            // every address is linear in the step: the slots of a run stay inside one 16-slot column of the image (constant
+            // pad term).  No branch: a step outside the run reads the run's first slot with a zero tap.
+            // (the 16 lanes of an output differ in the phase only, and a phase is 16 banks on: every lane starts its walk at
+            // another step -- p >> 2 steps on, cyclically -- so that the lanes of one read fall into different banks)
+            const bool left = eo < kDecEdge;
+            const int cnt = left ? eo : 2 * kDecEdge - eo;                         // steps of the run (left: C - k with k = C - eo)
+            const int s_lo = left ? kDecSteps - eo : 0;                            // its first step
+            const int idx_lo = left ? 0 : 256 - kDecCentre + (eo - kDecEdge);      // and that step's bin group: i + s_lo - C
+            const float2 *slot0 = img + p * kDecPitch + dec_slot(idx_lo + 8);
+            const float *tap0 = ltaps + 16 * p + (cnt ? s_lo : 0);
+            int r = p >> 2;
 #pragma unroll
-            for (int it = 0; it < kDecSteps; it++) {
-                int s2 = it + (p >> 2);
-                s2 = s2 >= kDecSteps ? s2 - kDecSteps : s2;
-                const int idx = i + s2 - kDecCentre;               // slot of the bin group; inside the tile: 0..255
-                if (idx >= 0 && idx < 256) {
-                    const float hh = ltaps[16 * p + s2];
-                    const float2 v = img[p * kDecPitch + dec_slot(idx + 8)];
-                    e.x += hh * v.x;
-                    e.y += hh * v.y;
-                }
+            for (int it = 0; it < kDecCentre; it++) {
+                const bool on = r < cnt;
+                const int rr = on ? r : 0;
+                const float hh = on ? tap0[rr] : 0.0f;
+                const float2 v = slot0[rr];
+                e.x += hh * v.x;
+                e.y += hh * v.y;
+                r = r + 1 == kDecCentre ? 0 : r + 1;
             }
         }
         e.x = row16_sum(e.x);

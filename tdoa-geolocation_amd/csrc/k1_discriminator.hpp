@@ -157,6 +157,15 @@ __device__ __forceinline__ float k1_normalise(int stored, float mean, float scal
     return d * scale;
 }
 
+// Single-look K1 (k1_single_look.hpp): the subtrahend is an integer m0 and the factor a power of two s0, so
+// (float(code) - m0) s0 is exact whenever |code - m0| < 2^24 and one fused multiply-add gives the same float:
+// w = float(stored) * nscale + off,  nscale = -s0,  off = -m0 s0   (2 instructions per sample instead of 3).  Beyond 2^24
+// the two forms may differ by one rounding of a 25-bit difference (2^-24 relative, once).
+__device__ __forceinline__ float k1_normalise_fma(int stored, float nscale, float off)
+{
+    return __builtin_fmaf((float)stored, nscale, off);
+}
+
 // window sums of the codes.  code^2 < 2^46, so S2 needs more than 64 bits for long windows: a workgroup's partial sum
 // (< 2^63) is added as its low 32 bits into s2a and the rest into s2b; S2 = s2b 2^32 + s2a.
 struct StatsPartial {

@@ -813,12 +813,15 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
                 const long long blocks = (groups + 7) / 8 * 8 * pairs_per_window;
                 if (blocks < (1ll << 31)) { gp = pairs_per_window; grid = dim3((unsigned int)blocks); }
             }
+            // W_N^DK, DK = N2 / 8 bins between a thread's consecutive elements of a tile (N = 2 Nc)
+            const double ang = -2.0 * M_PI * (double)(pl.N2 / 8) / (2.0 * (double)pl.Nc);
+            const float2 rot = make_float2((float)std::cos(ang), (float)std::sin(ang));
             if (pl.N2 == 256)
                 hipLaunchKernelGGL(k_pair_decimate16<8>, grid, dim3(512), sizeof(float2) * 2 * 16 * kDecPitch, st,
-                                   d_pw, spectra, g, edges, pl, static_cast<const float *>(ctx->dec_taps.p), ps2.N2, gp, n_pw);
+                                   d_pw, spectra, g, edges, pl, static_cast<const float *>(ctx->dec_taps.p), ps2.N2, gp, n_pw, rot);
             else
                 hipLaunchKernelGGL(k_pair_decimate16<9>, grid, dim3(512), sizeof(float2) * 2 * 16 * kDecPitch, st,
-                                   d_pw, spectra, g, edges, pl, static_cast<const float *>(ctx->dec_taps.p), ps2.N2, gp, n_pw);
+                                   d_pw, spectra, g, edges, pl, static_cast<const float *>(ctx->dec_taps.p), ps2.N2, gp, n_pw, rot);
         }
         {
             ProfScope ps(ctx, TDOA_K_INV_COL, 3.0 * 8.0 * (double)rc_pts * n_pw);
