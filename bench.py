@@ -17,6 +17,11 @@ Multi-GPU (one rank per GPU, torch.distributed over RCCL; no collective on the d
   --scaling strong (BASELINE config 4 as written: `--config cfg4 --scaling strong`): ONE capture set; rank r runs
       tdoa_process(ctx, r, world) on the windows it owns (wid % world == r), one all-gather, byte-wise owner merge and the
       N-station least-squares solve on rank 0 -- all inside the timed region.  value = the job's station-samples / time.
+  At N > 1 the default run (cfg2, weak) times BOTH: its contract line is the weak-scaled cfg2 job, and the sharded cfg4 job
+  is timed right after it in the same process group and attached as `sharded_cfg4`.
+  Multi-rank jobs correlate captures with TRUE delays (--sim fmdelay: one frequency-modulated carrier from TX, every
+  station's copy delayed by its propagation time), so the solve inside the timed region has a position to find: the run
+  FAILS unless every pair's median target-block lag equals the geometry's and the fix lies within 150 m of TX.
 
 Prints ONE JSON line on rank 0 (see the contract in the task description).
 """
@@ -71,8 +76,8 @@ def station_table(n):
     return out
 
 
-HOT_SOURCES = ("device_common.hpp", "k1_discriminator.hpp", "fft_stockham.hpp", "fft_radix16.hpp", "fft_radix8.hpp",
-               "tdoa_mi355x.hip")
+HOT_SOURCES = ("device_common.hpp", "k1_discriminator.hpp", "k1_single_look.hpp", "fft_stockham.hpp", "fft_radix16.hpp",
+               "fft_radix8.hpp", "tdoa_mi355x.hip")
 
 
 def source_hash():
@@ -91,12 +96,12 @@ def _latest_profile(pattern):
     return files[-1] if files else None
 
 
-def pmc_traffic(kernels):
-    """HBM-side bytes per launch from the committed rocprofv3 --pmc passes (scripts/collect_pmc.sh); bench.py cannot
-    profile itself, so this is read back from profiles/ -- and only if the file was taken on the current kernel sources.
-    `kernels`: the kernel names one profiling scope of the library covers.
+def pmc_traffic(cfg_name, kernels):
+    """HBM-side bytes per launch from the committed rocprofv3 --pmc passes of THIS configuration (scripts/collect_pmc.sh
+    <tag> <cfg>); bench.py cannot profile itself, so this is read back from profiles/ -- and only if the file was taken on
+    the current kernel sources.  `kernels`: the kernel names one profiling scope of the library covers.
     returns (bytes per launch summed over `kernels`, source label, sum over the step's kernels)"""
-    f = _latest_profile("*pmc_traffic.json")
+    f = _latest_profile("*pmc_traffic_%s.json" % cfg_name)
     if not f:
         return None, None, None
     try:
@@ -114,11 +119,11 @@ def pmc_traffic(kernels):
 N_SIMD, N_SE = 1024, 32          # MI355X: 256 CUs x 4 SIMDs; 8 XCDs x 4 shader engines
 
 
-def sq_issue(kernel):
-    """vector-instruction issue share of a kernel from the committed SQ counter table (scripts/collect_sq.sh):
+def sq_issue(cfg_name, kernel):
+    """vector-instruction issue share of a kernel from the committed SQ counter table of THIS configuration (scripts/collect_sq.sh):
     SQ_ACTIVE_INST_VALU counts quad-cycles summed over the SIMDs, SQ_BUSY_CYCLES cycles summed over the shader engines
     (MI355X_MICROARCH.md, SQ PMC units).  None unless the table was taken on the current kernel sources."""
-    f = _latest_profile("*sq_cfg2.csv")
+    f = _latest_profile("*sq_%s.csv" % cfg_name)
     if not f:
         return None
     try:
@@ -140,13 +145,14 @@ def sq_issue(kernel):
 
 
 def decimation_fits(nc, max_lag):
-    """the library's rule (tdoa_mi355x.hip decimation_applies): the Kaiser filter for 140 dB between the pass band
-    |m| <= M = max_lag/2 + 2 and the stop band |m| >= Nc/16 - M must fit 111 taps a side"""
+    """the library's rule (tdoa_mi355x.hip decimation_design): a Kaiser filter of at most 95 taps a side must reach 120 dB
+    between the pass band |m| <= M = max_lag/2 + 2 and the stop band |m| >= Nc/16 - M"""
     m, r = max_lag // 2 + 2, nc // 16
     if r - 2 * m <= 0:
         return False
     dw = 2.0 * math.pi * (r - 2 * m) / nc
-    return math.ceil((140.0 - 8.0) / (2.285 * dw) / 2.0) <= 111
+    t = min(95, math.ceil((140.0 - 8.0) / (2.285 * dw) / 2.0))
+    return 8.0 + 2.285 * dw * 2.0 * t >= 120.0
 
 
 def cpu_info():
@@ -262,6 +268,7 @@ def cpu_baseline_leg(ctx, peaks, block, wlen, max_lag, budget_s):
     return {
         "value": round(6 * n1 / t1 / 1e6, 4), "unit": "Msamples/s", "cores": 1, "kind": "port",
         "cpu_model": model, "physical_cores": phys, "hardware_threads": threads,
+        "compare_against": "value (ONE thread: the reference is a single-threaded program); all_cores and same_algorithm_f64_fft are context",
         "sample": "oracle restatement of processor.go crossCorrelate (power gate, moving-average filter chain, time-domain "
                   "correlation), the reference's 6-call pattern: 3 pairs x {reference block, target block}, first %d samples "
                   "of each, same bytes as the GPU run, ONE thread (the reference is single-threaded), %.1f s" % (n1, t1),
@@ -272,100 +279,143 @@ def cpu_baseline_leg(ctx, peaks, block, wlen, max_lag, budget_s):
     }, parity
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", choices=sorted(CONFIGS), default=None)
-    ap.add_argument("--scaling", choices=("strong", "weak"), default=None)
-    ap.add_argument("--seconds", type=float, default=None, help="capture length per station (overrides the config)")
-    ap.add_argument("--batch", type=int, default=0, help="windows per launch group (0 = library default)")
-    ap.add_argument("--max-lag", type=int, default=20000, help="search range in samples (reference: 20000, processor.go:633)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph-leg", action="store_true")
-    ap.add_argument("--cpu-budget", type=float, default=10.0)
-    ap.add_argument("--sim", choices=("config", "fm", "random"), default="config",
-                    help="capture bytes: the config's simulator (+-1..3 LSB tones + noise), 'fm' = frequency-modulated carriers at "
-                         "half scale like oracle simulate_delayed_fm (what a well-set RTL-SDR gain delivers), 'random' = uniform "
-                         "random bytes (every table entry of K1 equally likely)")
-    ap.add_argument("--force-dist", action="store_true",
-                    help="at --gpus 1: initialise torch.distributed (nccl = RCCL, world size 1) and run the multi-GPU step -- "
-                         "tdoa_process(rank, world), all_gather_into_tensor of the peak records, owner merge, solve -- on one GPU")
-    args = ap.parse_args()
+def propagation_delays(stations, fs):
+    """whole-sample propagation delay of every station from TX (what --sim fmdelay applies to the carrier)"""
+    import tdoa_amd
+    tx = tdoa_amd.capi.latlon_to_ecef(*TX)
+    out = []
+    for st in stations:
+        p = tdoa_amd.capi.latlon_to_ecef(*st)
+        dist = math.sqrt(sum((a - b) ** 2 for a, b in zip(tx, p)))
+        out.append(int(round(dist / 299792458.0 * fs)))
+    return out
 
+
+def synth_torch_captures(ctx, torch, sim, S, block, seed0, delays):
+    """capture bytes generated by torch in HBM and attached without a copy (returns the buffers: they must outlive ctx).
+    random : uniform random bytes (every table entry of K1 equally likely)
+    fm     : independent frequency-modulated carriers at half scale per station (what a well-set RTL-SDR gain delivers)
+    fmdelay: ONE frequency-modulated carrier per block (the transmitter at TX), every station receiving it `delays[s]`
+             samples late plus its own noise -- captures whose pairs correlate at lag delays[j] - delays[i]"""
+    piece = 1 << 24
+    bufs = [torch.empty(2 * 3 * block, dtype=torch.uint8, device="cuda") for _ in range(S)]
+
+    def fm_phase(gen, n, phase0=0.0):
+        # phi = running sum of a smoothed noise message (modulation index 1)
+        msg = torch.randn(n + 63, device="cuda", generator=gen)
+        msg = torch.nn.functional.conv1d(msg.view(1, 1, -1), torch.full((1, 1, 64), 1.0 / 8.0, device="cuda")).view(-1)
+        return torch.cumsum(msg.double(), 0) + phase0
+
+    def to_bytes(phi, gen):
+        ph = torch.remainder(phi, 2.0 * math.pi).float()
+        noise = (torch.rand(2 * ph.numel(), device="cuda", generator=gen) * 2 - 1) * 0.02
+        iq = torch.stack([0.5 * torch.cos(ph), 0.5 * torch.sin(ph)], dim=1).view(-1) + noise
+        return torch.clamp(torch.trunc(iq * 127.5 + 127.5), 0, 255).to(torch.uint8)
+
+    if sim == "fmdelay":
+        dmax = max(delays)
+        for b in range(3):
+            gen = torch.Generator(device="cuda")
+            gen.manual_seed(seed0 * 8 + b)
+            phi = torch.empty(block + dmax, dtype=torch.float64, device="cuda")       # the transmitter's phase, dmax samples early
+            phase0 = 0.0
+            for lo in range(0, block + dmax, piece):
+                m = min(piece, block + dmax - lo)
+                phi[lo:lo + m] = fm_phase(gen, m, phase0)
+                phase0 = float(phi[lo + m - 1])
+            for s_ in range(S):
+                gn = torch.Generator(device="cuda")
+                gn.manual_seed(seed0 * 8 + 64 * (s_ + 1) + b)
+                off = dmax - delays[s_]                                                # station sample n = transmitter sample n - delay
+                for lo in range(0, block, piece):
+                    m = min(piece, block - lo)
+                    bufs[s_][2 * (b * block + lo):2 * (b * block + lo + m)] = to_bytes(phi[off + lo:off + lo + m], gn)
+            del phi
+    else:
+        for s_ in range(S):
+            gen = torch.Generator(device="cuda")
+            gen.manual_seed(seed0 + s_)
+            phase0 = 0.0
+            for lo in range(0, 3 * block, piece):
+                m = min(piece, 3 * block - lo)
+                if sim == "random":
+                    bufs[s_][2 * lo:2 * (lo + m)] = torch.randint(0, 256, (2 * m,), dtype=torch.uint8, device="cuda", generator=gen)
+                else:
+                    phi = fm_phase(gen, m, phase0)
+                    phase0 = float(phi[-1])
+                    bufs[s_][2 * lo:2 * (lo + m)] = to_bytes(phi, gen)
+    for s_ in range(S):
+        ctx.capture_attach_device(s_, bufs[s_].data_ptr(), 3 * block)
+    return bufs
+
+
+def sample_clocks(run_steps):
+    """shader clock and socket power while `run_steps()` keeps the GPU busy (rocm-smi polled from a thread; the timed
+    region of a cfg2 run lasts 30 ms -- too short to poll -- so the same step is replayed for ~1.5 s right after it)"""
+    import re
+    import statistics
+    import subprocess
+    import threading
+    samples, stop = [], threading.Event()
+    dev = os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("ROCR_VISIBLE_DEVICES", "")).split(",")[0]
+
+    def poll():
+        while not stop.is_set():
+            try:
+                txt = subprocess.run(["/opt/rocm/bin/rocm-smi", "--showpower", "--showclocks", "--csv"], capture_output=True,
+                                     text=True, timeout=5).stdout
+                for line in txt.splitlines():
+                    m = re.match(r"card(\d+),\((\d+)Mhz\),\d+,\((\d+)Mhz\),\d+,\((\d+)Mhz\),\d+,\((\d+)Mhz\),\w+,([\d.]+)", line)
+                    if m:
+                        samples.append((int(m.group(1)), int(m.group(4)), float(m.group(6))))
+            except Exception:
+                return
+            time.sleep(0.1)
+
+    th = threading.Thread(target=poll, daemon=True)
+    th.start()
+    run_steps()
+    stop.set()
+    th.join(timeout=10)
+    if not samples:
+        return None
+    # the card under load: the one with the highest power draw (one GPU per box here; HIP_VISIBLE_DEVICES names it otherwise)
+    cards = sorted({c for c, _, _ in samples})
+    card = int(dev) if dev.isdigit() and int(dev) in cards else max(cards, key=lambda c: max(p for cc, _, p in samples if cc == c))
+    busy = [(sc, pw) for c, sc, pw in samples if c == card and pw > 0.6 * max(p for cc, _, p in samples if cc == card)]
+    if not busy:
+        return None
+    return {"sclk_MHz": statistics.median(sc for sc, _ in busy), "socket_W": statistics.median(pw for _, pw in busy),
+            "samples": len(busy), "source": "rocm-smi polled during ~1.5 s of the same step replayed right after the timed region"}
+
+
+def run_job(args, env, cfg_name, scaling, sim, steps, warmup, full):
+    """one job (configuration + sharding mode) on the process group `env`: captures, warm-up, timed region; `full`: also the
+    per-kernel table, the roofline object, the graph-replay leg, clocks (the contract line's job).  Returns (result dict for
+    rank 0 | None, parity flag)."""
     import numpy as np
     import torch
     import tdoa_amd
     from tdoa_amd import sharding
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
-    # The default at every N is BASELINE config 2, WEAK-scaled: one job of N x 99 windows, window-major -- rank r holds and
-    # processes its own 99 windows (its own capture set, different seeds), the peak records are all-gathered over RCCL and
-    # rank 0 decodes all of them and solves every set.  Per-GPU work is fixed, so value(N) / (N value(1)) is the scaling
-    # efficiency.  `--config cfg4 --scaling strong` is BASELINE config 4 as written: ONE 8-station capture set, its windows
-    # dealt wid % N to the ranks.
-    cfg_name = args.config or "cfg2"
+    world, rank, device, backend, dist, use_dist = env["world"], env["rank"], env["device"], env["backend"], env["dist"], env["use_dist"]
     cfg = dict(CONFIGS[cfg_name])
-    scaling = args.scaling or "weak"
-    steps = args.steps if args.steps is not None else cfg["steps"]
-    # one rank per GPU; TDOA_BENCH_BACKEND=gloo is a rehearsal mode (several ranks may then share
-    # a GPU and the peak records travel through host memory) -- the driver always runs nccl (= RCCL)
-    backend = os.environ.get("TDOA_BENCH_BACKEND", "nccl")
-    device = local_rank % torch.cuda.device_count() if backend == "gloo" else local_rank
-    torch.cuda.set_device(device)
-    dist = None
-    use_dist = world > 1 or args.force_dist
-    if use_dist:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29531")
-        kw = {} if world > 1 else {"rank": 0, "world_size": 1}
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device), **kw)
-        else:
-            dist.init_process_group(backend=backend, **kw)
-
     fs, wlen, max_lag = cfg["fs"], cfg["wlen"], args.max_lag
     S = cfg["stations"]
     block = int(args.seconds * fs) // 3 if args.seconds else cfg["block"]
     stations = station_table(S)
     ctx = tdoa_amd.Context(device=device, window_len=wlen, max_lag=max_lag, sample_rate=fs, windows_per_batch=args.batch)
     seed0 = SEED_BASE + (16 * rank if scaling == "weak" else 0)        # strong: every rank holds the SAME capture set
-    attached = []                                                      # torch buffers the library reads in place
-    for s in range(S):
-        if args.sim != "config":
-            # byte distributions K1's table lookups see on real captures; generated by torch in HBM
-            # in pieces, attached without a copy
-            n = 3 * block
-            buf = torch.empty(2 * n, dtype=torch.uint8, device="cuda")
-            gen = torch.Generator(device="cuda")
-            gen.manual_seed(seed0 + s)
-            piece = 1 << 24
-            phase0 = 0.0
-            for lo in range(0, n, piece):
-                m = min(piece, n - lo)
-                if args.sim == "random":
-                    buf[2 * lo:2 * (lo + m)] = torch.randint(0, 256, (2 * m,), dtype=torch.uint8, device="cuda", generator=gen)
-                else:
-                    # x = 0.5 exp(i phi), phi = running sum of a smoothed noise message (modulation index 1), noise 0.02
-                    msg = torch.randn(m + 63, device="cuda", generator=gen)
-                    msg = torch.nn.functional.conv1d(msg.view(1, 1, -1), torch.full((1, 1, 64), 1.0 / 8.0, device="cuda")).view(-1)
-                    phi = torch.cumsum(msg.double(), 0) + phase0
-                    phase0 = float(phi[-1])
-                    noise = (torch.rand(2 * m, device="cuda", generator=gen) * 2 - 1) * 0.02
-                    iq = torch.stack([0.5 * torch.cos(phi).float(), 0.5 * torch.sin(phi).float()], dim=1).view(-1) + noise
-                    buf[2 * lo:2 * (lo + m)] = torch.clamp(torch.trunc(iq * 127.5 + 127.5), 0, 255).to(torch.uint8)
-            ctx.capture_attach_device(s, buf.data_ptr(), n)
-            attached.append(buf)
-        elif cfg["sim"] == "weak":
-            ctx.synth_weak_capture(s, block, stations[s], TX, seed0 + s, tgt_power=20000.0)
-        else:
-            ctx.synth_capture(s, block, stations[s], TX, seed0 + s)
+    delays = propagation_delays(stations, fs)
+    attached = None                                                    # torch buffers the library reads in place
+    if sim != "config":
+        attached = synth_torch_captures(ctx, torch, sim, S, block, seed0, delays)
+    else:
+        for s in range(S):
+            if cfg["sim"] == "weak":
+                ctx.synth_weak_capture(s, block, stations[s], TX, seed0 + s, tgt_power=20000.0)
+            else:
+                ctx.synth_capture(s, block, stations[s], TX, seed0 + s)
     wpb, n_windows = ctx.num_windows()
     n_pairs = ctx.num_pairs()
     wl = min(wlen, block)
@@ -377,16 +427,19 @@ def main():
     gathered = torch.zeros(peak_bytes * world, dtype=torch.uint8, device="cuda") if use_dist else None
     state = {"peaks": None, "fix": None}
     tgt_rows = np.arange(wpb, 2 * wpb)                                    # windows of the target block
+    pair_list = [(i, j) for i in range(S) for j in range(i + 1, S)]
 
     def solve(pk):
         """downstream of the path (processor.go:892-926): median target-block lag per pair -> range differences ->
         least-squares position (3 stations: the reference's solver; more: tdoa_solve_nstation weighted by |corr|)"""
         lag = np.median(pk["lag"][tgt_rows], axis=0)
-        wgt = np.median(pk["abs_corr"][tgt_rows], axis=0).astype(np.float64)
+        wgt = np.maximum(np.median(pk["abs_corr"][tgt_rows], axis=0).astype(np.float64), 1e-12)
         rd = lag / fs * 299792458.0
-        if S == 3:
-            return tdoa_amd.capi.solve_3station(stations, rd)
-        return tdoa_amd.capi.solve_nstation(stations, rd, weights=np.maximum(wgt, 1e-12))
+        ref = tdoa_amd.capi.solve_3station(stations, rd) if S == 3 else tdoa_amd.capi.solve_nstation(stations, rd, weights=wgt)
+        # the reference freezes ECEF Z at the centroid (processor.go:1004): a plane that misses a ground transmitter by
+        # hundreds of metres; the fix that is CHECKED holds the position on the ellipsoid instead (tdoa_solve_surface)
+        fix = tdoa_amd.capi.solve_surface(stations, rd, weights=wgt, height_m=sum(s_[2] for s_ in stations) / S)
+        return fix + (lag, ref)
 
     def step():
         if not use_dist:
@@ -413,6 +466,7 @@ def main():
             fixes = [solve(sharding.bytes_as_peaks(parts[r], n_windows, n_pairs)) for r in range(world)]
             state["peaks"] = sharding.bytes_as_peaks(parts[0], n_windows, n_pairs)
             state["fix"] = fixes[0]
+            state["fixes"] = fixes
 
     def fence():
         if use_dist:
@@ -432,56 +486,65 @@ def main():
             dt_ = float(tt.item())
         return dt_
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
-    # (untimed) every kernel scope of a few steps with events: the per-kernel table of the JSON line and the name of the
-    # dominant kernel.  Kernels launched one by one, an event at every kernel boundary.
-    ctx.profile_enable(True)
-    ctx.profile_select(None)
-    ctx.profile_reset()
-    table_steps = steps
-    for _ in range(table_steps):
-        step()
-    torch.cuda.synchronize()
-    table = ctx.profile()
-    dominant = max(table.items(), key=lambda kv: kv[1]["ms"])[0]
-    # timed region of the contract: the library's default path -- the whole step replayed as ONE hipGraph -- with two
-    # event-record nodes spliced into the captured graph around the DOMINANT kernel (the roofline's launch durations,
-    # measured live on the library's stream inside the timed steps).  The same steps without any event are timed right
-    # after (graph_replay).
-    timed_mode = 2
-    ctx.profile_select([dominant])
-    try:
-        ctx.profile_enable(2)
-        step()                                                            # captures and instruments the graph (untimed)
+    table, dominant, timed_mode, table_steps = None, None, 0, steps
+    if full:
+        # (untimed) every kernel scope of a few steps with events: the per-kernel table of the JSON line and the name of the
+        # dominant kernel.  Kernels launched one by one, an event at every kernel boundary.
+        ctx.profile_enable(True)
+        ctx.profile_select(None)
         ctx.profile_reset()
-        step()
-        if not ctx.profile()[dominant]["launches"]:
-            raise tdoa_amd.TdoaError("no event-record node fired")
-    except tdoa_amd.TdoaError as e:
-        # a runtime without working event-record nodes: the launch-by-launch path with events around the same kernel
-        print("bench: graph-mode profiling unavailable (%s); timing the launch-by-launch path" % e, file=sys.stderr)
-        timed_mode = 1
-        ctx.profile_enable(1)
-        step()
-    ctx.profile_reset()
+        for _ in range(table_steps):
+            step()
+        torch.cuda.synchronize()
+        table = ctx.profile()
+        dominant = max(table.items(), key=lambda kv: kv[1]["ms"])[0]
+        # timed region of the contract: the library's default path -- the whole step replayed as ONE hipGraph -- with two
+        # event-record nodes spliced into the captured graph around the DOMINANT kernel (the roofline's launch durations,
+        # measured live on the library's stream inside the timed steps).  The same steps without any event are timed right
+        # after (graph_replay).  With TDOA_NO_GRAPH=1 (no step graph) or a runtime whose event-record nodes do not fire: the
+        # launch-by-launch path with events around the same kernel.
+        timed_mode = 2
+        ctx.profile_select([dominant])
+        graph_marks_ok = os.environ.get("TDOA_NO_GRAPH") != "1"
+        if graph_marks_ok:
+            ctx.profile_enable(2)
+            step()                                                        # captures and instruments the graph (untimed)
+            ctx.profile_reset()
+            step()
+            graph_marks_ok = bool(ctx.profile()[dominant]["launches"])
+        if not graph_marks_ok:
+            print("bench: graph-mode profiling unavailable (no step graph, or no event-record node fired); timing the "
+                  "launch-by-launch path", file=sys.stderr)
+            timed_mode = 1
+            ctx.profile_enable(1)
+            step()
+        ctx.profile_reset()
     dt = timed(steps)
-    ctx.profile_enable(False)
-    ctx.profile_select(None)
-    prof_timed = ctx.profile()
-    if not prof_timed[dominant]["launches"]:
-        raise SystemExit("profiling recorded nothing for %s" % dominant)
-    prof = {k: {"ms": v["ms"] * steps / table_steps, "launches": v["launches"] * steps // table_steps, "bytes": v["bytes"] * steps / table_steps}
-            for k, v in table.items()}                                   # the table, scaled to `steps` steps
-    prof[dominant] = prof_timed[dominant]                               # the dominant kernel: measured inside the timed region
+    prof_timed = None
+    if full:
+        ctx.profile_enable(False)
+        ctx.profile_select(None)
+        prof_timed = ctx.profile()
+        if not prof_timed[dominant]["launches"]:
+            raise SystemExit("profiling recorded nothing for %s" % dominant)
     timed_peaks = None if state["peaks"] is None else state["peaks"].copy()     # what the contract's timed region produced
+    timed_fix = state["fix"]
     graph_leg = None
-    if not args.no_graph_leg:
+    if full and not args.no_graph_leg:
         step()                                                            # captures the graph
         dtg = timed(steps)
         graph_leg = {"ms_per_step": round(dtg / steps * 1e3, 4), "value": round(samples_per_step / (dtg / steps) / 1e6, 2),
                      "identical_to_timed_path": None if timed_peaks is None else bool(np.array_equal(timed_peaks, state["peaks"])),
                      "note": "the same steps, the same graph without the two event-record nodes"}
+    clocks = None
+    if full and not args.no_clocks:
+        n_sustain = max(steps, int(1.5 / max(dt / steps, 1e-6)))          # the same count on every rank (dt is the max over ranks)
+        if rank == 0:
+            clocks = sample_clocks(lambda: timed(n_sustain))
+        else:
+            timed(n_sustain)
 
     if world > 1 and scaling == "strong" and n_windows >= world:
         # every rank's part must be what the owner merge expects: its own windows, zeros elsewhere
@@ -495,88 +558,11 @@ def main():
         if not torch.equal(got[rank], dev_peaks.cpu()):
             raise SystemExit("all-gather of peak records is inconsistent on rank %d" % rank)
 
-    rc = 0
+    out, parity = None, None
     if rank == 0:
         ms_per_step = dt / steps * 1e3
         value = samples_per_step / (dt / steps) / 1e6
         n_fft, n1, n2 = ctx.plan_info()
-        name, rec = max(prof.items(), key=lambda kv: kv[1]["ms"])
-        # kernels behind every profiling scope of the library on this plan (names as rocprofv3 prints them, no template suffix)
-        hot = {}
-        if n1 == 4096:          # the radix-16 register kernels (fft_radix16.hpp); the column pass depends on N2
-            fused_k1 = n2 in (256, 512, 2048, 4096) and os.environ.get("TDOA_NO_FUSED_K1") != "1" and max_lag > 1024
-            if fused_k1:
-                col = ["k_fwd_col512_k1"] if n2 == 512 else ["k_fwd_col256_k1"] + (["k_fwd_col_finish"] if n2 > 256 else [])
-            else:
-                col = (["k_fwd_col16x_c16"] if n2 <= 128 else ["k_fwd_col256_c16"] if n2 == 256 else ["k_fwd_colx_c16"] if n2 <= 1024
-                       else ["k_fwd_col256_c16", "k_fwd_col_finish"])
-            hot = {"k_fm_demod": ["k_fm_demod"], "k_fwd_col": col, "k_fwd_row": ["k_fwd_row4096"],
-                   "k_inv_row_pair": ["k_inv_row_pair4096"], "k_inv_col_peak": ["k_inv_col_pruned"]}
-        reach = max_lag                     # lags -(max_lag - 1) .. max_lag - 1 plus the refinement neighbours
-        decimated = (n1 == 4096 and n2 in (256, 512) and reach > 4095 and os.environ.get("TDOA_NO_DECIMATE") != "1"
-                     and decimation_fits(n1 * n2, max_lag))
-        if decimated:     # K3 + 16:1 FIR decimation of the pair spectrum, then an Nc/16-point inverse
-            hot = dict(hot, k_fwd_row=["k_fwd_row4096_unpack"], k_inv_row_pair=["k_pair_decimate16"],
-                       k_inv_col_peak=["k_inv_rows_plain_r8", "k_small_col_peak"])
-        if max_lag <= 1024 and n1 == 4096:
-            # segment form; with 3+ pairs per window the station transforms are shared (quads)
-            hot = dict(hot, k_inv_row_pair=["k_xcorr_segments_quad" if n_pairs >= 3 and os.environ.get("TDOA_NO_SEGMENT_QUADS") != "1"
-                                            else "k_xcorr_segments"], k_inv_col_peak=["k_segments_reduce"])
-        roof = None
-        pmc_total = None
-        if rec["launches"]:
-            per_launch_bytes = rec["bytes"] / rec["launches"]
-            avg_s = rec["ms"] / rec["launches"] / 1e3
-            achieved = per_launch_bytes / avg_s / 1e9
-            traffic, src = None, None
-            default_cfg = cfg_name == "cfg2" and args.seconds is None and args.batch == 0 and world == 1 and max_lag == 20000 \
-                and args.sim == "config"
-            kernels = hot.get(name, [name])
-            sq = None
-            if default_cfg and name in hot:
-                traffic, src, pmc_total = pmc_traffic(kernels)
-                sq = sq_issue(kernels[0])
-            # what limits the kernel, from the evidence at hand: its vector-instruction issue share (SQ counters) against
-            # its share of the HBM peak
-            hbm_frac = None if traffic is None else traffic / avg_s / 1e9 / HBM_PEAK_GBS
-            # ("hbm": its memory-side bytes per second are a larger share of what a plain fill sustains than its issue share)
-            limiter = None
-            if sq is not None:
-                hbm_of_fill = (hbm_frac or 0.0) * HBM_PEAK_GBS / HBM_FILL_GBS
-                limiter = "valu_issue" if sq["valu_issue_frac"] > max(0.6, hbm_of_fill) else "hbm"
-            roof = {"bound": "hbm", "kernel": " + ".join(kernels),
-                    "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                    "frac_of_measured_achievable": round(achieved / 6290.0, 4),   # guide: 6.29 TB/s achievable
-                    "frac_of_fill_rate": round(achieved / HBM_FILL_GBS, 4),
-                    "traffic": traffic, "traffic_source": src,
-                    # HBM side: bytes the memory-side counters saw per launch / launch time / 8 TB/s
-                    "hbm_frac": None if hbm_frac is None else round(hbm_frac, 4),
-                    "valu_issue_frac": None if sq is None else sq["valu_issue_frac"],
-                    "valu_instructions_per_wave": None if sq is None else sq["valu_instructions_per_wave"],
-                    "lds_conflict_frac": None if sq is None else sq["lds_conflict_frac"],
-                    "sq_source": None if sq is None else sq["source"],
-                    "limiter": limiter,
-                    "algorithmic_bytes_per_launch": per_launch_bytes,
-                    "avg_launch_us": round(avg_s * 1e6, 2), "launches": rec["launches"],
-                    "kernels_ms_per_step": {k: round(v["ms"] / steps, 4) for k, v in prof.items()},
-                    "note": "frac = algorithmic bytes of the launch (the library's per-kernel byte model, DESIGN.md section 3) / "
-                            "HIP-event time / 8 TB/s: a request rate.  hbm_frac = what the memory-side counters saw "
-                            "(profiles/, same kernel sources) over the same time.  valu_issue_frac = share of the kernel's time "
-                            "its SIMDs spend issuing vector instructions: above ~0.8 the kernel is bound by instruction "
-                            "issue, whatever its bytes"}
-            if roof["kernel"] == "k_pair_decimate16":
-                roof["note"] += ("; decimated inverse: the kernel reads the two station spectra of a pair once (16 Nc bytes) and "
-                                 "writes 1/16 of a spectrum (Nc/2): 16.5 Nc = 8.25 N per pair-window, where SURVEY's model of the "
-                                 "pair step (two spectra read, V written, V read) charges 32 Nc = 16 N")
-            if roof["kernel"].startswith("k_xcorr_segments"):
-                roof["note"] += ("; segment form: 4096-point transforms in LDS and registers, limited by vector-instruction issue "
-                                 "(DESIGN.md section 3); its HBM traffic is the 4-byte phase codes only")
-        # whole-pipeline algorithmic bytes: k = ceil(log2 N / 12) passes of 4096-point tiles, e = 4 B:
-        # 2L + e N (2k - 1) per station-window, e N 2k per pair-window  (k = 2: 2L + 12N and 16N; k = 3: 2L + 20N and 24N)
-        k_pass = max(2, math.ceil(math.log2(n_fft) / 12.0))
-        units_w = n_windows * (world if scaling == "weak" else 1)
-        a_bytes = units_w * (S * (2 * wl + 4 * n_fft * (2 * k_pass - 1)) + n_pairs * 4 * n_fft * 2 * k_pass)
         if use_dist and scaling == "strong":
             par = ("one capture set, windows dealt wid %% %d to the ranks, %s all-gather of the peak records, owner merge + "
                    "least-squares solve on rank 0, all inside the timed region" % (world, "RCCL" if backend == "nccl" else backend))
@@ -586,67 +572,305 @@ def main():
                    % (world, n_windows, n_windows, "RCCL" if backend == "nccl" else backend))
         else:
             par = "single GPU"
+        data_note = {"config": "", "fm": "; capture bytes: independent half-scale FM carriers (torch)",
+                     "random": "; capture bytes: uniform random (torch)",
+                     "fmdelay": "; capture bytes: one half-scale FM carrier from TX, every station's copy delayed by its propagation "
+                                "time (torch) -- the pairs correlate at the geometry's lags"}[sim]
+        if sim == "config" and cfg["sim"] == "weak":
+            data_note = ("; weak_signal_simulator.go model with tgt_power = 20000 where its example call passes 1000 "
+                         "(weak_signal_simulator.go:298): at 1000 the target tone is below one LSB and every window is constant bytes")
         out = {
             "metric": "IQ Msamples/s through demod+xcorr", "value": round(value, 2), "unit": "Msamples/s",
-            "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32",      # K1: integer phase codes of pi/2^23 per step, exact in f32; transforms in f32
             "data": "synthetic",
-            "config": {"workload": "%s%s, %d pairs x %d windows of %d samples, FFT N=%d (%dx%d), max_lag %d; peaks on the host"
+            "config": {"workload": "%s%s, %d pairs x %d windows of %d samples, FFT N=%d (%dx%d), max_lag %d; peaks on the host%s"
                                    % (cfg["label"], " per GPU" if (scaling == "weak" and world > 1) else "", n_pairs, n_windows, wl,
-                                      n_fft, n1, n2, max_lag),
-                       "name": cfg_name, "capture_bytes": args.sim, "stations": S, "pairs": n_pairs, "windows": n_windows, "window_len": wl,
+                                      n_fft, n1, n2, max_lag, data_note),
+                       "name": cfg_name, "capture_bytes": sim, "stations": S, "pairs": n_pairs, "windows": n_windows, "window_len": wl,
                        "fft_n": n_fft, "sample_rate": fs, "parallelism": par},
-            "timed_path": ("the whole step replayed as one hipGraph (the library's default path) with event-record nodes around the "
-                           "dominant kernel (the roofline's source)" if timed_mode == 2 else
-                           "kernels launched one by one, HIP events around the dominant kernel's launches (the roofline's source)")
-                          + "; the other kernels' times come from %d untimed steps launched kernel by kernel with an event at every "
-                            "boundary; graph_replay: the whole step replayed as one hipGraph without any event" % table_steps,
-            "graph_replay": graph_leg,
-            # SURVEY.md 8d byte model (a fixed price list per sample, NOT what this pipeline moves: the decimated inverse and
-            # the fused K1 move less) -- kept under its own name
-            "pipeline_survey_model_GBps": round(a_bytes / (dt / steps) / 1e9, 1),
-            # the bytes the launched kernels are charged with by the library (per-kernel figures of tdoa_profile_get: the
-            # decimated pair step at its own 16.5 Nc per pair-window, the fused K1 with no code round trip)
-            "pipeline_kernel_bytes_GBps": round(sum(v["bytes"] for v in prof.values()) / max(steps, 1) / (dt / steps) / 1e9, 1),
-            # HBM side of the whole step: memory-side counters of every kernel of a step (profiles/, same sources) / step time
-            "pipeline_pmc_GBps": None if not pmc_total else round(pmc_total / (dt / steps) / 1e9, 1),
-            "pipeline_frac_of_hbm_peak": None if not pmc_total else round(pmc_total / (dt / steps) / 1e9 / HBM_PEAK_GBS / world, 4),
-            # SURVEY.md 8d secondary figure: pair-samples correlated per second (P*W*L/t), whole job
-            "pair_Msamples_per_s": round(samples_per_step / S * n_pairs / (dt / steps) / 1e6, 2),
-            "roofline": roof,
+            "source_sha16": source_hash(),
+            "k1_path": "single look (every capture byte read once; csrc/k1_single_look.hpp)" if ctx.last_k1(0)[1]
+                       else "statistics pre-pass + discriminator in the column pass (capture bytes read twice)",
+            "clocks": clocks,
         }
-        if world > 1:
-            # the N = 1 default of this script is the headline config (cfg2); a scaling figure for THIS job needs the
-            # one-GPU rate of the same config, which is a committed measurement, not something this run can time
-            ref_file = os.path.join(ROOT, "profiles", "r02_%s_bench.json" % cfg_name)
-            try:
-                with open(ref_file) as f:
-                    ref = json.loads(f.read().strip().splitlines()[-1])
-                if ref.get("n_gpus") == 1 and ref.get("config", {}).get("name") == cfg_name:
-                    out["same_config_one_gpu"] = {
-                        "value": ref["value"], "ms_per_step": ref["ms_per_step"], "source": "profiles/r02_%s_bench.json" % cfg_name,
-                        "note": "one MI355X, same config and command with --gpus 1 --config %s: the reference for this job's "
-                                "%s-scaling efficiency (bench.py --gpus 1 without --config runs the headline cfg2 instead)"
-                                % (cfg_name, scaling)}
-            except (OSError, ValueError, KeyError, IndexError):
-                pass
-        if state["fix"] is not None:
-            frc, flle, fit = state["fix"]
-            out["solve"] = {"status": int(frc), "lat": round(float(flle[0]), 6), "lon": round(float(flle[1]), 6),
-                            "iterations": int(fit),
-                            "note": "the merge + least-squares solve run inside the timed region; the synthetic captures restate "
-                                    "simulator.go (unmodulated tones + noise), so the peaks are noise peaks and a non-zero status "
-                                    "(7 = singular Jacobian, processor.go:997-999) is the solver's honest answer to them"}
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"], out["parity_window0"] = cpu_baseline_leg(ctx, timed_peaks, block, wl, max_lag, args.cpu_budget)
-            if out["parity_window0"] is False:
-                rc = 3
-        print(json.dumps(out), flush=True)
+        if full:
+            out.update(roofline_fields(args, env, cfg_name, scaling, sim, table, prof_timed, dominant, timed_mode, table_steps, steps,
+                                       dt, samples_per_step, n_fft, n1, n2, n_windows, n_pairs, S, wl, max_lag, graph_leg))
+        if timed_fix is not None:
+            fixes = state.get("fixes") or [timed_fix]
+            frc, flle, fit, flag, fref = timed_fix
+            sol = {"status": int(frc), "lat": round(float(flle[0]), 6), "lon": round(float(flle[1]), 6), "iterations": int(fit),
+                   "solver": "tdoa_solve_surface: weighted Gauss-Newton over all pairs, position held on the ellipsoid at the "
+                             "stations' mean elevation",
+                   "reference_solver": {"status": int(fref[0]), "lat": round(float(fref[1][0]), 6), "lon": round(float(fref[1][1]), 6),
+                                        "note": "processor.go:932-1020 (3 stations) / its N-station form: ECEF X,Y with Z frozen at the "
+                                                "centroid, 0.5 damping, 10 iterations -- also run inside the timed region"},
+                   "median_target_lags": [float(x) for x in flag]}
+            if sim == "fmdelay":
+                want = np.array([delays[j] - delays[i] for (i, j) in pair_list], dtype=np.float64)
+                errs = []
+                for (rc_, lle_, _, lag_, _) in fixes:
+                    a = tdoa_amd.capi.latlon_to_ecef(float(lle_[0]), float(lle_[1]), TX[2])
+                    b = tdoa_amd.capi.latlon_to_ecef(TX[0], TX[1], TX[2])
+                    errs.append(math.sqrt(sum((x - y) ** 2 for x, y in zip(a, b))))
+                    if int(rc_) != 0 or not np.array_equal(np.asarray(lag_, dtype=np.float64), want) or errs[-1] > 150.0:
+                        raise SystemExit("bench: the solve inside the timed region did not find the transmitter: status %d, lags %r "
+                                         "(geometry: %r), fix (%.6f, %.6f), %.1f m from TX" % (int(rc_), list(lag_), list(want),
+                                                                                               float(lle_[0]), float(lle_[1]), errs[-1]))
+                sol.update({"expected_lags": [float(x) for x in want], "lags_equal_geometry": True,
+                            "horizontal_error_m": round(max(errs), 1), "capture_sets_solved": len(fixes),
+                            "note": "merge + least-squares solve inside the timed region; every pair's median target-block lag equals "
+                                    "delay_j - delay_i of the synthetic geometry and the fix lies within 150 m of TX (one sample = 150 m "
+                                    "of range) -- checked for every capture set, the run fails otherwise"})
+            else:
+                sol["note"] = ("the merge + least-squares solve run inside the timed region; these captures restate simulator.go "
+                               "(unmodulated tones + noise, carrier PHASE delays only), so the peaks are noise peaks and a non-zero "
+                               "status (7 = singular Jacobian, processor.go:997-999) is the solver's honest answer to them")
+            out["solve"] = sol
+        if full and world == 1 and not use_dist and not args.no_h2d and 2 * S * 3 * block <= (4 << 30):
+            out["end_to_end_h2d"] = end_to_end_h2d(ctx, tdoa_amd, np, S, block, wlen, max_lag, fs, args.batch, device, timed_peaks)
+        if full and world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"], parity = cpu_baseline_leg(ctx, timed_peaks, block, wl, max_lag, args.cpu_budget)
+            out["parity_window0"] = parity
     ctx.close()
+    del attached, dev_peaks, gathered
+    torch.cuda.empty_cache()
+    return out, parity
+
+
+def end_to_end_h2d(ctx, tdoa_amd, np, S, block, wlen, max_lag, fs, batch, device, timed_peaks):
+    """SURVEY 8d's secondary figure: the same job from HOST bytes (pageable buffers, the boundary a cgo caller hands over:
+    tdoa_process_u8) to peaks on the host -- staging through pinned buffers, H2D over PCIe, the same step.  Never `value`."""
+    caps = [ctx.capture_download(s, 0, 3 * block) for s in range(S)]
+    with tdoa_amd.Context(device=device, window_len=wlen, max_lag=max_lag, sample_rate=fs, windows_per_batch=batch) as c2:
+        c2.process_u8([x[:2 * 3 * min(block, 2 * wlen)] for x in caps])           # warm-up: plans, tables, staging buffers
+        c2.process_u8(caps)                                                      # ... and the device buffers at full size
+        t0 = time.perf_counter()
+        pk = c2.process_u8(caps)
+        dt = time.perf_counter() - t0
+    n = S * pk.shape[0] * min(wlen, block)
+    return {"value": round(n / dt / 1e6, 1), "unit": "Msamples/s", "seconds": round(dt, 4),
+            "GB_per_s_h2d": round(sum(x.size for x in caps) / dt / 1e9, 2),
+            "identical_to_timed_path": None if timed_peaks is None else bool(np.array_equal(pk, timed_peaks)),
+            "note": "tdoa_process_u8 on pageable host buffers (%d x %.0f MB): staged H2D + the same step; link-bound, never `value`"
+                    % (S, caps[0].size / 1e6)}
+
+
+def roofline_fields(args, env, cfg_name, scaling, sim, table, prof_timed, dominant, timed_mode, table_steps, steps, dt,
+                    samples_per_step, n_fft, n1, n2, n_windows, n_pairs, S, wl, max_lag, graph_leg):
+    world = env["world"]
+    prof = {k: {"ms": v["ms"] * steps / table_steps, "launches": v["launches"] * steps // table_steps, "bytes": v["bytes"] * steps / table_steps}
+            for k, v in table.items()}                                   # the untimed table, scaled to `steps` steps
+    prof[dominant] = prof_timed[dominant]                               # the dominant kernel: measured inside the timed region
+    name, rec = dominant, prof_timed[dominant]                          # the roofline's kernel: the one that was timed live
+    nc = n_fft // 2
+    # kernels behind every profiling scope of the library on this plan (names as rocprofv3 prints them, no template suffix)
+    hot = {}
+    once = os.environ.get("TDOA_NO_K1_ONCE") != "1"
+    if n1 == 4096:          # the radix-16 register kernels (fft_radix16.hpp); the column pass depends on N2
+        fused_k1 = n2 in (256, 512, 2048, 4096) and os.environ.get("TDOA_NO_FUSED_K1") != "1" and max_lag > 1024
+        if fused_k1:
+            col = ["k_fwd_col512_k1"] if n2 == 512 else ["k_fwd_col256_k1"] + (["k_fwd_col_finish"] if n2 > 256 else [])
+        else:
+            col = (["k_fwd_col16x_c16"] if n2 <= 128 else ["k_fwd_col256_c16"] if n2 == 256 else ["k_fwd_colx_c16"] if n2 <= 1024
+                   else ["k_fwd_col256_c16", "k_fwd_col_finish"])
+        hot = {"k_fm_demod": ["k_once_estimate", "k_once_edges", "k_once_final"] if (fused_k1 and once and max_lag > 4095) else ["k_fm_demod"],
+               "k_fwd_col": col, "k_fwd_row": ["k_fwd_row4096"],
+               "k_inv_row_pair": ["k_inv_row_pair4096"], "k_inv_col_peak": ["k_inv_col_pruned"]}
+    reach = max_lag                     # lags -(max_lag - 1) .. max_lag - 1 plus the refinement neighbours
+    decimated = (n1 == 4096 and n2 in (256, 512) and reach > 4095 and os.environ.get("TDOA_NO_DECIMATE") != "1"
+                 and decimation_fits(n1 * n2, max_lag))
+    if decimated:     # K3 + 16:1 FIR decimation of the pair spectrum, then an Nc/16-point inverse (DESIGN.md section 3)
+        hot = dict(hot, k_fwd_row=["k_fwd_row4096_unpack"], k_inv_row_pair=["k_pair_decimate16"],
+                   k_inv_col_peak=["k_inv_rows_plain_r8", "k_small_col_peak"])
+    if max_lag <= 1024 and n1 == 4096:
+        # segment form; with 3+ pairs per window the station transforms are shared (quads)
+        hot = dict(hot, k_inv_row_pair=["k_xcorr_segments_quad" if n_pairs >= 3 and os.environ.get("TDOA_NO_SEGMENT_QUADS") != "1"
+                                        else "k_xcorr_segments"], k_inv_col_peak=["k_segments_reduce"])
+    roof, pmc_total = None, None
+    if rec["launches"]:
+        requested = rec["bytes"] / rec["launches"]                      # the library's per-kernel byte model: what the launch ASKS for
+        avg_s = rec["ms"] / rec["launches"] / 1e3
+        kernels = hot.get(name, [name])
+        windows_per_launch = n_windows                                    # (every window of the rank in one launch group)
+        # HBM side of a pair step whose P pairs share S station spectra: each spectrum comes from memory once (its other
+        # readers are served by L2 / Infinity Cache), the pair's own output is written -- the compulsory bytes of the launch
+        compulsory = requested
+        if name == "k_inv_row_pair" and n_pairs > 0:
+            out_per_pair = 8.0 * nc / 16 if decimated else 8.0 * nc
+            compulsory = min(requested, windows_per_launch * (S * 8.0 * nc + n_pairs * out_per_pair))
+        standard = args.seconds is None and args.batch == 0 and world == 1 and max_lag == 20000 and sim == "config"
+        traffic, src, sq = None, None, None
+        if standard and name in hot:
+            traffic, src, pmc_total = pmc_traffic(cfg_name, kernels)
+            sq = sq_issue(cfg_name, kernels[0])
+        # the fraction the contract asks for is an HBM fraction: memory-side bytes (counters when they were taken on these
+        # sources, else the compulsory bytes above) over the launch time -- never the request rate of a kernel whose
+        # operands are served on-die (rounds 2-3 printed 1.05 / 1.17 for cfg4 / cfg5 that way)
+        hbm_bytes = traffic if traffic is not None else compulsory
+        hbm_bytes = min(hbm_bytes, requested) if traffic is None else hbm_bytes
+        achieved = hbm_bytes / avg_s / 1e9
+        hbm_frac = achieved / HBM_PEAK_GBS
+        limiter = None
+        if sq is not None:
+            limiter = "valu_issue" if sq["valu_issue_frac"] > max(0.6, achieved / HBM_FILL_GBS) else "hbm"
+        roof = {"bound": "hbm", "kernel": " + ".join(kernels),
+                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(hbm_frac, 4),
+                "bytes_source": ("PMC (FETCH_SIZE + WRITE_SIZE, %s)" % src) if traffic is not None else
+                                ("compulsory HBM bytes of the launch: every station spectrum once + the pairs' outputs (its %d pairs "
+                                 "per window re-read the spectra on-die)" % n_pairs if compulsory < requested else
+                                 "the library's byte model of the launch (every operand streamed once)"),
+                "frac_of_measured_achievable": round(achieved / 6290.0, 4),   # guide: 6.29 TB/s achievable
+                "frac_of_fill_rate": round(achieved / HBM_FILL_GBS, 4),
+                "traffic": traffic, "traffic_source": src,
+                "requested_GBps": round(requested / avg_s / 1e9, 1),          # request rate: operands asked for, wherever they come from
+                "hbm_frac": round(hbm_frac, 4),
+                "valu_issue_frac": None if sq is None else sq["valu_issue_frac"],
+                "valu_instructions_per_wave": None if sq is None else sq["valu_instructions_per_wave"],
+                "lds_conflict_frac": None if sq is None else sq["lds_conflict_frac"],
+                "sq_source": None if sq is None else sq["source"],
+                "limiter": limiter,
+                "algorithmic_bytes_per_launch": hbm_bytes, "requested_bytes_per_launch": requested,
+                "avg_launch_us": round(avg_s * 1e6, 2), "launches": rec["launches"],
+                "kernels_ms_per_step": {k: round(v["ms"] / steps, 4) for k, v in prof.items()},
+                "kernels_ms_per_step_source": "%s: HIP events inside the timed region; the others: %d untimed steps launched kernel by "
+                                              "kernel with an event at every boundary" % (name, table_steps),
+                "note": "achieved / frac = HBM-side bytes of the launch (bytes_source) / HIP-event time / 8 TB/s.  requested_GBps = "
+                        "the operands the launch asks for / the same time (a request rate: on-die hits included).  "
+                        "valu_issue_frac = share of the kernel's time its SIMDs spend issuing vector instructions (SQ counters "
+                        "in profiles/, same kernel sources): limiter = valu_issue when that share exceeds both 0.6 and the kernel's "
+                        "share of the 5.8 TB/s a plain fill sustains"}
+    # whole-pipeline algorithmic bytes (SURVEY.md 8d): k = ceil(log2 N / 12) passes of 4096-point tiles, e = 4 B:
+    # 2L + e N (2k - 1) per station-window, e N 2k per pair-window  (k = 2: 2L + 12N and 16N; k = 3: 2L + 20N and 24N)
+    k_pass = max(2, math.ceil(math.log2(n_fft) / 12.0))
+    units_w = n_windows * (world if scaling == "weak" else 1)
+    a_bytes = units_w * (S * (2 * wl + 4 * n_fft * (2 * k_pass - 1)) + n_pairs * 4 * n_fft * 2 * k_pass)
+    return {
+        "timed_path": ("the whole step replayed as one hipGraph (the library's default path) with event-record nodes around the "
+                       "dominant kernel (the roofline's source)" if timed_mode == 2 else
+                       "kernels launched one by one, HIP events around the dominant kernel's launches (the roofline's source)")
+                      + "; the other kernels' times come from %d untimed steps launched kernel by kernel with an event at every "
+                        "boundary; graph_replay: the whole step replayed as one hipGraph without any event" % table_steps,
+        "graph_replay": graph_leg,
+        # SURVEY.md 8d byte model (a fixed price list per sample, NOT what this pipeline moves: the decimated inverse and
+        # the fused K1 move less) -- kept under its own name
+        "pipeline_survey_model_GBps": round(a_bytes / (dt / steps) / 1e9, 1),
+        # the bytes the launched kernels are charged with by the library (per-kernel figures of tdoa_profile_get: the
+        # decimated pair step at its own 16.5 Nc per pair-window, the fused K1 with no code round trip): a request rate
+        "pipeline_kernel_bytes_GBps": round(sum(v["bytes"] for v in prof.values()) / max(steps, 1) / (dt / steps) / 1e9, 1),
+        # HBM side of the whole step: memory-side counters of every kernel of a step (profiles/, same sources) / step time
+        "pipeline_pmc_GBps": None if not pmc_total else round(pmc_total / (dt / steps) / 1e9, 1),
+        "pipeline_frac_of_hbm_peak": None if not pmc_total else round(pmc_total / (dt / steps) / 1e9 / HBM_PEAK_GBS / world, 4),
+        # SURVEY.md 8d secondary figure: pair-samples correlated per second (P*W*L/t), whole job
+        "pair_Msamples_per_s": round(samples_per_step / S * n_pairs / (dt / steps) / 1e6, 2),
+        "roofline": roof,
+    }
+
+
+def same_config_one_gpu(cfg_name):
+    """the one-GPU rate of a configuration from the newest committed bench line of this round's collection -- only if it was
+    taken on the current kernel sources"""
+    f = _latest_profile("*_%s_bench.json" % cfg_name)
+    if not f:
+        return {"value": None, "note": "no committed one-GPU line for %s" % cfg_name}
+    try:
+        ref = json.loads(open(f).read().strip().splitlines()[-1])
+        if ref.get("n_gpus") != 1 or ref.get("config", {}).get("name") != cfg_name:
+            return {"value": None, "note": "%s is not a one-GPU %s line" % (os.path.basename(f), cfg_name)}
+        if ref.get("source_sha16") != source_hash():
+            return {"value": None, "source": "profiles/" + os.path.basename(f),
+                    "note": "stale: taken on other kernel sources (%.1f Msamples/s there)" % ref["value"]}
+        return {"value": ref["value"], "ms_per_step": ref["ms_per_step"], "source": "profiles/" + os.path.basename(f),
+                "note": "one MI355X, `bench.py --gpus 1 --config %s`, same kernel sources" % cfg_name}
+    except (OSError, ValueError, KeyError, IndexError):
+        return {"value": None, "note": "unreadable: %s" % os.path.basename(f)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default=None)
+    ap.add_argument("--scaling", choices=("strong", "weak"), default=None)
+    ap.add_argument("--seconds", type=float, default=None, help="capture length per station (overrides the config)")
+    ap.add_argument("--batch", type=int, default=0, help="windows per launch group (0 = library default)")
+    ap.add_argument("--max-lag", type=int, default=20000, help="search range in samples (reference: 20000, processor.go:633)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph-leg", action="store_true")
+    ap.add_argument("--no-clocks", action="store_true", help="skip the ~1.5 s sustained replay that samples clock and power")
+    ap.add_argument("--no-h2d", action="store_true", help="skip the end-to-end leg from host buffers (SURVEY 8d secondary figure)")
+    ap.add_argument("--no-sharded-leg", action="store_true", help="at N > 1: only the contract line's job, no sharded cfg4 job")
+    ap.add_argument("--cpu-budget", type=float, default=10.0)
+    ap.add_argument("--sim", choices=("config", "fm", "random", "fmdelay"), default=None,
+                    help="capture bytes: 'config' = the config's simulator (+-1..3 LSB tones + noise; the default on one GPU), 'fm' = "
+                         "independent frequency-modulated carriers at half scale (what a well-set RTL-SDR gain delivers), 'random' = "
+                         "uniform random bytes (every table entry of K1 equally likely), 'fmdelay' = one FM carrier from TX delayed "
+                         "per station by its propagation time (the default of multi-rank jobs: the solve has a position to find)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="at --gpus 1: initialise torch.distributed (nccl = RCCL, world size 1) and run the multi-GPU step -- "
+                         "tdoa_process(rank, world), all_gather_into_tensor of the peak records, owner merge, solve -- on one GPU")
+    args = ap.parse_args()
+
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    # The default at every N is BASELINE config 2, WEAK-scaled: one job of N x 99 windows, window-major -- rank r holds and
+    # processes its own 99 windows (its own capture set, different seeds), the peak records are all-gathered over RCCL and
+    # rank 0 decodes all of them and solves every set.  Per-GPU work is fixed, so value(N) / (N value(1)) is the scaling
+    # efficiency.  `--config cfg4 --scaling strong` is BASELINE config 4 as written: ONE 8-station capture set, its windows
+    # dealt wid % N to the ranks; the default multi-rank run times it too (sharded_cfg4).
+    cfg_name = args.config or "cfg2"
+    scaling = args.scaling or "weak"
+    steps = args.steps if args.steps is not None else CONFIGS[cfg_name]["steps"]
+    # one rank per GPU; TDOA_BENCH_BACKEND=gloo is a rehearsal mode (several ranks may then share
+    # a GPU and the peak records travel through host memory) -- the driver always runs nccl (= RCCL)
+    backend = os.environ.get("TDOA_BENCH_BACKEND", "nccl")
+    device = local_rank % torch.cuda.device_count() if backend == "gloo" else local_rank
+    torch.cuda.set_device(device)
+    dist = None
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        kw = {} if world > 1 else {"rank": 0, "world_size": 1}
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device), **kw)
+        else:
+            dist.init_process_group(backend=backend, **kw)
+    env = {"world": world, "rank": rank, "device": device, "backend": backend, "dist": dist, "use_dist": use_dist}
+    sim = args.sim or ("fmdelay" if use_dist else "config")
+
+    out, parity = run_job(args, env, cfg_name, scaling, sim, steps, args.warmup, full=True)
+    # the sharded job BASELINE config 4 names, in the same run (default multi-rank invocation only)
+    if use_dist and args.config is None and args.scaling is None and not args.no_sharded_leg:
+        s_steps = min(steps, CONFIGS["cfg4"]["steps"])
+        sh, _ = run_job(args, env, "cfg4", "strong", sim, s_steps, 1, full=False)
+        if rank == 0:
+            one = same_config_one_gpu("cfg4")
+            out["sharded_cfg4"] = {
+                "value": sh["value"], "unit": "Msamples/s", "ms_per_step": sh["ms_per_step"], "steps": s_steps, "scaling": "strong",
+                "config": sh["config"], "solve": sh.get("solve"),
+                "same_config_one_gpu": one,
+                "efficiency_vs_same_config_one_gpu": None if not one.get("value") else round(sh["value"] / (world * one["value"]), 4),
+                "note": "BASELINE config 4 as written, timed right after the contract line's job in the same process group: ONE "
+                        "8-station capture set, windows dealt wid % N, one all-gather of the peak records, owner merge and "
+                        "N-station solve on rank 0, all inside the timed region"}
+    if rank == 0:
+        if world > 1:
+            out["same_config_one_gpu"] = same_config_one_gpu(cfg_name)
+        print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
-    if rc:
+    if parity is False:
         raise SystemExit("parity check of window 0 against the oracle FAILED")
 
 

@@ -310,6 +310,12 @@ int  tdoa_solve_3station(const double stations_lle[9], const double *range_diff,
  * 10 iterations, 1 m stop rule as processor.go:950-1010. */
 int  tdoa_solve_nstation(const double *stations_lle, int n_stations, const double *range_diff,
                          const double *weights, int solve_z, double out_lle[3], int *iterations);
+/* Ground transmitter: the same residuals and weights with the position held on the ellipsoid at height_m (unknowns
+ * latitude, longitude; undamped Gauss-Newton from the stations' centroid, at most 20 iterations, 1 m stop rule).  The
+ * reference's frozen ECEF Z (processor.go:1004) is a plane that misses a transmitter north or south of the centroid by
+ * hundreds of metres to kilometres; this form is what bench.py checks its multi-GPU fix with. */
+int  tdoa_solve_surface(const double *stations_lle, int n_stations, const double *range_diff, const double *weights,
+                        double height_m, double out_lle[3], int *iterations);
 
 /* ---- measurement ----------------------------------------------------------- */
 enum {

@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 i=0
 for grp in "$@"; do
   rocprofv3 --pmc $grp --kernel-trace --output-format csv -d gpurun_out/sq_${TAG}_$i -- \
-      python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline $BENCH_ARGS > gpurun_out/sq_${TAG}_$i.log 2>&1
+      python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph-leg --no-clocks --no-h2d $BENCH_ARGS > gpurun_out/sq_${TAG}_$i.log 2>&1
   i=$((i+1))
 done
 python3 scripts/sq_summary.py gpurun_out/sq_${TAG}_ $i

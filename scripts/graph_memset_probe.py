@@ -35,12 +35,14 @@ def part1(memset):
         info = c.graph_info(dot)
     print("part 1, memset nodes %s: %r; replay identical: %s" % (memset, info, bool((a == b).all())))
     txt = open(dot).read()
-    nodes = re.findall(r'^\s*"?(\w+)"?\s*\[(.*)\];?$', txt, re.M)
+    # hipGraphDebugDotPrint's node lines are not of one shape across ROCm versions: count "label" lines and arrows, and print
+    # every line that mentions a memset verbatim (its parameters -- element size, width, height, value -- are in the label)
+    labels = [ln for ln in txt.splitlines() if "label" in ln and "->" not in ln]
     edges = re.findall(r'->', txt)
-    print("  dot file: %d node lines, %d edges" % (len(nodes), len(edges)))
-    for name, attr in nodes:
-        if "MEMSET" in attr.upper():
-            print("  memset node %s: %s" % (name, attr[:400]))
+    print("  dot file: %d node lines, %d edges" % (len(labels), len(edges)))
+    for ln in txt.splitlines():
+        if "memset" in ln.lower():
+            print("  memset node: %s" % ln.strip()[:600])
     return info
 
 

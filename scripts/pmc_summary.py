@@ -7,7 +7,7 @@ coalesced loads.  Calibration on this pipeline's own kernels (known byte counts,
   k_fwd_col256_c16 (4 B/lane, 128-B runs): 0.94 -> x1 (left uncorrected)
   k_pair_decimate16 (8 B/lane float2, contiguous 4 KB runs of a tile): as k_fwd_row4096 -> x2 (checked: see DESIGN.md 6)
   WRITE_SIZE*1024 / bytes written = 1.000 for every kernel -> x1
-usage: pmc_summary.py <fetch_dir> <write_dir> <out.json>"""
+usage: pmc_summary.py <fetch_dir> <write_dir> <out.json> [config name]"""
 import collections
 import csv
 import glob
@@ -25,7 +25,9 @@ FETCH_CORRECTION = {"k_fm_demod": 2.0, "k_fwd_row4096": 2.0, "k_fwd_row4096_unpa
                     # (FETCH_SIZE*1024 / bytes = 1.00); the 1024-thread form reads 256-byte runs per wave and counts like
                     # the wide streaming loads: 0.635 GB reported for the same 1.19 GB (ratio 0.534 = 1/2 + the boundary
                     # samples and the tables) -> x2
-                    "k_fwd_col256_k1": 2.0}
+                    "k_fwd_col256_k1": 2.0, "k_fwd_col512_k1": 2.0,      # (the N2 = 512 column kernel: the same construction)
+                    # round 4: the running sums of the window edges are streamed like k_fm_demod (16 B per lane)
+                    "k_once_edges": 2.0}
 
 
 def load(d):
@@ -51,7 +53,9 @@ def main():
         rec["FETCH_SIZE_KiB"] += f
         rec["WRITE_SIZE_KiB"] += w
         rec["traffic_bytes_per_launch"] += f * 1024 * corr + w * 1024
-    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py cfg2, batch = all windows",
+    cfg = sys.argv[4] if len(sys.argv) > 4 else "cfg2"
+    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --config %s, batch = all windows" % cfg,
+               "config": cfg,
                "source_sha16": source_hash(), "kernels": res}, open(sys.argv[3], "w"), indent=1, sort_keys=True)
     print(json.dumps(res, indent=1))
 

@@ -155,4 +155,81 @@ inline int solve_nstation(const double *st_lle, int n, const double *rd, const d
     return 0;
 }
 
+// Ground transmitter: the position constrained to the ellipsoid surface at height h0 (unknowns latitude, longitude).
+// The reference freezes ECEF Z at the stations' centroid (processor.go:1004) -- a plane that does not contain a transmitter
+// a few kilometres north or south of that centroid, so its fix is off by hundreds of metres to kilometres however good the
+// delays are.  Same residuals and weights as solve_nstation, undamped Gauss-Newton from the centroid, stops below tol_m.
+// returns 0 ok, -1 singular normal matrix, -2 unsupported station count, -3 too few usable pairs / bad weights.
+inline int solve_surface(const double *st_lle, int n, const double *rd, const double *wt, double h0, int max_iter, double tol_m,
+                         double out[3], int *iters)
+{
+    if (n < 3 || n > 64) return -2;
+    double s[64][3], c[2] = {0, 0};
+    for (int i = 0; i < n; i++) {
+        latlon_to_ecef(st_lle[3 * i], st_lle[3 * i + 1], st_lle[3 * i + 2], s[i]);
+        c[0] += st_lle[3 * i] / n;
+        c[1] += st_lle[3 * i + 1] / n;
+    }
+    {
+        int used = 0, p = 0;
+        for (int i = 0; i < n; i++)
+            for (int j = i + 1; j < n; j++, p++) {
+                const double w = wt ? wt[p] : 1.0;
+                if (!(w >= 0) || !std::isfinite(w)) return -3;
+                if (w == 0) continue;
+                if (!std::isfinite(rd[p])) return -3;
+                used++;
+            }
+        if (used < 2) return -3;
+    }
+    double phi = c[0] * kPi / 180, lam = c[1] * kPi / 180;
+    int it = 0;
+    for (; it < max_iter; it++) {
+        const double sp = std::sin(phi), cp = std::cos(phi), sl = std::sin(lam), cl = std::cos(lam);
+        const double nu = prime_vertical(sp), den = 1 - kE2 * sp * sp;
+        const double mer = kA * (1 - kE2) / (den * std::sqrt(den));      // meridional radius of curvature
+        const double x[3] = {(nu + h0) * cp * cl, (nu + h0) * cp * sl, (nu * (1 - kE2) + h0) * sp};
+        const double dphi[3] = {-(mer + h0) * sp * cl, -(mer + h0) * sp * sl, (mer + h0) * cp};
+        const double dlam[3] = {-(nu + h0) * cp * sl, (nu + h0) * cp * cl, 0.0};
+        double r[64], jp[64], jl[64];
+        for (int i = 0; i < n; i++) {
+            r[i] = range(x, s[i]);
+            jp[i] = jl[i] = 0;
+            for (int k = 0; k < 3; k++) {
+                const double u = (x[k] - s[i][k]) / r[i];
+                jp[i] += u * dphi[k];
+                jl[i] += u * dlam[k];
+            }
+        }
+        double A[2][2] = {{0, 0}, {0, 0}}, g[2] = {0, 0}, worst = 0;
+        int p = 0;
+        for (int i = 0; i < n; i++)
+            for (int j = i + 1; j < n; j++, p++) {
+                const double w = wt ? wt[p] : 1.0;
+                if (w == 0) continue;
+                const double f = (r[j] - r[i]) - rd[p];
+                worst = std::fmax(worst, std::fabs(f));
+                const double a = jp[j] - jp[i], b = jl[j] - jl[i];
+                g[0] += w * a * f;
+                g[1] += w * b * f;
+                A[0][0] += w * a * a;
+                A[0][1] += w * a * b;
+                A[1][1] += w * b * b;
+            }
+        A[1][0] = A[0][1];
+        const double det = A[0][0] * A[1][1] - A[0][1] * A[1][0];
+        if (!(std::fabs(det) > 1e-6 * A[0][0] * A[1][1]) ) { if (iters) *iters = it; return -1; }
+        const double d0 = (-g[0] * A[1][1] + g[1] * A[0][1]) / det, d1 = (g[0] * A[1][0] - g[1] * A[0][0]) / det;
+        phi += d0;
+        lam += d1;
+        // (a least-squares fit does not drive the residuals of inconsistent delays to zero: stop on the step as well)
+        if (worst < tol_m || std::hypot(d0 * (mer + h0), d1 * (nu + h0) * cp) < 1e-3) { it++; break; }
+    }
+    if (iters) *iters = it;
+    out[0] = phi * 180.0 / kPi;
+    out[1] = lam * 180.0 / kPi;
+    out[2] = h0;
+    return 0;
+}
+
 }  // namespace geo

@@ -764,11 +764,11 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
 #define TDOA_SEGMENTS(PQ)                                                                                            \
     do {                                                                                                             \
         if (seg_quads) {                                                                                             \
-            ProfScope ps(ctx, TDOA_K_INV_ROW, 4.0 * 2.0 * 4096.0 * frames * n_quads);  /* four frames of 2-byte codes */ \
+            ProfScope ps(ctx, TDOA_K_INV_ROW, 4.0 * 4.0 * 4096.0 * frames * n_quads);  /* four frames of 4-byte codes */ \
             hipLaunchKernelGGL(k_xcorr_segments_quad<PQ>, dim3(seg_chunks, n_quads), dim3(512), lds_seg, st, d_sw,    \
                                d_quads, codes, code_stride, stats, v, pl, seg_chunks);                               \
         } else {                                                                                                     \
-            ProfScope ps(ctx, TDOA_K_INV_ROW, 2.0 * 2.0 * 4096.0 * frames * n_pw);   /* two frames of 2-byte codes */  \
+            ProfScope ps(ctx, TDOA_K_INV_ROW, 2.0 * 4.0 * 4096.0 * frames * n_pw);   /* two frames of 4-byte codes */  \
             hipLaunchKernelGGL(k_xcorr_segments<PQ>, dim3(seg_chunks, n_pw), dim3(512), lds_seg, st, d_sw, d_pw, codes, \
                                code_stride, stats, v, pl, seg_chunks);                                               \
         }                                                                                                            \
@@ -2062,6 +2062,14 @@ int tdoa_solve_nstation(const double *stations_lle, int n_stations, const double
     if (!stations_lle || !range_diff || !out_lle) return TDOA_ERR_INVALID;
     const int rc = geo::solve_nstation(stations_lle, n_stations, range_diff, weights, solve_z, 10, 0.5, 1.0, out_lle,
                                        iterations);
+    return rc == 0 ? TDOA_OK : (rc == -2 ? TDOA_ERR_UNSUPPORTED : rc == -3 ? TDOA_ERR_INVALID : TDOA_ERR_SINGULAR);
+}
+
+int tdoa_solve_surface(const double *stations_lle, int n_stations, const double *range_diff, const double *weights,
+                       double height_m, double out_lle[3], int *iterations)
+{
+    if (!stations_lle || !range_diff || !out_lle || !std::isfinite(height_m)) return TDOA_ERR_INVALID;
+    const int rc = geo::solve_surface(stations_lle, n_stations, range_diff, weights, height_m, 20, 1.0, out_lle, iterations);
     return rc == 0 ? TDOA_OK : (rc == -2 ? TDOA_ERR_UNSUPPORTED : rc == -3 ? TDOA_ERR_INVALID : TDOA_ERR_SINGULAR);
 }
 

@@ -73,7 +73,7 @@ SYMBOLS = [
     "tdoa_process_fine", "tdoa_fm_xcorr_fine_u8", "tdoa_window_quality_all", "tdoa_window_quality_u8",
     "tdoa_fm_xcorr_u8", "tdoa_fm_preprocess_u8", "tdoa_fm_xcorr_lags_u8", "tdoa_debug_force_generic",
     "tdoa_debug_flags", "tdoa_debug_last_k1", "tdoa_debug_graph_info", "tdoa_debug_segment_quads", "tdoa_cross_correlate_batch_c64",
-    "tdoa_latlon_to_ecef", "tdoa_ecef_to_latlon", "tdoa_solve_3station", "tdoa_solve_nstation",
+    "tdoa_latlon_to_ecef", "tdoa_ecef_to_latlon", "tdoa_solve_3station", "tdoa_solve_nstation", "tdoa_solve_surface",
     "tdoa_profile_enable", "tdoa_profile_select", "tdoa_profile_reset", "tdoa_profile_get", "tdoa_kernel_name",
     "tdoa_plan_info",
 ]
@@ -151,6 +151,7 @@ def load(build_if_missing=True):
     L.tdoa_ecef_to_latlon.restype = None
     L.tdoa_solve_3station.argtypes = [dp, dp, dp, C.POINTER(C.c_int)]
     L.tdoa_solve_nstation.argtypes = [dp, C.c_int, dp, dp, C.c_int, dp, C.POINTER(C.c_int)]
+    L.tdoa_solve_surface.argtypes = [dp, C.c_int, dp, dp, C.c_double, dp, C.POINTER(C.c_int)]
     L.tdoa_profile_enable.argtypes = [vp, C.c_int]
     L.tdoa_profile_select.argtypes = [vp, C.c_uint]
     L.tdoa_profile_reset.argtypes = [vp]
@@ -536,4 +537,17 @@ def solve_nstation(stations_lle, range_diff, weights=None, solve_z=False):
     it = C.c_int()
     rc = load().tdoa_solve_nstation(_d(st.reshape(-1)), n, _d(rd), _d(wt) if wt is not None else None,
                                     1 if solve_z else 0, _d(out), C.byref(it))
+    return rc, out, it.value
+
+
+def solve_surface(stations_lle, range_diff, weights=None, height_m=0.0):
+    """tdoa_solve_surface: least-squares fix on the ellipsoid at `height_m` -> (status, lle, iterations)"""
+    st = np.ascontiguousarray(stations_lle, dtype=np.float64)
+    n = st.size // 3
+    rd = np.ascontiguousarray(range_diff, dtype=np.float64)
+    wt = None if weights is None else np.ascontiguousarray(weights, dtype=np.float64)
+    out = np.zeros(3)
+    it = C.c_int()
+    rc = load().tdoa_solve_surface(_d(st.reshape(-1)), n, _d(rd), _d(wt) if wt is not None else None, float(height_m),
+                                   _d(out), C.byref(it))
     return rc, out, it.value

@@ -119,6 +119,35 @@ def test_nstation_solver_reduces_to_reference_and_uses_all_pairs(capi, oracle):
     assert capi.solve_nstation(st[:2], [0.0])[0] != 0       # needs >= 3 stations
 
 
+def test_surface_solver_finds_a_ground_transmitter_where_the_frozen_z_plane_cannot(capi, oracle):
+    """tdoa_solve_surface (position held on the ellipsoid): exact range differences of simulator.go's example transmitter
+    (simulator.go:229) give it back to a metre for 3, 8 and 16 stations; whole-sample delays (one sample = 150 m of range,
+    PROJECT_NOTES.md:29-32) stay inside 150 m; the reference's own solver (ECEF Z frozen at the centroid,
+    processor.go:1004) is kilometres off on the same input -- which is why bench.py checks its fix with this one"""
+    import math
+    import bench
+    for n, fs in ((3, 2e6), (8, 2e6), (16, 4e6)):
+        st = bench.station_table(n)
+        tx = capi.latlon_to_ecef(*bench.TX)
+        dist = [math.dist(tx, capi.latlon_to_ecef(*s)) for s in st]
+        h0 = sum(s[2] for s in st) / n
+        pairs = [(i, j) for i in range(n) for j in range(i + 1, n)]
+
+        def err(lle):
+            return math.dist(capi.latlon_to_ecef(float(lle[0]), float(lle[1]), bench.TX[2]), tx)
+        rc, lle, it = capi.solve_surface(st, [dist[j] - dist[i] for i, j in pairs], None, h0)
+        assert rc == 0 and it <= 6 and err(lle) < 1.0
+        delay = [round(d / 299792458.0 * fs) for d in dist]
+        assert delay == bench.propagation_delays(st, fs)
+        rd = [(delay[j] - delay[i]) / fs * 299792458.0 for i, j in pairs]
+        rc, lle, it = capi.solve_surface(st, rd, None, h0)
+        assert rc == 0 and err(lle) < 150.0
+        ref = capi.solve_3station(st, rd) if n == 3 else capi.solve_nstation(st, rd)
+        assert ref[0] == 0 and err(ref[1]) > 1000.0
+    assert capi.solve_surface(bench.station_table(3)[:2], [0.0])[0] != 0        # needs >= 3 stations
+    assert capi.solve_surface(bench.station_table(3), [0.0, 0.0, 0.0], [1.0, -1.0, 1.0])[0] != 0      # negative weight
+
+
 def test_unit_ownership_window_major_and_pair_major():
     from tdoa_amd import sharding
     # enough windows: a window's pairs all live on one rank

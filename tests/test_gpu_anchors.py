@@ -142,6 +142,36 @@ def test_k5_go_lag_set_edge_cases(oracle):
             assert gd == 0 and abs(peaks[wid, p]["corr"] - gc) <= 1e-6 * np.sqrt(69000.0), (wid, p, peaks[wid, p], gc)
 
 
+def test_k5_go_lag_set_on_the_timed_batch_plan(oracle, capsys):
+    """tdoa_process with lag_mode = TDOA_LAGS_GO at the TIMED geometry: windows of 2 000 000 samples, max_lag 20000 -- the
+    4096 x 256 plan, K1 fused into the column pass, full inverse restricted to lag 0 -- on three simulator.go stations:
+    every window has one length, so timeDomainCorrelation evaluates lag 0 only (processor.go:668-678, 772-780) over the
+    first 1999 blocks of 1000 samples (:691); every (window, pair) must return (0, corr) with corr = the oracle's
+    timeDomainCorrelation on the SAME preprocessed windows to 1e-5 (of full scale where the value at lag 0 is noise)."""
+    import tdoa_amd
+    blk, wl = 4_000_000, 2_000_000
+    caps = [oracle.simulate_station(nm, blk, oracle.SEED_BASE + i) for i, nm in enumerate(oracle.COLLECTORS)]
+    with tdoa_amd.Context(max_lag=ML, window_len=wl, lag_mode=tdoa_amd.capi.LAGS_GO) as c:
+        peaks = c.process_u8(caps)
+        assert tuple(c.plan_info())[1:] == (4096, 256) and c.graph_info()["roots"] == 1
+        again = c.process()                                                       # the replayed step graph
+        assert not c.last_k1(0)[1]                                                # (statistics over the whole windows: pre-pass)
+    assert peaks.shape == (6, 3) and not peaks["lag"].any() and np.array_equal(again, peaks)
+    worst = 0.0
+    for wid in (0, 2, 3, 5):                                                      # reference, target and second reference block
+        off = (wid // 2) * blk + (wid % 2) * wl
+        pre = [oracle.b_preprocess(cp[2 * off:2 * (off + wl)])[0].astype(np.complex64) for cp in caps]
+        for p, (i, j) in enumerate(((0, 1), (0, 2), (1, 2))):
+            gd, gc = oracle.time_domain_correlation(pre[i], pre[j], ML)
+            assert gd == 0
+            # the value at lag 0 of these captures is noise of order 1 against a full scale of sqrt(1 999 000) = 1414
+            err = abs(peaks[wid, p]["corr"] - gc)
+            worst = max(worst, err)
+            assert err <= 1e-5 * abs(gc) + 1e-6 * np.sqrt(1_999_000.0), (wid, p, peaks[wid, p], gc)
+    with capsys.disabled():
+        print("\n  TDOA_LAGS_GO on the 4096 x 256 batch plan: 12 (window, pair) units at lag 0, worst |dcorr| %.2e (full scale 1414)" % worst)
+
+
 def test_k1_exact_reversals_bit_exact(oracle):
     """exactly reversed samples (+pi), collinear reversals of different magnitude, and non-collinear samples whose
     angle codes are exactly opposite (sign of Im p decides), in the vector fast path and in the window head / tail"""
