@@ -8,7 +8,9 @@
 // element per 16 so that the stride-16 writes of the first stage do not pile onto one bank.
 #pragma once
 
+#include <initializer_list>
 #include <type_traits>
+#include <utility>
 
 #include "device_common.hpp"
 #include "fft_stockham.hpp"
@@ -380,6 +382,35 @@ __device__ __forceinline__ void col_k1_fetch(const ColK1Tile &t, int G, int N1, 
     sb = t.p[ib >= 0 && ib < t.len ? ib : 0];                                        // if the window has one
 }
 
+// rows of a tile whose table reads are in flight together (2 reads per row): 4 -> 8 reads; TDOA_COL_BATCH=8 for an A/B
+#ifndef TDOA_COL_BATCH
+#define TDOA_COL_BATCH 4
+#endif
+constexpr int kColBatch = TDOA_COL_BATCH;
+// row kColBatch g + Q of a tile through `f` (g is a loop variable of a fully unrolled loop: the row index has to be a
+// compile-time constant for f, so every g is spelled out)
+template <typename F, int Q>
+__device__ __forceinline__ void batch_rows_general(F &f, int g, std::integral_constant<int, Q>)
+{
+    if (g == 0) f(std::integral_constant<int, Q>{});
+    if constexpr (kColBatch < 16) if (g == 1) f(std::integral_constant<int, kColBatch + Q>{});
+    if constexpr (kColBatch < 8) if (g == 2) f(std::integral_constant<int, 2 * kColBatch + Q>{});
+    if constexpr (kColBatch < 8) if (g == 3) f(std::integral_constant<int, 3 * kColBatch + Q>{});
+    if constexpr (kColBatch < 4) {
+        if (g == 4) f(std::integral_constant<int, 4 * kColBatch + Q>{});
+        if (g == 5) f(std::integral_constant<int, 5 * kColBatch + Q>{});
+        if (g == 6) f(std::integral_constant<int, 6 * kColBatch + Q>{});
+        if (g == 7) f(std::integral_constant<int, 7 * kColBatch + Q>{});
+    }
+}
+static_assert(kColBatch == 2 || kColBatch == 4 || kColBatch == 8 || kColBatch == 16, "rows per batch");
+
+template <typename F, int... Q>
+__device__ __forceinline__ void batch_general(F &f, int g, std::integer_sequence<int, Q...>)
+{
+    (void)std::initializer_list<int>{(batch_rows_general(f, g, std::integral_constant<int, Q>{}), 0)...};
+}
+
 // ONCE (k1_single_look.hpp): `stats` holds the estimates (m0, s0) of k_once_edges, and every tile leaves the exact sums of
 // its stored codes in once_tiles[tile].
 template <bool SUB, bool ONCE = false>
@@ -435,19 +466,14 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
             // in N = 2^25) --, or general
             const int jw = __builtin_amdgcn_readfirstlane(j);
             double t1 = 0.0, t2 = 0.0;                            // ONCE: exact sums of this thread's stored codes
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                // The previous tile's output in v[r] leaves just before the register is needed again: the 16 stores of a
-                // thread go out one per ~35 instructions of discriminator work instead of as a burst of 256 store
-                // instructions from the sixteen waves of the CU at the end of a trip (0.98 -> 0.96 ms).  Unconditional: on
-                // a workgroup's first trip v[] is zero and goes to the place of THIS tile, which the same thread
-                // overwrites with the real values one trip later (one wave's stores to an address stay in order).
-                store_at(outp + (size_t)(16 * oreg(r)) * N1, offp, v[r]);
+            // one row r of the wave: the general form (any position of the row against the window)
+            auto row_general = [&](auto r_c) {
+                constexpr int r = decltype(r_c)::value;
                 const int i_first = 2 * ((a + G * (jw + 16 * r)) * N1 + (t.bx << LOGW));
                 const int i_end = i_first + 2 * W;                                                   // one past the wave's last sample of this r
                 if (__builtin_expect(i_first >= len, 0)) {
                     v[r] = make_float2(0.0f, 0.0f);
-                    continue;
+                    return;
                 }
                 int a0, a1;
                 k1_angle2_quadrant<true>(raw[r], lut, a0, a1);
@@ -464,6 +490,49 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
                                 : make_float2(k1_normalise(st0, mean, scale), k1_normalise(st1, mean, scale));
                 } else {
                     v[r] = k1_element_from<true, ONCE>(a0, a1, ap, i_first + 2 * c, len, mean, scale, r == 0, &t1, &t2);
+                }
+            };
+            // Rows are taken FOUR at a time.  The previous tile's outputs in v[4g .. 4g+3] leave just before the registers are
+            // needed again: the 16 stores of a thread go out a few per ~150 instructions of discriminator work instead of as a
+            // burst of 256 store instructions from the sixteen waves of the CU at the end of a trip.  Unconditional: on a
+            // workgroup's first trip v[] is zero and goes to the place of THIS tile, which the same thread overwrites with the
+            // real values one trip later (one wave's stores to an address stay in order).
+            // When the four rows lie inside the window (all but the window's first row and its tail) their EIGHT table reads
+            // are issued back to back and only then placed: one read followed by its placement (the form above) waits out the
+            // LDS latency for every sample while the CU's sixteen waves all queue at the LDS at the same time.
+#pragma unroll
+            for (int g = 0; g < 16 / kColBatch; g++) {
+#pragma unroll
+                for (int q = 0; q < kColBatch; q++) store_at(outp + (size_t)(16 * oreg(kColBatch * g + q)) * N1, offp, v[kColBatch * g + q]);
+                const int i_first0 = 2 * ((a + G * (jw + 16 * (kColBatch * g))) * N1 + (t.bx << LOGW));
+                const int i_end3 = 2 * ((a + G * (jw + 16 * (kColBatch * g + kColBatch - 1))) * N1 + (t.bx << LOGW)) + 2 * W;
+                if (__builtin_expect(i_first0 > 0 && i_end3 <= len, 1)) {
+                    unsigned int neg[kColBatch];
+                    int c0[kColBatch], c1[kColBatch];
+#pragma unroll
+                    for (int q = 0; q < kColBatch; q++) {
+                        const unsigned int x = k1_index_bytes(raw[kColBatch * g + q]);
+                        neg[q] = ~raw[kColBatch * g + q];
+                        c0[q] = k1_table_read<true>(lut, k1_quadrant_offset<false>(x));
+                        c1[q] = k1_table_read<true>(lut, k1_quadrant_offset<true>(x));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);                  // (the eight reads stay ahead of their placements)
+#pragma unroll
+                    for (int q = 0; q < kColBatch; q++) {
+                        const int r = kColBatch * g + q;
+                        const int a0 = k1_quadrant_place<false>(c0[q], neg[q]), a1 = k1_quadrant_place<true>(c1[q], neg[q]);
+                        const int bnd = __builtin_amdgcn_readlane(ab, r);
+                        const int ap = __builtin_amdgcn_update_dpp(bnd, a1, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+                        const int st0 = k1_stored_code_scaled(a0, ap), st1 = k1_stored_code_scaled(a1, a0);
+                        if (ONCE) {
+                            col_once_accumulate(st0, t1, t2);
+                            col_once_accumulate(st1, t1, t2);
+                        }
+                        v[r] = ONCE ? make_float2(k1_normalise_fma(st0, nscale, noff), k1_normalise_fma(st1, nscale, noff))
+                                    : make_float2(k1_normalise(st0, mean, scale), k1_normalise(st1, mean, scale));
+                    }
+                } else {
+                    batch_general(row_general, g, std::make_integer_sequence<int, kColBatch>{});      // the batch's rows, one by one
                 }
             }
             if (ONCE) col_once_wave_reduce(t1, t2, once_red, tid >> 6);
@@ -711,14 +780,13 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
             const int ab = k1_angle_quadrant<false, true>(k1_index_bytes(sb_next), ~sb_next, lut);
             const int jw = __builtin_amdgcn_readfirstlane(j & ~1), pw = __builtin_amdgcn_readfirstlane(par);
             double t1 = 0.0, t2 = 0.0;                            // ONCE: exact sums of this thread's stored codes
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                store_at(outp + (size_t)(16 * oreg(r)) * N1, offp, v[r]);      // (unconditional: see k_fwd_col256_k1)
+            auto row_general = [&](auto r_c) {
+                constexpr int r = decltype(r_c)::value;
                 const int i_first = 2 * ((F * (jw + 16 * r) + pw) * N1 + t.bx * C);
                 const int i_end = 2 * ((F * (jw + 1 + 16 * r) + pw) * N1 + t.bx * C + C);      // one past the wave's last sample of this r
                 if (__builtin_expect(i_first >= len, 0)) {
                     v[r] = make_float2(0.0f, 0.0f);
-                    continue;
+                    return;
                 }
                 int a0, a1;
                 k1_angle2_quadrant<true>(raw[r], lut, a0, a1);
@@ -736,6 +804,43 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
                 } else {
                     v[r] = k1_element_from<true, ONCE>(a0, a1, ap, i_first + 2 * (F * (j - jw) * N1 + c), len, mean, scale, r == 0,
                                                        &t1, &t2);
+                }
+            };
+            // rows four at a time, their eight table reads in flight together (see k_fwd_col256_k1)
+#pragma unroll
+            for (int g = 0; g < 16 / kColBatch; g++) {
+#pragma unroll
+                for (int q = 0; q < kColBatch; q++) store_at(outp + (size_t)(16 * oreg(kColBatch * g + q)) * N1, offp, v[kColBatch * g + q]);      // (unconditional: see k_fwd_col256_k1)
+                const int i_first0 = 2 * ((F * (jw + 16 * (kColBatch * g)) + pw) * N1 + t.bx * C);
+                const int i_end3 = 2 * ((F * (jw + 1 + 16 * (kColBatch * g + kColBatch - 1)) + pw) * N1 + t.bx * C + C);
+                if (__builtin_expect(i_first0 > 0 && i_end3 <= len, 1)) {
+                    unsigned int neg[kColBatch];
+                    int c0[kColBatch], c1[kColBatch];
+#pragma unroll
+                    for (int q = 0; q < kColBatch; q++) {
+                        const unsigned int x = k1_index_bytes(raw[kColBatch * g + q]);
+                        neg[q] = ~raw[kColBatch * g + q];
+                        c0[q] = k1_table_read<true>(lut, k1_quadrant_offset<false>(x));
+                        c1[q] = k1_table_read<true>(lut, k1_quadrant_offset<true>(x));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);                  // (the eight reads stay ahead of their placements)
+#pragma unroll
+                    for (int q = 0; q < kColBatch; q++) {
+                        const int r = kColBatch * g + q;
+                        const int a0 = k1_quadrant_place<false>(c0[q], neg[q]), a1 = k1_quadrant_place<true>(c1[q], neg[q]);
+                        const int left = wave_shift_right1(a1);
+                        const int bnd = __shfl(ab, 2 * r + (lane >> LOGC), kWave);
+                        const int ap = c ? left : bnd;
+                        const int st0 = k1_stored_code_scaled(a0, ap), st1 = k1_stored_code_scaled(a1, a0);
+                        if (ONCE) {
+                            col_once_accumulate(st0, t1, t2);
+                            col_once_accumulate(st1, t1, t2);
+                        }
+                        v[r] = ONCE ? make_float2(k1_normalise_fma(st0, nscale, noff), k1_normalise_fma(st1, nscale, noff))
+                                    : make_float2(k1_normalise(st0, mean, scale), k1_normalise(st1, mean, scale));
+                    }
+                } else {
+                    batch_general(row_general, g, std::make_integer_sequence<int, kColBatch>{});      // the batch's rows, one by one
                 }
             }
             if (ONCE) col_once_wave_reduce(t1, t2, once_red, tid >> 6);

@@ -69,11 +69,13 @@ __device__ __forceinline__ void k1_assert_lds0(const int *lut)
 // turn = 2^32): a difference of two scaled angles wraps in the 32-bit subtraction itself, so k1_stored_code's sign
 // extension of 24 bits disappears (k1_stored_code_scaled); 256 x code is still exact in a float32 and the factor is
 // divided out with the window's scale (k1_normalise_scaled: bit-identical results).
-template <bool HI, bool ABS0 = false>
-__device__ __forceinline__ int k1_angle_quadrant(unsigned int x, unsigned int neg, const int *qlut)
+// The look-up in two halves, so that a kernel can put several table reads in flight before it uses the first (round 4: the
+// column kernels issue the 8 reads of four rows back to back; one read followed by its placement waits out the LDS
+// latency 32 times per tile): byte offset of the entry (3 instructions), then -- on the value read -- the placement (6).
+template <bool HI>
+__device__ __forceinline__ unsigned int k1_quadrant_offset(unsigned int x)
 {
     unsigned int oa, oq, off;
-    int k, mi, mq, c;
     if (!HI) {
         asm("v_lshlrev_b32_sdwa %0, 2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(oa) : "v"(x));
         asm("v_lshlrev_b32_sdwa %0, 9, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(oq) : "v"(x));
@@ -82,7 +84,13 @@ __device__ __forceinline__ int k1_angle_quadrant(unsigned int x, unsigned int ne
         asm("v_lshlrev_b32_sdwa %0, 9, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(oq) : "v"(x));
     }
     asm("v_or_b32 %0, %1, %2" : "=v"(off) : "v"(oa), "v"(oq));                    // byte offset 4 (128 iq + ia)
-    c = k1_table_read<ABS0>(qlut, off);
+    return off;
+}
+
+template <bool HI>
+__device__ __forceinline__ int k1_quadrant_place(int c, unsigned int neg)
+{
+    int k, mi, mq;
     if (!HI) asm("v_bfe_i32 %0, %1, 7, 1" : "=v"(mi) : "v"(neg));               // -1: I < 0
     else asm("v_bfe_i32 %0, %1, 23, 1" : "=v"(mi) : "v"(neg));
     asm("v_and_b32 %0, 0x80000001, %1" : "=v"(k) : "v"(mi));
@@ -92,6 +100,12 @@ __device__ __forceinline__ int k1_angle_quadrant(unsigned int x, unsigned int ne
     asm("v_xor_b32 %0, %1, %2" : "=v"(c) : "v"(c), "v"(mq));
     asm("v_sub_u32 %0, %1, %2" : "=v"(c) : "v"(c), "v"(mq));                    // c -> -c
     return c;
+}
+
+template <bool HI, bool ABS0 = false>
+__device__ __forceinline__ int k1_angle_quadrant(unsigned int x, unsigned int neg, const int *qlut)
+{
+    return k1_quadrant_place<HI>(k1_table_read<ABS0>(qlut, k1_quadrant_offset<HI>(x)), neg);
 }
 
 __device__ __forceinline__ unsigned int k1_index_bytes(unsigned int w) { return w ^ (0x7f7f7f7fu + ((w >> 7) & 0x01010101u)); }
