@@ -1,16 +1,62 @@
 #!/bin/bash
-# Everything the round's DESIGN.md / bench roofline quote, in one GPU call (about 12 minutes):
-#   bash scripts/collect_round.sh r03
+# Everything the round's DESIGN.md / bench roofline quote, in one GPU call (about 25 minutes):
+#   bash scripts/collect_round.sh r04 [quick]
+# Order matters: the counter tables of every configuration are copied into profiles/ BEFORE the bench lines are taken, so
+# that bench.py's roofline can quote them (same kernel sources: source_sha16).
 set -e
-TAG=${1:-r03}
+TAG=${1:-r04}
+QUICK=$2
+mkdir -p gpurun_out
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+say() { echo "[collect $(date +%H:%M:%S)] $*"; }
+say hbm microbench
 python3 scripts/hbm_microbench.py > gpurun_out/${TAG}_hbm_microbench.txt 2>&1
 cp gpurun_out/${TAG}_hbm_microbench.txt profiles/
-bash scripts/collect_profiles.sh $TAG > gpurun_out/${TAG}_collect.log 2>&1
-bash scripts/collect_k1_bytes.sh $TAG > gpurun_out/${TAG}_k1bytes.log 2>&1
-cp gpurun_out/${TAG}_k1_bytes.json profiles/
+CFGS="cfg2 cfg4 cfg5 cfg3"
+[ "$QUICK" = quick ] && CFGS="cfg2 cfg4"
+for cfg in $CFGS; do
+  say pmc $cfg
+  bash scripts/collect_pmc.sh $TAG $cfg > gpurun_out/${TAG}_pmc_$cfg.log 2>&1
+  cp gpurun_out/${TAG}_pmc_traffic_$cfg.json profiles/
+  say sq $cfg
+  BENCH_ARGS="--config $cfg" bash scripts/collect_sq.sh ${TAG}_$cfg "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \
+      "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS" \
+      "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" > gpurun_out/${TAG}_sq_$cfg.csv
+  cp gpurun_out/${TAG}_sq_$cfg.csv profiles/
+done
+run_stats() {   # name, bench args...
+  local name=$1; shift
+  say stats $name
+  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${TAG}_$name -- \
+      python3 bench.py --no-cpu-baseline --no-graph-leg --no-h2d "$@" > gpurun_out/${TAG}_${name}_bench.json 2> gpurun_out/prof_${TAG}_$name.log
+  local f=$(ls gpurun_out/prof_${TAG}_$name/*/*kernel_stats.csv | head -1)
+  cp "$f" gpurun_out/${TAG}_${name}_kernel_stats.csv
+  cp gpurun_out/${TAG}_${name}_bench.json gpurun_out/${TAG}_${name}_kernel_stats.csv profiles/
+}
+run_stats cfg2 --steps 20 --warmup 5
+run_stats cfg4 --config cfg4 --steps 5 --warmup 2
+if [ "$QUICK" != quick ]; then
+  run_stats cfg2_maxlag512 --steps 20 --warmup 5 --max-lag 512
+  run_stats cfg3 --config cfg3 --steps 2 --warmup 1
+  run_stats cfg5 --config cfg5 --steps 2 --warmup 1
+fi
+say default bench
 python3 bench.py > gpurun_out/${TAG}_default_bench.json 2> gpurun_out/${TAG}_default_bench.err
+cp gpurun_out/${TAG}_default_bench.json profiles/
+say A/B single-look K1 against the pre-pass
+TDOA_NO_K1_ONCE=1 python3 bench.py --no-cpu-baseline --no-h2d > gpurun_out/${TAG}_cfg2_prepass_bench.json 2> gpurun_out/${TAG}_prepass.err
+cp gpurun_out/${TAG}_cfg2_prepass_bench.json profiles/
+say multi-rank rehearsals
 python3 bench.py --force-dist --no-cpu-baseline > gpurun_out/${TAG}_forcedist_rccl_world1_bench.json 2> gpurun_out/${TAG}_forcedist.err
-python3 scripts/graph_memset_probe.py > gpurun_out/${TAG}_graph_memset_probe.txt 2>&1 || true
-for f in cfg2 cfg2_maxlag512 cfg3 cfg4 cfg5; do cp gpurun_out/${TAG}_${f}_bench.json gpurun_out/${TAG}_${f}_kernel_stats.csv profiles/; done
-cp gpurun_out/${TAG}_default_bench.json gpurun_out/${TAG}_forcedist_rccl_world1_bench.json gpurun_out/${TAG}_graph_memset_probe.txt profiles/
-tail -1 gpurun_out/${TAG}_default_bench.json
+TDOA_BENCH_BACKEND=gloo python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29613 \
+    bench.py --gpus 2 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_bench_2rank_gloo.json 2> gpurun_out/${TAG}_gloo2.err
+cp gpurun_out/${TAG}_forcedist_rccl_world1_bench.json gpurun_out/${TAG}_bench_2rank_gloo.json profiles/
+if [ "$QUICK" != quick ]; then
+  say K1 on other byte distributions
+  bash scripts/collect_k1_bytes.sh $TAG > gpurun_out/${TAG}_k1bytes.log 2>&1 || true
+  cp gpurun_out/${TAG}_k1_bytes.json profiles/ || true
+  python3 scripts/graph_memset_probe.py > gpurun_out/${TAG}_graph_memset_probe.txt 2>&1 || true
+  cp gpurun_out/${TAG}_graph_memset_probe.txt profiles/ || true
+fi
+say done
+tail -1 gpurun_out/${TAG}_default_bench.json | head -c 600
