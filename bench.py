@@ -534,6 +534,7 @@ def run_job(args, env, cfg_name, scaling, sim, steps, warmup, full):
     graph_leg = None
     if full and not args.no_graph_leg:
         step()                                                            # captures the graph
+        step()                                                            # (its first replay next to a collective pays a one-time ~40 ms)
         dtg = timed(steps)
         graph_leg = {"ms_per_step": round(dtg / steps * 1e3, 4), "value": round(samples_per_step / (dtg / steps) / 1e6, 2),
                      "identical_to_timed_path": None if timed_peaks is None else bool(np.array_equal(timed_peaks, state["peaks"])),
@@ -838,6 +839,8 @@ def main():
     use_dist = world > 1 or args.force_dist
     if use_dist:
         import torch.distributed as dist
+        if os.environ.get("NCCL_DEBUG", "VERSION").upper() == "VERSION":      # RCCL's version banner goes to STDOUT: keep it off the JSON line
+            os.environ["NCCL_DEBUG"] = "WARN"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         kw = {} if world > 1 else {"rank": 0, "world_size": 1}

@@ -269,35 +269,43 @@ __global__ __launch_bounds__(kDemodThreads) void k_once_edges(const SWDesc *sw, 
         int tot = 0;
         double incl = 0.0;
         if (piece < pieces) {
-            if (region + piece * kOncePiece >= 1 && (piece + 1) * kOncePiece <= k_max) {
-                // every position of the piece has a code and a predecessor inside the window
-                uint4 qs[4];
+            // A lane's 32 positions are either all codes of the region (pos0 + 32 <= K: the vector path -- every lane of
+            // every piece but the one that holds position K), all beyond it (zeros), or -- one lane per region -- straddle K:
+            // sample by sample, never reading beyond the window.  The window's first sample has no predecessor:
+            // code_0 := code_1.
+            const bool whole = pos0 + 32 <= k_max, partial = !whole && pos0 < k_max;
+            uint4 qs[4] = {};
+            if (whole) {
 #pragma unroll
                 for (int h = 0; h < 4; h++) qs[h] = k1_fetch8(p, i0 + 8 * h);
-                const unsigned int before = p[region + piece * kOncePiece - 1];
-                int a[33];
+            }
+            const int first = region + piece * kOncePiece;         // the piece's first sample
+            const unsigned int before = p[first > 0 ? first - 1 : 0];
+            int a[33];
 #pragma unroll
-                for (int h = 0; h < 4; h++) {
-                    k1_direct_angle2(qs[h].x, dlut, a[8 * h + 1], a[8 * h + 2]);
-                    k1_direct_angle2(qs[h].y, dlut, a[8 * h + 3], a[8 * h + 4]);
-                    k1_direct_angle2(qs[h].z, dlut, a[8 * h + 5], a[8 * h + 6]);
-                    k1_direct_angle2(qs[h].w, dlut, a[8 * h + 7], a[8 * h + 8]);
-                }
-                const int left = wave_shift_right1(a[32]);
-                a[0] = lane ? left : k1_direct_angle(before, dlut);
+            for (int h = 0; h < 4; h++) {
+                k1_direct_angle2(qs[h].x, dlut, a[8 * h + 1], a[8 * h + 2]);
+                k1_direct_angle2(qs[h].y, dlut, a[8 * h + 3], a[8 * h + 4]);
+                k1_direct_angle2(qs[h].z, dlut, a[8 * h + 5], a[8 * h + 6]);
+                k1_direct_angle2(qs[h].w, dlut, a[8 * h + 7], a[8 * h + 8]);
+            }
+            const int left = wave_shift_right1(a[32]);             // (a lane left of a `whole` lane is whole)
+            a[0] = lane ? left : k1_direct_angle(before, dlut);
 #pragma unroll
-                for (int k = 0; k < 32; k++) c[k] = -k1_stored_code(a[k + 1], a[k]) - m0;
-            } else {
-                // first piece of the head region (code_0 := code_1), last piece of a region: sample by sample
-#pragma unroll
-                for (int k = 0; k < 32; k++) {
-                    const int pos = pos0 + k, i = i0 + k;
-                    int v = 0;
-                    if (pos < k_max && i < len) {
-                        const int ii = i == 0 ? 1 : i;
-                        v = -k1_stored_code(k1_direct_angle(p[ii], dlut), k1_direct_angle(p[ii - 1], dlut)) - m0;
+            for (int k = 0; k < 32; k++) c[k] = whole ? -k1_stored_code(a[k + 1], a[k]) - m0 : 0;
+            if (i0 == 0 && whole) c[0] = c[1];                     // code_0 := code_1
+            if (__builtin_amdgcn_ballot_w64(partial)) {
+                if (partial) {
+#pragma unroll 1
+                    for (int k = 0; k < 32; k++) {
+                        const int i = i0 + k;
+                        int v = 0;
+                        if (pos0 + k < k_max && i < len) {
+                            const int ii = i == 0 ? 1 : i;
+                            v = -k1_stored_code(k1_direct_angle(p[ii], dlut), k1_direct_angle(p[ii - 1], dlut)) - m0;
+                        }
+                        c[k] = v;
                     }
-                    c[k] = v;
                 }
             }
             // running sums inside the lane (|code - m0| < 2^24, 32 of them: int32), then over the lanes (exact in float64)
