@@ -109,7 +109,7 @@ def pmc_traffic(cfg_name, kernels):
         if doc.get("source_sha16") != source_hash():
             return None, "stale: %s was taken on other kernel sources" % os.path.basename(f), None
         recs = [doc["kernels"].get(k) for k in kernels]
-        total = sum(v["traffic_bytes_per_launch"] for v in doc["kernels"].values())
+        total = sum(v.get("traffic_bytes_per_step", v["traffic_bytes_per_launch"]) for v in doc["kernels"].values())      # one step
         mine = sum(r["traffic_bytes_per_launch"] for r in recs if r) if any(recs) else None
         return mine, os.path.basename(f), total
     except Exception:

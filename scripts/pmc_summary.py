@@ -41,21 +41,29 @@ def load(d):
 
 def main():
     fetch, write = load(sys.argv[1]), load(sys.argv[2])
+    # a step may take several launches of a kernel (launch groups of windows): per-step sums = all launches of the pass /
+    # the steps of the pass (k_decode_peaks runs once per step; every step does the same work)
+    steps_f = max(1, len(fetch.get("k_decode_peaks", [0.0])))
+    steps_w = max(1, len(write.get("k_decode_peaks", [0.0])))
     res = {}
     for k in sorted(set(fetch) & set(write)):
         if not k.startswith("k_") or k.startswith("k_synth"):
             continue
         base = k.split("<")[0]                      # template instances of one kernel are summed
-        f, w = fetch[k][-1], write[k][-1]           # last launch = a timed step
+        f, w = sum(fetch[k]) / steps_f, sum(write[k]) / steps_w
         corr = FETCH_CORRECTION.get(base, 1.0)
         rec = res.setdefault(base, {"FETCH_SIZE_KiB": 0.0, "WRITE_SIZE_KiB": 0.0, "fetch_correction": corr,
-                                    "traffic_bytes_per_launch": 0.0})
+                                    "traffic_bytes_per_step": 0.0, "launches_per_step": 0.0})
         rec["FETCH_SIZE_KiB"] += f
         rec["WRITE_SIZE_KiB"] += w
-        rec["traffic_bytes_per_launch"] += f * 1024 * corr + w * 1024
+        rec["traffic_bytes_per_step"] += f * 1024 * corr + w * 1024
+        rec["launches_per_step"] = max(rec["launches_per_step"], len(fetch[k]) / steps_f)      # (instances of one scope launch together)
+    for rec in res.values():
+        rec["traffic_bytes_per_launch"] = rec["traffic_bytes_per_step"] / max(rec["launches_per_step"], 1.0)
     cfg = sys.argv[4] if len(sys.argv) > 4 else "cfg2"
-    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --config %s, batch = all windows" % cfg,
-               "config": cfg,
+    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --config %s; per-step sums over "
+                         "the launch groups of a step" % cfg,
+               "config": cfg, "steps_in_pass": steps_f,
                "source_sha16": source_hash(), "kernels": res}, open(sys.argv[3], "w"), indent=1, sort_keys=True)
     print(json.dumps(res, indent=1))
 

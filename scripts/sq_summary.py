@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-kernel table of the SQ counters collected by collect_sq.sh (last launch of each kernel).
+"""Per-kernel table of the SQ counters collected by collect_sq.sh (summed over the launches of the pass).
 usage: sq_summary.py <dir prefix> <n groups>"""
 import collections
 import csv
@@ -19,7 +19,9 @@ def main():
             for r in csv.DictReader(open(path)):
                 name = r["Kernel_Name"].split("(")[0].replace("tdoa::", "").replace("void ", "")
                 if name.startswith("k_") and not name.startswith("k_synth"):
-                    table[name][r["Counter_Name"]] = float(r["Counter_Value"])     # last launch wins
+                    # summed over every launch of the pass (a step may take several launch groups; every ratio the tables are
+                    # read for -- issue share, instructions per wave, conflict share -- is a ratio of two such sums)
+                    table[name][r["Counter_Name"]] = table[name].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
     ctrs = sorted({c for v in table.values() for c in v})
     print("# source_sha16=" + source_hash())
     print("kernel," + ",".join(ctrs))

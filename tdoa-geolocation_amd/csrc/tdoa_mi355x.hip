@@ -91,6 +91,7 @@ struct tdoa_ctx {
 
     // whole-step hipGraph of tdoa_process (launch-bound when windows are processed in many groups)
     int n_cu = 256;                         // multiprocessors of this device
+    double workspace_limit = 24.0 * 1073741824.0;      // bytes of FFT workspace one launch group may take: a third of the device's memory
     bool use_graph = true;                  // TDOA_NO_GRAPH=1 at tdoa_create time turns the whole-step hipGraph off
     bool short_lag = true;                  // TDOA_NO_SHORT_LAG=1 at tdoa_create time forces the general inverse for short searches
     bool segment_form = true;               // TDOA_NO_SEGMENT_FORM=1: no LDS-resident overlap-save form for short searches
@@ -1169,6 +1170,9 @@ int tdoa_create(const tdoa_params *p, tdoa_ctx **out)
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, prm.device) == hipSuccess && cus > 0)
             ctx->n_cu = cus;
+        size_t total_mem = 0;
+        if (hipDeviceTotalMem(&total_mem, prm.device) == hipSuccess && total_mem > 0)
+            ctx->workspace_limit = std::max(8.0 * 1073741824.0, (double)total_mem / 3.0);
     }
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
@@ -1539,14 +1543,19 @@ static int process_impl(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host,
         for (int p = 0; p < P && !any; p++) any = owns(w, p);
         if (any) mine.push_back(w);
     }
-    // default: every window of this rank in one launch group (launch tails cost more than cache
-    // residency gains), bounded by ~24 GiB of workspace
+    // default: every window of this rank in one launch group (launch tails cost more than cache residency gains), bounded
+    // by a third of the device's memory for the workspace (96 GB of an MI355X's 288: cfg4's 99 windows x 36 spectra are one
+    // group of 30 GB; round 3 stopped at 24 GiB and ran them as 85 + 14)
     int per_batch = ctx->prm.windows_per_batch > 0 ? ctx->prm.windows_per_batch : (int)std::max<size_t>(mine.size(), 1);
     const double bytes_per_window = 8.0 * (double)pl.Nc * (S + P) + 2.0 * (double)(wlen + 16) * S;
-    per_batch = (int)std::max(1.0, std::min<double>(per_batch, 24.0 * 1073741824.0 / bytes_per_window));
+    per_batch = (int)std::max(1.0, std::min<double>(per_batch, ctx->workspace_limit / bytes_per_window));
     // per_batch * S and per_batch * P become gridDim.y of the FFT kernels (HIP limit 65535)
     if (std::max(S, P) > 65535) return fail(ctx, TDOA_ERR_UNSUPPORTED, "too many station pairs for one launch group");
     per_batch = std::max(1, std::min(per_batch, 65535 / std::max(S, P)));
+    if (!mine.empty()) {                     // groups of equal size (99 windows at most 85 at a time: 50 + 49, not 85 + 14)
+        const int groups = ((int)mine.size() + per_batch - 1) / per_batch;
+        per_batch = ((int)mine.size() + groups - 1) / groups;
+    }
 
     // all descriptors, uploaded once; window wi of this rank owns sw[sw_off[wi] .. sw_off[wi+1]) and likewise pw
     std::vector<SWDesc> sw;
