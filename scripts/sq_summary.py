@@ -17,7 +17,8 @@ def main():
     for i in range(n):
         for path in glob.glob("%s%d/**/*counter_collection.csv" % (prefix, i), recursive=True):
             for r in csv.DictReader(open(path)):
-                name = r["Kernel_Name"].split("(")[0].replace("tdoa::", "").replace("void ", "")
+                # template instances of one kernel are summed under its plain name (their argument lists hold commas)
+                name = r["Kernel_Name"].split("(")[0].replace("tdoa::", "").replace("void ", "").split("<")[0]
                 if name.startswith("k_") and not name.startswith("k_synth"):
                     # summed over every launch of the pass (a step may take several launch groups; every ratio the tables are
                     # read for -- issue share, instructions per wave, conflict share -- is a ratio of two such sums)

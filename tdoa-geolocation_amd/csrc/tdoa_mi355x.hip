@@ -112,6 +112,10 @@ struct tdoa_ctx {
     long long dec_nc = 0;
     int dec_reach = -1, dec_T = 0;
     bool xcd_rows = true;                   // TDOA_NO_XCD_ROWS=1: plain 2-D grid of the pair kernel even with more pairs than stations
+    int xcd_pair_mb = 48;                   // TDOA_XCD_PAIR_MB=n: k_pair_decimate16 groups a window's pair-windows on one XCD when the
+                                            // window's spectra exceed n MB (round 4, same-box A/B: cfg4, 8 x 8.4 MB, 11.05 ms grouped
+                                            // against 11.20 -- its pair step pulled 27 GB per step through the fabric for 5.6 GB of
+                                            // spectra; cfg2, 3 x 8.4 MB: 0.69 ms grouped against 0.66 plain)
     uint64_t alloc_gen = 0;                 // bumped whenever a workspace buffer moves
     std::vector<uint64_t> graph_key;
     hipGraph_t graph = nullptr;
@@ -804,12 +808,12 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
             ProfScope ps(ctx, TDOA_K_INV_ROW, 2.0 * nc8 * n_pw + 8.0 * (double)rc_pts * n_pw);      // two spectra read, G written
             float2 *edges = v + dec_edge_offset(pl, n_pw), *spectra = v + dec_spectra_offset(pl, n_pw);
             // pair-windows of a window that share station tiles on one XCD (k_pair_decimate16): when the batch is uniform and
-            // a window's spectra are too many to wait in the Infinity Cache for their other readers (cfg5: 16 stations x 16.8
-            // MB; its step 258 -> 237 ms.  cfg4, 8 x 8.4 MB: neutral; cfg2, 3 x 8.4 MB: the plain grid is 4 % faster)
+            // a window's spectra are too many to come from on-die memory for their other readers (ctx->xcd_pair_mb: cfg5, 16
+            // stations x 16.8 MB: its step 258 -> 237 ms in round 3; cfg4, 8 x 8.4 MB: -1.3 % since round 4; cfg2: plain grid)
             int gp = 0;
             dim3 grid(pl.N2 / 2, n_pw);
             if (ctx->xcd_rows && pairs_per_window > 1 && n_pw % pairs_per_window == 0 && n_sw > 0 &&
-                (size_t)(n_sw / (n_pw / pairs_per_window)) * (size_t)pl.Nc * sizeof(float2) > ((size_t)128 << 20)) {
+                (size_t)(n_sw / (n_pw / pairs_per_window)) * (size_t)pl.Nc * sizeof(float2) > ((size_t)ctx->xcd_pair_mb << 20)) {
                 const long long groups = (long long)(n_pw / pairs_per_window) * (pl.N2 / 2);
                 const long long blocks = (groups + 7) / 8 * 8 * pairs_per_window;
                 if (blocks < (1ll << 31)) { gp = pairs_per_window; grid = dim3((unsigned int)blocks); }
@@ -1221,6 +1225,7 @@ int tdoa_create(const tdoa_params *p, tdoa_ctx **out)
     if (const char *e = std::getenv("TDOA_SEG_CHUNKS")) ctx->seg_chunks_override = std::max(0, std::atoi(e));
     if (const char *e = std::getenv("TDOA_DEBUG_MEMSET_NODES")) ctx->memset_nodes = e[0] == '1';
     if (const char *e = std::getenv("TDOA_NO_XCD_ROWS")) ctx->xcd_rows = !(e[0] == '1');
+    if (const char *e = std::getenv("TDOA_XCD_PAIR_MB")) ctx->xcd_pair_mb = std::max(0, std::atoi(e));
     *out = ctx;
     return TDOA_OK;
 }
@@ -1638,7 +1643,7 @@ static int process_impl(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host,
                                      ((uint64_t)ctx->segment_form << 3) | ((uint64_t)ctx->xcd_rows << 4) |
                                      ((uint64_t)ctx->segment_quads << 6) |
                                      ((uint64_t)ctx->decimate << 8) | ((uint64_t)ctx->fused_k1 << 9) | ((uint64_t)ctx->k1_once << 11) |
-                                     ((uint64_t)ctx->memset_nodes << 10) | ((uint64_t)ctx->seg_chunks_override << 16),
+                                     ((uint64_t)ctx->memset_nodes << 10) | ((uint64_t)ctx->seg_chunks_override << 16) | ((uint64_t)ctx->xcd_pair_mb << 40),
                                  ctx->alloc_gen, (uint64_t)(fine_host != nullptr), 0};
     std::memcpy(&key.back(), &gate, sizeof(double));
     for (auto &c : ctx->caps) {
