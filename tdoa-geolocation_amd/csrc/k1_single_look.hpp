@@ -141,11 +141,14 @@ __device__ __forceinline__ double wave_sum_f64_lane63(double x)
     return x;
 }
 
-// A tile's record: three float64 that hold exact integers.  A lane's t2 = 2^16 q with q < 2^51 an integer, and 1024 such
-// lanes would exceed 2^53, so q is split first: hi = floor(q / 2^26) < 2^25, lo = q - 2^26 hi < 2^26; over a workgroup's
-// 1024 lanes the parts stay below 2^35 and 2^36.  t1 = -256 x (a lane's sum of codes), |sum over the tile| <= 1024 x 2^36.
+// A WAVE's record for one tile: three float64 that hold exact integers.  A lane's t2 = 2^16 q with q < 2^51 an integer, and
+// 64 such lanes would exceed 2^53, so q is split first: hi = floor(q / 2^26) < 2^25, lo = q - 2^26 hi < 2^26; over a wave's 64
+// lanes the parts stay below 2^31 and 2^32.  t1 = -256 x (a lane's sum of codes), |sum over the wave| <= 64 x 2^36.
+// Lane 63 writes the record straight to memory (16 records per tile, 32 bytes each: 10 MB per cfg2 step) -- no LDS, no
+// barrier, nothing for another wave to wait for; k_once_final adds a window's records up.
+constexpr int kOnceWavesPerTile = 16;
 struct OnceTile {
-    double s1;             // sum st over the tile           (= -256 x sum code)
+    double s1;             // sum st over the wave's part of the tile           (= -256 x sum code)
     double q_hi, q_lo;     // sum of floor(q / 2^26) and of q mod 2^26, q = sum code^2 of a lane
     double pad;
 };
@@ -157,9 +160,7 @@ __device__ __forceinline__ void col_once_split(double t2, double &q_hi, double &
     q_lo = __builtin_fma(q_hi, -0x1p26, q);              // exact
 }
 
-// the wave's three sums -> red[wave][3] in LDS (lane 63 writes); after the workgroup's next barrier thread q < 3 adds the
-// waves' entries and writes the tile's record
-__device__ __forceinline__ void col_once_wave_reduce(double t1, double t2, double *red, int wave)
+__device__ __forceinline__ void col_once_wave_record(double t1, double t2, OnceTile *rec)
 {
     double hi, lo;
     col_once_split(t2, hi, lo);
@@ -167,18 +168,10 @@ __device__ __forceinline__ void col_once_wave_reduce(double t1, double t2, doubl
     hi = wave_sum_f64_lane63(hi);
     lo = wave_sum_f64_lane63(lo);
     if ((threadIdx.x & 63) == 63) {
-        red[3 * wave + 0] = t1;
-        red[3 * wave + 1] = hi;
-        red[3 * wave + 2] = lo;
-    }
-}
-
-__device__ __forceinline__ void col_once_store_tile(const double *red, int n_waves, OnceTile *rec)
-{
-    if (threadIdx.x < 3) {
-        double s = 0.0;
-        for (int w = 0; w < n_waves; w++) s += red[3 * w + threadIdx.x];
-        reinterpret_cast<double *>(rec)[threadIdx.x] = s;
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        d2 *o = reinterpret_cast<d2 *>(rec);
+        o[0] = d2{t1, hi};
+        o[1] = d2{lo, 0.0};
     }
 }
 
@@ -350,7 +343,8 @@ __global__ __launch_bounds__(kDemodThreads) void k_once_edges(const SWDesc *sw, 
 // ---- k_once_final ---------------------------------------------------------------------------------------------------
 // One wave per station-window adds its tiles' records (integers; any order gives the same bits) and evaluates the
 // statistics with the expressions of k_fm_stats_final, then eps and g against the (m0, s0) the column kernel used.
-// tiles: record of tile (w, a, bx) at index (w G + a) nbx + bx, i.e. tiles_per_sw consecutive records per window.
+// tiles: the records of tile (w, a, bx) at index ((w G + a) nbx + bx) 16 + wave, i.e. 16 tiles_per_sw consecutive records
+// per window (tiles_per_sw counts records here).
 __global__ __launch_bounds__(64) void k_once_final(const SWDesc *sw, const OnceTile *tiles, int tiles_per_sw, FmStats *stats,
                                                    OnceFin *fin, int n_sw)
 {
