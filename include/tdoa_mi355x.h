@@ -279,10 +279,8 @@ enum {
     TDOA_DEBUG_NO_XCD_ROWS     = 16, /* plain 2-D grid of the pair kernel even with more pairs than stations          */
     TDOA_DEBUG_NO_SEGMENT_QUADS = 64, /* segment form one pair-window at a time: no station transforms shared by pairs */
     TDOA_DEBUG_NO_DECIMATE     = 256, /* full inverse transform even where the decimated one applies (4096 x 256 / x 512 plans, search ranges above 4095 lags) */
-    TDOA_DEBUG_NO_K1_ONCE      = 512, /* the K1 statistics pre-pass everywhere: no single-look K1 (every capture byte read once,
+    TDOA_DEBUG_NO_K1_ONCE      = 512 /* the K1 statistics pre-pass everywhere: no single-look K1 (every capture byte read once,
                                         the mean's residual removed where the lags come out; csrc/k1_single_look.hpp)      */
-    TDOA_DEBUG_NO_K1_HALF      = 1024 /* the fused column kernel with the 64 KB quadrant table and a whole-tile exchange plane
-                                         instead of the 128 KB half-plane table and a half-tile plane                        */
 };
 int tdoa_debug_flags(tdoa_ctx *ctx, unsigned flags);
 /* inspection: the K1 statistics of station-window `sw_index` of the last batch (the order of the batch's descriptors:

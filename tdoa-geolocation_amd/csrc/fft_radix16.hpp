@@ -413,20 +413,18 @@ __device__ __forceinline__ void batch_general(F &f, int g, std::integer_sequence
 
 // ONCE (k1_single_look.hpp): `stats` holds the estimates (m0, s0) of k_once_estimate, and every wave leaves the exact sums
 // of its stored codes of a tile in once_tiles[16 tile + wave].
-// HALF (round 4): the whole half-plane table (128 KB, scaled entries: k1_direct_angle2_scaled) instead of the quadrant
-// table -- 5.5 instructions per sample for a look-up instead of 13 (index bytes included) -- next to an exchange plane of
-// HALF the tile, [256][32] floats (32 KB: 160 KB of LDS in all, everything a CU has): the two column halves of every wave
-// take turns in the exchange, which doubles its LDS instructions and its barriers (8 per tile instead of 4).
-constexpr size_t kColK1HalfLds = kK1DirectBytes + sizeof(float) * 256 * 32;
-template <bool SUB, bool ONCE = false, bool HALF = false>
+// (Round 4 also built this kernel with the whole 128 KB half-plane table in LDS -- 5.5 instructions per look-up instead of
+// 13 -- next to an exchange plane of half the tile: bit-identical results, 2 % SLOWER on cfg2 / cfg4 / cfg3, because the
+// half plane doubles the exchange's barriers (8 per tile) and LDS instructions.  Commit f53a7d8)
+template <bool SUB, bool ONCE = false>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_fwd_col256_k1(const SWDesc *__restrict__ sw, const int *__restrict__ table, const FmStats *__restrict__ stats, float2 *__restrict__ T,
                                                        FftPlan pl, int n_sw, OnceTile *__restrict__ once_tiles)
 {
     constexpr int LOGW = 6, W = 1 << LOGW;                      // 64 columns per tile
-    constexpr int kTableEntries = HALF ? kK1DirectEntries : kK1QuadrantEntries;
+    constexpr int kTableEntries = kK1QuadrantEntries;
     extern __shared__ int lds_k1[];                             // the table at offset 0 (the offset IS the address), then the plane
     int *lut = lds_k1;
-    float *plane = reinterpret_cast<float *>(lds_k1 + kTableEntries);           // [256][W], HALF: [256][W / 2]
+    float *plane = reinterpret_cast<float *>(lds_k1 + kTableEntries);           // [256][W]
     k1_assert_lds0(lut);
     const int G = SUB ? pl.N2 >> 8 : 1;
     const int N1 = pl.N1, nbx = N1 >> LOGW;
@@ -466,9 +464,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
 #pragma unroll
             for (int r = 0; r < 16; r++) raw[r] = raw_next[r];
             // boundary samples: lane L took row r = L & 15 of the wave's item
-            int ab, ab_unused;
-            if constexpr (HALF) k1_direct_angle2_scaled<true>(sb_next | 0x80000000u, lut, ab, ab_unused);      // (high half: any sample with Q > 0)
-            else ab = k1_angle_quadrant<false, true>(k1_index_bytes(sb_next), ~sb_next, lut);
+            const int ab = k1_angle_quadrant<false, true>(k1_index_bytes(sb_next), ~sb_next, lut);
             // rows are classified per wave (it holds item j of every r): entirely inside the window -- no bounds selects,
             // the common case --, entirely beyond it -- zero padding, nothing to look up (40 % of the rows of a 10 s window
             // in N = 2^25) --, or general
@@ -484,8 +480,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
                     return;
                 }
                 int a0, a1;
-                if constexpr (HALF) k1_direct_angle2_scaled<true>(raw[r], lut, a0, a1);
-                else k1_angle2_quadrant<true>(raw[r], lut, a0, a1);
+                k1_angle2_quadrant<true>(raw[r], lut, a0, a1);
                 // the angle of sample 2m - 1 is the left lane's second angle; lane 0 keeps `old` = the boundary sample's
                 const int bnd = __builtin_amdgcn_readlane(ab, r);
                 const int ap = __builtin_amdgcn_update_dpp(bnd, a1, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
@@ -516,32 +511,20 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
                 const int i_first0 = 2 * ((a + G * (jw + 16 * (kColBatch * g))) * N1 + (t.bx << LOGW));
                 const int i_end3 = 2 * ((a + G * (jw + 16 * (kColBatch * g + kColBatch - 1))) * N1 + (t.bx << LOGW)) + 2 * W;
                 if (__builtin_expect(i_first0 > 0 && i_end3 <= len, 1)) {
-                    unsigned int neg[kColBatch];                          // HALF: the reflection masks
+                    unsigned int neg[kColBatch];
                     int c0[kColBatch], c1[kColBatch];
 #pragma unroll
                     for (int q = 0; q < kColBatch; q++) {
-                        if constexpr (HALF) {
-                            const K1DirectOffsets o = k1_direct_offsets(raw[kColBatch * g + q]);
-                            neg[q] = o.pm;
-                            c0[q] = k1_table_read<true>(lut, o.off0);
-                            c1[q] = k1_table_read<true>(lut, o.off1);
-                        } else {
-                            const unsigned int x = k1_index_bytes(raw[kColBatch * g + q]);
-                            neg[q] = ~raw[kColBatch * g + q];
-                            c0[q] = k1_table_read<true>(lut, k1_quadrant_offset<false>(x));
-                            c1[q] = k1_table_read<true>(lut, k1_quadrant_offset<true>(x));
-                        }
+                        const unsigned int x = k1_index_bytes(raw[kColBatch * g + q]);
+                        neg[q] = ~raw[kColBatch * g + q];
+                        c0[q] = k1_table_read<true>(lut, k1_quadrant_offset<false>(x));
+                        c1[q] = k1_table_read<true>(lut, k1_quadrant_offset<true>(x));
                     }
                     __builtin_amdgcn_sched_barrier(0);                  // (the eight reads stay ahead of their placements)
 #pragma unroll
                     for (int q = 0; q < kColBatch; q++) {
                         const int r = kColBatch * g + q;
-                        int a0, a1;
-                        if constexpr (HALF) k1_direct_place_scaled(neg[q], c0[q], c1[q], a0, a1);
-                        else {
-                            a0 = k1_quadrant_place<false>(c0[q], neg[q]);
-                            a1 = k1_quadrant_place<true>(c1[q], neg[q]);
-                        }
+                        const int a0 = k1_quadrant_place<false>(c0[q], neg[q]), a1 = k1_quadrant_place<true>(c1[q], neg[q]);
                         const int bnd = __builtin_amdgcn_readlane(ab, r);
                         const int ap = __builtin_amdgcn_update_dpp(bnd, a1, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
                         const int st0 = k1_stored_code_scaled(a0, ap), st1 = k1_stored_code_scaled(a1, a0);
@@ -567,43 +550,6 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         }
         __builtin_amdgcn_sched_barrier(0);
         fft16<false>(v);
-        if constexpr (HALF) {
-            // exchange through a plane of HALF the tile: lanes 0..31 of every wave, then lanes 32..63; real parts, then
-            // imaginary parts (.y keeps the stage-1 outputs in oreg order until its turn)
-            const int ch = c & 31;
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-                if ((c >> 5) == h) {
-#pragma unroll
-                    for (int k = 0; k < 16; k++) plane[((16 * j + k) << 5) + ch] = v[oreg(k)].x;
-                }
-                __syncthreads();
-                if ((c >> 5) == h) {
-                    float xr[16];
-#pragma unroll
-                    for (int r = 0; r < 16; r++) xr[r] = plane[((j + 16 * r) << 5) + ch];
-#pragma unroll
-                    for (int r = 0; r < 16; r++) v[r].x = xr[r];
-                }
-                __syncthreads();
-            }
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-                if ((c >> 5) == h) {
-#pragma unroll
-                    for (int k = 0; k < 16; k++) plane[((16 * j + k) << 5) + ch] = v[oreg(k)].y;
-                }
-                __syncthreads();
-                if ((c >> 5) == h) {
-                    float yr[16];
-#pragma unroll
-                    for (int r = 0; r < 16; r++) yr[r] = plane[((j + 16 * r) << 5) + ch];
-#pragma unroll
-                    for (int r = 0; r < 16; r++) v[r].y = yr[r];
-                }
-                __syncthreads();                                 // (the last one: the next tile writes the plane again)
-            }
-        } else {
         // exchange through one float plane: real parts, then imaginary parts
 #pragma unroll
         for (int k = 0; k < 16; k++) plane[((16 * j + k) << LOGW) + c] = v[oreg(k)].x;
@@ -617,7 +563,6 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
 #pragma unroll
         for (int r = 0; r < 16; r++) v[r].y = plane[((j + 16 * r) << LOGW) + c];
         __syncthreads();                                         // the next tile writes the plane again
-        }
         mul_powers16(v, opaque(wj));                             // (laundered: its 15 powers are rebuilt per tile, not kept)
         fft16<false>(v);
         if (SUB) {

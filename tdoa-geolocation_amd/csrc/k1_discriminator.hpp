@@ -141,37 +141,6 @@ __device__ __forceinline__ void k1_direct_angle2(unsigned int w, const int *dlut
     a1 = c1 | (int)((pm >> 8) & 0x800000u);
 }
 
-// The same table with its entries SCALED BY 256 (a full turn = 2^32, like the quadrant table's), for the column kernel
-// variant that keeps the whole half-plane table in LDS (k_fwd_col256_k1<.., HALF>): the reflection's half turn is bit 31
-// (an entry is below 2^31: angles of the upper half plane), and a difference of two angles wraps in the subtraction.
-// In two halves like the quadrant look-up, so that several reads can be in flight: mask + offsets (6 instructions per
-// dword), the two reads, the placements (3).
-struct K1DirectOffsets {
-    unsigned int pm, off0, off1;
-};
-__device__ __forceinline__ K1DirectOffsets k1_direct_offsets(unsigned int w)
-{
-    typedef short short2v __attribute__((ext_vector_type(2)));
-    const short2v nq = __builtin_bit_cast(short2v, ~w) >> (short)15;          // per half: 0xffff if Q < 0 (v_pk_ashrrev_i16)
-    K1DirectOffsets o;
-    o.pm = __builtin_bit_cast(unsigned int, nq);
-    const unsigned int fw = w ^ o.pm;                                          // reflected where Q < 0: now b_Q >= 128
-    o.off0 = (fw << 2) & 0x1fffcu;
-    o.off1 = (fw >> 14) & 0x1fffcu;
-    return o;
-}
-__device__ __forceinline__ void k1_direct_place_scaled(unsigned int pm, int c0, int c1, int &a0, int &a1)
-{
-    a0 = c0 | (int)((pm << 16) & 0x80000000u);                                 // + half a turn if reflected
-    a1 = c1 | (int)(pm & 0x80000000u);
-}
-template <bool ABS0>
-__device__ __forceinline__ void k1_direct_angle2_scaled(unsigned int w, const int *dlut, int &a0, int &a1)
-{
-    const K1DirectOffsets o = k1_direct_offsets(w);
-    k1_direct_place_scaled(o.pm, k1_table_read<ABS0>(dlut, o.off0), k1_table_read<ABS0>(dlut, o.off1), a0, a1);
-}
-
 __device__ __forceinline__ int k1_direct_angle(unsigned int s, const int *dlut)
 {
     int a0, a1;

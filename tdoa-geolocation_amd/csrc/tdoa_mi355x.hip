@@ -63,8 +63,6 @@ struct tdoa_ctx {
 
     DevBuf k1_direct;                       // kK1DirectEntries half-plane angle codes of the streaming K1 kernel
     DevBuf k1_quad;                         // kK1QuadrantEntries first-quadrant angle codes (k_fwd_col256_k1)
-    DevBuf k1_direct_scaled;                // the half-plane table with entries x 256 (k_fwd_col256_k1<.., HALF>)
-    bool k1_half = true;                    // TDOA_NO_K1_HALF=1: the quadrant-table form of k_fwd_col256_k1 (64 KB table + 64 KB plane)
     DevBuf sw_desc, pw_desc, partials, stats, codes, codes_lp, k1_power, tz, v, keys, scales, peaks, scratch_a, scratch_b, lagdump;
     DevBuf ex_a, ex_b, ex_c, ex_d, ex_part;
 
@@ -673,17 +671,9 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
         // two-sweep column pass (N2 = 2048, 4096): 8 Nc written, read and written again -- SURVEY's third pass
         ProfScope ps(ctx, TDOA_K_FWD_COL, (fused_k1 ? 2.0 : 4.0) * sum_len + (col2pass ? 3.0 : 1.0) * nc8 * n_sw);
         const auto *qtable = static_cast<const int *>(ctx->k1_quad.p);
-        // k_fwd_col256_k1<SUB, ONCE, HALF>: HALF = the 128 KB half-plane table + a half-tile exchange plane (ctx->k1_half)
-        const auto *htable = static_cast<const int *>(ctx->k1_direct_scaled.p);
 #define TDOA_COL256(SUB, ONCE_)                                                                                       \
-    do {                                                                                                              \
-        if (ctx->k1_half)                                                                                             \
-            hipLaunchKernelGGL((k_fwd_col256_k1<SUB, ONCE_, true>), dim3(ctx->n_cu), dim3(1024), kColK1HalfLds, st, d_sw, htable, \
-                               stats, tz, pl, n_sw, ONCE_ ? once_tiles : static_cast<OnceTile *>(nullptr));             \
-        else                                                                                                          \
-            hipLaunchKernelGGL((k_fwd_col256_k1<SUB, ONCE_, false>), dim3(ctx->n_cu), dim3(1024), kColK1Lds, st, d_sw, qtable,   \
-                               stats, tz, pl, n_sw, ONCE_ ? once_tiles : static_cast<OnceTile *>(nullptr));             \
-    } while (0)
+    hipLaunchKernelGGL((k_fwd_col256_k1<SUB, ONCE_>), dim3(ctx->n_cu), dim3(1024), kColK1Lds, st, d_sw, qtable, stats, tz, pl,    \
+                       n_sw, ONCE_ ? once_tiles : static_cast<OnceTile *>(nullptr))
         if (fused_k1 && col16) {
             if (once) TDOA_COL256(false, true);
             else TDOA_COL256(false, false);
@@ -933,15 +923,10 @@ int allow_big_lds(tdoa_ctx *ctx)
     if ((rc = set_lds(ctx, k_fwd_col512_k1<false>, all))) return rc;
     if ((rc = set_lds(ctx, k_fwd_col512_k1<true>, all))) return rc;
     if ((rc = set_lds(ctx, k_fwd_row4096_unpack, all))) return rc;
-    if ((rc = set_lds(ctx, (k_fwd_col256_k1<false, false, false>), all))) return rc;
-    if ((rc = set_lds(ctx, (k_fwd_col256_k1<true, false, false>), all))) return rc;
-    if ((rc = set_lds(ctx, (k_fwd_col256_k1<false, true, false>), all))) return rc;
-    if ((rc = set_lds(ctx, (k_fwd_col256_k1<true, true, false>), all))) return rc;
-    const size_t whole = 160 * 1024;      // the HALF forms take every byte of a CU's LDS
-    if ((rc = set_lds(ctx, (k_fwd_col256_k1<false, false, true>), whole))) return rc;
-    if ((rc = set_lds(ctx, (k_fwd_col256_k1<true, false, true>), whole))) return rc;
-    if ((rc = set_lds(ctx, (k_fwd_col256_k1<false, true, true>), whole))) return rc;
-    if ((rc = set_lds(ctx, (k_fwd_col256_k1<true, true, true>), whole))) return rc;
+    if ((rc = set_lds(ctx, (k_fwd_col256_k1<false, false>), all))) return rc;
+    if ((rc = set_lds(ctx, (k_fwd_col256_k1<true, false>), all))) return rc;
+    if ((rc = set_lds(ctx, (k_fwd_col256_k1<false, true>), all))) return rc;
+    if ((rc = set_lds(ctx, (k_fwd_col256_k1<true, true>), all))) return rc;
     if ((rc = set_lds(ctx, k_fwd_col_c16, all))) return rc;
     if ((rc = set_lds(ctx, k_fwd_row, all))) return rc;
     if ((rc = set_lds(ctx, k_inv_row_pair, all))) return rc;
@@ -1218,26 +1203,6 @@ int tdoa_create(const tdoa_params *p, tdoa_ctx **out)
         }
         ctx->k1_quad.p = dq;
         ctx->k1_quad.cap = kK1QuadrantBytes;
-        {
-            void *ds = nullptr;
-            std::vector<int32_t> scaled(direct.size());
-            for (size_t k = 0; k < direct.size(); k++) scaled[k] = (int32_t)((uint32_t)direct[k] << 8);      // angles of the upper half plane: < 2^31
-            if (hipMalloc(&ds, kK1DirectBytes) != hipSuccess) {
-                tdoa_destroy(ctx);
-                return TDOA_ERR_NOMEM;
-            }
-            ctx->k1_direct_scaled.p = ds;
-            ctx->k1_direct_scaled.cap = kK1DirectBytes;
-            if (hipMemcpy(ds, scaled.data(), kK1DirectBytes, hipMemcpyHostToDevice) != hipSuccess) {
-                tdoa_destroy(ctx);
-                return TDOA_ERR_HIP;
-            }
-        }
-        if (hipMemcpy(dq, quad.data(), kK1QuadrantBytes, hipMemcpyHostToDevice) != hipSuccess ||
-            hipMemcpy(dt, direct.data(), kK1DirectBytes, hipMemcpyHostToDevice) != hipSuccess) {
-            tdoa_destroy(ctx);
-            return TDOA_ERR_HIP;
-        }
     }
     // run-time switches are read ONCE here (a captured graph must not depend on an environment that changes later)
     if (const char *e = std::getenv("TDOA_NO_GRAPH")) ctx->use_graph = !(e[0] == '1');
@@ -1246,7 +1211,6 @@ int tdoa_create(const tdoa_params *p, tdoa_ctx **out)
     if (const char *e = std::getenv("TDOA_NO_SEGMENT_QUADS")) ctx->segment_quads = !(e[0] == '1');
     if (const char *e = std::getenv("TDOA_NO_DECIMATE")) ctx->decimate = !(e[0] == '1');
     if (const char *e = std::getenv("TDOA_NO_K1_ONCE")) ctx->k1_once = !(e[0] == '1');
-    if (const char *e = std::getenv("TDOA_NO_K1_HALF")) ctx->k1_half = !(e[0] == '1');
     if (const char *e = std::getenv("TDOA_ZPAD")) {
         const int v = std::atoi(e);
         ctx->zpad = v < 0 ? 0 : v > 4096 ? 4096 : v & ~15;      // rows stay 128-byte aligned (the finish sweep reads 16-byte pairs)
@@ -1271,7 +1235,7 @@ void tdoa_destroy(tdoa_ctx *ctx)
     clear_graph_marks(ctx);
     if (ctx->graph) (void)hipGraphDestroy(ctx->graph);
     tdoa_capture_clear(ctx);
-    DevBuf *bufs[] = {&ctx->k1_direct, &ctx->k1_quad, &ctx->k1_direct_scaled, &ctx->sw_desc, &ctx->pw_desc, &ctx->partials, &ctx->stats, &ctx->codes, &ctx->codes_lp, &ctx->k1_power, &ctx->dec_taps, &ctx->dec_gain, &ctx->tz, &ctx->v, &ctx->keys,
+    DevBuf *bufs[] = {&ctx->k1_direct, &ctx->k1_quad, &ctx->sw_desc, &ctx->pw_desc, &ctx->partials, &ctx->stats, &ctx->codes, &ctx->codes_lp, &ctx->k1_power, &ctx->dec_taps, &ctx->dec_gain, &ctx->tz, &ctx->v, &ctx->keys,
                       &ctx->scales, &ctx->peaks, &ctx->scratch_a, &ctx->scratch_b, &ctx->lagdump,
                       &ctx->ex_a, &ctx->ex_b, &ctx->ex_c, &ctx->ex_d, &ctx->ex_part,
                       &ctx->g_sw_desc, &ctx->g_pw_desc, &ctx->g_quad_desc, &ctx->g_scales, &ctx->g_keys, &ctx->fine_raw, &ctx->fine, &ctx->qual,
@@ -1672,7 +1636,7 @@ static int process_impl(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host,
                                  (uint64_t)ctx->force_generic | ((uint64_t)ctx->short_lag << 1) |
                                      ((uint64_t)ctx->segment_form << 3) | ((uint64_t)ctx->xcd_rows << 4) |
                                      ((uint64_t)ctx->segment_quads << 6) |
-                                     ((uint64_t)ctx->decimate << 8) | ((uint64_t)ctx->fused_k1 << 9) | ((uint64_t)ctx->k1_once << 11) | ((uint64_t)ctx->k1_half << 12) |
+                                     ((uint64_t)ctx->decimate << 8) | ((uint64_t)ctx->fused_k1 << 9) | ((uint64_t)ctx->k1_once << 11) |
                                      ((uint64_t)ctx->memset_nodes << 10) | ((uint64_t)ctx->seg_chunks_override << 16) | ((uint64_t)ctx->xcd_pair_mb << 40),
                                  ctx->alloc_gen, (uint64_t)(fine_host != nullptr), 0};
     std::memcpy(&key.back(), &gate, sizeof(double));
@@ -2040,7 +2004,6 @@ int tdoa_debug_flags(tdoa_ctx *ctx, unsigned flags)
     ctx->decimate = !(flags & TDOA_DEBUG_NO_DECIMATE);
     ctx->fused_k1 = !(flags & TDOA_DEBUG_NO_FUSED_K1);
     ctx->k1_once = !(flags & TDOA_DEBUG_NO_K1_ONCE);
-    ctx->k1_half = !(flags & TDOA_DEBUG_NO_K1_HALF);
     return TDOA_OK;
 }
 

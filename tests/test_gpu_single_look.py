@@ -183,23 +183,3 @@ def test_single_look_with_a_biased_estimate():
         la, lr = c.fm_xcorr_lags(a, b, ML), ref.fm_xcorr_lags(a, b, ML)
     assert got[0] == want[0] == 37 and abs(got[1] - want[1]) <= 2e-6 * abs(want[1])
     assert np.abs(la - lr).max() <= 4e-6 * np.abs(lr).max()
-
-
-@pytest.mark.parametrize("once", [True, False])
-def test_half_plane_table_column_kernel_is_bit_identical(oracle, once):
-    """k_fwd_col256_k1<.., HALF> (128 KB half-plane table, half-tile exchange plane) forms the same angle codes and runs the
-    same arithmetic in the same order as the quadrant-table form: every lag and the statistics must come out bit for bit
-    equal -- one-sweep plan (N2 = 256) and the first sweep of the two-sweep plan (N2 = 2048), windows that start on an odd
-    2-byte boundary and end inside a row"""
-    import tdoa_amd
-    for n, ml in ((1_100_001, ML), (9_000_001, 5000)):
-        a = oracle.simulate_delayed_fm(n + 1, 0, 77, 1)[2:]
-        b = oracle.simulate_station("n3pay", n + 1, 5)[2:2 + 2 * n]
-        with tdoa_amd.Context(max_lag=ml, window_len=n) as c, tdoa_amd.Context(max_lag=ml, window_len=n) as q:
-            c.debug_flags(no_k1_once=not once)
-            q.debug_flags(no_k1_once=not once, no_k1_half=True)
-            la, lq = c.fm_xcorr_lags(a, b, ml), q.fm_xcorr_lags(a, b, ml)
-            assert c.last_k1(0)[1] == once and tuple(c.plan_info())[1:] == ((4096, 256) if n < 2_000_000 else (4096, 2048))
-            assert np.array_equal(la, lq) and la.any()
-            assert c.fm_xcorr(a, b, ml) == q.fm_xcorr(a, b, ml)
-            assert _stats_tuple(c.last_k1(1)[0]) == _stats_tuple(q.last_k1(1)[0])
