@@ -1203,6 +1203,11 @@ int tdoa_create(const tdoa_params *p, tdoa_ctx **out)
         }
         ctx->k1_quad.p = dq;
         ctx->k1_quad.cap = kK1QuadrantBytes;
+        if (hipMemcpy(dq, quad.data(), kK1QuadrantBytes, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(dt, direct.data(), kK1DirectBytes, hipMemcpyHostToDevice) != hipSuccess) {
+            tdoa_destroy(ctx);
+            return TDOA_ERR_HIP;
+        }
     }
     // run-time switches are read ONCE here (a captured graph must not depend on an environment that changes later)
     if (const char *e = std::getenv("TDOA_NO_GRAPH")) ctx->use_graph = !(e[0] == '1');
