@@ -341,20 +341,22 @@ __global__ __launch_bounds__(kDemodThreads) void k_once_edges(const SWDesc *sw, 
 }
 
 // ---- k_once_final ---------------------------------------------------------------------------------------------------
-// One wave per station-window adds its tiles' records (integers; any order gives the same bits) and evaluates the
+// One 256-thread workgroup per station-window adds its tiles' records (integers; any order gives the same bits) and evaluates the
 // statistics with the expressions of k_fm_stats_final, then eps and g against the (m0, s0) the column kernel used.
 // tiles: the records of tile (w, a, bx) at index ((w G + a) nbx + bx) 16 + wave, i.e. 16 tiles_per_sw consecutive records
 // per window (tiles_per_sw counts records here).
-__global__ __launch_bounds__(64) void k_once_final(const SWDesc *sw, const OnceTile *tiles, int tiles_per_sw, FmStats *stats,
-                                                   OnceFin *fin, int n_sw)
+__global__ __launch_bounds__(256) void k_once_final(const SWDesc *sw, const OnceTile *tiles, int tiles_per_sw, FmStats *stats,
+                                                    OnceFin *fin, int n_sw)
 {
 #pragma clang fp contract(off)
-    const int w = blockIdx.x, lane = threadIdx.x;
+    __shared__ long long red1[4];
+    __shared__ unsigned long long red2[4], red3[4];
+    const int w = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (w >= n_sw) return;
     const OnceTile *t = tiles + (size_t)w * tiles_per_sw;
     long long s1 = 0;
     unsigned long long hi = 0, lo = 0;
-    for (int k = lane; k < tiles_per_sw; k += kWave) {
+    for (int k = threadIdx.x; k < tiles_per_sw; k += 256) {
         s1 += (long long)t[k].s1;
         hi += (unsigned long long)t[k].q_hi;
         lo += (unsigned long long)t[k].q_lo;
@@ -365,7 +367,12 @@ __global__ __launch_bounds__(64) void k_once_final(const SWDesc *sw, const OnceT
         hi += __shfl_xor(hi, off, kWave);
         lo += __shfl_xor(lo, off, kWave);
     }
-    if (lane) return;
+    if (lane == 0) { red1[wv] = s1; red2[wv] = hi; red3[wv] = lo; }
+    __syncthreads();
+    if (threadIdx.x) return;
+    s1 = red1[0] + red1[1] + red1[2] + red1[3];
+    hi = red2[0] + red2[1] + red2[2] + red2[3];
+    lo = red3[0] + red3[1] + red3[2] + red3[3];
     // S1 = -(sum st) / 256; S2 = hi 2^26 + lo as a 128-bit integer
     const long long S1 = -(s1 / 256);
     const unsigned long long h_lo = hi << 26, h_hi = hi >> 38;

@@ -731,7 +731,7 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
     if (once) {
         // the tiles' exact sums -> the window statistics (bit-identical to the pre-pass's), eps and g of every station-window
         ProfScope ps(ctx, TDOA_K_STATS, sizeof(OnceTile) * (double)once_tiles_per_sw(pl) * n_sw);
-        hipLaunchKernelGGL(k_once_final, dim3(n_sw), dim3(64), 0, st, d_sw, once_tiles, once_tiles_per_sw(pl), stats,
+        hipLaunchKernelGGL(k_once_final, dim3(n_sw), dim3(256), 0, st, d_sw, once_tiles, once_tiles_per_sw(pl), stats,
                            static_cast<OnceFin *>(ctx->once_fin.p), n_sw);
     }
     // XCD-aware 1-D grid of the pair kernel when every window of the group carries the same `pairs_per_window` > S pairs
@@ -831,8 +831,12 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
             ProfScope ps(ctx, TDOA_K_INV_COL, 3.0 * 8.0 * (double)rc_pts * n_pw);
             hipLaunchKernelGGL(k_inv_rows_plain_r8, dim3(ps2.N2 / 2, n_pw), dim3(512), sizeof(float2) * 2 * kRow8Lds, st, g,
                                v + dec_edge_offset(pl, n_pw), vs, ps2, pl.N2);
-            hipLaunchKernelGGL(k_small_col_peak, dim3(ps2.N1 / 256, n_pw), dim3(256), 0, st, vs, d_keys, d_pw, ps2, lag_lo, lag_hi,
-                               np2, nn2, lag_dump, dump_scale, static_cast<const float *>(ctx->dec_gain.p), oc);
+            if (np2 == 3 && nn2 == 3)          // the reference's 20 000 lags on either small plan
+                hipLaunchKernelGGL((k_small_col_peak<3, 3>), dim3(ps2.N1 / 256, n_pw), dim3(256), 0, st, vs, d_keys, d_pw, ps2, lag_lo,
+                                   lag_hi, np2, nn2, lag_dump, dump_scale, static_cast<const float *>(ctx->dec_gain.p), oc);
+            else
+                hipLaunchKernelGGL((k_small_col_peak<0, 0>), dim3(ps2.N1 / 256, n_pw), dim3(256), 0, st, vs, d_keys, d_pw, ps2, lag_lo,
+                                   lag_hi, np2, nn2, lag_dump, dump_scale, static_cast<const float *>(ctx->dec_gain.p), oc);
         }
     } else if (n_pw) {
         {
