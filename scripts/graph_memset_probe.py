@@ -40,9 +40,9 @@ def part1(memset):
     labels = [ln for ln in txt.splitlines() if "label" in ln and "->" not in ln]
     edges = re.findall(r'->', txt)
     print("  dot file: %d node lines, %d edges" % (len(labels), len(edges)))
-    for ln in txt.splitlines():
-        if "memset" in ln.lower():
-            print("  memset node: %s" % ln.strip()[:600])
+    if os.path.exists(dot + ".memsets"):                  # hipGraphMemsetNodeGetParams of every memset node (tdoa_debug_graph_info)
+        for ln in open(dot + ".memsets").read().splitlines():
+            print("  " + ln)
     return info
 
 

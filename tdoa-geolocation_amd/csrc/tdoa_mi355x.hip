@@ -1997,8 +1997,26 @@ int tdoa_debug_graph_info(tdoa_ctx *ctx, int32_t info[4], const char *dot_path)
     info[1] = ctx->graph_edges;
     info[2] = ctx->graph_roots;
     info[3] = ctx->graph_memsets;
-    if (dot_path && dot_path[0])
+    if (dot_path && dot_path[0]) {
         HIPCHK(ctx, hipGraphDebugDotPrint(ctx->graph, dot_path, hipGraphDebugDotFlagsVerbose));
+        // the parameters of the memset nodes (probe builds only), read back from the graph itself: <dot_path>.memsets
+        size_t n_nodes = 0;
+        HIPCHK(ctx, hipGraphGetNodes(ctx->graph, nullptr, &n_nodes));
+        std::vector<hipGraphNode_t> nodes(n_nodes);
+        if (n_nodes) HIPCHK(ctx, hipGraphGetNodes(ctx->graph, nodes.data(), &n_nodes));
+        const std::string mp = std::string(dot_path) + ".memsets";
+        if (FILE *f = std::fopen(mp.c_str(), "w")) {
+            for (hipGraphNode_t nd : nodes) {
+                hipGraphNodeType ty;
+                hipMemsetParams mpz;
+                if (hipGraphNodeGetType(nd, &ty) == hipSuccess && ty == hipGraphNodeTypeMemset &&
+                    hipGraphMemsetNodeGetParams(nd, &mpz) == hipSuccess)
+                    std::fprintf(f, "memset node: dst %p elementSize %u width %zu height %zu pitch %zu value %u\n", mpz.dst,
+                                 mpz.elementSize, mpz.width, mpz.height, mpz.pitch, mpz.value);
+            }
+            std::fclose(f);
+        }
+    }
     return TDOA_OK;
 }
 
