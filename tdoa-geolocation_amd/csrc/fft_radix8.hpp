@@ -355,11 +355,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_
                 qa[sa1 + (DK / 16) * (it - 1)] = q;
                 qb[sb1 - (DK / 16) * (it - 1)] = qm;
             } else {
-                // (DK is a multiple of 16: the phase stays, the slot index moves by DK / 16 per trip; only the pad term is
-                // rebuilt -- slot_of from scratch cost 7 instructions per store in a kernel that issues 82 % of its time)
-                const int ia = (o0 >> 4) + 8 + (DK / 16) * it, ib = ((4096 - o0) >> 4) + 8 - (DK / 16) * it;
-                qa[(o0 & 15) * kDecPitch + ia + ((ia + 8) >> 4)] = q;
-                qb[((4096 - o0) & 15) * kDecPitch + ib + ((ib + 8) >> 4)] = qm;
+                // N2 = 512 (COLS = 8, DK = 64): the phase stays and the slot index moves by 4 per trip, across the pad slot
+                // that follows every 16 slots.  Where it crosses is known at compile time: with o0 = (t >> 3) + 512 (t & 7)
+                // the slot index of A is = t >> 7 (0..3) mod 16 once the pad's 8 is added, so (ia + 8) >> 4 steps up exactly
+                // at trip 4; B counts down from a slot that is 12..15 mod 16 -- one step down at trip 4 -- except for the
+                // threads t < 8 (0 mod 16: one step down from trip 1 on, a second one from trip 5 on).  Two bases and
+                // compile-time offsets instead of rebuilding the pad term per store (5 instructions x 14 stores).
+                static_assert(LOGN2 == 9 && COLS == 8 && DK == 64, "slot walk of the 4096 x 512 plan");
+                const int z = t < 8 ? 1 : 0;
+                qa[sa1 + 4 * (it - 1) + (it >= 4 ? 1 : 0)] = q;
+                qb[(it == 4 ? sb1 + z : sb1) - 4 * (it - 1) - (it >= 4 ? 1 : 0)] = qm;
             }
             w = cmul(w, rot);
         }
