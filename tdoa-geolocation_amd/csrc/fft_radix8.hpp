@@ -848,10 +848,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_
     fft8<true>(cy);
     rows2_r8_finish<true>(cx, cy, la, lb, t, t, t);
     const size_t pitch = 2 * P + 8;
-#pragma unroll
-    for (int o = 0; o < 4; o++) {
-        if (q.pw[o] < 0) continue;
-        float *part = reinterpret_cast<float *>(V + (size_t)q.pw[o] * pl.Nc) + (size_t)blockIdx.x * pitch;
+    // (the four outputs spelled out with their pair-window in a scalar: indexing q.pw[] with the loop variable of a loop that
+    // `continue`s kept the descriptor in 48 bytes of scratch)
+    auto emit = [&](int pwi, auto o_c) {
+        constexpr int o = decltype(o_c)::value;
+        if (pwi < 0) return;
+        float *part = reinterpret_cast<float *>(V + (size_t)pwi * pl.Nc) + (size_t)blockIdx.x * pitch;
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const int n = t + 512 * k;
@@ -860,7 +862,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_
             if (512 * k <= P && n <= P) part[P + n] = c;
             if (512 * (k + 1) > 4096 - P && n >= 4096 - P) part[n - (4096 - P)] = c;
         }
-    }
+    };
+    const int pw0 = q.pw[0], pw1 = q.pw[1], pw2 = q.pw[2], pw3 = q.pw[3];
+    emit(pw0, std::integral_constant<int, 0>{});
+    emit(pw1, std::integral_constant<int, 1>{});
+    emit(pw2, std::integral_constant<int, 2>{});
+    emit(pw3, std::integral_constant<int, 3>{});
 }
 
 // chunk sums in a fixed order -> lag array (kept for the sub-sample refinement: lags[li] = c[li - P], unscaled like the
