@@ -745,6 +745,28 @@ def roofline_fields(args, env, cfg_name, scaling, sim, table, prof_timed, domina
                         "valu_issue_frac = share of the kernel's time its SIMDs spend issuing vector instructions (SQ counters "
                         "in profiles/, same kernel sources): limiter = valu_issue when that share exceeds both 0.6 and the kernel's "
                         "share of the 5.8 TB/s a plain fill sustains"}
+    # every scope of the step next to the dominant one: HBM-side rate and issue share from the same counter files, times from
+    # the untimed kernel-by-kernel table (the dominant scope: from inside the timed region).  cfg2's two largest kernels are
+    # within 3 % of each other -- one at the HBM roof, one bound by instruction issue -- and which of them is "dominant"
+    # changes from box to box; this table shows both.
+    by_kernel = None
+    standard = args.seconds is None and args.batch == 0 and world == 1 and max_lag == 20000 and sim == "config"
+    if standard and hot:
+        by_kernel = []
+        for scope, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"]):
+            if not v["launches"] or scope not in hot:
+                continue
+            tr, _, _ = pmc_traffic(cfg_name, hot[scope])
+            sqk = sq_issue(cfg_name, hot[scope][0])
+            t_s = v["ms"] / v["launches"] / 1e3
+            gbps = None if tr is None else tr / t_s / 1e9
+            by_kernel.append({"scope": scope, "kernel": " + ".join(hot[scope]), "ms_per_step": round(v["ms"] / steps, 4),
+                              "timed": "inside the timed region" if scope == dominant else "untimed table",
+                              "hbm_GBps": None if gbps is None else round(gbps, 1),
+                              "frac": None if gbps is None else round(gbps / HBM_PEAK_GBS, 4),
+                              "valu_issue_frac": None if sqk is None else sqk["valu_issue_frac"],
+                              "limiter": None if (sqk is None or gbps is None) else
+                                         ("valu_issue" if sqk["valu_issue_frac"] > max(0.6, gbps / HBM_FILL_GBS) else "hbm")})
     # whole-pipeline algorithmic bytes: k = ceil(log2 N / 12) passes of 4096-point tiles, e = 4 B:
     # 2L + e N (2k - 1) per station-window, e N 2k per pair-window  (k = 2: 2L + 12N and 16N; k = 3: 2L + 20N and 24N)
     k_pass = max(2, math.ceil(math.log2(n_fft) / 12.0))
@@ -769,6 +791,7 @@ def roofline_fields(args, env, cfg_name, scaling, sim, table, prof_timed, domina
         # SURVEY.md 8d secondary figure: pair-samples correlated per second (P*W*L/t), whole job
         "pair_Msamples_per_s": round(samples_per_step / S * n_pairs / (dt / steps) / 1e6, 2),
         "roofline": roof,
+        "roofline_by_kernel": by_kernel,
     }
 
 
