@@ -183,3 +183,33 @@ def test_single_look_with_a_biased_estimate():
         la, lr = c.fm_xcorr_lags(a, b, ML), ref.fm_xcorr_lags(a, b, ML)
     assert got[0] == want[0] == 37 and abs(got[1] - want[1]) <= 2e-6 * abs(want[1])
     assert np.abs(la - lr).max() <= 4e-6 * np.abs(lr).max()
+
+
+def test_single_look_seeded_sweep(oracle):
+    """window lengths, search ranges (decimated inverse, full inverse where the filter does not fit, odd and even lengths)
+    and byte distributions drawn from a seed: peak identical and the whole lag array within 3e-6 of the pre-pass form's"""
+    import tdoa_amd
+    rng = np.random.default_rng(20260404)
+    for case in range(8):
+        n = int(rng.integers(1_050_000, 1_500_000))
+        ml = int(rng.choice([4096, 5000, 12345, 20000, 26000, 32000]))
+        delay = int(rng.integers(-ml + 2, ml - 1))
+        kind = case % 4
+        if kind == 0:
+            a, b = oracle.simulate_delayed_fm(n, max(0, -delay), 100 + case, 1), oracle.simulate_delayed_fm(n, max(0, delay), 100 + case, 2)
+        elif kind == 1:
+            st = [oracle.simulate_station(nm, n, oracle.SEED_BASE + 7 * case + i) for i, nm in enumerate(oracle.COLLECTORS[:2])]
+            a, b = st[0][:2 * n], st[1][:2 * n]
+        elif kind == 2:
+            a, b = (rng.integers(0, 256, size=2 * n, dtype=np.uint8) for _ in range(2))           # uniform random bytes
+        else:
+            a = oracle.simulate_delayed_fm(n, 0, 200 + case, 1)
+            b = np.roll(a.reshape(-1, 2), max(0, delay) % 1000, axis=0).reshape(-1).copy()      # a strong, exactly shifted copy
+        with tdoa_amd.Context(max_lag=ml, window_len=n) as c, tdoa_amd.Context(max_lag=ml, window_len=n) as ref:
+            ref.debug_flags(no_k1_once=True)
+            got, want = c.fm_xcorr(a, b, ml), ref.fm_xcorr(a, b, ml)
+            assert c.last_k1(0)[1] and not ref.last_k1(0)[1], (case, n, ml)
+            la, lr = c.fm_xcorr_lags(a, b, ml), ref.fm_xcorr_lags(a, b, ml)
+        assert got[0] == want[0], (case, n, ml, got, want)
+        assert abs(got[1] - want[1]) <= 3e-6 * abs(want[1]), (case, n, ml, got, want)
+        assert np.abs(la - lr).max() <= 3e-6 * np.abs(lr).max(), (case, n, ml)
