@@ -1,38 +1,33 @@
 #!/usr/bin/env python3
-"""Static instruction mix of the gfx950 kernels (no GPU needed): compiles tdoa_mi355x.hip to assembly and counts, per
-kernel, the vector / packed-vector / LDS / global / scratch instructions.   usage: scripts/isa_mix.py [regex]"""
+"""Instruction mix of the hot kernels from a --save-temps gfx950 .s file (static counts, whole kernel body):
+   python3 scripts/isa_mix.py /tmp/isa/tdoa_mi355x-hip-amdgcn-amd-amdhsa-gfx950.s [name-substring ...]"""
 import collections
-import os
 import re
-import subprocess
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "tdoa-geolocation_amd", "csrc", "tdoa_mi355x.hip")
-OUT = "/tmp/tdoa_isa.s"
+HOT = ("k_fwd_col256_k1ILb0ELb1", "k_pair_decimate16", "k_fwd_row4096_unpack", "k_inv_rows_plain_r8", "k_small_col_peak", "k_once_edges")
 
 
 def main():
-    pat = re.compile(sys.argv[1] if len(sys.argv) > 1 else ".")
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
-                           "-o", OUT, SRC], stderr=subprocess.DEVNULL)
-    txt = open(OUT).read()
-    for f in re.split(r"\n(?=_Z\w+:)", txt):
-        m = re.match(r"(_Z\w+):", f)
-        if not m or "k_" not in m.group(1) or not pat.search(m.group(1)):
+    txt = open(sys.argv[1]).read()
+    want = sys.argv[2:] or HOT
+    parts = re.split(r"\n(_Z\w+): *;[^\n]*\n", txt)
+    for i in range(1, len(parts), 2):
+        name, body = parts[i], parts[i + 1].split("s_endpgm")[0]
+        if not any(k in name for k in want):
             continue
-        body = f.split(".end_amdhsa_kernel")[0]
-        ins = []
+        c, top = collections.Counter(), collections.Counter()
         for line in body.split("\n"):
-            s = line.strip()
-            if not line.startswith("\t") or not s or s[0] in ".;":
+            t = line.strip()
+            if not line.startswith("\t") or not t or t[0] in ".;":
                 continue
-            ins.append(s.split()[0])
-        c = collections.Counter(ins)
-        tot = lambda p: sum(v for k, v in c.items() if k.startswith(p))
-        print("%-100s valu %5d pk %4d ds %4d glob %4d scratch %3d salu %4d" % (
-            m.group(1)[:100], tot("v_"), tot("v_pk_"), tot("ds_"), tot("global_") + tot("buffer_") + tot("flat_"),
-            tot("scratch_"), tot("s_")))
+            op = t.split()[0]
+            top[op] += 1
+            c["v_pk" if op.startswith("v_pk_") else "valu" if op.startswith("v_") else "lds" if op.startswith("ds_") else
+              "salu" if op.startswith("s_") else "vmem" if op.startswith(("global_", "buffer_", "flat_", "scratch_")) else "other"] += 1
+        print(name[:90])
+        print("   ", dict(c))
+        print("   ", ", ".join("%s %d" % kv for kv in top.most_common(24)))
 
 
 if __name__ == "__main__":

@@ -89,6 +89,60 @@ __device__ __forceinline__ int code_at(const int *row, unsigned byte_off)
     return *reinterpret_cast<const int *>(reinterpret_cast<const char *>(row) + byte_off);
 }
 
+// a station-window's normalisation in the segment kernels: two instructions per code (v_cvt_f32_i32 + v_fma_f32)
+struct SegNorm {
+    float ns, ns_unit, off;
+    __device__ __forceinline__ SegNorm(const FmStats &st, float unit)
+    {
+#pragma clang fp contract(off)
+        ns = -st.scale;
+        ns_unit = ns * unit;
+        off = -(st.mean * st.scale);
+    }
+    __device__ __forceinline__ float fast(int raw) const { return __builtin_fmaf((float)raw, ns_unit, off); }     // raw in units of `unit`
+    __device__ __forceinline__ float plain(int stored) const { return __builtin_fmaf((float)stored, ns, off); }
+};
+
+// a segment kernel's view of a code row: int32 codes (4 bytes) or packed ones (3 bytes, k1_store8_packed)
+template <bool PACK3>
+struct SegCodes {
+    static constexpr unsigned int kBytes = PACK3 ? 3u : 4u;
+    const unsigned char *row;
+    __device__ __forceinline__ SegCodes(const int *codes, int sw_index, long long code_stride)
+        : row(reinterpret_cast<const unsigned char *>(codes) + (size_t)kBytes * (size_t)sw_index * (size_t)code_stride) {}
+    // code at a 32-bit unsigned BYTE offset (= kBytes x sample index) from the uniform row pointer
+    __device__ __forceinline__ int at(unsigned int byte_off) const
+    {
+        return PACK3 ? k1_code3_at(row, byte_off) : code_at(reinterpret_cast<const int *>(row), byte_off);
+    }
+    __device__ __forceinline__ int operator[](int i) const { return at(kBytes * (unsigned int)i); }
+    // The fast path of a frame: the four lanes of a quad want four CONSECUTIVE codes whose first index is a multiple of 4 --
+    // on packed rows three aligned dwords W0 W1 W2.  Lane q loads W[min(q, 2)], takes its left neighbour's dword by DPP
+    // (lane 0: its own) and one v_perm_b32 puts the three bytes of its code (bytes 3 q .. 3 q + 2 of W2:W1:W0) above a zero
+    // byte: 256 x code, sign in place -- the factor goes into the window's scale (unit()).  One aligned, coalesced load + two
+    // vector instructions per code.  (A lane-private unaligned dword load at 3 i, the obvious form, made the quad kernel
+    // 13 % slower than int32 rows; DPP + v_alignbit + v_bfe 8 % slower: the kernel is short of issue slots, not of bytes.)
+    //   lane_off(t) = 12 (t >> 2) + 4 min(t & 3, 2)  [+ 3 x first sample of the frame, + 1536 per row of 512 positions]
+    //   lane_sel(t): v_perm selector, bytes 0-3 = the neighbour's dword, 4-7 = the lane's own, 0x0c = zero
+    static constexpr float kUnit = PACK3 ? 1.0f / 256.0f : 1.0f;        // what quad_at's value counts in
+    __device__ static __forceinline__ unsigned int lane_off(int t)
+    {
+        return PACK3 ? 12u * (unsigned int)(t >> 2) + 4u * (unsigned int)((t & 3) < 2 ? (t & 3) : 2) : 4u * (unsigned int)t;
+    }
+    __device__ static __forceinline__ unsigned int lane_sel(int t)
+    {
+        const int q = t & 3;
+        return q == 0 ? 0x0201000cu : q == 1 ? 0x0504030cu : q == 2 ? 0x0403020cu : 0x0302010cu;
+    }
+    __device__ __forceinline__ int quad_at(unsigned int off, unsigned int sel) const
+    {
+        const int w = code_at(reinterpret_cast<const int *>(row), off);
+        if (!PACK3) return w;
+        const int left = __builtin_amdgcn_mov_dpp(w, 0x90, 0xf, 0xf, true);          // quad_perm [0, 0, 1, 2]
+        return (int)__builtin_amdgcn_perm((unsigned int)w, (unsigned int)left, sel);
+    }
+};
+
 constexpr int kRow8Lds = 4096;       // float2 per row image (no padding)
 
 // Stages 2..4 of TWO 4096-point row transforms side by side (row x through image la, row y through lb), whose
@@ -648,7 +702,7 @@ __global__ __launch_bounds__(256) void k_small_col_peak(const float2 *V, unsigne
 // c, c + n_chunks, ...; its 2P + 1 lag sums (d = -P .. P) go to part[pw][c][2P + 8] (floats, at V + pw * Nc),
 // k_segments_reduce adds the chunks in a fixed order.
 // ---------------------------------------------------------------------------
-template <int PQ>
+template <int PQ, bool PACK3>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_PLAIN_DS_OPS)) void k_xcorr_segments(const SWDesc *sw, const PWDesc *pw, const int *codes, long long code_stride, const FmStats *stats, float2 *V, FftPlan pl, int n_chunks)
 {
     constexpr int P = 256 * PQ, H = 4096 - 2 * P;
@@ -657,9 +711,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_
     const int t = threadIdx.x;
     const PWDesc d = pw[blockIdx.y];
     const int len_t = sw[d.sw_a].len, len_s = sw[d.sw_b].len;
-    const int *ct = codes + (size_t)d.sw_a * code_stride, *cs = codes + (size_t)d.sw_b * code_stride;
-    const float mean_t = stats[d.sw_a].mean, scale_t = stats[d.sw_a].scale;
-    const float mean_s = stats[d.sw_b].mean, scale_s = stats[d.sw_b].scale;
+    const SegCodes<PACK3> ct(codes, d.sw_a, code_stride), cs(codes, d.sw_b, code_stride);
+    // (float(code) - mean) scale as ONE fma on the stored (negated) code: stored x (-scale) + (-mean scale); the fast
+    // path's values count in SegCodes::kUnit (packed rows: 256 x code, a power of two that goes into the factor exactly)
+    const SegNorm nt(stats[d.sw_a], SegCodes<PACK3>::kUnit), ns(stats[d.sw_b], SegCodes<PACK3>::kUnit);
     const int n_seg = (len_t + H - 1) / H, len_min = len_t < len_s ? len_t : len_s;
     // forward stage roots of this thread, once (6 VGPRs instead of three root evaluations per trip)
     const float2 w2 = unit_root((float)(t & 7), 2.0f / 64.0f, false), w3 = unit_root((float)(t & 63), 2.0f / 512.0f, false),
@@ -679,13 +734,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_
             // both frames lie inside both windows (all but the first and last trips): no bounds checks; the template
             // part of a frame is the positions [P, P + H): whole values r of every thread, except that with P = 256
             // the band starts and ends in the middle of r = 0 and r = 7
+            constexpr unsigned kB = SegCodes<PACK3>::kBytes;
+            const unsigned bo = kB * (unsigned)(s0 * H - P) + SegCodes<PACK3>::lane_off(t), sh = SegCodes<PACK3>::lane_sel(t);
 #pragma unroll
             for (int r = 0; r < 8; r++) {
                 const bool tpos = t + 512 * r >= P && t + 512 * r < P + H;
-                const int a0 = tpos ? (int)ct[i0 + 512 * r] : 0, b0 = cs[i0 + 512 * r];
-                const int a1 = tpos ? (int)ct[i1 + 512 * r] : 0, b1 = cs[i1 + 512 * r];
-                x[r] = make_float2(tpos ? k1_normalise(a0, mean_t, scale_t) : 0.0f, k1_normalise(b0, mean_s, scale_s));
-                y[r] = make_float2(tpos ? k1_normalise(a1, mean_t, scale_t) : 0.0f, k1_normalise(b1, mean_s, scale_s));
+                const int a0 = tpos ? ct.quad_at(bo + 512u * kB * r, sh) : 0, b0 = cs.quad_at(bo + 512u * kB * r, sh);
+                const int a1 = tpos ? ct.quad_at(bo + kB * H + 512u * kB * r, sh) : 0, b1 = cs.quad_at(bo + kB * H + 512u * kB * r, sh);
+                x[r] = make_float2(tpos ? nt.fast(a0) : 0.0f, ns.fast(b0));
+                y[r] = make_float2(tpos ? nt.fast(a1) : 0.0f, ns.fast(b1));
             }
         } else {
             const bool odd_ok = s0 + 1 < n_seg;     // the odd segment of the last pair may not exist: then BOTH its
@@ -698,14 +755,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_
                 {
                     const int i = i0 + 512 * r;
                     const bool in_t = tpos && i < len_t, in_s = i >= 0 && i < len_s;
-                    const int qt = in_t ? (int)ct[i] : 0, qs = in_s ? (int)cs[i] : 0;
-                    x[r] = make_float2(in_t ? k1_normalise(qt, mean_t, scale_t) : 0.0f, in_s ? k1_normalise(qs, mean_s, scale_s) : 0.0f);
+                    const int qt = in_t ? ct[i] : 0, qs = in_s ? cs[i] : 0;
+                    x[r] = make_float2(in_t ? nt.plain(qt) : 0.0f, in_s ? ns.plain(qs) : 0.0f);
                 }
                 {
                     const int i = i1 + 512 * r;
                     const bool in_t = tpos && i < len_t, in_s = odd_ok && i >= 0 && i < len_s;
-                    const int qt = in_t ? (int)ct[i] : 0, qs = in_s ? (int)cs[i] : 0;
-                    y[r] = make_float2(in_t ? k1_normalise(qt, mean_t, scale_t) : 0.0f, in_s ? k1_normalise(qs, mean_s, scale_s) : 0.0f);
+                    const int qt = in_t ? ct[i] : 0, qs = in_s ? cs[i] : 0;
+                    y[r] = make_float2(in_t ? nt.plain(qt) : 0.0f, in_s ? ns.plain(qs) : 0.0f);
                 }
             }
         }
@@ -764,7 +821,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_
 // subtracted between accumulators (the pair form's A[k] - A[-k] is gone).
 // grid (n_chunks, n_quads), 512 threads, dynamic LDS 64 KB; chunk c takes the segments c, c + n_chunks, ...; output
 // layout as above, one part row per wanted pair-window.
-template <int PQ>
+template <int PQ, bool PACK3>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_PLAIN_DS_OPS)) void k_xcorr_segments_quad(const SWDesc *sw, const QuadDesc *quads, const int *codes, long long code_stride, const FmStats *stats, float2 *V, FftPlan pl, int n_chunks)
 {
     constexpr int P = 256 * PQ, H = 4096 - 2 * P;
@@ -775,10 +832,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_
     const bool has_b = q.sw_tb >= 0, has_d = q.sw_sd >= 0;
     const int ia = q.sw_ta, ib = has_b ? q.sw_tb : q.sw_ta, ic = q.sw_sc, id = has_d ? q.sw_sd : q.sw_sc;
     const int len_a = sw[ia].len, len_b = has_b ? sw[ib].len : 0, len_c = sw[ic].len, len_d = has_d ? sw[id].len : 0;
-    const int *ca = codes + (size_t)ia * code_stride, *cb = codes + (size_t)ib * code_stride;
-    const int *cc = codes + (size_t)ic * code_stride, *cd = codes + (size_t)id * code_stride;
-    const float mean_a = stats[ia].mean, scale_a = stats[ia].scale, mean_b = stats[ib].mean, scale_b = stats[ib].scale;
-    const float mean_c = stats[ic].mean, scale_c = stats[ic].scale, mean_d = stats[id].mean, scale_d = stats[id].scale;
+    const SegCodes<PACK3> ca(codes, ia, code_stride), cb(codes, ib, code_stride), cc(codes, ic, code_stride), cd(codes, id, code_stride);
+    const SegNorm na(stats[ia], SegCodes<PACK3>::kUnit), nb(stats[ib], SegCodes<PACK3>::kUnit), nc(stats[ic], SegCodes<PACK3>::kUnit),
+        nd(stats[id], SegCodes<PACK3>::kUnit);
     const int len_t = len_a > len_b ? len_a : len_b, n_seg = (len_t + H - 1) / H;
     int len_min = len_a < len_c ? len_a : len_c;
     len_min = len_min < len_b ? len_min : len_b;
@@ -796,14 +852,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_
         if (s0 * H - P >= 0 && s0 * H - P + 4096 <= len_min) {
             // uniform row pointer (SGPR pair) + unsigned 32-bit byte offset of the lane: one offset register serves all
             // four streams, where signed sample indices would cost a 64-bit address pair per stream and position
-            const unsigned bo = 4u * (unsigned)i0;
+            constexpr unsigned kB = SegCodes<PACK3>::kBytes;
+            const unsigned bo = kB * (unsigned)(s0 * H - P) + SegCodes<PACK3>::lane_off(t), sh = SegCodes<PACK3>::lane_sel(t);
 #pragma unroll
             for (int r = 0; r < 8; r++) {
                 const bool tpos = t + 512 * r >= P && t + 512 * r < P + H;
-                const int a0 = tpos ? code_at(ca, bo + 2048u * r) : 0, b0 = tpos ? code_at(cb, bo + 2048u * r) : 0;
-                const int c0 = code_at(cc, bo + 2048u * r), d0 = code_at(cd, bo + 2048u * r);
-                x[r] = make_float2(tpos ? k1_normalise(a0, mean_a, scale_a) : 0.0f, tpos ? k1_normalise(b0, mean_b, scale_b) : 0.0f);
-                y[r] = make_float2(k1_normalise(c0, mean_c, scale_c), k1_normalise(d0, mean_d, scale_d));
+                const int a0 = tpos ? ca.quad_at(bo + 512u * kB * r, sh) : 0, b0 = tpos ? cb.quad_at(bo + 512u * kB * r, sh) : 0;
+                const int c0 = cc.quad_at(bo + 512u * kB * r, sh), d0 = cd.quad_at(bo + 512u * kB * r, sh);
+                x[r] = make_float2(tpos ? na.fast(a0) : 0.0f, tpos ? nb.fast(b0) : 0.0f);
+                y[r] = make_float2(nc.fast(c0), nd.fast(d0));
             }
         } else {
 #pragma unroll
@@ -812,9 +869,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_
                 const int i = i0 + 512 * r;
                 const bool in_a = tpos && i < len_a, in_b = tpos && i < len_b;
                 const bool in_c = i >= 0 && i < len_c, in_d = i >= 0 && i < len_d;
-                const int qa = in_a ? (int)ca[i] : 0, qb = in_b ? (int)cb[i] : 0, qc = in_c ? (int)cc[i] : 0, qd = in_d ? (int)cd[i] : 0;
-                x[r] = make_float2(in_a ? k1_normalise(qa, mean_a, scale_a) : 0.0f, in_b ? k1_normalise(qb, mean_b, scale_b) : 0.0f);
-                y[r] = make_float2(in_c ? k1_normalise(qc, mean_c, scale_c) : 0.0f, in_d ? k1_normalise(qd, mean_d, scale_d) : 0.0f);
+                const int qa = in_a ? ca[i] : 0, qb = in_b ? cb[i] : 0, qc = in_c ? cc[i] : 0, qd = in_d ? cd[i] : 0;
+                x[r] = make_float2(in_a ? na.plain(qa) : 0.0f, in_b ? nb.plain(qb) : 0.0f);
+                y[r] = make_float2(in_c ? nc.plain(qc) : 0.0f, in_d ? nd.plain(qd) : 0.0f);
             }
         }
         fft8<false>(x);

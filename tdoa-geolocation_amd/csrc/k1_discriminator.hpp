@@ -308,6 +308,37 @@ __device__ __forceinline__ void k1_store8(int *dst, const int (&c)[8])
     reinterpret_cast<int4 *>(dst)[1] = make_int4(c[4], c[5], c[6], c[7]);
 }
 
+// The same 8 codes as 24 bytes (PACKED code rows, round 4: the segment form's array -- a stored code has 24 significant
+// bits, and that consumer reads every code once or twice, so the fourth byte was a quarter of both kernels' traffic).
+// Code i of a row lives at bytes [3 i, 3 i + 3), little-endian; a reader loads the (unaligned) dword at 3 i and keeps its
+// low 24 bits sign-extended (k1_code3_at).  dst is 8-byte aligned: rows start on multiples of 24 bytes and a thread's 8
+// codes at a multiple of 8 codes.
+__device__ __forceinline__ void k1_store8_packed(unsigned char *dst, const int (&c)[8])
+{
+    unsigned int w[6];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const unsigned int a = (unsigned int)c[4 * h] & 0xffffffu, b = (unsigned int)c[4 * h + 1] & 0xffffffu,
+                           d = (unsigned int)c[4 * h + 2] & 0xffffffu, e = (unsigned int)c[4 * h + 3];
+        w[3 * h] = a | (b << 24);
+        w[3 * h + 1] = (b >> 8) | (d << 16);
+        w[3 * h + 2] = (d >> 16) | (e << 8);
+    }
+    reinterpret_cast<uint2 *>(dst)[0] = make_uint2(w[0], w[1]);
+    reinterpret_cast<uint2 *>(dst)[1] = make_uint2(w[2], w[3]);
+    reinterpret_cast<uint2 *>(dst)[2] = make_uint2(w[4], w[5]);
+}
+
+// stored code at byte offset `off` (= 3 i) of a packed row: one global_load_dword (SGPR row base + 32-bit lane offset; the
+// unaligned access mode of HSA queues) + v_bfe_i32.  The dword of a row's last code ends one byte past the row: inside
+// the allocation (rows are followed by another row or by the array's slack).
+typedef int __attribute__((aligned(1))) k1_unaligned_int;
+__device__ __forceinline__ int k1_code3_at(const unsigned char *row, unsigned int off)
+{
+    const int v = *reinterpret_cast<const k1_unaligned_int *>(row + off);
+    return (int)((unsigned int)v << 8) >> 8;
+}
+
 // wave sums of a thread's (s1, s2) -> block sums -> the window's accumulators; 256-thread kernels
 __device__ __forceinline__ void k1_block_stats_256(long long s1, unsigned long long s2, StatsPartial *acc)
 {
@@ -360,10 +391,11 @@ __global__ __launch_bounds__(256) void k_k1_envelope(const SWDesc *sw, const uns
 // work items round-robin.  Window sums go straight into per-window integer accumulators with atomic adds: exact,
 // hence independent of arrival order.
 // WRITE = false: the statistics pre-pass of the fused path -- capture bytes in, three atomics per 65536 samples out.
-// WRITE = true: also the stored codes, codes[n_sw][code_stride] int32, code_stride a multiple of 8.
+// WRITE = true: also the stored codes, codes[n_sw][code_stride] int32, code_stride a multiple of 8; PACK3: the same rows
+// at 3 bytes per code (k1_store8_packed; row w starts at byte 3 code_stride w of `codes`).
 // acc: [n_sw], zeroed before the launch.  power: nullptr, or the windows' power sums (optional gate: windows in the
 // envelope class are skipped here).
-template <bool WRITE>
+template <bool WRITE, bool PACK3 = false>
 __global__ __launch_bounds__(kDemodThreads) void k_fm_demod(const SWDesc *sw, int n_sw, int pieces_per_window,
                                                             const int *dtable, int *codes, long long code_stride,
                                                             StatsPartial *acc, const unsigned long long *power)
@@ -387,7 +419,8 @@ __global__ __launch_bounds__(kDemodThreads) void k_fm_demod(const SWDesc *sw, in
         const int len = d.len;
         if (power && k1_envelope_class(power[w], len)) continue;      // power gate on: k_k1_envelope has this window
         const gptr16 p = k1_global(d.base);
-        int *out = WRITE ? codes + (size_t)w * code_stride : nullptr;
+        int *out = WRITE && !PACK3 ? codes + (size_t)w * code_stride : nullptr;
+        unsigned char *out3 = PACK3 ? reinterpret_cast<unsigned char *>(codes) + 3 * (size_t)w * (size_t)code_stride : nullptr;
         long long s1 = 0;
         unsigned long long s2 = 0;
         for (int piece = run * kDemodItem + wv; piece < (run + 1) * kDemodItem; piece += kDemodThreads / kWave) {
@@ -424,7 +457,8 @@ __global__ __launch_bounds__(kDemodThreads) void k_fm_demod(const SWDesc *sw, in
                         const double cd = (double)c[k];
                         t2 = __builtin_fma(cd, cd, t2);
                     }
-                    if (WRITE) k1_store8(out + start + h * 512 + lane * 8, c);
+                    if (PACK3) k1_store8_packed(out3 + 3 * (size_t)(start + h * 512 + lane * 8), c);
+                    else if (WRITE) k1_store8(out + start + h * 512 + lane * 8, c);
                 }
                 s1 += t1;
                 s2 += (unsigned long long)t2;
@@ -450,7 +484,8 @@ __global__ __launch_bounds__(kDemodThreads) void k_fm_demod(const SWDesc *sw, in
                             s2 += (unsigned long long)((long long)v * v);
                         }
                     }
-                    if (WRITE) k1_store8(out + i0, c);
+                    if (PACK3) k1_store8_packed(out3 + 3 * (size_t)i0, c);
+                    else if (WRITE) k1_store8(out + i0, c);
                 }
             }
         }

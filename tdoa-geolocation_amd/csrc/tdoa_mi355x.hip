@@ -98,6 +98,7 @@ struct tdoa_ctx {
     bool segment_quads = true;              // TDOA_NO_SEGMENT_QUADS=1: segment form one pair-window at a time (no shared station transforms)
     bool memset_nodes = false;              // TDOA_DEBUG_MEMSET_NODES=1 (probe only): zero the step's accumulators with
                                             // hipMemsetAsync nodes instead of k_zero_u64 kernel nodes
+    bool seg_pack3 = true;                  // TDOA_NO_SEG_PACK3=1: the segment form reads int32 code rows (round 3's layout)
     int seg_chunks_override = 0;            // TDOA_SEG_CHUNKS=n at tdoa_create time: chunk count of the segment form
     int graph_nodes = 0, graph_edges = 0, graph_roots = 0, graph_memsets = 0;      // structure of the captured step (tdoa_debug_graph_info)
     bool fused_k1 = true;                   // TDOA_NO_FUSED_K1=1: K1 always materialises its codes (no discriminator inside the column kernels)
@@ -373,8 +374,10 @@ void zero_partials(hipStream_t st, StatsPartial *partials, int n_sw, bool memset
 // kernels evaluate the discriminator themselves).
 // Optional steps (tdoa_params): k1_gate -- the prebuilt binary's power gate (windows of mean power <= 0.01 get envelope
 // codes instead of phase codes); k1_smooth -- its moving average on the discriminator output.  Both need the codes.
+// pack3: the codes go to memory at 3 bytes each (k1_store8_packed; only the segment kernels read that layout, so it is
+// never combined with k1_gate / k1_smooth, whose kernels work on int32 rows).
 int *launch_k1(tdoa_ctx *ctx, hipStream_t st, const SWDesc *d_sw, int n_sw, int maxlen, int pieces, long long code_stride,
-               bool materialise)
+               bool materialise, bool pack3 = false)
 {
     auto *partials = static_cast<StatsPartial *>(ctx->partials.p);
     auto *stats = static_cast<FmStats *>(ctx->stats.p);
@@ -390,7 +393,10 @@ int *launch_k1(tdoa_ctx *ctx, hipStream_t st, const SWDesc *d_sw, int n_sw, int 
     zero_partials(st, partials, n_sw, ctx->memset_nodes);
     const long long items = (long long)((pieces + kDemodItem - 1) / kDemodItem) * n_sw;      // workgroup items
     const int blocks = (int)std::max<long long>(1, std::min<long long>(items, ctx->n_cu));        // one workgroup per CU (128 KB table)
-    if (materialise)
+    if (materialise && pack3)
+        hipLaunchKernelGGL((k_fm_demod<true, true>), dim3(blocks), dim3(kDemodThreads), kK1DirectBytes, st, d_sw, n_sw, pieces, table,
+                           codes, code_stride, partials, power);
+    else if (materialise)
         hipLaunchKernelGGL(k_fm_demod<true>, dim3(blocks), dim3(kDemodThreads), kK1DirectBytes, st, d_sw, n_sw, pieces, table,
                            codes, code_stride, partials, power);
     else
@@ -631,6 +637,8 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
             if (cost(c) <= 1.03 * best) seg_chunks = c;
         if (ctx->seg_chunks_override > 0) seg_chunks = std::max(1, std::min({ctx->seg_chunks_override, trips, pl.N2 / 2 - 1}));
     }
+    // its code rows at 3 bytes per code (round 4; the gate and the smoother work on int32 rows)
+    const bool seg_pack3 = seg_chunks > 0 && ctx->seg_pack3 && !ctx->prm.k1_gate && ctx->prm.k1_smooth <= 1;
     const bool fused_k1 = fused_k1_applies(ctx, pl, lag_lo, lag_hi, n_pw, allow_fused_k1);
     // single-look K1 (k1_single_look.hpp): no statistics pre-pass.  Needs windows of one length, the peak picked by
     // k_small_col_peak or a pruned column kernel, and head / tail runs of K samples that do not meet.
@@ -659,8 +667,8 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
     } else {
         // K1: capture bytes -> exact window statistics (fused: nothing else; the column pass evaluates the discriminator
         // itself) and, materialised, the 24-bit phase codes as int32
-        ProfScope ps(ctx, TDOA_K_STATS, (fused_k1 ? 2.0 : 6.0) * sum_len);
-        codes = launch_k1(ctx, st, d_sw_stats ? d_sw_stats : d_sw, n_sw, maxlen, pieces, code_stride, !fused_k1);
+        ProfScope ps(ctx, TDOA_K_STATS, (fused_k1 ? 2.0 : seg_pack3 ? 5.0 : 6.0) * sum_len);
+        codes = launch_k1(ctx, st, d_sw_stats ? d_sw_stats : d_sw, n_sw, maxlen, pieces, code_stride, !fused_k1, seg_pack3);
     }
     const size_t lds_col = sizeof(float2) * 2 * (size_t)pl.N2 * pl.C;
     const size_t lds_row = sizeof(float2) * 2 * (size_t)pl.N1;
@@ -765,17 +773,23 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
         const double frames = (double)((maxlen + hop - 1) / hop);
         const float mul = (float)(4.0 * 2.0 * (double)pl.Nc / 4096.0);          // 4 N / M
         const size_t lds_seg = sizeof(float2) * 2 * kRow8Lds;
-#define TDOA_SEGMENTS(PQ)                                                                                            \
+        const double code_bytes = seg_pack3 ? 3.0 : 4.0;
+#define TDOA_SEGMENTS_AS(PQ, PACK)                                                                                   \
     do {                                                                                                             \
         if (seg_quads) {                                                                                             \
-            ProfScope ps(ctx, TDOA_K_INV_ROW, 4.0 * 4.0 * 4096.0 * frames * n_quads);  /* four frames of 4-byte codes */ \
-            hipLaunchKernelGGL(k_xcorr_segments_quad<PQ>, dim3(seg_chunks, n_quads), dim3(512), lds_seg, st, d_sw,    \
+            ProfScope ps(ctx, TDOA_K_INV_ROW, 4.0 * code_bytes * 4096.0 * frames * n_quads);  /* four frames of codes */ \
+            hipLaunchKernelGGL((k_xcorr_segments_quad<PQ, PACK>), dim3(seg_chunks, n_quads), dim3(512), lds_seg, st, d_sw, \
                                d_quads, codes, code_stride, stats, v, pl, seg_chunks);                               \
         } else {                                                                                                     \
-            ProfScope ps(ctx, TDOA_K_INV_ROW, 2.0 * 4.0 * 4096.0 * frames * n_pw);   /* two frames of 4-byte codes */  \
-            hipLaunchKernelGGL(k_xcorr_segments<PQ>, dim3(seg_chunks, n_pw), dim3(512), lds_seg, st, d_sw, d_pw, codes, \
+            ProfScope ps(ctx, TDOA_K_INV_ROW, 2.0 * code_bytes * 4096.0 * frames * n_pw);   /* two frames of codes */  \
+            hipLaunchKernelGGL((k_xcorr_segments<PQ, PACK>), dim3(seg_chunks, n_pw), dim3(512), lds_seg, st, d_sw, d_pw, codes, \
                                code_stride, stats, v, pl, seg_chunks);                                               \
         }                                                                                                            \
+    } while (0)
+#define TDOA_SEGMENTS(PQ)                                                                                            \
+    do {                                                                                                             \
+        if (seg_pack3) TDOA_SEGMENTS_AS(PQ, true);                                                                   \
+        else TDOA_SEGMENTS_AS(PQ, false);                                                                            \
         {                                                                                                            \
             ProfScope ps(ctx, TDOA_K_INV_COL, 4.0 * 512.0 * PQ * (seg_chunks + 1) * n_pw);                            \
             hipLaunchKernelGGL(k_segments_reduce<PQ>, dim3(2 * PQ + 1, n_pw), dim3(256), 0, st, v, d_keys, d_pw, pl,  \
@@ -790,6 +804,7 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
         else if (seg_pq == 2) TDOA_SEGMENTS(2);
         else TDOA_SEGMENTS(4);
 #undef TDOA_SEGMENTS
+#undef TDOA_SEGMENTS_AS
     } else if (n_pw && decim) {
         // decimated inverse: K3 + FIR decimation of the pair's spectrum (one read of the two station spectra), then the
         // R = Nc/16-point inverse on the small plan (rows, pruned column pass with the window divided out, K5)
@@ -949,12 +964,19 @@ int allow_big_lds(tdoa_ctx *ctx)
     if ((rc = set_lds(ctx, k_inv_row_pair4096<true, 4>, all))) return rc;
     if ((rc = set_lds(ctx, k_inv_row_pair4096<false, 8>, all))) return rc;
     if ((rc = set_lds(ctx, k_inv_row_pair4096<true, 8>, all))) return rc;
-    if ((rc = set_lds(ctx, k_xcorr_segments<1>, all))) return rc;
-    if ((rc = set_lds(ctx, k_xcorr_segments<2>, all))) return rc;
-    if ((rc = set_lds(ctx, k_xcorr_segments<4>, all))) return rc;
-    if ((rc = set_lds(ctx, k_xcorr_segments_quad<1>, all))) return rc;
-    if ((rc = set_lds(ctx, k_xcorr_segments_quad<2>, all))) return rc;
-    if ((rc = set_lds(ctx, k_xcorr_segments_quad<4>, all))) return rc;
+    if ((rc = set_lds(ctx, (k_fm_demod<true, true>), all))) return rc;
+    if ((rc = set_lds(ctx, (k_xcorr_segments<1, false>), all))) return rc;
+    if ((rc = set_lds(ctx, (k_xcorr_segments<2, false>), all))) return rc;
+    if ((rc = set_lds(ctx, (k_xcorr_segments<4, false>), all))) return rc;
+    if ((rc = set_lds(ctx, (k_xcorr_segments_quad<1, false>), all))) return rc;
+    if ((rc = set_lds(ctx, (k_xcorr_segments_quad<2, false>), all))) return rc;
+    if ((rc = set_lds(ctx, (k_xcorr_segments_quad<4, false>), all))) return rc;
+    if ((rc = set_lds(ctx, (k_xcorr_segments<1, true>), all))) return rc;
+    if ((rc = set_lds(ctx, (k_xcorr_segments<2, true>), all))) return rc;
+    if ((rc = set_lds(ctx, (k_xcorr_segments<4, true>), all))) return rc;
+    if ((rc = set_lds(ctx, (k_xcorr_segments_quad<1, true>), all))) return rc;
+    if ((rc = set_lds(ctx, (k_xcorr_segments_quad<2, true>), all))) return rc;
+    if ((rc = set_lds(ctx, (k_xcorr_segments_quad<4, true>), all))) return rc;
     if ((rc = set_lds(ctx, k_pair_decimate16<8>, all))) return rc;
     if ((rc = set_lds(ctx, k_pair_decimate16<9>, all))) return rc;
     if ((rc = set_lds(ctx, k_inv_rows_plain_r8, all))) return rc;
@@ -1225,6 +1247,7 @@ int tdoa_create(const tdoa_params *p, tdoa_ctx **out)
         ctx->zpad = v < 0 ? 0 : v > 4096 ? 4096 : v & ~15;      // rows stay 128-byte aligned (the finish sweep reads 16-byte pairs)
     }
     if (const char *e = std::getenv("TDOA_NO_FUSED_K1")) ctx->fused_k1 = !(e[0] == '1');
+    if (const char *e = std::getenv("TDOA_NO_SEG_PACK3")) ctx->seg_pack3 = !(e[0] == '1');
     if (const char *e = std::getenv("TDOA_SEG_CHUNKS")) ctx->seg_chunks_override = std::max(0, std::atoi(e));
     if (const char *e = std::getenv("TDOA_DEBUG_MEMSET_NODES")) ctx->memset_nodes = e[0] == '1';
     if (const char *e = std::getenv("TDOA_NO_XCD_ROWS")) ctx->xcd_rows = !(e[0] == '1');
@@ -1645,7 +1668,7 @@ static int process_impl(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host,
                                  (uint64_t)ctx->force_generic | ((uint64_t)ctx->short_lag << 1) |
                                      ((uint64_t)ctx->segment_form << 3) | ((uint64_t)ctx->xcd_rows << 4) |
                                      ((uint64_t)ctx->segment_quads << 6) |
-                                     ((uint64_t)ctx->decimate << 8) | ((uint64_t)ctx->fused_k1 << 9) | ((uint64_t)ctx->k1_once << 11) |
+                                     ((uint64_t)ctx->decimate << 8) | ((uint64_t)ctx->fused_k1 << 9) | ((uint64_t)ctx->k1_once << 11) | ((uint64_t)ctx->seg_pack3 << 12) |
                                      ((uint64_t)ctx->memset_nodes << 10) | ((uint64_t)ctx->seg_chunks_override << 16) | ((uint64_t)ctx->xcd_pair_mb << 40),
                                  ctx->alloc_gen, (uint64_t)(fine_host != nullptr), 0};
     std::memcpy(&key.back(), &gate, sizeof(double));
@@ -2031,6 +2054,7 @@ int tdoa_debug_flags(tdoa_ctx *ctx, unsigned flags)
     ctx->decimate = !(flags & TDOA_DEBUG_NO_DECIMATE);
     ctx->fused_k1 = !(flags & TDOA_DEBUG_NO_FUSED_K1);
     ctx->k1_once = !(flags & TDOA_DEBUG_NO_K1_ONCE);
+    ctx->seg_pack3 = !(flags & TDOA_DEBUG_NO_SEG_PACK3);
     return TDOA_OK;
 }
 

@@ -515,6 +515,30 @@ def test_segment_form_ragged_and_full_size(oracle, n1, n2, max_lag, delay):
     assert lag == olag and abs(corr - ocorr) <= REL_TOL * abs(ocorr)
 
 
+@pytest.mark.parametrize("n1,n2,max_lag", [(300_000, 300_000, 512), (123_457, 99_991, 200), (50_001, 50_000, 1023),
+                                           (2_000_000, 1_999_999, 256), (4097, 8191, 100), (2, 5000, 64)])
+def test_segment_form_packed_code_rows_are_bit_identical(oracle, n1, n2, max_lag):
+    """the segment form reads its code rows at 3 bytes per code (k1_store8_packed / k1_code3_at: a stored code has 24
+    significant bits); the int32 rows of round 3 behind TDOA_DEBUG_NO_SEG_PACK3 hold the same codes, so every lag sum is
+    the same float -- on random bytes (every code value, both signs), odd lengths and windows shorter than a frame"""
+    import tdoa_amd
+    rng = np.random.default_rng(n1 + max_lag)
+    a = rng.integers(0, 256, size=2 * n1, dtype=np.uint8)
+    b = rng.integers(0, 256, size=2 * n2, dtype=np.uint8)
+    k = min(n1, n2) // 2
+    b[2 * 7:2 * (7 + k)] = a[:2 * k]                                # a common stretch: a real peak at lag 7
+    with tdoa_amd.Context(max_lag=max_lag, window_len=max(n1, n2)) as c:
+        packed, peak_p = c.fm_xcorr_lags(a, b, max_lag), c.fm_xcorr(a, b, max_lag)
+        c.debug_flags(no_seg_pack3=True)
+        plain, peak_i = c.fm_xcorr_lags(a, b, max_lag), c.fm_xcorr(a, b, max_lag)
+        c.debug_flags(no_segment_quads=True)
+        pair_p = c.fm_xcorr_lags(a, b, max_lag)
+    assert np.array_equal(packed, plain) and peak_p == peak_i
+    assert np.array_equal(pair_p, packed)
+    if k > 4 * max_lag:
+        assert peak_p[0] == 7
+
+
 @pytest.mark.parametrize("n_st,ml,per_batch", [(3, 512, 0), (3, 100, 2), (4, 200, 0), (5, 1000, 0), (8, 120, 4)])
 def test_segment_quads_vs_one_pair_at_a_time(oracle, n_st, ml, per_batch):
     """segment form with station transforms shared by the pairs of a window (k_xcorr_segments_quad: two packed
