@@ -77,7 +77,7 @@ def station_table(n):
 
 
 HOT_SOURCES = ("device_common.hpp", "k1_discriminator.hpp", "k1_single_look.hpp", "fft_stockham.hpp", "fft_radix16.hpp",
-               "fft_radix8.hpp", "tdoa_mi355x.hip")
+               "fft_radix8.hpp", "dec_stream.hpp", "tdoa_mi355x.hip")
 
 
 def source_hash():
@@ -682,10 +682,11 @@ def roofline_fields(args, env, cfg_name, scaling, sim, table, prof_timed, domina
                "k_fwd_col": col, "k_fwd_row": ["k_fwd_row4096"],
                "k_inv_row_pair": ["k_inv_row_pair4096"], "k_inv_col_peak": ["k_inv_col_pruned"]}
     reach = max_lag                     # lags -(max_lag - 1) .. max_lag - 1 plus the refinement neighbours
-    decimated = (n1 == 4096 and n2 in (256, 512) and reach > 4095 and os.environ.get("TDOA_NO_DECIMATE") != "1"
+    decimated = (n1 == 4096 and n2 in (256, 512, 4096) and reach > 4095 and os.environ.get("TDOA_NO_DECIMATE") != "1"
                  and decimation_fits(n1 * n2, max_lag))
-    if decimated:     # K3 + 16:1 FIR decimation of the pair spectrum, then an Nc/16-point inverse
-        hot = dict(hot, k_fwd_row=["k_fwd_row4096_unpack"], k_inv_row_pair=["k_pair_decimate16"],
+    if decimated:     # K3 + 16:1 FIR decimation of the pair spectrum, then an Nc/16-point inverse;
+        #               on the 4096 x 4096 plan the FIR walks the columns of the spectrum (dec_stream.hpp)
+        hot = dict(hot, k_fwd_row=["k_fwd_row4096_unpack"], k_inv_row_pair=["k_pair_decimate_stream" if n2 == 4096 else "k_pair_decimate16"],
                    k_inv_col_peak=["k_inv_rows_plain_r8", "k_small_col_peak"])
     if max_lag <= 1024 and n1 == 4096:
         # segment form; with 3+ pairs per window the station transforms are shared (quads)

@@ -13,7 +13,7 @@ def main():
     want = sys.argv[2:] or HOT
     parts = re.split(r"\n(_Z\w+): *;[^\n]*\n", txt)
     for i in range(1, len(parts), 2):
-        name, body = parts[i], parts[i + 1].split("s_endpgm")[0]
+        name, body = parts[i], re.split(r"\n\.Lfunc_end\d+:", parts[i + 1])[0]
         if not any(k in name for k in want):
             continue
         c, top = collections.Counter(), collections.Counter()

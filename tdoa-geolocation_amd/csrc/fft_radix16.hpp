@@ -180,6 +180,9 @@ __global__ __launch_bounds__(256) void k_fwd_row4096(float2 *TZ, FftPlan pl, boo
 // TZ keeps the column-pass output.
 // grid (N2/2, n_sw), 512 threads (t >> 8: which row of the pair), dynamic LDS 2 x 34 KB.
 // ---------------------------------------------------------------------------
+// ROWMAJOR (4096 x 4096 plan, dec_stream.hpp): U goes back to the rows it came from, `tiled` = TZ -- a workgroup has both of
+// its rows in registers before it stores, and no other workgroup touches them.
+template <bool ROWMAJOR = false>
 __global__ __launch_bounds__(512) void k_fwd_row4096_unpack(const float2 *TZ, FftPlan pl, float2 *tiled, bool pre_tw)
 {
     extern __shared__ float2 lds2[];                             // [2][kRowLds]
@@ -214,7 +217,11 @@ __global__ __launch_bounds__(512) void k_fwd_row4096_unpack(const float2 *TZ, Ff
         if (k == 0 && row0 && j == 0) u = make_float2(2.0f * (z.x + z.y), 2.0f * (z.x - z.y));
         v[oreg(k)] = u;
     }
-    {
+    if (ROWMAJOR) {
+        float2 *out = tiled + (size_t)blockIdx.y * pl.Zs + (size_t)k2 * 4096 + (size_t)(k2 >> 8) * pl.zpad + j;
+#pragma unroll
+        for (int k = 0; k < 16; k++) out[256 * k] = v[oreg(k)];
+    } else {
         // tiles of COLS = 4096 / N2 columns x N2 rows = 4096 elements: column k1 = j + 256 k -> tile k1 / COLS
         const int cols = 4096 / pl.N2;
         float2 *out = tiled + (size_t)blockIdx.y * pl.Nc + (size_t)(j / cols) * 4096 + (size_t)k2 * cols + (j % cols);

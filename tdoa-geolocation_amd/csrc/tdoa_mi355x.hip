@@ -23,6 +23,7 @@
 #include "fft_stockham.hpp"
 #include "fft_radix16.hpp"
 #include "fft_radix8.hpp"
+#include "dec_stream.hpp"
 #include "exact_reference.hpp"
 #include "synth_capture.hpp"
 #include "window_quality.hpp"
@@ -440,7 +441,7 @@ DecDesign decimation_design(const FftPlan &pl, int reach)
 
 bool decimation_applies(const tdoa_ctx *ctx, const FftPlan &pl, int lag_lo, int lag_hi)
 {
-    if (!ctx->decimate || ctx->force_generic || pl.N1 != 4096 || (pl.N2 != 256 && pl.N2 != 512)) return false;
+    if (!ctx->decimate || ctx->force_generic || pl.N1 != 4096 || (pl.N2 != 256 && pl.N2 != 512 && pl.N2 != 4096)) return false;
     const int reach = std::max(lag_hi + 1, -(lag_lo - 1));
     if (reach <= 4095) return false;                       // the short-lag forms take those
     return decimation_design(pl, reach).ok;
@@ -465,6 +466,8 @@ size_t dec_spectra_offset(const FftPlan &pl, int n_pw)
 {
     return dec_edge_offset(pl, n_pw) + (size_t)n_pw * (size_t)pl.N2 * (2 * kDecEdge);
 }
+// the 4096 x 4096 plan keeps its unpacked spectra in TZ, row-major (dec_stream.hpp): no tiled copy in the V workspace
+bool dec_streams_rows(const FftPlan &pl) { return pl.N2 == 4096; }
 
 // taps h[t] = sinc(t/16) * kaiser(t), |t| <= T, rounded to f32; gain[m] = 1 / w[m], w[m] = sum_t h[t] cos(2 pi t m / Nc) / 16
 // evaluated from the ROUNDED taps, so the correction is exact for the filter that runs.  No-op when already built.
@@ -489,10 +492,16 @@ int ensure_decimation(tdoa_ctx *ctx, const FftPlan &pl, int lag_lo, int lag_hi)
         gain[m] = (float)((double)kDecD / w);
     }
     // the kernel's layout: phase p x step s, the tap t = 16 (s - kDecCentre) + p (zero where |t| > T)
-    std::vector<float> tab(256, 0.0f);
+    // (then W_N^p, p = 0..15, N = 2 Nc, as float2: the row rotations of k_pair_decimate_stream)
+    std::vector<float> tab(256 + 32, 0.0f);
     for (int t = -T; t <= T; t++) {
         const int p = ((t % 16) + 16) % 16, sidx = (t - p) / 16 + kDecCentre;
         tab[16 * p + sidx] = taps[t + T];
+    }
+    for (int p = 0; p < 16; p++) {
+        const double ang = -M_PI * (double)p / (double)pl.Nc;
+        tab[256 + 2 * p] = (float)std::cos(ang);
+        tab[256 + 2 * p + 1] = (float)std::sin(ang);
     }
     int rc;
     if ((rc = ensure(ctx, ctx->dec_taps, sizeof(float) * tab.size()))) return rc;
@@ -557,7 +566,7 @@ int reserve_fm_batch(tdoa_ctx *ctx, int n_sw, int maxlen, int n_pw, const FftPla
     if (n_pw && decimation_applies(ctx, pl, lag_lo, lag_hi) && (rc = ensure_decimation(ctx, pl, lag_lo, lag_hi))) return rc;
     size_t v_elems = (size_t)pl.Nc * n_pw;
     if (n_pw && decimation_applies(ctx, pl, lag_lo, lag_hi))      // G + V' of the pairs, then the tiled spectra of the stations
-        v_elems = std::max(v_elems, dec_spectra_offset(pl, n_pw) + (size_t)pl.Nc * n_sw);
+        v_elems = std::max(v_elems, dec_spectra_offset(pl, n_pw) + (dec_streams_rows(pl) ? 0 : (size_t)pl.Nc * n_sw));
     if (n_pw && (rc = ensure(ctx, ctx->v, sizeof(float2) * v_elems))) return rc;
     return TDOA_OK;
 }
@@ -760,8 +769,11 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
     }
     if (!seg_chunks) {
         ProfScope ps(ctx, TDOA_K_FWD_ROW, 2.0 * nc8 * n_sw);
-        if (row16 && decim)     // unpacked spectra in COLS-column tiles behind G and V' in the V workspace (k_pair_decimate16 streams them)
-            hipLaunchKernelGGL(k_fwd_row4096_unpack, dim3(pl.N2 / 2, n_sw), dim3(512), sizeof(float2) * 2 * kRowLds, st, tz, pl,
+        if (row16 && decim && dec_streams_rows(pl))     // unpacked spectra back into their rows (k_pair_decimate_stream walks the columns)
+            hipLaunchKernelGGL(k_fwd_row4096_unpack<true>, dim3(pl.N2 / 2, n_sw), dim3(512), sizeof(float2) * 2 * kRowLds, st, tz, pl,
+                               tz, fused_k1 && (col16 || colx == 2));
+        else if (row16 && decim)     // unpacked spectra in COLS-column tiles behind G and V' in the V workspace (k_pair_decimate16 streams them)
+            hipLaunchKernelGGL(k_fwd_row4096_unpack<false>, dim3(pl.N2 / 2, n_sw), dim3(512), sizeof(float2) * 2 * kRowLds, st, tz, pl,
                                v + dec_spectra_offset(pl, n_pw), fused_k1 && (col16 || colx == 2));
         else if (row16)
             hipLaunchKernelGGL(k_fwd_row4096, dim3(pl.N2, n_sw), dim3(256), 0, st, tz, pl, fused_k1 && (col16 || colx == 2));
@@ -835,7 +847,17 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
             // W_N^DK, DK = N2 / 8 bins between a thread's consecutive elements of a tile (N = 2 Nc)
             const double ang = -2.0 * M_PI * (double)(pl.N2 / 8) / (2.0 * (double)pl.Nc);
             const float2 rot = make_float2((float)std::cos(ang), (float)std::sin(ang));
-            if (pl.N2 == 256)
+            if (dec_streams_rows(pl)) {
+                dim3 sgrid(16, n_pw);
+                int sgp = 0;
+                if (ctx->xcd_rows && pairs_per_window > 1 && n_pw % pairs_per_window == 0) {
+                    const long long groups = (long long)(n_pw / pairs_per_window) * 16;
+                    const long long blocks = (groups + 7) / 8 * 8 * pairs_per_window;
+                    if (blocks < (1ll << 31)) { sgp = pairs_per_window; sgrid = dim3((unsigned int)blocks); }
+                }
+                hipLaunchKernelGGL(k_pair_decimate_stream, sgrid, dim3(256), 0, st, d_pw, tz, g, edges, pl,
+                                   static_cast<const float *>(ctx->dec_taps.p), sgp, n_pw);
+            } else if (pl.N2 == 256)
                 hipLaunchKernelGGL(k_pair_decimate16<8>, grid, dim3(512), sizeof(float2) * 2 * 16 * kDecPitch, st,
                                    d_pw, spectra, g, edges, pl, static_cast<const float *>(ctx->dec_taps.p), ps2.N2, gp, n_pw, rot);
             else
@@ -941,7 +963,8 @@ int allow_big_lds(tdoa_ctx *ctx)
     if ((rc = set_lds(ctx, k_fm_demod<false>, all))) return rc;
     if ((rc = set_lds(ctx, k_fwd_col512_k1<false>, all))) return rc;
     if ((rc = set_lds(ctx, k_fwd_col512_k1<true>, all))) return rc;
-    if ((rc = set_lds(ctx, k_fwd_row4096_unpack, all))) return rc;
+    if ((rc = set_lds(ctx, k_fwd_row4096_unpack<false>, all))) return rc;
+    if ((rc = set_lds(ctx, k_fwd_row4096_unpack<true>, all))) return rc;
     if ((rc = set_lds(ctx, (k_fwd_col256_k1<false, false>), all))) return rc;
     if ((rc = set_lds(ctx, (k_fwd_col256_k1<true, false>), all))) return rc;
     if ((rc = set_lds(ctx, (k_fwd_col256_k1<false, true>), all))) return rc;

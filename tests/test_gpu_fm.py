@@ -244,6 +244,29 @@ def test_two_sweep_plan_padded_rows_in_every_form(oracle):
         _assert_lags_close(c.fm_xcorr_lags(a, b, 3000), lags)
 
 
+@pytest.mark.parametrize("n1,n2,delay,max_lag", [(20_000_000, 20_000_000, 88, 20000), (20_000_000, 19_876_543, -19999, 20000),
+                                                 (18_000_001, 20_000_000, 7, 12000)])
+def test_decimated_inverse_on_the_ten_second_plan(oracle, n1, n2, delay, max_lag):
+    """N = 2^25 (4096 x 4096): consecutive bins run down the columns of the spectrum, and the decimating FIR walks them as a
+    column stencil (k_pair_decimate_stream, dec_stream.hpp) over the unpacked spectra the row pass leaves in place; against
+    the full inverse of the same context (TDOA_DEBUG_NO_DECIMATE), lag by lag, with and without the single-look K1"""
+    import tdoa_amd
+    a = oracle.simulate_delayed_fm(n1, max(0, -delay), 61, 1)
+    b = oracle.simulate_delayed_fm(n2, max(0, delay), 61, 2)
+    with tdoa_amd.Context(max_lag=max_lag, window_len=max(n1, n2)) as c:
+        dec_lags, dec_peak = c.fm_xcorr_lags(a, b, max_lag), c.fm_xcorr(a, b, max_lag)
+        assert tuple(c.plan_info()) == (1 << 25, 4096, 4096)
+        c.debug_flags(no_k1_once=True)
+        pre_lags = c.fm_xcorr_lags(a, b, max_lag)
+        c.debug_flags(no_decimate=True)
+        full_lags, full_peak = c.fm_xcorr_lags(a, b, max_lag), c.fm_xcorr(a, b, max_lag)
+    assert dec_peak[0] == full_peak[0] == delay
+    assert abs(dec_peak[1] - full_peak[1]) <= 2e-6 * abs(full_peak[1])
+    scale = np.abs(full_lags).max()
+    assert np.abs(dec_lags - full_lags).max() <= 2e-6 * scale
+    assert np.abs(pre_lags - full_lags).max() <= 2e-6 * scale
+
+
 def test_profiling_inside_the_replayed_graph(oracle):
     """tdoa_profile_enable(2): the step keeps replaying as one hipGraph and the selected scope is timed by event-record
     nodes spliced into the captured graph; the results must not change and only the selected scope may report launches"""
