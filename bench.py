@@ -686,7 +686,10 @@ def roofline_fields(args, env, cfg_name, scaling, sim, table, prof_timed, domina
                  and decimation_fits(n1 * n2, max_lag))
     if decimated:     # K3 + 16:1 FIR decimation of the pair spectrum, then an Nc/16-point inverse;
         #               on the 4096 x 4096 plan the FIR walks the columns of the spectrum (dec_stream.hpp)
-        hot = dict(hot, k_fwd_row=["k_fwd_row4096_unpack"], k_inv_row_pair=["k_pair_decimate_stream" if n2 == 4096 else "k_pair_decimate16"],
+        #               the FIR walks the columns of the spectrum (dec_stream.hpp) on the 4096 x 4096 plan and wherever a window
+        #               carries more pairs than stations (tdoa_mi355x.hip dec_walks_columns); else 4096-bin tiles in LDS
+        cols = os.environ.get("TDOA_NO_DEC_COLS") != "1" and (n2 == 4096 or n_pairs > S or os.environ.get("TDOA_DEC_COLS_ALWAYS") == "1")
+        hot = dict(hot, k_fwd_row=["k_fwd_row4096_unpack"], k_inv_row_pair=["k_pair_decimate_cols" if cols else "k_pair_decimate16"],
                    k_inv_col_peak=["k_inv_rows_plain_r8", "k_small_col_peak"])
     if max_lag <= 1024 and n1 == 4096:
         # segment form; with 3+ pairs per window the station transforms are shared (quads)

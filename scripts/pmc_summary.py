@@ -27,7 +27,10 @@ FETCH_CORRECTION = {"k_fm_demod": 2.0, "k_fwd_row4096": 2.0, "k_fwd_row4096_unpa
                     # samples and the tables) -> x2
                     "k_fwd_col256_k1": 2.0, "k_fwd_col512_k1": 2.0,      # (the N2 = 512 column kernel: the same construction)
                     # round 4: the running sums of the window edges are streamed like k_fm_demod (16 B per lane)
-                    "k_once_edges": 2.0}
+                    "k_once_edges": 2.0,
+                    # the column walk of the decimated pair step reads 8 B per lane along the rows, 512-byte runs per wave,
+                    # like k_fwd_row4096
+                    "k_pair_decimate_cols": 2.0}
 
 
 def load(d):

@@ -534,7 +534,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_
 // near the tile boundaries (k_pair_decimate16): i < kDecEdge gets E[tile - 1][kDecEdge + i], i >= 256 - kDecEdge gets
 // E[tile + 1][i - (256 - kDecEdge)].
 // grid (N2'/2, n_pw), 512 threads, dynamic LDS 64 KB.
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_PLAIN_DS_OPS)) void k_inv_rows_plain_r8(const float2 *G, const float2 *E, float2 *V, FftPlan pl, int big_n2)
+// by_column (k_pair_decimate_cols, dec_stream.hpp): the shares arrive as X[pw][12][4096] -- row i < kDecEdge of G gets slot
+// row kDecEdge + i of the column to its left, row i >= N2' - kDecEdge slot row i - (N2' - kDecEdge) of the column to its
+// right (slot row 0 is all zeros and is skipped): one more coalesced row read for 11 of the N2' rows.
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_PLAIN_DS_OPS)) void k_inv_rows_plain_r8(const float2 *G, const float2 *E, float2 *V, FftPlan pl, int big_n2, int by_column)
 {
     extern __shared__ float2 lds[];   // 2 * kRow8Lds
     float2 *la = lds, *lb = lds + kRow8Lds;
@@ -551,6 +554,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_
     // j = row + N2' (t + 512 r): its place in the tile, i = j & 255, does not depend on r (N2' 512 is a multiple of 256),
     // so a thread either needs an edge share for all eight of its elements of a row or for none (one lane in 16 does)
     auto merge = [&](int row, float2 (&v)[8]) {
+        if (by_column) {
+            const bool left = row < kDecEdge;
+            if ((!left && row < pl.N2 - kDecEdge) || row == pl.N2 - kDecEdge) return;
+            const float2 *x = E + ((size_t)blockIdx.y * (2 * kDecEdge) + (size_t)(left ? kDecEdge + row : row - (pl.N2 - kDecEdge))) * 4096;
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const float2 s = x[(t + 512 * r + (left ? 4095 : 1)) & 4095];
+                v[r].x += s.x;
+                v[r].y += s.y;
+            }
+            return;
+        }
         const int i = (row + pl.N2 * t) & 255;
         if (i >= kDecEdge && i < 256 - kDecEdge) return;
 #pragma unroll

@@ -99,6 +99,8 @@ struct tdoa_ctx {
     bool segment_quads = true;              // TDOA_NO_SEGMENT_QUADS=1: segment form one pair-window at a time (no shared station transforms)
     bool memset_nodes = false;              // TDOA_DEBUG_MEMSET_NODES=1 (probe only): zero the step's accumulators with
                                             // hipMemsetAsync nodes instead of k_zero_u64 kernel nodes
+    bool dec_cols = true;                   // TDOA_NO_DEC_COLS=1: the tile form of the decimated pair step (k_pair_decimate16; none on 4096 x 4096 plans)
+    bool dec_cols_always = false;           // TDOA_DEC_COLS_ALWAYS=1: the column walk wherever the decimated inverse applies (measurements)
     bool seg_pack3 = true;                  // TDOA_NO_SEG_PACK3=1: the segment form reads int32 code rows (round 3's layout)
     int seg_chunks_override = 0;            // TDOA_SEG_CHUNKS=n at tdoa_create time: chunk count of the segment form
     int graph_nodes = 0, graph_edges = 0, graph_roots = 0, graph_memsets = 0;      // structure of the captured step (tdoa_debug_graph_info)
@@ -442,6 +444,7 @@ DecDesign decimation_design(const FftPlan &pl, int reach)
 bool decimation_applies(const tdoa_ctx *ctx, const FftPlan &pl, int lag_lo, int lag_hi)
 {
     if (!ctx->decimate || ctx->force_generic || pl.N1 != 4096 || (pl.N2 != 256 && pl.N2 != 512 && pl.N2 != 4096)) return false;
+    if (pl.N2 == 4096 && !ctx->dec_cols) return false;    // only the column walk (dec_stream.hpp) has that plan
     const int reach = std::max(lag_hi + 1, -(lag_lo - 1));
     if (reach <= 4095) return false;                       // the short-lag forms take those
     return decimation_design(pl, reach).ok;
@@ -462,12 +465,23 @@ double bessel_i0(double x)
 // layout of the decimated inverse inside the V workspace (float2 elements): G [n_pw][R], V' [n_pw][R], the tiles' edge
 // shares E [n_pw][N2][2 kDecEdge], then the stations' spectra in tiles [n_sw][Nc]
 size_t dec_edge_offset(const FftPlan &pl, int n_pw) { return 2 * (size_t)(pl.Nc / kDecD) * (size_t)n_pw; }
+// (E: [n_pw][N2][12] for the tile kernel, X: [n_pw][12][4096] for the column walk -- room for the larger)
 size_t dec_spectra_offset(const FftPlan &pl, int n_pw)
 {
-    return dec_edge_offset(pl, n_pw) + (size_t)n_pw * (size_t)pl.N2 * (2 * kDecEdge);
+    return dec_edge_offset(pl, n_pw) + (size_t)n_pw * (size_t)std::max(pl.N2, 4096) * (2 * kDecEdge);
 }
-// the 4096 x 4096 plan keeps its unpacked spectra in TZ, row-major (dec_stream.hpp): no tiled copy in the V workspace
-bool dec_streams_rows(const FftPlan &pl) { return pl.N2 == 4096; }
+// Which form the decimated pair step takes.  The column walk (dec_stream.hpp; unpacked spectra in TZ, row-major) is the only
+// one on the 4096 x 4096 plan and the faster one where the pair step is bound by instruction issue: batches whose windows
+// carry more pairs than stations (cfg4: 4.2 ms against 5.05 per step, cfg5: 108 against 118).  With as many pairs as stations
+// the step waits for the spectra's first trip from memory and the tile form, which asks for a tile's 32 KB at once, is
+// ahead (cfg2: 0.66 ms against 0.73).
+bool dec_walks_columns(const tdoa_ctx *ctx, const FftPlan &pl, int n_sw, int n_pw, int pairs_per_window)
+{
+    if (!ctx->dec_cols) return false;
+    if (pl.N2 == 4096 || ctx->dec_cols_always) return true;
+    if (pairs_per_window <= 0 || n_pw % pairs_per_window != 0 || n_sw <= 0) return false;
+    return pairs_per_window > n_sw / (n_pw / pairs_per_window);
+}
 
 // taps h[t] = sinc(t/16) * kaiser(t), |t| <= T, rounded to f32; gain[m] = 1 / w[m], w[m] = sum_t h[t] cos(2 pi t m / Nc) / 16
 // evaluated from the ROUNDED taps, so the correction is exact for the filter that runs.  No-op when already built.
@@ -566,7 +580,7 @@ int reserve_fm_batch(tdoa_ctx *ctx, int n_sw, int maxlen, int n_pw, const FftPla
     if (n_pw && decimation_applies(ctx, pl, lag_lo, lag_hi) && (rc = ensure_decimation(ctx, pl, lag_lo, lag_hi))) return rc;
     size_t v_elems = (size_t)pl.Nc * n_pw;
     if (n_pw && decimation_applies(ctx, pl, lag_lo, lag_hi))      // G + V' of the pairs, then the tiled spectra of the stations
-        v_elems = std::max(v_elems, dec_spectra_offset(pl, n_pw) + (dec_streams_rows(pl) ? 0 : (size_t)pl.Nc * n_sw));
+        v_elems = std::max(v_elems, dec_spectra_offset(pl, n_pw) + (pl.N2 == 4096 ? 0 : (size_t)pl.Nc * n_sw));
     if (n_pw && (rc = ensure(ctx, ctx->v, sizeof(float2) * v_elems))) return rc;
     return TDOA_OK;
 }
@@ -769,7 +783,7 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
     }
     if (!seg_chunks) {
         ProfScope ps(ctx, TDOA_K_FWD_ROW, 2.0 * nc8 * n_sw);
-        if (row16 && decim && dec_streams_rows(pl))     // unpacked spectra back into their rows (k_pair_decimate_stream walks the columns)
+        if (row16 && decim && dec_walks_columns(ctx, pl, n_sw, n_pw, pairs_per_window))     // unpacked spectra back into their rows (k_pair_decimate_stream walks the columns)
             hipLaunchKernelGGL(k_fwd_row4096_unpack<true>, dim3(pl.N2 / 2, n_sw), dim3(512), sizeof(float2) * 2 * kRowLds, st, tz, pl,
                                tz, fused_k1 && (col16 || colx == 2));
         else if (row16 && decim)     // unpacked spectra in COLS-column tiles behind G and V' in the V workspace (k_pair_decimate16 streams them)
@@ -847,16 +861,18 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
             // W_N^DK, DK = N2 / 8 bins between a thread's consecutive elements of a tile (N = 2 Nc)
             const double ang = -2.0 * M_PI * (double)(pl.N2 / 8) / (2.0 * (double)pl.Nc);
             const float2 rot = make_float2((float)std::cos(ang), (float)std::sin(ang));
-            if (dec_streams_rows(pl)) {
-                dim3 sgrid(16, n_pw);
+            if (dec_walks_columns(ctx, pl, n_sw, n_pw, pairs_per_window)) {
+                dim3 sgrid(8, n_pw);
                 int sgp = 0;
                 if (ctx->xcd_rows && pairs_per_window > 1 && n_pw % pairs_per_window == 0) {
-                    const long long groups = (long long)(n_pw / pairs_per_window) * 16;
+                    const long long groups = (long long)(n_pw / pairs_per_window) * 8;
                     const long long blocks = (groups + 7) / 8 * 8 * pairs_per_window;
                     if (blocks < (1ll << 31)) { sgp = pairs_per_window; sgrid = dim3((unsigned int)blocks); }
                 }
-                hipLaunchKernelGGL(k_pair_decimate_stream, sgrid, dim3(256), 0, st, d_pw, tz, g, edges, pl,
-                                   static_cast<const float *>(ctx->dec_taps.p), sgp, n_pw);
+                const float *tp = static_cast<const float *>(ctx->dec_taps.p);
+                if (pl.N2 == 256) hipLaunchKernelGGL(k_pair_decimate_cols<8>, sgrid, dim3(256), 0, st, d_pw, tz, g, edges, pl, tp, sgp, n_pw);
+                else if (pl.N2 == 512) hipLaunchKernelGGL(k_pair_decimate_cols<9>, sgrid, dim3(256), 0, st, d_pw, tz, g, edges, pl, tp, sgp, n_pw);
+                else hipLaunchKernelGGL(k_pair_decimate_cols<12>, sgrid, dim3(256), 0, st, d_pw, tz, g, edges, pl, tp, sgp, n_pw);
             } else if (pl.N2 == 256)
                 hipLaunchKernelGGL(k_pair_decimate16<8>, grid, dim3(512), sizeof(float2) * 2 * 16 * kDecPitch, st,
                                    d_pw, spectra, g, edges, pl, static_cast<const float *>(ctx->dec_taps.p), ps2.N2, gp, n_pw, rot);
@@ -867,7 +883,7 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
         {
             ProfScope ps(ctx, TDOA_K_INV_COL, 3.0 * 8.0 * (double)rc_pts * n_pw);
             hipLaunchKernelGGL(k_inv_rows_plain_r8, dim3(ps2.N2 / 2, n_pw), dim3(512), sizeof(float2) * 2 * kRow8Lds, st, g,
-                               v + dec_edge_offset(pl, n_pw), vs, ps2, pl.N2);
+                               v + dec_edge_offset(pl, n_pw), vs, ps2, pl.N2, dec_walks_columns(ctx, pl, n_sw, n_pw, pairs_per_window) ? 1 : 0);
             if (np2 == 3 && nn2 == 3)          // the reference's 20 000 lags on either small plan
                 hipLaunchKernelGGL((k_small_col_peak<3, 3>), dim3(ps2.N1 / 256, n_pw), dim3(256), 0, st, vs, d_keys, d_pw, ps2, lag_lo,
                                    lag_hi, np2, nn2, lag_dump, dump_scale, static_cast<const float *>(ctx->dec_gain.p), oc);
@@ -1270,6 +1286,8 @@ int tdoa_create(const tdoa_params *p, tdoa_ctx **out)
         ctx->zpad = v < 0 ? 0 : v > 4096 ? 4096 : v & ~15;      // rows stay 128-byte aligned (the finish sweep reads 16-byte pairs)
     }
     if (const char *e = std::getenv("TDOA_NO_FUSED_K1")) ctx->fused_k1 = !(e[0] == '1');
+    if (const char *e = std::getenv("TDOA_NO_DEC_COLS")) ctx->dec_cols = !(e[0] == '1');
+    if (const char *e = std::getenv("TDOA_DEC_COLS_ALWAYS")) ctx->dec_cols_always = e[0] == '1';
     if (const char *e = std::getenv("TDOA_NO_SEG_PACK3")) ctx->seg_pack3 = !(e[0] == '1');
     if (const char *e = std::getenv("TDOA_SEG_CHUNKS")) ctx->seg_chunks_override = std::max(0, std::atoi(e));
     if (const char *e = std::getenv("TDOA_DEBUG_MEMSET_NODES")) ctx->memset_nodes = e[0] == '1';
@@ -1691,7 +1709,7 @@ static int process_impl(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host,
                                  (uint64_t)ctx->force_generic | ((uint64_t)ctx->short_lag << 1) |
                                      ((uint64_t)ctx->segment_form << 3) | ((uint64_t)ctx->xcd_rows << 4) |
                                      ((uint64_t)ctx->segment_quads << 6) |
-                                     ((uint64_t)ctx->decimate << 8) | ((uint64_t)ctx->fused_k1 << 9) | ((uint64_t)ctx->k1_once << 11) | ((uint64_t)ctx->seg_pack3 << 12) |
+                                     ((uint64_t)ctx->decimate << 8) | ((uint64_t)ctx->fused_k1 << 9) | ((uint64_t)ctx->k1_once << 11) | ((uint64_t)ctx->seg_pack3 << 12) | ((uint64_t)ctx->dec_cols << 13) | ((uint64_t)ctx->dec_cols_always << 14) |
                                      ((uint64_t)ctx->memset_nodes << 10) | ((uint64_t)ctx->seg_chunks_override << 16) | ((uint64_t)ctx->xcd_pair_mb << 40),
                                  ctx->alloc_gen, (uint64_t)(fine_host != nullptr), 0};
     std::memcpy(&key.back(), &gate, sizeof(double));
@@ -2078,6 +2096,8 @@ int tdoa_debug_flags(tdoa_ctx *ctx, unsigned flags)
     ctx->fused_k1 = !(flags & TDOA_DEBUG_NO_FUSED_K1);
     ctx->k1_once = !(flags & TDOA_DEBUG_NO_K1_ONCE);
     ctx->seg_pack3 = !(flags & TDOA_DEBUG_NO_SEG_PACK3);
+    ctx->dec_cols = !(flags & TDOA_DEBUG_NO_DEC_COLS);
+    ctx->dec_cols_always = (flags & TDOA_DEBUG_DEC_COLS_ALWAYS) != 0;
     return TDOA_OK;
 }
 

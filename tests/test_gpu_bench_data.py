@@ -27,7 +27,12 @@ def test_fm_captures_with_true_delays_locate_the_transmitter(n_stations):
         peaks = c.process()
         assert c.last_k1(0)[1]                                       # the single-look path
         again = c.process()
+        # the other form of the decimated pair step (8 stations: the library walks the spectrum columns, 3: 4096-bin tiles)
+        c.debug_flags(no_dec_cols=True) if n_stations > 3 else c.debug_flags(dec_cols_always=True)
+        other = c.process()
         del bufs
+    assert np.array_equal(other["lag"], peaks["lag"])
+    assert np.abs(other["corr"] - peaks["corr"]).max() <= 5e-7 * np.abs(peaks["corr"]).max()
     assert peaks.shape == (6, len(pairs)) and np.array_equal(peaks, again)
     assert (peaks["lag"] == want[None, :]).all(), peaks["lag"]
     assert (peaks["abs_corr"] > 100.0).all()                         # strong peaks: sqrt(1.1e6) = 1049 at full correlation

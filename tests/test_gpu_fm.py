@@ -244,6 +244,27 @@ def test_two_sweep_plan_padded_rows_in_every_form(oracle):
         _assert_lags_close(c.fm_xcorr_lags(a, b, 3000), lags)
 
 
+@pytest.mark.parametrize("n1,n2,max_lag,delay", [(2_000_000, 2_000_000, 20000, 57), (1_234_567, 1_999_999, 20000, -19876),
+                                                 (4_000_000, 3_999_000, 20000, 1234), (2_200_000, 3_100_000, 26000, -25001)])
+def test_decimated_pair_step_column_walk_vs_tiles(oracle, n1, n2, max_lag, delay):
+    """the two forms of the decimated pair step on the 4096 x 256 and 4096 x 512 plans: k_pair_decimate_cols (a thread walks
+    a spectrum column; the library's choice for batches with more pairs than stations) against k_pair_decimate16 (4096-bin
+    tiles in LDS): same filter, same outputs -- lag arrays equal to rounding, and both against the full inverse"""
+    import tdoa_amd
+    a = oracle.simulate_delayed_fm(n1, max(0, -delay), 71, 1)
+    b = oracle.simulate_delayed_fm(n2, max(0, delay), 71, 2)
+    with tdoa_amd.Context(max_lag=max_lag, window_len=max(n1, n2)) as c:
+        tiles, peak_t = c.fm_xcorr_lags(a, b, max_lag), c.fm_xcorr(a, b, max_lag)
+        c.debug_flags(dec_cols_always=True)
+        cols, peak_c = c.fm_xcorr_lags(a, b, max_lag), c.fm_xcorr(a, b, max_lag)
+        c.debug_flags(no_decimate=True)
+        full = c.fm_xcorr_lags(a, b, max_lag)
+    assert peak_t[0] == peak_c[0] == delay
+    scale = np.abs(full).max()
+    assert np.abs(cols - tiles).max() <= 5e-7 * scale
+    assert np.abs(cols - full).max() <= 2e-6 * scale
+
+
 @pytest.mark.parametrize("n1,n2,delay,max_lag", [(20_000_000, 20_000_000, 88, 20000), (20_000_000, 19_876_543, -19999, 20000),
                                                  (18_000_001, 20_000_000, 7, 12000)])
 def test_decimated_inverse_on_the_ten_second_plan(oracle, n1, n2, delay, max_lag):
