@@ -138,20 +138,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TDOA_DEC_ST
     // rows (k2, k1) of both stations and their partners (N2 - k2, 4095 - k1), through four per-lane pointers that move one
     // row per fetch (+ the plan's padding after every 256 rows).  The partner of row 0 is not a row of the walk: its slot
     // reads row 0 again (the value is dropped) and the pointers then jump to row N2 - 1.
-    const float2 *pta = row_at(Ua, 0) + k1, *ptb = row_at(Ub, 0) + k1, *pma = row_at(Ua, 0) + km, *pmb = row_at(Ub, 0) + km;
+    // (wave-uniform row pointers + a 32-bit lane offset: global_load with an SGPR base, no vector instruction per address)
+    const float2 *rta = row_at(Ua, 0), *rtb = row_at(Ub, 0), *rma = rta, *rmb = rtb;
+    const unsigned int off_t = 8u * (unsigned int)k1, off_m = 8u * (unsigned int)km;
+    auto at_off = [](const float2 *base, unsigned int byte_off) {
+        return *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(base) + byte_off);
+    };
     auto fetch_row = [&](float2 (&dst)[4], int k2) {                // row k2, then on to row k2 + 1
-        dst[0] = *pta;
-        dst[1] = *pma;
-        dst[2] = *ptb;
-        dst[3] = *pmb;
+        dst[0] = at_off(rta, off_t);
+        dst[1] = at_off(rma, off_m);
+        dst[2] = at_off(rtb, off_t);
+        dst[3] = at_off(rmb, off_m);
         long long dt = N1 + ((k2 & 255) == 255 ? zpad : 0);         // row k2 + 1 starts a block of 256 rows
         long long dm = -(long long)N1 - ((k2 & 255) == 0 ? zpad : 0);   // row N2 - k2 ends one (going down)
         if (k2 == 0) dm = (long long)(N2 - 1) * N1 + (long long)((N2 - 1) >> 8) * zpad;
         if (k2 >= N2 - 1) dt = dm = 0;                              // (the prefetch past the last row re-reads it)
-        pta += dt;
-        ptb += dt;
-        pma += dm;
-        pmb += dm;
+        rta += dt;
+        rtb += dt;
+        rma += dm;
+        rmb += dm;
     };
     // One row: K3 (pair_u_pk) on the four values, then the twelve multiply-adds of either walk.  The phase is a RUN-TIME
     // value: the loop below is not unrolled over a group's 16 phases -- unrolled, every form of the tap fetch (scalar loads,
