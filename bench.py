@@ -856,6 +856,11 @@ def main():
     # rank 0 decodes all of them and solves every set.  Per-GPU work is fixed, so value(N) / (N value(1)) is the scaling
     # efficiency.  `--config cfg4 --scaling strong` is BASELINE config 4 as written: ONE 8-station capture set, its windows
     # dealt wid % N to the ranks; the default multi-rank run times it too (sharded_cfg4).
+    # stdout carries ONE line, the JSON: RCCL writes its version banner and its warnings ("Missing iommu=pt ...") to fd 1, gloo
+    # its rank chatter -- everything that is not the result goes to stderr from here on, at the descriptor level
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     cfg_name = args.config or "cfg2"
     scaling = args.scaling or "weak"
     steps = args.steps if args.steps is not None else CONFIGS[cfg_name]["steps"]
@@ -898,7 +903,8 @@ def main():
     if rank == 0:
         if world > 1:
             out["same_config_one_gpu"] = same_config_one_gpu(cfg_name)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
