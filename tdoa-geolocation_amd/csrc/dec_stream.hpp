@@ -21,7 +21,7 @@
 //     them in X[pw][12][4096] (slot 6 + i': output i' = 0..5 of the NEXT column; slot i' + 6, i' = -6..-1: output N2/16 + i'
 //     of the PREVIOUS one) and k_inv_rows_plain_r8 adds slot rows of the neighbouring columns when it loads G -- coalesced
 //     like G itself.  No thread ever waits for another.
-// grid: 8 column blocks x n_pw (or the XCD-grouped 1-D form of k_pair_decimate16), 256 threads, 1 KB of LDS (the taps).
+// grid (32 column blocks of 64, ceil(n_pw / kDecWavesPerWg)), 64 kDecWavesPerWg threads, 1 KB of LDS (the taps).
 #pragma once
 
 #include "fft_radix8.hpp"
@@ -36,36 +36,41 @@ namespace tdoa {
 #endif
 constexpr int kDecStreamBatch = TDOA_DEC_STREAM_BATCH; // rows fetched ahead, per buffer (two buffers)
 constexpr int kDecShareRows = 2 * kDecEdge;            // X: rows per pair-window (each 4096 columns)
+#ifndef TDOA_DEC_WAVES_PER_WG
+#define TDOA_DEC_WAVES_PER_WG 4
+#endif
+constexpr int kDecWavesPerWg = TDOA_DEC_WAVES_PER_WG;  // pair-windows per workgroup (one wave each, the same 64 columns)
 
 // taps: the tile kernel's table [16 phases][16 steps] (256 floats), then rot[16] = W_N^p as float2 (N = 2 Nc)
 template <int LOGN2>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TDOA_DEC_STREAM_WAVES, TDOA_DEC_STREAM_WAVES))) void k_pair_decimate_cols(const PWDesc *pw, const float2 *U, float2 *G, float2 *X, FftPlan pl,
-                                                              const float *__restrict__ taps, int group_pairs, int n_pw)
+__global__ __launch_bounds__(64 * kDecWavesPerWg) __attribute__((amdgpu_waves_per_eu(TDOA_DEC_STREAM_WAVES, TDOA_DEC_STREAM_WAVES))) void k_pair_decimate_cols(const PWDesc *pw, const float2 *U, float2 *G, float2 *X, FftPlan pl,
+                                                              const float *__restrict__ taps, int n_pw)
 {
     constexpr int N2 = 1 << LOGN2, N1 = 4096, C = kDecCentre, S = kDecSteps, B = kDecStreamBatch;
     constexpr int NG = N2 / 16;                                     // groups of 16 rows = outputs per column
-    constexpr int kColBlocks = N1 / 2 / 256;
+    // A workgroup = kDecWavesPerWg waves, every one of them the SAME 64 columns (and their 64 partners) of a DIFFERENT
+    // pair-window: wave w of workgroup (cb, q) walks pair-window kDecWavesPerWg q + w.  Consecutive pair-windows are a
+    // window's pairs in the order (0,1), (0,2), ... -- they mostly share the template station, so the waves of a workgroup ask
+    // for the same template rows within a few hundred cycles of each other: one of them brings a row in, the others find it
+    // in the CU's L1 / the XCD's L2.  (One 256-column block of ONE pair-window per workgroup pulled 24 GB per cfg4 step through
+    // the fabric for 5.6 GB of spectra: walks that share a station started whenever a slot came free, tens of microseconds
+    // apart against an L2 turnover of ~6.)
+    constexpr int W = kDecWavesPerWg;                               // (grid.x: the 32 column blocks of 64 of the left half)
     static_assert(NG >= 2 * C + 2 && N2 % (2 * B) == 0 && 16 % (2 * B) == 0, "ring and loop geometry");
-    unsigned int cbu = blockIdx.x, pwu = blockIdx.y;
-    if (group_pairs > 0) {                                          // same XCD grouping as k_pair_decimate16
-        const unsigned int L = blockIdx.x, xcd = L & 7u, slot = L >> 3;
-        const unsigned int g = slot / (unsigned int)group_pairs, p = slot % (unsigned int)group_pairs;
-        const unsigned int Gi = g * 8u + xcd, w = Gi / kColBlocks;
-        if (w * (unsigned int)group_pairs >= (unsigned int)n_pw) return;
-        cbu = Gi % kColBlocks;
-        pwu = w * (unsigned int)group_pairs + p;
-    }
     // LDS: the taps [phase][step]; phase 16 = phase 0 with its steps reversed (the upward walk's row of phase 0); then the 16
     // row rotations
     __shared__ __attribute__((aligned(16))) float ltaps[17 * S];
     __shared__ __attribute__((aligned(16))) float2 lrot[16];
-    const int t = threadIdx.x, k1 = (int)cbu * 256 + t, km = N1 - 1 - k1;
-    if (t < 17 * S) {
-        const int p = t / S, s = t % S;
-        ltaps[t] = p < 16 ? taps[16 * p + s] : taps[S - 1 - s];
+    const int t = threadIdx.x;
+    for (int e = t; e < 17 * S; e += 64 * W) {
+        const int p = e / S, s = e % S;
+        ltaps[e] = p < 16 ? taps[16 * p + s] : taps[S - 1 - s];
     }
     if (t < 16) lrot[t] = reinterpret_cast<const float2 *>(taps + 256)[t];
     __syncthreads();
+    const unsigned int cbu = blockIdx.x, pwu = (unsigned int)blockIdx.y * W + (unsigned int)__builtin_amdgcn_readfirstlane(t >> 6);
+    if (pwu >= (unsigned int)n_pw) return;
+    const int k1 = (int)cbu * 64 + (t & 63), km = N1 - 1 - k1;
     const PWDesc d = pw[pwu];
     const float2 *Ua = U + (size_t)d.sw_a * pl.Zs, *Ub = U + (size_t)d.sw_b * pl.Zs;
     const int zpad = pl.zpad;

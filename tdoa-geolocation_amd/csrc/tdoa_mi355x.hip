@@ -862,17 +862,11 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
             const double ang = -2.0 * M_PI * (double)(pl.N2 / 8) / (2.0 * (double)pl.Nc);
             const float2 rot = make_float2((float)std::cos(ang), (float)std::sin(ang));
             if (dec_walks_columns(ctx, pl, n_sw, n_pw, pairs_per_window)) {
-                dim3 sgrid(8, n_pw);
-                int sgp = 0;
-                if (ctx->xcd_rows && pairs_per_window > 1 && n_pw % pairs_per_window == 0) {
-                    const long long groups = (long long)(n_pw / pairs_per_window) * 8;
-                    const long long blocks = (groups + 7) / 8 * 8 * pairs_per_window;
-                    if (blocks < (1ll << 31)) { sgp = pairs_per_window; sgrid = dim3((unsigned int)blocks); }
-                }
+                const dim3 sgrid(32, (unsigned int)((n_pw + kDecWavesPerWg - 1) / kDecWavesPerWg)), sblock(64 * kDecWavesPerWg);
                 const float *tp = static_cast<const float *>(ctx->dec_taps.p);
-                if (pl.N2 == 256) hipLaunchKernelGGL(k_pair_decimate_cols<8>, sgrid, dim3(256), 0, st, d_pw, tz, g, edges, pl, tp, sgp, n_pw);
-                else if (pl.N2 == 512) hipLaunchKernelGGL(k_pair_decimate_cols<9>, sgrid, dim3(256), 0, st, d_pw, tz, g, edges, pl, tp, sgp, n_pw);
-                else hipLaunchKernelGGL(k_pair_decimate_cols<12>, sgrid, dim3(256), 0, st, d_pw, tz, g, edges, pl, tp, sgp, n_pw);
+                if (pl.N2 == 256) hipLaunchKernelGGL(k_pair_decimate_cols<8>, sgrid, sblock, 0, st, d_pw, tz, g, edges, pl, tp, n_pw);
+                else if (pl.N2 == 512) hipLaunchKernelGGL(k_pair_decimate_cols<9>, sgrid, sblock, 0, st, d_pw, tz, g, edges, pl, tp, n_pw);
+                else hipLaunchKernelGGL(k_pair_decimate_cols<12>, sgrid, sblock, 0, st, d_pw, tz, g, edges, pl, tp, n_pw);
             } else if (pl.N2 == 256)
                 hipLaunchKernelGGL(k_pair_decimate16<8>, grid, dim3(512), sizeof(float2) * 2 * 16 * kDecPitch, st,
                                    d_pw, spectra, g, edges, pl, static_cast<const float *>(ctx->dec_taps.p), ps2.N2, gp, n_pw, rot);
