@@ -603,7 +603,7 @@ __global__ __launch_bounds__(256) void k_small_col_peak(const float2 *V, unsigne
 {
     constexpr bool FIXED = NP > 0 && NN > 0;
     const int np = FIXED ? NP : np_rt, nn = FIXED ? NN : nn_rt;
-    __shared__ float2 wtab[256];                   // e^{+2 pi i k / N2'}  (N2' = 16, 32; 256 behind k_pair_decimate_stream)
+    __shared__ float2 wtab[256];                   // e^{+2 pi i k / N2'}  (N2' = 16, 32; 256 behind k_pair_decimate_cols<12>)
     __shared__ unsigned long long red[4];
     const int N2 = pl.N2, N1 = pl.N1;
     if (threadIdx.x < N2) wtab[threadIdx.x] = unit_root((float)threadIdx.x, 2.0f / (float)N2, true);

@@ -506,7 +506,7 @@ int ensure_decimation(tdoa_ctx *ctx, const FftPlan &pl, int lag_lo, int lag_hi)
         gain[m] = (float)((double)kDecD / w);
     }
     // the kernel's layout: phase p x step s, the tap t = 16 (s - kDecCentre) + p (zero where |t| > T)
-    // (then W_N^p, p = 0..15, N = 2 Nc, as float2: the row rotations of k_pair_decimate_stream)
+    // (then W_N^p, p = 0..15, N = 2 Nc, as float2: the row rotations of k_pair_decimate_cols)
     std::vector<float> tab(256 + 32, 0.0f);
     for (int t = -T; t <= T; t++) {
         const int p = ((t % 16) + 16) % 16, sidx = (t - p) / 16 + kDecCentre;
@@ -783,7 +783,7 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
     }
     if (!seg_chunks) {
         ProfScope ps(ctx, TDOA_K_FWD_ROW, 2.0 * nc8 * n_sw);
-        if (row16 && decim && dec_walks_columns(ctx, pl, n_sw, n_pw, pairs_per_window))     // unpacked spectra back into their rows (k_pair_decimate_stream walks the columns)
+        if (row16 && decim && dec_walks_columns(ctx, pl, n_sw, n_pw, pairs_per_window))     // unpacked spectra back into their rows (k_pair_decimate_cols walks the columns)
             hipLaunchKernelGGL(k_fwd_row4096_unpack<true>, dim3(pl.N2 / 2, n_sw), dim3(512), sizeof(float2) * 2 * kRowLds, st, tz, pl,
                                tz, fused_k1 && (col16 || colx == 2));
         else if (row16 && decim)     // unpacked spectra in COLS-column tiles behind G and V' in the V workspace (k_pair_decimate16 streams them)

@@ -269,7 +269,7 @@ def test_decimated_pair_step_column_walk_vs_tiles(oracle, n1, n2, max_lag, delay
                                                  (18_000_001, 20_000_000, 7, 12000)])
 def test_decimated_inverse_on_the_ten_second_plan(oracle, n1, n2, delay, max_lag):
     """N = 2^25 (4096 x 4096): consecutive bins run down the columns of the spectrum, and the decimating FIR walks them as a
-    column stencil (k_pair_decimate_stream, dec_stream.hpp) over the unpacked spectra the row pass leaves in place; against
+    column stencil (k_pair_decimate_cols<12>, dec_stream.hpp) over the unpacked spectra the row pass leaves in place; against
     the full inverse of the same context (TDOA_DEBUG_NO_DECIMATE), lag by lag, with and without the single-look K1"""
     import tdoa_amd
     a = oracle.simulate_delayed_fm(n1, max(0, -delay), 61, 1)
