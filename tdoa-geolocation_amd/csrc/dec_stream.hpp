@@ -150,10 +150,14 @@ __global__ __launch_bounds__(64 * kDecWavesPerWg) __attribute__((amdgpu_waves_pe
         return *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(base) + byte_off);
     };
     auto fetch_row = [&](float2 (&dst)[4], int k2) {                // row k2, then on to row k2 + 1
-        dst[0] = at_off(rta, off_t);
-        dst[1] = at_off(rma, off_m);
-        dst[2] = at_off(rtb, off_t);
-        dst[3] = at_off(rmb, off_m);
+        // (the two lane offsets pass through an empty asm per fetch: hoisted out of the loop as 64-bit values they cost a
+        // v_lshl_add_u64 per load; seen as 32-bit values next to the load they become its offset operand -- global_load v, v_off, s[base])
+        unsigned int ot = off_t, om = off_m;
+        asm volatile("" : "+v"(ot), "+v"(om));
+        dst[0] = at_off(rta, ot);
+        dst[1] = at_off(rma, om);
+        dst[2] = at_off(rtb, ot);
+        dst[3] = at_off(rmb, om);
         long long dt = N1 + ((k2 & 255) == 255 ? zpad : 0);         // row k2 + 1 starts a block of 256 rows
         long long dm = -(long long)N1 - ((k2 & 255) == 0 ? zpad : 0);   // row N2 - k2 ends one (going down)
         if (k2 == 0) dm = (long long)(N2 - 1) * N1 + (long long)((N2 - 1) >> 8) * zpad;
