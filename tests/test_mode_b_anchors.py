@@ -208,3 +208,90 @@ def test_spectrum_decimation_math_in_float64(oracle, capsys):
         print("\n  spectrum decimation 16:1, %d taps (float64): max error of the %d packed lags, relative to the peak" % (2 * th + 1, m.size))
         for name, _, err in rows:
             print("    %-24s %.2e" % (name, err))
+
+
+def _column_walk_float64(Q, n2, n1, tab, steps=12):
+    """csrc/dec_stream.hpp (k_pair_decimate_cols + the merge in k_inv_rows_plain_r8) restated line by line in float64: the
+    FIR G[j] = sum_t h[t] Q[16 j + t] evaluated as a stencil DOWN the columns of Q[k2][k1] (k = k2 + N2 k1).  A walker
+    owns column c downwards (rows 0 .. N2-1) and column N1-1-c upwards (rows N2-1 .. 0), twelve ring accumulators each; what a
+    column's bins add to the six outputs next to it in the neighbouring columns goes to X[12][N1] and is merged afterwards.
+    tab[p][s]: the tap t = 16 (s - C) + p, zero where |t| > T -- the table ensure_decimation uploads."""
+    C, S, ng = steps // 2, steps, n2 // 16
+    col = Q.reshape(n1, n2)                                   # col[c][k2] = Q[k2 + N2 c]
+    G = np.zeros((ng, n1), dtype=complex)                     # the small plan's layout: output i of column c at [i][c]
+    X = np.zeros((12, n1), dtype=complex)
+    for c in range(n1 // 2):
+        cm = n1 - 1 - c
+        # downward walk of column c: row (g, p) -> output g + C - s in at[s], tap (p, s)
+        at = np.zeros(S, dtype=complex)
+
+        def top_leaves(i):
+            nonlocal at
+            if i < 0:
+                X[6 + i, c] = at[S - 1]
+            elif i < ng:
+                G[i, c] = at[S - 1]
+            else:
+                X[6 + i - ng, c] = at[S - 1]
+            at = np.concatenate(([0.0], at[:-1]))
+
+        for k2 in range(n2):
+            p, g = k2 & 15, k2 >> 4
+            at += tab[p, :S] * col[c, k2]
+            if p == 15:
+                top_leaves(g - (S - 1 - C))
+        for n in range(S - 1):
+            top_leaves(ng - (S - 1 - C) + n)
+        # upward walk of column cm: row N2 - k2 (k2 = 1 .. N2 - 1), then row 0; slot u holds output gb - (C - 1) + u
+        ab = np.zeros(S, dtype=complex)
+
+        def bottom_leaves(i):
+            nonlocal ab
+            if i >= ng:
+                X[6 + i - ng, cm] = ab[S - 1]
+            elif i >= 0:
+                G[i, cm] = ab[S - 1]
+            else:
+                X[6 + i, cm] = ab[S - 1]
+            ab = np.concatenate(([0.0], ab[:-1]))
+
+        for k2 in range(1, n2):
+            p, g = k2 & 15, k2 >> 4
+            q = col[cm, n2 - k2]
+            if p:
+                ab += tab[p, :S] * q                          # phase 16 - p of its own group: the same twelve taps (symmetry)
+            else:
+                ab += tab[0, :S][::-1] * q                    # phase 0 of group NG - g, that group's last row
+                bottom_leaves(ng - g + C)
+        ab += tab[0, :S][::-1] * col[cm, 0]
+        for n in range(S):
+            bottom_leaves(C - n)
+    # k_inv_rows_plain_r8, by_column: row i < 6 gets slot row 6 + i of the column to the left, row i >= NG - 6 slot row
+    # i - (NG - 6) of the column to the right
+    out = G.copy()
+    for i in range(6):
+        out[i] += np.roll(X[6 + i], 1)
+    for i in range(ng - 6, ng):
+        out[i] += np.roll(X[i - (ng - 6)], -1)
+    return out.T.reshape(-1)                                  # G[(N2/16) c + i]
+
+
+@pytest.mark.parametrize("n2,n1,th", [(256, 8, 95), (256, 6, 75), (512, 4, 87)])
+def test_column_walk_bookkeeping_in_float64(n2, n1, th):
+    """the decimated pair step as a column walk (dec_stream.hpp): rings, the tap symmetry the upward walk relies on, the
+    neighbour shares and their merge reproduce the plain circular FIR G[j] = sum_t h[t] Q[16 j + t] to float64 rounding"""
+    rng = np.random.default_rng(n2 + n1)
+    nc = n2 * n1
+    Q = rng.standard_normal(nc) + 1j * rng.standard_normal(nc)
+    t = np.arange(-th, th + 1)
+    h = (np.sinc(t / 16) * np.kaiser(2 * th + 1, 12.0)).astype(np.float32).astype(np.float64)     # any symmetric taps do
+    tab = np.zeros((16, 16))
+    for tt, ht in zip(t, h):
+        pp = tt % 16
+        tab[pp, (tt - pp) // 16 + 6] = ht
+    want = np.zeros(nc // 16, dtype=complex)
+    for tt, ht in zip(t, h):
+        want += ht * Q[(16 * np.arange(nc // 16) + tt) % nc]
+    got = _column_walk_float64(Q, n2, n1, tab)
+    assert np.abs(got - want).max() < 1e-12 * np.abs(want).max()
+
