@@ -182,6 +182,16 @@ __global__ __launch_bounds__(256) void k_fwd_row4096(float2 *TZ, FftPlan pl, boo
 // ---------------------------------------------------------------------------
 // ROWMAJOR (4096 x 4096 plan, dec_stream.hpp): U goes back to the rows it came from, `tiled` = TZ -- a workgroup has both of
 // its rows in registers before it stores, and no other workgroup touches them.
+// The spectra leave the row pass with NON-TEMPORAL stores (round 4): they are 2.5 GB per cfg2 step, read again only by the pair
+// step, long after they have left every cache; stored plainly they pushed the NEXT kernel's first reads out of L2 / the Infinity
+// Cache on their way: cfg2 2.61-2.63 -> 2.54-2.58 ms per step (the pair step 0.657 -> 0.620 ms, the row pass itself 0.88-0.90 ->
+// 0.86-0.90), cfg3 179.9 -> 177.1, cfg4 10.03-10.05 -> 9.96-10.00, same box.  (The column kernels' stores are a different case: non-temporal
+// they ran 12 % slower, store_at above.)  TDOA_ROW_PLAIN_STORES rebuilds the old form.
+#ifndef TDOA_ROW_PLAIN_STORES
+#define TDOA_ROW_STORE(p, val) store_nt(p, val)
+#else
+#define TDOA_ROW_STORE(p, val) (*(p) = (val))
+#endif
 template <bool ROWMAJOR = false>
 __global__ __launch_bounds__(512) void k_fwd_row4096_unpack(const float2 *TZ, FftPlan pl, float2 *tiled, bool pre_tw)
 {
@@ -220,13 +230,13 @@ __global__ __launch_bounds__(512) void k_fwd_row4096_unpack(const float2 *TZ, Ff
     if (ROWMAJOR) {
         float2 *out = tiled + (size_t)blockIdx.y * pl.Zs + (size_t)k2 * 4096 + (size_t)(k2 >> 8) * pl.zpad + j;
 #pragma unroll
-        for (int k = 0; k < 16; k++) out[256 * k] = v[oreg(k)];
+        for (int k = 0; k < 16; k++) TDOA_ROW_STORE(out + 256 * k, v[oreg(k)]);
     } else {
         // tiles of COLS = 4096 / N2 columns x N2 rows = 4096 elements: column k1 = j + 256 k -> tile k1 / COLS
         const int cols = 4096 / pl.N2;
         float2 *out = tiled + (size_t)blockIdx.y * pl.Nc + (size_t)(j / cols) * 4096 + (size_t)k2 * cols + (j % cols);
 #pragma unroll
-        for (int k = 0; k < 16; k++) out[(size_t)(256 / cols) * k * 4096] = v[oreg(k)];
+        for (int k = 0; k < 16; k++) TDOA_ROW_STORE(out + (size_t)(256 / cols) * k * 4096, v[oreg(k)]);
     }
 }
 
