@@ -61,6 +61,11 @@ CONFIGS = {
 }
 
 
+class BenchCheckFailed(Exception):
+    """a check after a job's timed region failed on this rank; main() makes every rank of the group agree on it (one
+    all-reduce) so that nobody is left waiting in a collective for a rank that has gone"""
+
+
 def station_table(n):
     """the 3 real collectors + synthetic ones on 12 / 7 km rings about their centroid"""
     out = list(STATIONS)
@@ -528,7 +533,7 @@ def run_job(args, env, cfg_name, scaling, sim, steps, warmup, full):
         ctx.profile_select(None)
         prof_timed = ctx.profile()
         if not prof_timed[dominant]["launches"]:
-            raise SystemExit("profiling recorded nothing for %s" % dominant)
+            raise BenchCheckFailed("profiling recorded nothing for %s" % dominant)
     timed_peaks = None if state["peaks"] is None else state["peaks"].copy()     # what the contract's timed region produced
     timed_fix = state["fix"]
     graph_leg = None
@@ -541,25 +546,36 @@ def run_job(args, env, cfg_name, scaling, sim, steps, warmup, full):
                      "first_pass_ms_per_step": round(dtg_first / steps * 1e3, 4),
                      "note": "the same steps, the same graph without the two event-record nodes; timed twice, the second pass counts "
                              "(the first replays of a newly instantiated graph are slow when collectives run between them)"}
-    clocks = None
+    clocks, sustained = None, None
     if full and not args.no_clocks:
+        # the contract's timed region lasts tens of milliseconds on cfg2 (20 x 2.6 ms): too short for anybody's sampler to see
+        # the GPU busy.  The same step is replayed for ~1.5 s right after it; its time is reported (`sustained`) next to the
+        # clocks and the socket power rocm-smi showed meanwhile.
         n_sustain = max(steps, int(1.5 / max(dt / steps, 1e-6)))          # the same count on every rank (dt is the max over ranks)
+        box = {}
+
+        def sustain():
+            box["dt"] = timed(n_sustain)
         if rank == 0:
-            clocks = sample_clocks(lambda: timed(n_sustain))
+            clocks = sample_clocks(sustain)
         else:
-            timed(n_sustain)
+            sustain()
+        sustained = {"steps": n_sustain, "ms_per_step": round(box["dt"] / n_sustain * 1e3, 4),
+                     "value": round(samples_per_step / (box["dt"] / n_sustain) / 1e6, 2), "seconds": round(box["dt"], 3),
+                     "note": "the timed region's step (the same step graph, no event-record nodes) replayed back to back right after it, "
+                             "barrier + synchronize on both sides, max over ranks"}
 
     if world > 1 and scaling == "strong" and n_windows >= world:
         # every rank's part must be what the owner merge expects: its own windows, zeros elsewhere
         mine = np.frombuffer(dev_peaks.cpu().numpy().tobytes(), dtype=tdoa_amd.capi.PEAK_DTYPE).reshape(n_windows, n_pairs)
         for wid in range(n_windows):
             if wid % world != rank and (mine[wid]["lag"].any() or mine[wid]["corr"].any()):
-                raise SystemExit("rank %d of %d wrote a window it does not own (%d): nonzero windows %r"
+                raise BenchCheckFailed("rank %d of %d wrote a window it does not own (%d): nonzero windows %r"
                                  % (rank, world, wid, [w for w in range(n_windows) if mine[w]["lag"].any() or mine[w]["corr"].any()]))
     if world > 1 and scaling == "weak":
         got = torch.frombuffer(bytearray(gathered.cpu().numpy().tobytes()), dtype=torch.uint8).view(world, -1)
         if not torch.equal(got[rank], dev_peaks.cpu()):
-            raise SystemExit("all-gather of peak records is inconsistent on rank %d" % rank)
+            raise BenchCheckFailed("all-gather of peak records is inconsistent on rank %d" % rank)
 
     out, parity = None, None
     if rank == 0:
@@ -595,7 +611,7 @@ def run_job(args, env, cfg_name, scaling, sim, steps, warmup, full):
             "source_sha16": source_hash(),
             "k1_path": "single look (every capture byte read once; csrc/k1_single_look.hpp)" if ctx.last_k1(0)[1]
                        else "statistics pre-pass + discriminator in the column pass (capture bytes read twice)",
-            "clocks": clocks,
+            "clocks": clocks, "sustained": sustained,
         }
         if full:
             out.update(roofline_fields(args, env, cfg_name, scaling, sim, table, prof_timed, dominant, timed_mode, table_steps, steps,
@@ -618,7 +634,7 @@ def run_job(args, env, cfg_name, scaling, sim, steps, warmup, full):
                     b = tdoa_amd.capi.latlon_to_ecef(TX[0], TX[1], TX[2])
                     errs.append(math.sqrt(sum((x - y) ** 2 for x, y in zip(a, b))))
                     if int(rc_) != 0 or not np.array_equal(np.asarray(lag_, dtype=np.float64), want) or errs[-1] > 150.0:
-                        raise SystemExit("bench: the solve inside the timed region did not find the transmitter: status %d, lags %r "
+                        raise BenchCheckFailed("bench: the solve inside the timed region did not find the transmitter: status %d, lags %r "
                                          "(geometry: %r), fix (%.6f, %.6f), %.1f m from TX" % (int(rc_), list(lag_), list(want),
                                                                                                float(lle_[0]), float(lle_[1]), errs[-1]))
                 sol.update({"expected_lags": [float(x) for x in want], "lags_equal_geometry": True,
@@ -705,49 +721,53 @@ def roofline_fields(args, env, cfg_name, scaling, sim, table, prof_timed, domina
         # readers are served by L2 / Infinity Cache), the pair's own output is written -- the compulsory bytes of the launch
         compulsory = requested
         if name == "k_inv_row_pair" and n_pairs > 0:
-            out_per_pair = 8.0 * nc / 16 if decimated else 8.0 * nc
+            out_per_pair = 8.0 * nc
+            if decimated:       # G (Nc/16 points) + the neighbour shares: X[12][4096] behind the column walk, E[N2][12] behind the tiles
+                out_per_pair = 8.0 * nc / 16 + 8.0 * 12 * (4096 if hot["k_inv_row_pair"] == ["k_pair_decimate_cols"] else n2)
             compulsory = min(requested, windows_per_launch * (S * 8.0 * nc + n_pairs * out_per_pair))
         standard = args.seconds is None and args.batch == 0 and world == 1 and max_lag == 20000 and sim == "config"
         traffic, src, sq = None, None, None
         if standard and name in hot:
             traffic, src, pmc_total = pmc_traffic(cfg_name, kernels)
             sq = sq_issue(cfg_name, kernels[0])
-        # the fraction the contract asks for is an HBM fraction: memory-side bytes (counters when they were taken on these
-        # sources, else the compulsory bytes above) over the launch time -- never the request rate of a kernel whose
-        # operands are served on-die (rounds 2-3 printed 1.05 / 1.17 for cfg4 / cfg5 that way)
-        hbm_bytes = traffic if traffic is not None else compulsory
-        hbm_bytes = min(hbm_bytes, requested) if traffic is None else hbm_bytes
-        achieved = hbm_bytes / avg_s / 1e9
-        hbm_frac = achieved / HBM_PEAK_GBS
+        # `achieved` / `frac` (the contract): ALGORITHMIC = compulsory bytes of the launch -- every operand from memory once,
+        # every result written once -- over the HIP-event time of the launch.  `traffic` = what the memory-side counters saw for
+        # the same launch; `traffic_over_algorithmic` above 1.25 names wasted re-reads (cfg4 / cfg5's pair step), `hbm_frac` is
+        # the rate the HBM side actually ran at.  Neither can exceed 1 (rounds 2-3 printed request rates: 1.05 / 1.17).
+        achieved = compulsory / avg_s / 1e9
+        hbm_side = (traffic if traffic is not None else compulsory) / avg_s / 1e9
         limiter = None
         if sq is not None:
-            limiter = "valu_issue" if sq["valu_issue_frac"] > max(0.6, achieved / HBM_FILL_GBS) else "hbm"
+            limiter = "valu_issue" if sq["valu_issue_frac"] > max(0.6, hbm_side / HBM_FILL_GBS) else "hbm"
         roof = {"bound": "hbm", "kernel": " + ".join(kernels),
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(hbm_frac, 4),
-                "bytes_source": ("PMC (FETCH_SIZE + WRITE_SIZE, %s)" % src) if traffic is not None else
-                                ("compulsory HBM bytes of the launch: every station spectrum once + the pairs' outputs (its %d pairs "
-                                 "per window re-read the spectra on-die)" % n_pairs if compulsory < requested else
-                                 "the library's byte model of the launch (every operand streamed once)"),
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "bytes_source": ("compulsory bytes of the launch: every station spectrum from memory once + the pairs' outputs (its %d "
+                                 "pairs per window re-read the spectra; whether on-die or not is what `traffic` shows)" % n_pairs
+                                 if compulsory < requested else
+                                 "the library's byte model of the launch (every operand streamed once, every result written once)"),
                 "frac_of_measured_achievable": round(achieved / 6290.0, 4),   # guide: 6.29 TB/s achievable
                 "frac_of_fill_rate": round(achieved / HBM_FILL_GBS, 4),
-                "traffic": traffic, "traffic_source": src,
+                "traffic": traffic, "traffic_source": None if traffic is None else "PMC (FETCH_SIZE + WRITE_SIZE, %s)" % src,
+                "traffic_note": src if traffic is None else None,
+                "traffic_over_algorithmic": None if traffic is None else round(traffic / compulsory, 3),
+                "hbm_GBps": round(hbm_side, 1), "hbm_frac": round(hbm_side / HBM_PEAK_GBS, 4),
                 "requested_GBps": round(requested / avg_s / 1e9, 1),          # request rate: operands asked for, wherever they come from
-                "hbm_frac": round(hbm_frac, 4),
                 "valu_issue_frac": None if sq is None else sq["valu_issue_frac"],
                 "valu_instructions_per_wave": None if sq is None else sq["valu_instructions_per_wave"],
                 "lds_conflict_frac": None if sq is None else sq["lds_conflict_frac"],
                 "sq_source": None if sq is None else sq["source"],
                 "limiter": limiter,
-                "algorithmic_bytes_per_launch": hbm_bytes, "requested_bytes_per_launch": requested,
+                "algorithmic_bytes_per_launch": compulsory, "requested_bytes_per_launch": requested,
                 "avg_launch_us": round(avg_s * 1e6, 2), "launches": rec["launches"],
                 "kernels_ms_per_step": {k: round(v["ms"] / steps, 4) for k, v in prof.items()},
                 "kernels_ms_per_step_source": "%s: HIP events inside the timed region; the others: %d untimed steps launched kernel by "
                                               "kernel with an event at every boundary" % (name, table_steps),
-                "note": "achieved / frac = HBM-side bytes of the launch (bytes_source) / HIP-event time / 8 TB/s.  requested_GBps = "
-                        "the operands the launch asks for / the same time (a request rate: on-die hits included).  "
+                "note": "achieved / frac = algorithmic (compulsory) bytes of the launch / HIP-event time / 8 TB/s.  traffic = memory-side "
+                        "counters of the same launch (profiles/, same kernel sources); hbm_GBps = traffic / the same time.  "
+                        "requested_GBps = the operands the launch asks for / the same time (a request rate: on-die hits included).  "
                         "valu_issue_frac = share of the kernel's time its SIMDs spend issuing vector instructions (SQ counters "
-                        "in profiles/, same kernel sources): limiter = valu_issue when that share exceeds both 0.6 and the kernel's "
+                        "in profiles/, same kernel sources): limiter = valu_issue when that share exceeds both 0.6 and the HBM side's "
                         "share of the 5.8 TB/s a plain fill sustains"}
     # every scope of the step next to the dominant one: HBM-side rate and issue share from the same counter files, times from
     # the untimed kernel-by-kernel table (the dominant scope: from inside the timed region).  cfg2's two largest kernels are
@@ -818,6 +838,35 @@ def same_config_one_gpu(cfg_name):
         return {"value": None, "note": "unreadable: %s" % os.path.basename(f)}
 
 
+def launch_ranks(gpus, argv, environ=None, run=None):
+    """`bench.py --gpus N` by itself: N > 1 with no WORLD_SIZE in the environment means the caller did not start the ranks, so
+    this process starts `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>` as a CHILD (never an
+    exec, and before torch or any HIP call has been touched: a process that has initialised the GPU must not be replaced),
+    passes its output through and returns its exit code.  Under a launcher (WORLD_SIZE set) the two must agree.
+    Returns None when this process is a rank and should go on."""
+    environ = os.environ if environ is None else environ
+    ws = environ.get("WORLD_SIZE")
+    if ws is not None:
+        if int(ws) != gpus:
+            print("bench.py: --gpus %d but WORLD_SIZE=%s: start one rank per GPU (torch.distributed.run --nproc-per-node %d) or "
+                  "drop WORLD_SIZE and let bench.py start them" % (gpus, ws, gpus), file=sys.stderr)
+            return 2
+        return None
+    if gpus <= 1:
+        return None
+    import socket
+    import subprocess
+    port = environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as sk:                      # a free port on the loopback interface
+            sk.bind(("127.0.0.1", 0))
+            port = str(sk.getsockname()[1])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + list(argv)
+    print("bench.py: starting %d ranks: %s" % (gpus, " ".join(cmd)), file=sys.stderr)
+    return (run or subprocess.call)(cmd, env=dict(environ))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -843,6 +892,10 @@ def main():
                     help="at --gpus 1: initialise torch.distributed (nccl = RCCL, world size 1) and run the multi-GPU step -- "
                          "tdoa_process(rank, world), all_gather_into_tensor of the peak records, owner merge, solve -- on one GPU")
     args = ap.parse_args()
+
+    rc = launch_ranks(args.gpus, sys.argv[1:])
+    if rc is not None:
+        sys.exit(rc)
 
     import torch
 
@@ -885,11 +938,30 @@ def main():
     env = {"world": world, "rank": rank, "device": device, "backend": backend, "dist": dist, "use_dist": use_dist}
     sim = args.sim or ("fmdelay" if use_dist else "config")
 
-    out, parity = run_job(args, env, cfg_name, scaling, sim, steps, args.warmup, full=True)
+    def agreed(job):
+        """run a job; a failed check on ANY rank ends every rank with a non-zero status (the others would otherwise sit in the
+        next collective until the launcher kills them)"""
+        err, res = None, (None, None)
+        try:
+            res = job()
+        except BenchCheckFailed as e:
+            err = "rank %d: %s" % (rank, e)
+            print("bench: " + err, file=sys.stderr)
+        if use_dist:
+            ok = torch.tensor([0 if err else 1], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                dist.destroy_process_group()
+                raise SystemExit(err or "rank %d: a check failed on another rank" % rank)
+        elif err:
+            raise SystemExit(err)
+        return res
+
+    out, parity = agreed(lambda: run_job(args, env, cfg_name, scaling, sim, steps, args.warmup, full=True))
     # the sharded job BASELINE config 4 names, in the same run (default multi-rank invocation only)
     if use_dist and args.config is None and args.scaling is None and not args.no_sharded_leg:
         s_steps = min(steps, CONFIGS["cfg4"]["steps"])
-        sh, _ = run_job(args, env, "cfg4", "strong", sim, s_steps, 1, full=False)
+        sh, _ = agreed(lambda: run_job(args, env, "cfg4", "strong", sim, s_steps, 1, full=False))
         if rank == 0:
             one = same_config_one_gpu("cfg4")
             out["sharded_cfg4"] = {

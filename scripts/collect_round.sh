@@ -1,10 +1,12 @@
 #!/bin/bash
 # Everything the round's DESIGN.md / bench roofline quote, in one GPU call (about 25 minutes):
-#   bash scripts/collect_round.sh r04 [quick]
+#   bash scripts/collect_round.sh r05 [quick]
+# (run_stats passes --no-clocks: the profiled process must not replay 1.5 s of extra steps next to rocm-smi children that
+#  inherit the profiler's preload; the clocks come from the unprofiled default bench line further down)
 # Order matters: the counter tables of every configuration are copied into profiles/ BEFORE the bench lines are taken, so
 # that bench.py's roofline can quote them (same kernel sources: source_sha16).
 set -e
-TAG=${1:-r04}
+TAG=${1:-r05}
 QUICK=$2
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
@@ -28,7 +30,7 @@ run_stats() {   # name, bench args...
   local name=$1; shift
   say stats $name
   rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${TAG}_$name -- \
-      python3 bench.py --no-cpu-baseline --no-graph-leg --no-h2d "$@" > gpurun_out/${TAG}_${name}_bench.json 2> gpurun_out/prof_${TAG}_$name.log
+      python3 bench.py --no-cpu-baseline --no-graph-leg --no-h2d --no-clocks "$@" > gpurun_out/${TAG}_${name}_bench.json 2> gpurun_out/prof_${TAG}_$name.log
   local f=$(ls gpurun_out/prof_${TAG}_$name/*/*kernel_stats.csv | head -1)
   cp "$f" gpurun_out/${TAG}_${name}_kernel_stats.csv
   cp gpurun_out/${TAG}_${name}_bench.json gpurun_out/${TAG}_${name}_kernel_stats.csv profiles/
@@ -55,8 +57,6 @@ if [ "$QUICK" != quick ]; then
   say K1 on other byte distributions
   bash scripts/collect_k1_bytes.sh $TAG > gpurun_out/${TAG}_k1bytes.log 2>&1 || true
   cp gpurun_out/${TAG}_k1_bytes.json profiles/ || true
-  python3 scripts/graph_memset_probe.py > gpurun_out/${TAG}_graph_memset_probe.txt 2>&1 || true
-  cp gpurun_out/${TAG}_graph_memset_probe.txt profiles/ || true
 fi
 say done
 tail -1 gpurun_out/${TAG}_default_bench.json | head -c 600

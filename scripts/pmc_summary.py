@@ -30,7 +30,11 @@ FETCH_CORRECTION = {"k_fm_demod": 2.0, "k_fwd_row4096": 2.0, "k_fwd_row4096_unpa
                     "k_once_edges": 2.0,
                     # the column walk of the decimated pair step reads 8 B per lane along the rows, 512-byte runs per wave,
                     # like k_fwd_row4096
-                    "k_pair_decimate_cols": 2.0}
+                    "k_pair_decimate_cols": 2.0,
+                    # round 5: the finish sweep of the two-sweep column pass reads 16 bytes per lane with non-temporal loads
+                    # (fft_radix16.hpp k_fwd_col_finish) and works in place -- it reads exactly what it writes, and its raw
+                    # FETCH_SIZE came out at half of its WRITE_SIZE (68.85 GB against 137.8 GB per cfg3 step, round 4) -> x2
+                    "k_fwd_col_finish": 2.0}
 
 
 def load(d):

@@ -41,6 +41,11 @@ constexpr int kDecShareRows = 2 * kDecEdge;            // X: rows per pair-windo
 #endif
 constexpr int kDecWavesPerWg = TDOA_DEC_WAVES_PER_WG;  // pair-windows per workgroup (one wave each, the same 64 columns)
 
+// The walk's register stencil is written for 8 or 12 steps per phase (whole float4 of taps, mac_all): a measurement build
+// with another filter length (TDOA_DEC_STEPS=14: the 140 dB filter of rounds 2-3) has the tile form only -- the library
+// then runs without the column walk (ctx->dec_cols off: no decimated inverse on the two-sweep plans).
+#if TDOA_DEC_STEPS == 8 || TDOA_DEC_STEPS == 12
+#define TDOA_HAVE_DEC_COLS 1
 // taps: the tile kernel's table [16 phases][16 steps] (256 floats), then rot[16] = W_N^p as float2 (N = 2 Nc)
 template <int LOGN2>
 __global__ __launch_bounds__(64 * kDecWavesPerWg) __attribute__((amdgpu_waves_per_eu(TDOA_DEC_STREAM_WAVES, TDOA_DEC_STREAM_WAVES))) void k_pair_decimate_cols(const PWDesc *pw, const float2 *U, float2 *G, float2 *X, FftPlan pl,
@@ -242,5 +247,8 @@ __global__ __launch_bounds__(64 * kDecWavesPerWg) __attribute__((amdgpu_waves_pe
 #pragma unroll
     for (int n = 0; n < S; n++) bottom_leaves(C - n);
 }
+#else
+#define TDOA_HAVE_DEC_COLS 0
+#endif
 
 }  // namespace tdoa

@@ -3,21 +3,25 @@
 // The fused column kernels (fft_radix16.hpp) used to need the window's mean and scale BEFORE they could transform
 // v_i = (code_i - mean) scale, which is what k_fm_demod<false> was for: a second look-up of every sample (9 % of a cfg2
 // step's HBM traffic, 12.7 % of its time).  Correlation is bilinear, so the exact mean and scale can come afterwards:
-//   * k_once_edges looks at a few thousand samples of every station-window (1024 evenly spaced runs of 32) and fixes an
-//     INTEGER estimate m0 of the mean code and a power of two s0 ~ 1/sigma; it also leaves the prefix sums of the first
-//     and the last K samples of  w_i = (code_i - m0) s0  (head[k] = sum_{i<k} w_i, tail[k] = sum_{i>=L-k} w_i, k <= K =
-//     the largest |lag| searched);
+//   * k_once_estimate looks at 4096 samples of every station-window (256 evenly spaced runs of 16) and fixes an INTEGER
+//     estimate m0 of the mean code and a power of two s0 ~ 1/sigma; k_once_edges leaves the prefix sums of the first and
+//     the last K samples of  w_i = (code_i - m0) s0  (head[k] = sum_{i<k} w_i, tail[k] = sum_{i>=L-k} w_i, k <= K = the
+//     largest |lag| searched);
 //   * the column kernels transform w (same code path as before: their `mean` is m0, their `scale` s0) and add up the
 //     EXACT integer window sums S1 = sum code, S2 = sum code^2 of the samples they look up anyway (float64 accumulators
 //     that cannot round: see col_once_accumulate), one record per tile -- no atomics, no zeroing;
 //   * k_once_final adds the tile records in integers and evaluates mean and scale with the formulas of k_fm_stats_final
 //     (the statistics are bit-identical to the pre-pass's), plus eps = (mean - m0) s0, the mean of w, and g = scale / s0;
-//   * with v = g (w - eps) the correlation of two windows of equal length L at lag d is
-//       sum_i v^t_i v^s_{i+d} = g_t g_s [ C_w(d) - eps_t eps_s (L + |d|) + eps_s X_t(|d|) + eps_t Y_s(|d|) ],
+//   * with v = g (w - eps), W = sum_i w_i (EXACT: s0 (S1 - L m0) from the integer window sum) and windows of equal length L
+//     the correlation at lag d is
+//       sum_i v^t_i v^s_{i+d} = g_t g_s [ C_w(d) - eps_s W_t - eps_t W_s + eps_t eps_s (L - |d|) + eps_s X_t(|d|) + eps_t Y_s(|d|) ],
 //     (X, Y) = (tail_t, head_s) for d >= 0 and (head_t, tail_s) for d < 0  (once_correction; derivation in DESIGN.md
-//     section 3): the K5 kernels add the bracket's last three terms to every candidate before it enters the argmax, and
-//     k_decode_peaks multiplies the winner by g_t g_s next to the slot's scale.
-// Nothing here is approximate: m0 and s0 only decide how large the removed terms are (|eps| ~ 1/200 on noise-like codes).
+//     section 3): the K5 kernels add the bracket's correction terms to every candidate before it enters the argmax, and
+//     k_decode_peaks multiplies the winner by g_t g_s next to the slot's scale.  eps is what the pre-pass path subtracts --
+//     (float32(mean) - m0) s0, the ROUNDED mean -- so W is not L eps: it differs by L s0 (float32(mean) - mean), first order
+//     in the mean's rounding, which a carrier with a large frequency offset (|mean| >> sigma) makes visible (round 5; rounds
+//     up to 4 used W = L eps).
+// Nothing here is approximate: m0 and s0 only decide how large the removed terms are (|eps| ~ 1/64 on noise-like codes).
 // Applies when every pair-window has two windows of the same length (always true for tdoa_process; pair calls with
 // n1 = n2), K < L/2, and the peak is picked by k_small_col_peak or the pruned column kernels; every other case keeps the
 // pre-pass.  TDOA_NO_K1_ONCE=1 / TDOA_DEBUG_NO_K1_ONCE: pre-pass everywhere.
@@ -34,8 +38,10 @@ constexpr int kOncePiece = 1 << kOncePieceLog;
 constexpr int kOnceMaxPieces = 16;     // K + 1 <= 16 x 2048 (host checks)
 
 struct OnceFin {           // per station-window, written by k_once_final
-    double eps;            // mean of w = (code - m0) s0 over the window
+    double eps;            // (float32(mean) - m0) s0: what the pre-pass path subtracts from w = (code - m0) s0
     double gain;           // true scale / s0
+    double wsum;           // W = sum of w over the window = s0 (S1 - L m0), exact
+    double pad;
 };
 
 struct OnceCorr {          // what a K5 kernel needs to correct its candidates (by value; fin == nullptr: no correction)
@@ -50,9 +56,10 @@ struct OnceCorr {          // what a K5 kernel needs to correct its candidates (
 // A pair-window's constants, set up once per thread.  With head(k) = H[k], tail(k) = T[K] - T[K - k] (H, T the running
 // sums of the head and of the tail region) the term of lag d is, for either sign of d,
 //   t0 + a |d| + bx E[off_x - d] + cy E[off_y + d]          (E = the edges buffer)
-//   d >= 0:  off_x = T_t + K, bx = -b, off_y = H_s,     cy = +c, t0 = a L + b T_t[K]
-//   d <  0:  off_x = H_t,     bx = +b, off_y = T_s + K, cy = -c, t0 = a L + c T_s[K]
-// a = -eps_t eps_s raw, b = eps_s raw, c = eps_t raw: two loads and four arithmetic instructions per candidate.
+//   d >= 0:  off_x = T_t + K, bx = -b, off_y = H_s,     cy = +c, t0 = z + b T_t[K]
+//   d <  0:  off_x = H_t,     bx = +b, off_y = T_s + K, cy = -c, t0 = z + c T_s[K]
+// a = -eps_t eps_s raw, b = eps_s raw, c = eps_t raw, z = -(a L + b W_t + c W_s) (float64, rounded once): two loads and four
+// arithmetic instructions per candidate.
 // The term is small against what it is added to (|eps| ~ 1/60: a few hundred units where the noise floor of C_w is
 // ~1400 and its peak >= 7000), so float32 evaluates it to ~1e-7 of ITSELF.
 struct OnceSide {
@@ -71,7 +78,8 @@ __device__ __forceinline__ OncePair once_pair(const OnceCorr &oc, const PWDesc &
     const float b = (float)(es * raw), c = (float)(et * raw);
     r.a = (float)(-et * es * raw);
     const int head_t = p.sw_a * 2 * oc.k1, tail_t = head_t + oc.k1, head_s = p.sw_b * 2 * oc.k1, tail_s = head_s + oc.k1;
-    const float al = r.a * (float)p.len_a;
+    // the lag-independent part: eps_t eps_s L - eps_s W_t - eps_t W_s  (= -eps_t eps_s L when W = L eps)
+    const float al = (float)(raw * (et * es * (double)p.len_a - es * oc.fin[p.sw_a].wsum - et * oc.fin[p.sw_b].wsum));
     r.pos.off_x = tail_t + oc.k_max;
     r.pos.bx = -b;
     r.pos.off_y = head_s;
@@ -390,6 +398,7 @@ __global__ __launch_bounds__(256) void k_once_final(const SWDesc *sw, const Once
         out.scale = 1.0f;
         f.eps = 0.0;
         f.gain = 1.0;
+        f.wsum = 0.0;
     } else {
         const double dn = (double)len;
         out.mean = (float)((double)S1 / dn);
@@ -400,7 +409,9 @@ __global__ __launch_bounds__(256) void k_once_final(const SWDesc *sw, const Once
         // the pre-pass path transforms (f32(code) - mean) scale with the float32 mean and scale: the same two numbers here
         f.eps = ((double)out.mean - m0) * s0;
         f.gain = (double)out.scale / s0;
+        f.wsum = ((double)S1 - dn * m0) * s0;                 // |S1|, L |m0| < 2^48: exact
     }
+    f.pad = 0.0;
     stats[w] = out;
     fin[w] = f;
 }

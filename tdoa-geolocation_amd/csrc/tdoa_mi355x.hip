@@ -109,7 +109,8 @@ struct tdoa_ctx {
                                             // 2 KB; measured on cfg3: 0 -> 107 ms column pass, 128 -> 91, 256 -> 87, 512 -> 89
     bool decimate = true;                   // TDOA_NO_DECIMATE=1: general form with the full inverse even where the decimated one applies
     bool k1_once = true;                    // TDOA_NO_K1_ONCE=1: the statistics pre-pass everywhere (no single-look K1, k1_single_look.hpp)
-    bool once_active = false;               // the last run_fm_batch took the single-look path: decode multiplies by slot_gain
+    bool once_active = false;               // the last step (run_fm_batch, or the replayed graph) took the single-look path: decode multiplies by slot_gain
+    bool graph_once = false;                // ... of the step the cached graph holds (a pair call on another path in between must not change what a replay reports)
     DevBuf once_edges, once_tiles, once_fin, slot_gain;
     // decimated inverse (k_pair_decimate16): FIR taps and window correction for (Nc, reach); small plan of the R-point inverse
     DevBuf dec_taps, dec_gain;
@@ -444,7 +445,7 @@ DecDesign decimation_design(const FftPlan &pl, int reach)
 bool decimation_applies(const tdoa_ctx *ctx, const FftPlan &pl, int lag_lo, int lag_hi)
 {
     if (!ctx->decimate || ctx->force_generic || pl.N1 != 4096 || (pl.N2 != 256 && pl.N2 != 512 && pl.N2 != 4096)) return false;
-    if (pl.N2 == 4096 && !ctx->dec_cols) return false;    // only the column walk (dec_stream.hpp) has that plan
+    if (pl.N2 == 4096 && !(ctx->dec_cols && TDOA_HAVE_DEC_COLS)) return false;    // only the column walk (dec_stream.hpp) has that plan
     const int reach = std::max(lag_hi + 1, -(lag_lo - 1));
     if (reach <= 4095) return false;                       // the short-lag forms take those
     return decimation_design(pl, reach).ok;
@@ -477,7 +478,7 @@ size_t dec_spectra_offset(const FftPlan &pl, int n_pw)
 // ahead (cfg2: 0.66 ms against 0.73).
 bool dec_walks_columns(const tdoa_ctx *ctx, const FftPlan &pl, int n_sw, int n_pw, int pairs_per_window)
 {
-    if (!ctx->dec_cols) return false;
+    if (!ctx->dec_cols || !TDOA_HAVE_DEC_COLS) return false;      // (TDOA_DEC_STEPS other than 8 / 12: the walk is not built)
     if (pl.N2 == 4096 || ctx->dec_cols_always) return true;
     if (pairs_per_window <= 0 || n_pw % pairs_per_window != 0 || n_sw <= 0) return false;
     return pairs_per_window > n_sw / (n_pw / pairs_per_window);
@@ -862,11 +863,13 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
             const double ang = -2.0 * M_PI * (double)(pl.N2 / 8) / (2.0 * (double)pl.Nc);
             const float2 rot = make_float2((float)std::cos(ang), (float)std::sin(ang));
             if (dec_walks_columns(ctx, pl, n_sw, n_pw, pairs_per_window)) {
+#if TDOA_HAVE_DEC_COLS
                 const dim3 sgrid(32, (unsigned int)((n_pw + kDecWavesPerWg - 1) / kDecWavesPerWg)), sblock(64 * kDecWavesPerWg);
                 const float *tp = static_cast<const float *>(ctx->dec_taps.p);
                 if (pl.N2 == 256) hipLaunchKernelGGL(k_pair_decimate_cols<8>, sgrid, sblock, 0, st, d_pw, tz, g, edges, pl, tp, n_pw);
                 else if (pl.N2 == 512) hipLaunchKernelGGL(k_pair_decimate_cols<9>, sgrid, sblock, 0, st, d_pw, tz, g, edges, pl, tp, n_pw);
                 else hipLaunchKernelGGL(k_pair_decimate_cols<12>, sgrid, sblock, 0, st, d_pw, tz, g, edges, pl, tp, n_pw);
+#endif
             } else if (pl.N2 == 256)
                 hipLaunchKernelGGL(k_pair_decimate16<8>, grid, dim3(512), sizeof(float2) * 2 * 16 * kDecPitch, st,
                                    d_pw, spectra, g, edges, pl, static_cast<const float *>(ctx->dec_taps.p), ps2.N2, gp, n_pw, rot);
@@ -1613,8 +1616,27 @@ static int process_impl(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host,
     // by a third of the device's memory for the workspace (96 GB of an MI355X's 288: cfg4's 99 windows x 36 spectra are one
     // group of 30 GB; round 3 stopped at 24 GiB and ran them as 85 + 14)
     int per_batch = ctx->prm.windows_per_batch > 0 ? ctx->prm.windows_per_batch : (int)std::max<size_t>(mine.size(), 1);
-    const double bytes_per_window = 8.0 * (double)pl.Nc * (S + P) + 2.0 * (double)(wlen + 16) * S;
-    per_batch = (int)std::max(1.0, std::min<double>(per_batch, ctx->workspace_limit / bytes_per_window));
+    // what reserve_fm_batch asks for per window (+ 1/8: ensure() rounds every buffer up): TZ, the V workspace in the form this
+    // plan's pair step uses (dec_spectra_offset + the tiled spectra behind the tile form), code rows where K1 is materialised
+    double bytes_per_window = 8.0 * (double)pl.Zs * S + 8.0 * (double)pl.Nc * P;
+    if (decimation_applies(ctx, pl, lag_lo, lag_hi))
+        bytes_per_window = 8.0 * (double)pl.Zs * S +
+                           8.0 * std::max((double)pl.Nc * P, (double)dec_spectra_offset(pl, P) + (pl.N2 == 4096 ? 0.0 : (double)pl.Nc * S));
+    if (!fused_k1_applies(ctx, pl, lag_lo, lag_hi, P, true)) bytes_per_window += 4.0 * (double)(wlen + 16) * S * (ctx->prm.k1_smooth > 1 ? 2 : 1);
+    bytes_per_window *= 1.125;
+    // the bound: a third of the device (tdoa_create), and not more than is FREE now plus what this context already holds of it
+    // (captures attached by the caller, other contexts, other ranks on the same card all count against the device)
+    double limit = ctx->workspace_limit;
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const double held = (double)ctx->tz.cap + (double)ctx->v.cap + (double)ctx->codes.cap + (double)ctx->codes_lp.cap;
+            limit = std::min(limit, std::max(0.0, (double)free_b + held - 1073741824.0));      // 1 GiB stays free: descriptors, edges, the runtime
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    per_batch = (int)std::max(1.0, std::min<double>(per_batch, limit / bytes_per_window));
     // per_batch * S and per_batch * P become gridDim.y of the FFT kernels (HIP limit 65535)
     if (std::max(S, P) > 65535) return fail(ctx, TDOA_ERR_UNSUPPORTED, "too many station pairs for one launch group");
     per_batch = std::max(1, std::min(per_batch, 65535 / std::max(S, P)));
@@ -1764,6 +1786,7 @@ static int process_impl(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host,
     };
 
     if (replay) {
+        ctx->once_active = ctx->graph_once;
         HIPCHK(ctx, hipGraphLaunch(ctx->graph_exec, st));
     } else if (graph_ok) {
         if (ctx->graph_exec) { (void)hipGraphExecDestroy(ctx->graph_exec); ctx->graph_exec = nullptr; }
@@ -1825,6 +1848,7 @@ static int process_impl(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host,
         }
         HIPCHK(ctx, hipGraphInstantiate(&ctx->graph_exec, g, nullptr, nullptr, 0));
         ctx->graph_key = key;
+        ctx->graph_once = ctx->once_active;
         HIPCHK(ctx, hipGraphLaunch(ctx->graph_exec, st));
     } else {
         if ((rc = enqueue())) return rc;

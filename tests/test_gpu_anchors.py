@@ -36,6 +36,9 @@ def test_gpu_vs_float_definition_full_size(oracle, capsys):
     with tdoa_amd.Context(max_lag=ML, window_len=L) as c:
         for name, a, b in _inputs(oracle):
             lag, corr = c.fm_xcorr(a, b, ML)
+            # these anchors judge the TIMED path: single-look K1 (every capture byte read once).  A change that silently
+            # routed them back through the statistics pre-pass would leave the numbers green and the claim empty.
+            assert c.last_k1(0)[1], (name, "the anchor ran through the pre-pass, not the single-look path")
             flag, fcorr, _ = fp.xcorr_peak_u8(a, b, ML)
             assert lag == flag, (name, lag, flag)
             if fcorr == 0.0:

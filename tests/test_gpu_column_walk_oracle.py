@@ -1,0 +1,87 @@
+"""GPU: the BATCHED column walk of the decimated pair step -- k_pair_decimate_cols<8> (4096 x 256 plan) and <9> (4096 x 512)
+with four pair-windows per workgroup, the form that dominates BASELINE configs 4 and 5 -- directly against the oracle
+(until round 5 it was only compared with the tile form, the full inverse and the geometry's lags).
+
+Every (window, pair) of a tdoa_process batch, in the reference's pair order i < j (processor.go:816-850), is held against
+oracle.b_xcorr_peak_fft (ob_* codes, float64 FFT correlation) on the bytes downloaded from the device: lag identical, corr
+within north_star's 1e-5; and two units of every batch against the independent float64 atan2 pipeline
+(oracle/float_pipeline.py).  The batches are sized so that the LAST workgroup of the walk is partial where the pair count
+allows it (pair-windows % 4 != 0: waves 2-3 of the last workgroup have nothing to walk)."""
+import numpy as np
+import pytest
+
+from oracle import float_pipeline as fp
+
+pytestmark = pytest.mark.gpu
+
+ML = 20000
+
+
+def _check_batch(oracle, c, peaks, n_stations, wl, blk, float_units, capsys, tag):
+    pairs = [(i, j) for i in range(n_stations) for j in range(i + 1, n_stations)]
+    wpb, n_windows = c.num_windows()
+    assert peaks.shape == (n_windows, len(pairs))
+    worst, rows = 0.0, []
+    for wid in range(n_windows):
+        first = (wid // wpb) * blk + (wid % wpb) * wl
+        raw = [c.capture_download(s, first, wl) for s in range(n_stations)]
+        pre = [oracle.b_preprocess(x)[0] for x in raw]
+        for p, (i, j) in enumerate(pairs):
+            olag, ocorr, _ = oracle.b_xcorr_peak_fft(pre[i], pre[j], ML)
+            g = peaks[wid, p]
+            assert int(g["lag"]) == olag, (tag, wid, (i, j), int(g["lag"]), olag)
+            dev = abs(float(g["corr"]) - ocorr) / abs(ocorr)
+            worst = max(worst, dev)
+            assert dev < 1e-5, (tag, wid, (i, j), dev)
+            if (wid, p) in float_units:
+                flag, fcorr, _ = fp.xcorr_peak_u8(raw[i], raw[j], ML)
+                fdev = abs(float(g["corr"]) - fcorr) / abs(fcorr)
+                assert int(g["lag"]) == flag and fdev < 1e-5, (tag, wid, (i, j), fdev)
+                rows.append((wid, i, j, olag, ocorr, fdev))
+    with capsys.disabled():
+        print("\n  %s: %d pair-windows vs ob_* (f64 FFT): lag identical, worst |dcorr|/|corr| %.2e" % (tag, peaks.size, worst))
+        for r in rows:
+            print("    window %d pair %d-%d lag %6d corr %12.5f  vs float64 atan2 pipeline %.2e" % r)
+
+
+@pytest.mark.parametrize("n_stations", [8, 5])
+def test_column_walk_batch_4096x256_vs_oracle(oracle, n_stations, capsys):
+    """8 stations: 28 pairs x 3 windows = 84 pair-windows, 21 full workgroups of the walk; 5 stations: 10 x 3 = 30, the
+    eighth workgroup half empty.  Delayed FM content per block, every station its own delay and noise."""
+    import tdoa_amd
+    wl = blk = 1_100_000
+    delays = [0, 41, -17, 203, -350, 19, 77, -5][:n_stations]
+    caps = [np.concatenate([oracle.simulate_delayed_fm(blk, 400 + d, 900 + k, 100 * (s + 1) + k) for k in range(3)])
+            for s, d in enumerate(delays)]
+    with tdoa_amd.Context(max_lag=ML, window_len=wl) as c:
+        peaks = c.process_u8(caps)
+        assert tuple(c.plan_info())[1:] == (4096, 256) and c.last_k1(0)[1]
+        assert peaks.size % 4 == (0 if n_stations == 8 else 2)
+        # (more pairs than stations: the library walks the columns by itself -- asserted through the tile form differing in
+        # the last bits, not being the same numbers)
+        c.debug_flags(no_dec_cols=True)
+        tiles = c.process()
+        c.debug_flags()
+        assert np.array_equal(tiles["lag"], peaks["lag"]) and not np.array_equal(tiles["corr"], peaks["corr"])
+        _check_batch(oracle, c, peaks, n_stations, wl, blk, {(0, 0), (2, len(delays))}, capsys,
+                     "k_pair_decimate_cols<8>, %d stations" % n_stations)
+    want = np.array([delays[j] - delays[i] for i in range(n_stations) for j in range(i + 1, n_stations)])
+    assert (peaks["lag"] == want[None, :]).all()
+
+
+def test_column_walk_batch_4096x512_vs_oracle(oracle, capsys):
+    """4 stations x 3 windows of 2 200 001 samples (odd: the last element of a window holds one sample):
+    2 200 001 + 20 000 -> N = 2^22 = 2 x 4096 x 512, k_pair_decimate_cols<9>; 6 pairs x 3 windows = 18 pair-windows, the
+    fifth workgroup of the walk half empty"""
+    import tdoa_amd
+    wl = blk = 2_200_001
+    delays = [0, -123, 64, 1999]
+    caps = [np.concatenate([oracle.simulate_delayed_fm(blk, 2100 + d, 1900 + k, 100 * (s + 1) + k) for k in range(3)])
+            for s, d in enumerate(delays)]
+    with tdoa_amd.Context(max_lag=ML, window_len=wl) as c:
+        peaks = c.process_u8(caps)
+        assert tuple(c.plan_info())[1:] == (4096, 512) and c.last_k1(0)[1]
+        assert peaks.size == 18
+        _check_batch(oracle, c, peaks, 4, wl, blk, {(0, 1), (1, 5)}, capsys, "k_pair_decimate_cols<9>, 4 stations")
+    want = np.array([delays[j] - delays[i] for i in range(4) for j in range(i + 1, 4)])
+    assert (peaks["lag"] == want[None, :]).all()

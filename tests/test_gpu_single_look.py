@@ -213,3 +213,50 @@ def test_single_look_seeded_sweep(oracle):
         assert got[0] == want[0], (case, n, ml, got, want)
         assert abs(got[1] - want[1]) <= 3e-6 * abs(want[1]), (case, n, ml, got, want)
         assert np.abs(la - lr).max() <= 3e-6 * np.abs(lr).max(), (case, n, ml)
+
+
+def _offset_carrier(n, omega, seed):
+    """a strong, almost unmodulated carrier far off the centre frequency: phase advance `omega` rad per sample plus a small
+    random walk, 100 LSB of amplitude, +-1 LSB of noise -- discriminator output = omega + a few hundredths of a radian, i.e.
+    |mean| / sigma in the hundreds"""
+    rng = np.random.default_rng(seed)
+    phi = omega * np.arange(n, dtype=np.float64) + np.cumsum(rng.standard_normal(n) * 0.003)
+    x = 100.0 * np.exp(1j * phi) + (rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n))
+    iq = np.empty(2 * n, dtype=np.uint8)
+    iq[0::2] = np.clip(np.trunc(x.real + 127.5), 0, 255).astype(np.uint8)
+    iq[1::2] = np.clip(np.trunc(x.imag + 127.5), 0, 255).astype(np.uint8)
+    return iq
+
+
+@pytest.mark.parametrize("omega", [2.5, -1.9])
+def test_single_look_with_a_large_mean_over_sigma(oracle, omega, capsys):
+    """the correction used W = L eps with eps built from the float32-ROUNDED mean; the true window sum differs by
+    L s0 (f32(mean) - mean), first order in the rounding, and |mean| >> sigma (a carrier with a large frequency offset and
+    little modulation) puts that into noise-level lag values: ~1e-4 of a noise-level peak.  With the exact window sum carried
+    in OnceFin the single-look path agrees with the pre-pass path like everywhere else, and both with the f64 oracle."""
+    import tdoa_amd
+    n = 1_100_000
+    # independent, and 0.0123 rad/sample apart (at one frequency the quantisation pattern of the rotating phasor is common to
+    # both and correlates): every lag value is noise-level
+    a, b = _offset_carrier(n, omega, 71), _offset_carrier(n, omega + 0.0123, 72)
+    with tdoa_amd.Context(max_lag=ML, window_len=n) as c, tdoa_amd.Context(max_lag=ML, window_len=n) as ref:
+        ref.debug_flags(no_k1_once=True)
+        la, lr = c.fm_xcorr_lags(a, b, ML), ref.fm_xcorr_lags(a, b, ML)
+        st, once = c.last_k1(0)
+        assert once and not ref.last_k1(0)[1]
+        got, want = c.fm_xcorr(a, b, ML), ref.fm_xcorr(a, b, ML)
+    sigma = 1.0 / float(st.scale)
+    assert abs(float(st.mean)) > 100.0 * sigma                                   # the regime the finding is about
+    ta, _ = oracle.b_preprocess(a)
+    tb, _ = oracle.b_preprocess(b)
+    olag, ocorr, olags = oracle.b_xcorr_peak_fft(ta, tb, ML)
+    peak = np.abs(olags).max()
+    assert peak < 12.0                                                           # noise-level (full correlation: 1049)
+    dev_pre = np.abs(la - lr).max() / peak
+    dev_orc = np.abs(la - olags).max() / peak
+    with capsys.disabled():
+        print("\n  offset carrier %.1f rad/sample: mean %.0f codes, sigma %.0f (|mean|/sigma %.0f); lag array vs pre-pass %.2e, "
+              "vs f64 oracle %.2e of the peak (%.2f)" % (omega, float(st.mean), sigma, abs(float(st.mean)) / sigma, dev_pre, dev_orc, peak))
+    assert got[0] == want[0] == olag
+    assert dev_pre < 2e-6 and dev_orc < 1e-5
+    assert abs(got[1] - ocorr) <= 1e-5 * abs(ocorr)
