@@ -5,7 +5,7 @@ A step = one pass of the hot path (u8 IQ -> FM discriminator -> FFT -> conj-mult
 over one synthetic capture set already resident in HBM; peaks end on the host.
 
   --config cfg2 (default)              3 stations x 2 Msps x 100 s, 99 windows x 3 pairs, L = 2 000 000, N = 2^21
-  --config cfg3                        weak_signal_simulator.go captures, 10 s windows (L = 2e7, N = 2^25), 342 windows
+  --config cfg3                        weak_signal_simulator.go captures, 10 s windows (L = 2e7, N = 5 x 2^22; TDOA_POW2_ONLY=1: 2^25), 342 windows
                                        x 3 pairs = 1026 pair-windows streamed in launch groups
   --config cfg4                        8 stations (28 pairs) x 2 Msps x 100 s
   --config cfg5                        16 stations (120 pairs) x 4 Msps x 300 s, 1 s windows (L = 4e6, N = 2^22)
@@ -688,7 +688,7 @@ def roofline_fields(args, env, cfg_name, scaling, sim, table, prof_timed, domina
     hot = {}
     once = os.environ.get("TDOA_NO_K1_ONCE") != "1"
     if n1 == 4096:          # the radix-16 register kernels (fft_radix16.hpp); the column pass depends on N2
-        fused_k1 = n2 in (256, 512, 2048, 4096) and os.environ.get("TDOA_NO_FUSED_K1") != "1" and max_lag > 1024
+        fused_k1 = n2 in (256, 512, 2048, 2560, 4096) and os.environ.get("TDOA_NO_FUSED_K1") != "1" and max_lag > 1024
         if fused_k1:
             col = ["k_fwd_col512_k1"] if n2 == 512 else ["k_fwd_col256_k1"] + (["k_fwd_col_finish"] if n2 > 256 else [])
         else:
@@ -698,13 +698,13 @@ def roofline_fields(args, env, cfg_name, scaling, sim, table, prof_timed, domina
                "k_fwd_col": col, "k_fwd_row": ["k_fwd_row4096"],
                "k_inv_row_pair": ["k_inv_row_pair4096"], "k_inv_col_peak": ["k_inv_col_pruned"]}
     reach = max_lag                     # lags -(max_lag - 1) .. max_lag - 1 plus the refinement neighbours
-    decimated = (n1 == 4096 and n2 in (256, 512, 4096) and reach > 4095 and os.environ.get("TDOA_NO_DECIMATE") != "1"
+    decimated = (n1 == 4096 and n2 in (256, 512, 2560, 4096) and reach > 4095 and os.environ.get("TDOA_NO_DECIMATE") != "1"
                  and decimation_fits(n1 * n2, max_lag))
     if decimated:     # K3 + 16:1 FIR decimation of the pair spectrum, then an Nc/16-point inverse;
         #               on the 4096 x 4096 plan the FIR walks the columns of the spectrum (dec_stream.hpp)
         #               the FIR walks the columns of the spectrum (dec_stream.hpp) on the 4096 x 4096 plan and wherever a window
         #               carries more pairs than stations (tdoa_mi355x.hip dec_walks_columns); else 4096-bin tiles in LDS
-        cols = os.environ.get("TDOA_NO_DEC_COLS") != "1" and (n2 == 4096 or n_pairs > S or os.environ.get("TDOA_DEC_COLS_ALWAYS") == "1")
+        cols = os.environ.get("TDOA_NO_DEC_COLS") != "1" and (n2 in (2560, 4096) or n_pairs > S or os.environ.get("TDOA_DEC_COLS_ALWAYS") == "1")
         hot = dict(hot, k_fwd_row=["k_fwd_row4096_unpack"], k_inv_row_pair=["k_pair_decimate_cols" if cols else "k_pair_decimate16"],
                    k_inv_col_peak=["k_inv_rows_plain_r8", "k_small_col_peak"])
     if max_lag <= 1024 and n1 == 4096:

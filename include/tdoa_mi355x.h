@@ -269,7 +269,7 @@ int tdoa_debug_force_generic(tdoa_ctx *ctx, int on);
 /* tests / measurements only: pick kernel variants by hand.  flags == 0 is the library's default path; every bit
  * set switches one specialised form OFF.  The same switches can be given once, at tdoa_create time, through the
  * environment (TDOA_NO_SHORT_LAG=1, TDOA_NO_SEGMENT_FORM=1, TDOA_NO_SEGMENT_QUADS=1, TDOA_NO_XCD_ROWS=1,
- * TDOA_NO_DECIMATE=1, TDOA_NO_FUSED_K1=1, TDOA_NO_K1_ONCE=1, TDOA_NO_SEG_PACK3=1, TDOA_NO_DEC_COLS=1); results are the same to rounding whichever form runs. */
+ * TDOA_NO_DECIMATE=1, TDOA_NO_FUSED_K1=1, TDOA_NO_K1_ONCE=1, TDOA_NO_SEG_PACK3=1, TDOA_NO_DEC_COLS=1, TDOA_POW2_ONLY=1); results are the same to rounding whichever form runs. */
 enum {
     TDOA_DEBUG_GENERIC_KERNELS = 1,  /* any-size LDS radix-4 kernels instead of the radix-16 register kernels        */
     TDOA_DEBUG_NO_SHORT_LAG    = 2,  /* general pruned inverse even when the search range is below 4095 lags          */
@@ -284,8 +284,11 @@ enum {
     TDOA_DEBUG_NO_SEG_PACK3    = 1024, /* the segment form reads int32 code rows instead of the packed 3-byte ones        */
     TDOA_DEBUG_NO_DEC_COLS     = 2048, /* the decimated pair step as 4096-bin tiles in LDS (k_pair_decimate16) instead of the column
                                         walk (csrc/dec_stream.hpp); 4096 x 4096 plans then take the full inverse             */
-    TDOA_DEBUG_DEC_COLS_ALWAYS = 4096 /* (the one bit that switches a form ON) the column walk wherever the decimated inverse
+    TDOA_DEBUG_DEC_COLS_ALWAYS = 4096, /* (switches a form ON) the column walk wherever the decimated inverse
                                         applies, also where the library would pick the tile form (as many pairs as stations)  */
+    TDOA_DEBUG_POW2_ONLY       = 8192 /* transform lengths are powers of two everywhere (the reference's padding rule,
+                                        processor.go:563): ten-second windows then run in N = 2^25 instead of 5 x 2^22
+                                        (environment: TDOA_POW2_ONLY=1)                                                      */
 };
 int tdoa_debug_flags(tdoa_ctx *ctx, unsigned flags);
 /* inspection: the K1 statistics of station-window `sw_index` of the last batch (the order of the batch's descriptors:

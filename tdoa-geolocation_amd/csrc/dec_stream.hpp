@@ -47,11 +47,14 @@ constexpr int kDecWavesPerWg = TDOA_DEC_WAVES_PER_WG;  // pair-windows per workg
 #if TDOA_DEC_STEPS == 8 || TDOA_DEC_STEPS == 12
 #define TDOA_HAVE_DEC_COLS 1
 // taps: the tile kernel's table [16 phases][16 steps] (256 floats), then rot[16] = W_N^p as float2 (N = 2 Nc)
-template <int LOGN2>
+// N2 is the template argument itself (round 5: 2560 = 5 x 512 next to the powers of two); where it is not a power of two
+// the row rotations W_N^k (N = 2 Nc = 5 x 2^k) come from unit_root_any.
+template <int N2_>
 __global__ __launch_bounds__(64 * kDecWavesPerWg) __attribute__((amdgpu_waves_per_eu(TDOA_DEC_STREAM_WAVES, TDOA_DEC_STREAM_WAVES))) void k_pair_decimate_cols(const PWDesc *pw, const float2 *U, float2 *G, float2 *X, FftPlan pl,
                                                               const float *__restrict__ taps, int n_pw)
 {
-    constexpr int N2 = 1 << LOGN2, N1 = 4096, C = kDecCentre, S = kDecSteps, B = kDecStreamBatch;
+    constexpr int N2 = N2_, N1 = 4096, C = kDecCentre, S = kDecSteps, B = kDecStreamBatch;
+    constexpr bool POW2 = (N2 & (N2 - 1)) == 0;
     constexpr int NG = N2 / 16;                                     // groups of 16 rows = outputs per column
     // A workgroup = kDecWavesPerWg waves, every one of them the SAME 64 columns (and their 64 partners) of a DIFFERENT
     // pair-window: wave w of workgroup (cb, q) walks pair-window kDecWavesPerWg q + w.  Consecutive pair-windows are a
@@ -81,6 +84,11 @@ __global__ __launch_bounds__(64 * kDecWavesPerWg) __attribute__((amdgpu_waves_pe
     const int zpad = pl.zpad;
     auto row_at = [&](const float2 *base, int k2) { return base + (size_t)k2 * N1 + (size_t)(k2 >> 8) * zpad; };
     const float invNc = 1.0f / (float)pl.Nc;
+    // W_N^num, N = 2 Nc, num = k2 + N2 k1 < Nc <= 2^24 (exact as a float)
+    auto w_n = [&](float num) {
+        if constexpr (POW2) return unit_root(num, invNc, false);
+        else return unit_root_any(num, 0.5f * (float)pl.Nc, 2.0f * invNc, false);
+    };
     const size_t rc = (size_t)(pl.Nc / kDecD);
     float2 *g_top = G + (size_t)pwu * rc + k1, *g_bot = G + (size_t)pwu * rc + km;
     float2 *x_top = X + (size_t)pwu * kDecShareRows * N1 + k1, *x_bot = X + (size_t)pwu * kDecShareRows * N1 + km;
@@ -139,7 +147,7 @@ __global__ __launch_bounds__(64 * kDecWavesPerWg) __attribute__((amdgpu_waves_pe
         const int kp = (N1 - k1) & (N1 - 1);
         const TapRow tr = tap_row(0);
         float2 q, qm;
-        pair_u_pk(ra[k1], ra[kp], rb[k1], rb[kp], unit_root((float)k1 * (float)N2, invNc, false), k1 == 0, q, qm);
+        pair_u_pk(ra[k1], ra[kp], rb[k1], rb[kp], w_n((float)k1 * (float)N2), k1 == 0, q, qm);
         mac_all(at, tr, q);
     }
     x_top[0] = make_float2(0.0f, 0.0f);          // the output 6 places before a column gets nothing from it (|t| >= 96)
@@ -219,7 +227,7 @@ __global__ __launch_bounds__(64 * kDecWavesPerWg) __attribute__((amdgpu_waves_pe
     for (int r = 0; r < B; r++) fetch_row(bufa[r], r);
 #pragma unroll 1
     for (int k2 = 0; k2 < N2; k2 += 2 * B) {
-        if ((k2 & 15) == 0) wg = unit_root((float)k2 + (float)k1 * (float)N2, invNc, false);     // W_N^(16 g + N2 k1): < 2^24, exact
+        if ((k2 & 15) == 0) wg = w_n((float)k2 + (float)k1 * (float)N2);     // W_N^(16 g + N2 k1): < 2^24, exact
 #pragma unroll
         for (int r = 0; r < B; r++) fetch_row(bufb[r], k2 + B + r);
         row(bufa[0], k2, std::true_type{});
@@ -240,7 +248,7 @@ __global__ __launch_bounds__(64 * kDecWavesPerWg) __attribute__((amdgpu_waves_pe
         const float2 *ra = row_at(Ua, 0), *rb = row_at(Ub, 0);
         const TapRow tr = tap_row(16);
         float2 q, qm;
-        pair_u_pk(ra[km], ra[k1 + 1], rb[km], rb[k1 + 1], unit_root((float)km * (float)N2, invNc, false), false, q, qm);
+        pair_u_pk(ra[km], ra[k1 + 1], rb[km], rb[k1 + 1], w_n((float)km * (float)N2), false, q, qm);
         mac_all(ab, tr, q);
     }
     // ab[u] holds output u - (C - 1): C .. 0 are column km's own, -1 .. -5 the previous column's last five

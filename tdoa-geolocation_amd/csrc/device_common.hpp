@@ -65,15 +65,10 @@ __device__ __forceinline__ float dpp_add(float x)
 __device__ __forceinline__ float quad_sum(float x) { return dpp_add<0x4E>(dpp_add<0xB1>(x)); }
 __device__ __forceinline__ float row16_sum(float x) { return dpp_add<0x140>(dpp_add<0x141>(quad_sum(x))); }
 
-// exp(sign * 2*pi*i * num / den), den a power of two, 0 <= num < 2^24 (exact in f32).
-// x = 2*num/den is an exact dyadic number, so the quadrant reduction x = q/2 + u/2, |u| <= 1/2, is
-// exact; sin and cos of (pi/2)u are degree-9 / degree-8 Taylor polynomials (truncation < 3e-8),
-// about 20 VALU instructions against ~60 for the library sincospif.
-__device__ __forceinline__ float2 unit_root(float num, float inv_den_times2, bool positive)
+// sin / cos of (pi/2)(q + u), |u| <= 1/2 (a hair beyond is harmless), q quarter turns: degree-9 / degree-8 Taylor polynomials
+// (truncation < 3e-8) and a rotation by sign flips and one swap
+__device__ __forceinline__ float2 unit_root_quarter(float u, int qi, bool positive)
 {
-    const float x = num * inv_den_times2;        // angle / pi, exact
-    const float q = rintf(2.0f * x);             // quarter turns
-    const float u = __builtin_fmaf(2.0f, x, -q); // exact, in [-1/2, 1/2]
     const float v = u * u;
     float s = 0.00016044118478735982f;           // (pi/2)^9 / 9!
     s = __builtin_fmaf(s, v, -0.0046817541353186881f);   // -(pi/2)^7 / 7!
@@ -87,7 +82,6 @@ __device__ __forceinline__ float2 unit_root(float num, float inv_den_times2, boo
     c = __builtin_fmaf(c, v, -1.2337005501361698f);      // -(pi/2)^2 / 2!
     c = __builtin_fmaf(c, v, 1.0f);
     // rotate by q quarter turns: 0 (c,s)  1 (-s,c)  2 (-c,-s)  3 (s,-c)
-    const int qi = (int)q;
     const float re = (qi & 1) ? s : c, im = (qi & 1) ? c : s;
     const unsigned int sre = ((unsigned int)(qi + 1) & 2u) << 30;   // negate re for q = 1, 2 (mod 4)
     const unsigned int sim = ((unsigned int)qi & 2u) << 30;         // negate im for q = 2, 3 (mod 4)
@@ -95,6 +89,31 @@ __device__ __forceinline__ float2 unit_root(float num, float inv_den_times2, boo
     float ii = __uint_as_float(__float_as_uint(im) ^ sim);
     if (!positive) ii = -ii;
     return make_float2(rr, ii);
+}
+
+// exp(sign * 2*pi*i * num / den), den a power of two, 0 <= num < 2^24 (exact in f32).
+// x = 2*num/den is an exact dyadic number, so the quadrant reduction x = q/2 + u/2, |u| <= 1/2, is
+// exact; about 20 VALU instructions against ~60 for the library sincospif.
+__device__ __forceinline__ float2 unit_root(float num, float inv_den_times2, bool positive)
+{
+    const float x = num * inv_den_times2;        // angle / pi, exact
+    const float q = rintf(2.0f * x);             // quarter turns
+    const float u = __builtin_fmaf(2.0f, x, -q); // exact, in [-1/2, 1/2]
+    return unit_root_quarter(u, (int)q, positive);
+}
+
+// The same for a denominator that is NOT a power of two (round 5: transform lengths 5 x 2^k):
+// exp(sign 2 pi i num / den), 0 <= num < 2^24 an integer, den a multiple of 4 with den / 4 exact in a float32 (5 x 2^k is).
+// num / den is no longer a dyadic number, so the quadrant reduction is done on the INTEGERS: q = round(4 num / den) quarter
+// turns -- any rounding of the quotient near a half is fine, the polynomials hold a little beyond |u| = 1/2 --, the
+// remainder r = num - q den/4 is exact (one fma: |r| <= den/8 + 1, an integer below 2^24), and u = r / (den/4) is off by one
+// rounding of a number below 1/2: 3e-8 of a quarter turn, the size of the polynomials' own truncation.  Four instructions
+// more than the dyadic form.
+__device__ __forceinline__ float2 unit_root_any(float num, float quarter_den, float inv_quarter_den, bool positive)
+{
+    const float q = rintf(num * inv_quarter_den);
+    const float r = __builtin_fmaf(-q, quarter_den, num);       // exact
+    return unit_root_quarter(r * inv_quarter_den, (int)q, positive);
 }
 
 // 64-bit peak key: [ |v| bits : 32 ][ (0x7fffffff - rank) : 31 ][ sign : 1 ]

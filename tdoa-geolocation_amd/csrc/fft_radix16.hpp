@@ -104,6 +104,19 @@ __device__ __forceinline__ void row_pre_twiddle(float2 (&v)[16], int k2, int j, 
     mul_base_step16_nat(v, unit_root((float)e0, inv2, false), unit_root((float)e1, inv2, false));
 }
 
+// Two-sweep column pass, first sweep: sub-transform a of G leaves Y_a[kb = j + 16 k] W_(256 G)^(a kb) = W^(a j) (W^(16 a))^k
+// (outputs in v[oreg(k)]).  N2 = 256 G; G = 10 (pl.odd = 5) takes its roots from unit_root_any.
+__device__ __forceinline__ void sub_twiddle16(float2 (&v)[16], int a, int j, const FftPlan &pl)
+{
+    if (pl.odd == 1) {
+        const float invg = 2.0f / (float)pl.N2;
+        mul_base_step16(v, unit_root((float)(a * j), invg, false), unit_root((float)(16 * a), invg, false));
+    } else {
+        const float qd = 0.25f * (float)pl.N2, iq = 4.0f / (float)pl.N2;      // a j, 16 a < N2
+        mul_base_step16(v, unit_root_any((float)(a * j), qd, iq, false), unit_root_any((float)(16 * a), qd, iq, false));
+    }
+}
+
 __device__ __forceinline__ int pad16(int i) { return i + (i >> 4); }
 
 // a fetched code pair rides in the registers of the float2 it will become
@@ -216,7 +229,9 @@ __global__ __launch_bounds__(512) void k_fwd_row4096_unpack(const float2 *TZ, Ff
     const bool row0 = a == 0 && g == 0;
     const float2 *mirror = lds2 + (a == 0 ? g : g ^ 1) * kRowLds + pad16(row0 ? 4096 - j : 4095 - j);
     // w = W_N^(k2 + N2 k1) = W_N^(k2 + N2 j) * W_32^k   (N2 * 256 / N = 1 / 32)
-    const float2 wb = unit_root((float)(k2 + pl.N2 * j), 1.0f / (float)pl.Nc, false);
+    // (k2 + N2 j < 2^20 N2/4096; pl.odd != 1: the denominator N = 2 Nc is 5 x 2^k -- unit_root_any with N/4 = Nc/2)
+    const float2 wb = pl.odd == 1 ? unit_root((float)(k2 + pl.N2 * j), 1.0f / (float)pl.Nc, false)
+                                  : unit_root_any((float)(k2 + pl.N2 * j), 0.5f * (float)pl.Nc, 2.0f / (float)pl.Nc, false);
 #pragma unroll
     for (int k = 0; k < 16; k++) {
         const float2 z = v[oreg(k)];
@@ -279,8 +294,7 @@ __global__ __launch_bounds__(512) void k_fwd_col256_c16(const SWDesc *sw, const 
     float2 *out = T + (size_t)blockIdx.y * pl.Zs;
     if (SUB) {
         // Y_a[kb = j + 16k] *= W_(256G)^(a kb) = W^(a j) * (W^(16 a))^k
-        const float invg = 2.0f / (float)pl.N2;
-        if (a) mul_base_step16(v, unit_root((float)(a * j), invg, false), unit_root((float)(16 * a), invg, false));
+        if (a) sub_twiddle16(v, a, j, pl);
 #pragma unroll
         for (int k = 0; k < 16; k++) out[(size_t)(a * 256 + j + 16 * k) * N1 + (size_t)a * pl.zpad + n1] = v[oreg(k)];
     } else {
@@ -584,8 +598,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         fft16<false>(v);
         if (SUB) {
             // Y_a[kb = j + 16k] *= W_(256G)^(a kb) = W^(a j) * (W^(16 a))^k
-            const float invg = 2.0f / (float)pl.N2;
-            if (a) mul_base_step16(v, unit_root((float)(a * j), invg, false), unit_root((float)(16 * a), invg, false));
+            if (a) sub_twiddle16(v, a, j, pl);
         }
         // (one-sweep plans: the four-step twiddle W_Nc^(n1 k2) is applied by the row pass to its inputs, row_pre_twiddle)
         prev = tile;
@@ -600,46 +613,120 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     }
 }
 
-// second half, G = 16 (N2 = 4096) or 8 (N2 = 2048): X[kb + 256 ka] = sum_a W_G^(a ka) Y_a[kb] in registers
-// (G = 8 runs the 16-point butterfly on inputs spread to the even slots: W_16^(2a k) = W_8^(a k)), then the
-// four-step twiddle W_Nc^(n1 k2) = W^(n1 kb) * (W^(256 n1))^ka; in place (a thread rewrites the rows it read).
+// 5-point DFT, forward (e^{-2 pi i n k / 5}), natural order in and out: 4 real factors, the classic sums and differences
+__device__ __forceinline__ void dft5(float2 &x0, float2 &x1, float2 &x2, float2 &x3, float2 &x4)
+{
+    constexpr float c1 = 0.30901699437494742f, c2 = -0.80901699437494742f;      // cos(2 pi/5), cos(4 pi/5)
+    constexpr float s1 = 0.95105651629515357f, s2 = 0.58778525229247313f;       // sin(2 pi/5), sin(4 pi/5)
+    const float2 t1 = cadd(x1, x4), t2 = cadd(x2, x3), t3 = csub(x1, x4), t4 = csub(x2, x3);
+    const cplx_v m1 = cv(x0) + c1 * cv(t1) + c2 * cv(t2), m2 = cv(x0) + c2 * cv(t1) + c1 * cv(t2);
+    const cplx_v r1 = s1 * cv(t3) + s2 * cv(t4), r2 = s2 * cv(t3) - s1 * cv(t4);
+    x0 = cf(cv(x0) + cv(t1) + cv(t2));
+    // X1 = m1 - i r1, X4 = m1 + i r1, X2 = m2 - i r2, X3 = m2 + i r2   (-i (a, b) = (b, -a))
+    x1 = make_float2(m1.x + r1.y, m1.y - r1.x);
+    x4 = make_float2(m1.x - r1.y, m1.y + r1.x);
+    x2 = make_float2(m2.x + r2.y, m2.y - r2.x);
+    x3 = make_float2(m2.x - r2.y, m2.y + r2.x);
+}
+
+// 10-point DFT, forward, natural order in and out: two 5-point DFTs over the even and the odd inputs, then
+// X[k] = E[k] + W_10^k O[k], X[k + 5] = E[k] - W_10^k O[k]
+__device__ __forceinline__ void dft10(float2 (&v)[10])
+{
+    dft5(v[0], v[2], v[4], v[6], v[8]);
+    dft5(v[1], v[3], v[5], v[7], v[9]);
+    constexpr float wr[5] = {1.0f, 0.80901699437494742f, 0.30901699437494742f, -0.30901699437494742f, -0.80901699437494742f};
+    constexpr float wi[5] = {0.0f, -0.58778525229247313f, -0.95105651629515357f, -0.95105651629515357f, -0.58778525229247313f};
+    float2 x[10];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        const float2 e = v[2 * k], o = k ? cmul(v[2 * k + 1], make_float2(wr[k], wi[k])) : v[1];
+        x[k] = cadd(e, o);
+        x[k + 5] = csub(e, o);
+    }
+#pragma unroll
+    for (int k = 0; k < 10; k++) v[k] = x[k];
+}
+
+// second half, G = 16 (N2 = 4096), 8 (N2 = 2048) or 10 (N2 = 2560, round 5): X[kb + 256 ka] = sum_a W_G^(a ka) Y_a[kb] in
+// registers (G = 8 runs the 16-point butterfly on inputs spread to the even slots: W_16^(2a k) = W_8^(a k); G = 10 a
+// 10-point DFT as 2 x 5), then the four-step twiddle W_Nc^(n1 k2) = W^(n1 kb) * (W^(256 n1))^ka; in place (a thread rewrites
+// the rows it read).
 // grid (N1/512, 256, n_sw), 256 threads = 512 adjacent columns.
 template <int G>
 __global__ __launch_bounds__(256) void k_fwd_col_finish(float2 *T, FftPlan pl)
 {
-    static_assert(G == 8 || G == 16, "two-sweep column pass: N2 = 2048 or 4096");
+    static_assert(G == 8 || G == 16 || G == 10, "two-sweep column pass: N2 = 2048, 2560 or 4096");
     // a thread takes TWO adjacent columns (one 16-byte access per row): a workgroup moves 4 KB runs of each of its 16 rows
     const int n1 = ((blockIdx.x << 8) + threadIdx.x) * 2, kb = blockIdx.y;
     float2 *base = T + (size_t)blockIdx.z * pl.Zs + (size_t)kb * pl.N1 + n1;
     const size_t stride = (size_t)256 * pl.N1 + pl.zpad;      // (zpad = 0: 27 % slower -- every row of the sum on one channel)
     typedef float f4v __attribute__((ext_vector_type(4)));
-    float2 v[16], u[16];
+    if constexpr (G == 10) {
+        float2 v[10], u[10];
 #pragma unroll
-    for (int r = 0; r < 16; r++) v[r] = u[r] = make_float2(0.0f, 0.0f);
+        for (int a = 0; a < 10; a++) {
+            const f4v x = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(base + a * stride));      // read once
+            v[a] = make_float2(x.x, x.y);
+            u[a] = make_float2(x.z, x.w);
+        }
+        dft10(v);
+        dft10(u);
+        // W_Nc^(n1 (kb + 256 ka)), Nc = 4096 x 2560: n1 kb, 256 n1 < 2^20 -- no wrap; the denominator is 5 x 2^21
+        const float qd = 0.25f * (float)pl.Nc, iq = 4.0f / (float)pl.Nc;
+        // base * step^ka, ka = 0..9, by products of depth <= 5 (like mul_base_step16): step^2, ^4, ^8 by squaring
+        auto twiddle10 = [&](float2 (&x)[10], int col) {
+            const float2 g = unit_root_any((float)(col * kb), qd, iq, false), s1 = unit_root_any((float)(col * 256), qd, iq, false);
+            const float2 s2 = cmul(s1, s1), s4 = cmul(s2, s2), s8 = cmul(s4, s4), g4 = cmul(g, s4), g8 = cmul(g, s8);
+            const float2 s3 = cmul(s2, s1);
+            x[0] = cmul(x[0], g);
+            x[1] = cmul(x[1], cmul(g, s1));
+            x[2] = cmul(x[2], cmul(g, s2));
+            x[3] = cmul(x[3], cmul(g, s3));
+            x[4] = cmul(x[4], g4);
+            x[5] = cmul(x[5], cmul(g4, s1));
+            x[6] = cmul(x[6], cmul(g4, s2));
+            x[7] = cmul(x[7], cmul(g4, s3));
+            x[8] = cmul(x[8], g8);
+            x[9] = cmul(x[9], cmul(g8, s1));
+        };
+        twiddle10(v, n1);
+        twiddle10(u, n1 + 1);
 #pragma unroll
-    for (int a = 0; a < G; a++) {
-        const f4v x = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(base + a * stride));      // read once
-        v[(16 / G) * a] = make_float2(x.x, x.y);
-        u[(16 / G) * a] = make_float2(x.z, x.w);
-    }
-    fft16<false>(v);
-    fft16<false>(u);
-    const float inv2 = 2.0f / (float)pl.Nc;
-    {
-        const long long e0 = ((long long)n1 * kb) & (pl.Nc - 1);
-        const long long e1 = ((long long)n1 * 256) & (pl.Nc - 1);
-        mul_base_step16(v, unit_root((float)e0, inv2, false), unit_root((float)e1, inv2, false));
-    }
-    {
-        const long long e0 = ((long long)(n1 + 1) * kb) & (pl.Nc - 1);
-        const long long e1 = ((long long)(n1 + 1) * 256) & (pl.Nc - 1);
-        mul_base_step16(u, unit_root((float)e0, inv2, false), unit_root((float)e1, inv2, false));
-    }
+        for (int ka = 0; ka < 10; ka++) {
+            f4v y;
+            y.x = v[ka].x; y.y = v[ka].y; y.z = u[ka].x; y.w = u[ka].y;
+            __builtin_nontemporal_store(y, reinterpret_cast<f4v *>(base + ka * stride));
+        }
+    } else {
+        float2 v[16], u[16];
 #pragma unroll
-    for (int ka = 0; ka < G; ka++) {
-        f4v y;
-        y.x = v[oreg(ka)].x; y.y = v[oreg(ka)].y; y.z = u[oreg(ka)].x; y.w = u[oreg(ka)].y;
-        __builtin_nontemporal_store(y, reinterpret_cast<f4v *>(base + ka * stride));
+        for (int r = 0; r < 16; r++) v[r] = u[r] = make_float2(0.0f, 0.0f);
+#pragma unroll
+        for (int a = 0; a < G; a++) {
+            const f4v x = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(base + a * stride));      // read once
+            v[(16 / G) * a] = make_float2(x.x, x.y);
+            u[(16 / G) * a] = make_float2(x.z, x.w);
+        }
+        fft16<false>(v);
+        fft16<false>(u);
+        const float inv2 = 2.0f / (float)pl.Nc;
+        {
+            const long long e0 = ((long long)n1 * kb) & (pl.Nc - 1);
+            const long long e1 = ((long long)n1 * 256) & (pl.Nc - 1);
+            mul_base_step16(v, unit_root((float)e0, inv2, false), unit_root((float)e1, inv2, false));
+        }
+        {
+            const long long e0 = ((long long)(n1 + 1) * kb) & (pl.Nc - 1);
+            const long long e1 = ((long long)(n1 + 1) * 256) & (pl.Nc - 1);
+            mul_base_step16(u, unit_root((float)e0, inv2, false), unit_root((float)e1, inv2, false));
+        }
+#pragma unroll
+        for (int ka = 0; ka < G; ka++) {
+            f4v y;
+            y.x = v[oreg(ka)].x; y.y = v[oreg(ka)].y; y.z = u[oreg(ka)].x; y.w = u[oreg(ka)].y;
+            __builtin_nontemporal_store(y, reinterpret_cast<f4v *>(base + ka * stride));
+        }
     }
 }
 

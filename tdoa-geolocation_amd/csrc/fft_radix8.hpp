@@ -240,11 +240,17 @@ __device__ __forceinline__ void inv_rows_twiddle_store(float2 (&va)[8], float2 (
                                                        float2 *out, const FftPlan &pl)
 {
     // V[k2][n1] = y[n1] * W_Nc^(-n1 k2), n1 = t + 512 k
-    const float inv2 = 2.0f / (float)pl.Nc;
-    const long long e0 = ((long long)t * a) & (pl.Nc - 1), e1 = ((long long)512 * a) & (pl.Nc - 1);
-    mul_base_step8(va, unit_root((float)e0, inv2, true), unit_root((float)e1, inv2, true));
-    const long long f0 = ((long long)t * b) & (pl.Nc - 1), f1 = ((long long)512 * b) & (pl.Nc - 1);
-    mul_base_step8(vb, unit_root((float)f0, inv2, true), unit_root((float)f1, inv2, true));
+    if (pl.odd == 1) {
+        const float inv2 = 2.0f / (float)pl.Nc;
+        const long long e0 = ((long long)t * a) & (pl.Nc - 1), e1 = ((long long)512 * a) & (pl.Nc - 1);
+        mul_base_step8(va, unit_root((float)e0, inv2, true), unit_root((float)e1, inv2, true));
+        const long long f0 = ((long long)t * b) & (pl.Nc - 1), f1 = ((long long)512 * b) & (pl.Nc - 1);
+        mul_base_step8(vb, unit_root((float)f0, inv2, true), unit_root((float)f1, inv2, true));
+    } else {      // the small plan of a 5 x 2^k transform (4096 x 160): t a, 512 a < 512 N2 < Nc -- no wrap
+        const float qd = 0.25f * (float)pl.Nc, iq = 4.0f / (float)pl.Nc;
+        mul_base_step8(va, unit_root_any((float)(t * a), qd, iq, true), unit_root_any((float)(512 * a), qd, iq, true));
+        mul_base_step8(vb, unit_root_any((float)(t * b), qd, iq, true), unit_root_any((float)(512 * b), qd, iq, true));
+    }
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         out[(size_t)a * 4096 + t + 512 * k] = va[oreg8(k)];
@@ -603,10 +609,12 @@ __global__ __launch_bounds__(256) void k_small_col_peak(const float2 *V, unsigne
 {
     constexpr bool FIXED = NP > 0 && NN > 0;
     const int np = FIXED ? NP : np_rt, nn = FIXED ? NN : nn_rt;
-    __shared__ float2 wtab[256];                   // e^{+2 pi i k / N2'}  (N2' = 16, 32; 256 behind k_pair_decimate_cols<12>)
+    __shared__ float2 wtab[256];                   // e^{+2 pi i k / N2'}  (N2' = 16, 32; 256 / 160 behind the column walk of the 4096 x 4096 / x 2560 plans)
     __shared__ unsigned long long red[4];
     const int N2 = pl.N2, N1 = pl.N1;
-    if (threadIdx.x < N2) wtab[threadIdx.x] = unit_root((float)threadIdx.x, 2.0f / (float)N2, true);
+    if (threadIdx.x < N2)
+        wtab[threadIdx.x] = pl.odd == 1 ? unit_root((float)threadIdx.x, 2.0f / (float)N2, true)
+                                        : unit_root_any((float)threadIdx.x, 0.25f * (float)N2, 4.0f / (float)N2, true);
     __syncthreads();
     const int n1 = blockIdx.x * 256 + threadIdx.x;
     const float2 *in = V + (size_t)blockIdx.y * pl.Nc + n1;
@@ -661,7 +669,7 @@ __global__ __launch_bounds__(256) void k_small_col_peak(const float2 *V, unsigne
                 for (int o = 0; o < kPruneMax; o++) {
                     if (o < nout) {
                         const int n2 = o < np ? o : N2 - nn + (o - np);
-                        const float2 w = wtab[(n2 * (k0 + u)) & (N2 - 1)];
+                        const float2 w = wtab[pl.odd == 1 ? (n2 * (k0 + u)) & (N2 - 1) : (n2 * (k0 + u)) % N2];
                         acc[o].x += x[u].x * w.x - x[u].y * w.y;
                         acc[o].y += x[u].x * w.y + x[u].y * w.x;
                     }

@@ -106,6 +106,11 @@ struct FftPlan {
     // otherwise lie exactly 256 N1 elements = 8 MB apart (k_fwd_col_finish); everywhere else zpad = 0 and Zs = Nc.
     int zpad;
     long long Zs;
+    // round 5: N2 = odd x 2^k with odd = 1 (every plan up to round 4), or 5: the 4096 x 2560 plan of ten-second windows
+    // (N = 5 x 2^22 instead of 2^25: the 20 020 000 samples + lags of BASELINE config 3 in 20 971 520 points instead of
+    // 33 554 432) and its small plan 4096 x 160.  Where odd != 1 the twiddles whose denominator holds N2 -- W_N2, W_Nc, W_2Nc --
+    // come from unit_root_any, and index wraps by N2 or Nc are no longer masks.
+    int odd;
 };
 
 // ---------------------------------------------------------------------------
@@ -429,7 +434,8 @@ __global__ __launch_bounds__(64) void k_refine_peaks(const float2 *V, const unsi
         float acc = 0.0f;
         for (int k2 = threadIdx.x; k2 < pl.N2; k2 += kWave) {
             const float2 x = in[(size_t)k2 * pl.N1 + n1];
-            const float2 w = unit_root((float)((n2 * k2) & (pl.N2 - 1)), inv2, true);
+            const float2 w = pl.odd == 1 ? unit_root((float)((n2 * k2) & (pl.N2 - 1)), inv2, true)
+                                         : unit_root_any((float)((n2 * k2) % pl.N2), 0.25f * (float)pl.N2, 4.0f / (float)pl.N2, true);
             acc += (l & 1) ? x.x * w.y + x.y * w.x : x.x * w.x - x.y * w.y;
         }
 #pragma unroll

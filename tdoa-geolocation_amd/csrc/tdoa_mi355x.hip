@@ -108,6 +108,7 @@ struct tdoa_ctx {
     int zpad = 256;                         // TDOA_ZPAD=n at tdoa_create time: padding (elements) after every 256 rows of a two-sweep plan's TZ:
                                             // 2 KB; measured on cfg3: 0 -> 107 ms column pass, 128 -> 91, 256 -> 87, 512 -> 89
     bool decimate = true;                   // TDOA_NO_DECIMATE=1: general form with the full inverse even where the decimated one applies
+    bool pow2_only = false;                 // TDOA_POW2_ONLY=1: transform lengths are powers of two everywhere (no 5 x 2^22 plan for ten-second windows)
     bool k1_once = true;                    // TDOA_NO_K1_ONCE=1: the statistics pre-pass everywhere (no single-look K1, k1_single_look.hpp)
     bool once_active = false;               // the last step (run_fm_batch, or the replayed graph) took the single-look path: decode multiplies by slot_gain
     bool graph_once = false;                // ... of the step the cached graph holds (a pair call on another path in between must not change what a replay reports)
@@ -204,8 +205,13 @@ constexpr size_t kLdsCap = 128 * 1024;
 int make_plan(long long n_real, bool packed, FftPlan *pl, int zpad = 0)
 {
     long long nc = packed ? n_real / 2 : n_real;
-    if (nc < 32 || nc > (1ll << 24) || (nc & (nc - 1))) return TDOA_ERR_UNSUPPORTED;
+    // 5 x 2^k (round 5): only the two shapes that have kernels -- 4096 x 2560 (N = 5 x 2^22, the column pass as ten 256-point
+    // sub-transforms + k_fwd_col_finish<10>, the pair step as a column walk) and the small plan of its decimated inverse,
+    // 4096 x 160
+    const int odd = (nc == 4096ll * 2560 || nc == 4096ll * 160) ? 5 : 1;
+    if (nc < 32 || nc > (1ll << 24) || (odd == 1 && (nc & (nc - 1)))) return TDOA_ERR_UNSUPPORTED;
     long long n1, n2;
+    pl->odd = odd;
     if (nc >= 65536) {
         n1 = 4096;
         n2 = nc / n1;
@@ -225,7 +231,7 @@ int make_plan(long long n_real, bool packed, FftPlan *pl, int zpad = 0)
     pl->C = (int)c;
     pl->logC = ilog2(c);
     pl->Nc = nc;
-    pl->zpad = n1 == 4096 && (n2 == 4096 || n2 == 2048) ? zpad : 0;      // two-sweep column pass (fft_stockham.hpp, FftPlan)
+    pl->zpad = n1 == 4096 && (n2 == 4096 || n2 == 2048 || n2 == 2560) ? zpad : 0;      // two-sweep column pass (fft_stockham.hpp, FftPlan)
     pl->Zs = nc + (long long)(n2 / 256) * pl->zpad;
     return TDOA_OK;
 }
@@ -442,10 +448,14 @@ DecDesign decimation_design(const FftPlan &pl, int reach)
     return {att >= kDecMinAttenuationDb, T, att};
 }
 
+// two-sweep plans with a decimated inverse: a 4096-bin tile of their spectrum is (less than) one column, so only the column
+// walk (dec_stream.hpp) serves them, and the row pass leaves the unpacked spectra in TZ
+bool cols_only_plan(const FftPlan &pl) { return pl.N1 == 4096 && (pl.N2 == 4096 || pl.N2 == 2560); }
+
 bool decimation_applies(const tdoa_ctx *ctx, const FftPlan &pl, int lag_lo, int lag_hi)
 {
-    if (!ctx->decimate || ctx->force_generic || pl.N1 != 4096 || (pl.N2 != 256 && pl.N2 != 512 && pl.N2 != 4096)) return false;
-    if (pl.N2 == 4096 && !(ctx->dec_cols && TDOA_HAVE_DEC_COLS)) return false;    // only the column walk (dec_stream.hpp) has that plan
+    if (!ctx->decimate || ctx->force_generic || pl.N1 != 4096 || (pl.N2 != 256 && pl.N2 != 512 && !cols_only_plan(pl))) return false;
+    if (cols_only_plan(pl) && !(ctx->dec_cols && TDOA_HAVE_DEC_COLS)) return false;
     const int reach = std::max(lag_hi + 1, -(lag_lo - 1));
     if (reach <= 4095) return false;                       // the short-lag forms take those
     return decimation_design(pl, reach).ok;
@@ -479,7 +489,7 @@ size_t dec_spectra_offset(const FftPlan &pl, int n_pw)
 bool dec_walks_columns(const tdoa_ctx *ctx, const FftPlan &pl, int n_sw, int n_pw, int pairs_per_window)
 {
     if (!ctx->dec_cols || !TDOA_HAVE_DEC_COLS) return false;      // (TDOA_DEC_STEPS other than 8 / 12: the walk is not built)
-    if (pl.N2 == 4096 || ctx->dec_cols_always) return true;
+    if (cols_only_plan(pl) || ctx->dec_cols_always) return true;
     if (pairs_per_window <= 0 || n_pw % pairs_per_window != 0 || n_sw <= 0) return false;
     return pairs_per_window > n_sw / (n_pw / pairs_per_window);
 }
@@ -547,7 +557,7 @@ int segment_pq(const tdoa_ctx *ctx, const FftPlan &pl, int lag_lo, int lag_hi, i
 bool fused_k1_applies(const tdoa_ctx *ctx, const FftPlan &pl, int lag_lo, int lag_hi, int n_pw, bool allow)
 {
     if (!allow || !ctx->fused_k1 || ctx->force_generic || ctx->prm.k1_smooth > 1 || ctx->prm.k1_gate) return false;
-    if (pl.N1 != 4096 || !(pl.N2 == 256 || pl.N2 == 512 || pl.N2 == 2048 || pl.N2 == 4096)) return false;
+    if (pl.N1 != 4096 || !(pl.N2 == 256 || pl.N2 == 512 || pl.N2 == 2048 || pl.N2 == 2560 || pl.N2 == 4096)) return false;
     return segment_pq(ctx, pl, lag_lo, lag_hi, n_pw) == 0;
 }
 
@@ -581,9 +591,18 @@ int reserve_fm_batch(tdoa_ctx *ctx, int n_sw, int maxlen, int n_pw, const FftPla
     if (n_pw && decimation_applies(ctx, pl, lag_lo, lag_hi) && (rc = ensure_decimation(ctx, pl, lag_lo, lag_hi))) return rc;
     size_t v_elems = (size_t)pl.Nc * n_pw;
     if (n_pw && decimation_applies(ctx, pl, lag_lo, lag_hi))      // G + V' of the pairs, then the tiled spectra of the stations
-        v_elems = std::max(v_elems, dec_spectra_offset(pl, n_pw) + (pl.N2 == 4096 ? 0 : (size_t)pl.Nc * n_sw));
+        v_elems = std::max(v_elems, dec_spectra_offset(pl, n_pw) + (cols_only_plan(pl) ? 0 : (size_t)pl.Nc * n_sw));
     if (n_pw && (rc = ensure(ctx, ctx->v, sizeof(float2) * v_elems))) return rc;
     return TDOA_OK;
+}
+
+// second sweep of the two-sweep column pass: the G = N2 / 256 rows kb + 256 a of every column, in place
+void launch_col_finish(hipStream_t st, float2 *tz, const FftPlan &pl, int n_sw)
+{
+    const dim3 grid(pl.N1 / 512, 256, n_sw), blk(256);
+    if (pl.N2 == 4096) hipLaunchKernelGGL(k_fwd_col_finish<16>, grid, blk, 0, st, tz, pl);
+    else if (pl.N2 == 2560) hipLaunchKernelGGL(k_fwd_col_finish<10>, grid, blk, 0, st, tz, pl);
+    else hipLaunchKernelGGL(k_fwd_col_finish<8>, grid, blk, 0, st, tz, pl);
 }
 
 // ---- mode B core: run stats + forward + inverse + peak over prepared descriptors
@@ -614,7 +633,7 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
     // fft_stockham.hpp
     const bool row16 = pl.N1 == 4096 && !ctx->force_generic;
     const bool col16 = row16 && pl.N2 == 256;
-    const bool col2pass = row16 && (pl.N2 == 4096 || pl.N2 == 2048);   // 256-point sub-transforms + 16-point finish (two sweeps)
+    const bool col2pass = row16 && (pl.N2 == 4096 || pl.N2 == 2048 || pl.N2 == 2560);   // 256-point sub-transforms + G-point finish (two sweeps)
     const int col16x = row16 && pl.N2 >= 16 && pl.N2 <= 128 ? pl.N2 / 16 : 0;   // short columns: k_fwd_col16x_c16<F>
     const int colx = row16 && (pl.N2 == 512 || pl.N2 == 1024) ? pl.N2 / 256 : 0;   // last radix of k_fwd_colx_c16
     int np = 0, nn = 0;
@@ -714,10 +733,7 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
             if (once) TDOA_COL256(true, true);
             else TDOA_COL256(true, false);
 #undef TDOA_COL256
-            if (pl.N2 == 4096)
-                hipLaunchKernelGGL(k_fwd_col_finish<16>, dim3(pl.N1 / 512, 256, n_sw), dim3(256), 0, st, tz, pl);
-            else
-                hipLaunchKernelGGL(k_fwd_col_finish<8>, dim3(pl.N1 / 512, 256, n_sw), dim3(256), 0, st, tz, pl);
+            launch_col_finish(st, tz, pl, n_sw);
         }
         else if (fused_k1 && colx == 2) {
             if (once)
@@ -733,10 +749,7 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
         else if (col2pass) {
             hipLaunchKernelGGL(k_fwd_col256_c16<true>, dim3(pl.N1 / 32, n_sw, pl.N2 / 256), dim3(512), lds_col16, st,
                                d_sw, codes, code_stride, stats, tz, pl);
-            if (pl.N2 == 4096)
-                hipLaunchKernelGGL(k_fwd_col_finish<16>, dim3(pl.N1 / 512, 256, n_sw), dim3(256), 0, st, tz, pl);
-            else
-                hipLaunchKernelGGL(k_fwd_col_finish<8>, dim3(pl.N1 / 512, 256, n_sw), dim3(256), 0, st, tz, pl);
+            launch_col_finish(st, tz, pl, n_sw);
         }
         else if (col16x == 1)
             hipLaunchKernelGGL(k_fwd_col16x_c16<1>, dim3(pl.N1 / 256, n_sw), dim3(256), 0, st, d_sw, codes, code_stride,
@@ -866,9 +879,10 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
 #if TDOA_HAVE_DEC_COLS
                 const dim3 sgrid(32, (unsigned int)((n_pw + kDecWavesPerWg - 1) / kDecWavesPerWg)), sblock(64 * kDecWavesPerWg);
                 const float *tp = static_cast<const float *>(ctx->dec_taps.p);
-                if (pl.N2 == 256) hipLaunchKernelGGL(k_pair_decimate_cols<8>, sgrid, sblock, 0, st, d_pw, tz, g, edges, pl, tp, n_pw);
-                else if (pl.N2 == 512) hipLaunchKernelGGL(k_pair_decimate_cols<9>, sgrid, sblock, 0, st, d_pw, tz, g, edges, pl, tp, n_pw);
-                else hipLaunchKernelGGL(k_pair_decimate_cols<12>, sgrid, sblock, 0, st, d_pw, tz, g, edges, pl, tp, n_pw);
+                if (pl.N2 == 256) hipLaunchKernelGGL(k_pair_decimate_cols<256>, sgrid, sblock, 0, st, d_pw, tz, g, edges, pl, tp, n_pw);
+                else if (pl.N2 == 512) hipLaunchKernelGGL(k_pair_decimate_cols<512>, sgrid, sblock, 0, st, d_pw, tz, g, edges, pl, tp, n_pw);
+                else if (pl.N2 == 2560) hipLaunchKernelGGL(k_pair_decimate_cols<2560>, sgrid, sblock, 0, st, d_pw, tz, g, edges, pl, tp, n_pw);
+                else hipLaunchKernelGGL(k_pair_decimate_cols<4096>, sgrid, sblock, 0, st, d_pw, tz, g, edges, pl, tp, n_pw);
 #endif
             } else if (pl.N2 == 256)
                 hipLaunchKernelGGL(k_pair_decimate16<8>, grid, dim3(512), sizeof(float2) * 2 * 16 * kDecPitch, st,
@@ -1027,6 +1041,29 @@ int check_ctx(tdoa_ctx *ctx)
     return TDOA_OK;
 }
 
+// Transform length for `need` = window + search range samples.  The reference's rule is the next power of two
+// (processor.go:563 -- dead code there, processor.go:638, and a design hint here: any N >= need gives the same linear
+// correlation).  Ten-second windows at 2 Msps need 20 020 000 points: 2^25 = 33 554 432 is 40 % zero padding that every pass
+// moves; 5 x 2^22 = 20 971 520 (packed 4096 x 2560) holds them with 4.5 %.  That plan exists where the step runs the fused /
+// two-sweep column pass and the decimated inverse as a column walk (decimation_applies): everything else -- short search
+// ranges, TDOA_LAGS_GO, TDOA_NO_DECIMATE, the any-size kernels -- keeps the power of two, and so does TDOA_POW2_ONLY=1 /
+// TDOA_DEBUG_POW2_ONLY (the A/B switch).
+long long choose_fft_size(const tdoa_ctx *ctx, long long need, int lag_lo, int lag_hi, int zpad, FftPlan *pl, int *rc)
+{
+    const long long p = std::max<long long>(next_pow2(need), 64);
+    const long long five = 5ll << 22;
+    if (!ctx->pow2_only && p == (1ll << 25) && need <= five) {
+        FftPlan q;
+        if (make_plan(five, true, &q, zpad) == TDOA_OK && decimation_applies(ctx, q, lag_lo, lag_hi)) {
+            *pl = q;
+            *rc = TDOA_OK;
+            return five;
+        }
+    }
+    *rc = make_plan(p, true, pl, zpad);
+    return p;
+}
+
 // timeDomainCorrelation's block count for a template of lt samples (processor.go:691: starts 0, cb, 2 cb, ... < lt - cb)
 long long go_blocks(long long lt, long long cb) { return lt > cb ? (lt - cb + cb - 1) / cb : 0; }
 
@@ -1089,9 +1126,9 @@ int fm_pair(tdoa_ctx *ctx, const uint8_t *iq1, size_t n1, const uint8_t *iq2, si
         lag_lo = 0;
         lag_hi = (int)eff - 1;
     }
-    long long n = std::max<long long>(next_pow2((long long)std::max(n1, n2) + max_lag), 64);
     FftPlan pl;
-    if ((rc = make_plan(n, true, &pl, ctx->zpad))) return fail(ctx, rc, "FFT size unsupported");
+    const long long n = choose_fft_size(ctx, (long long)std::max(n1, n2) + max_lag, lag_lo, lag_hi, ctx->zpad, &pl, &rc);
+    if (rc) return fail(ctx, rc, "FFT size unsupported");
     ctx->plan = pl;            // tdoa_plan_info reports the plan of the last call, pair calls included
     ctx->plan_n = n;
     SWDesc *d_sw;
@@ -1278,6 +1315,7 @@ int tdoa_create(const tdoa_params *p, tdoa_ctx **out)
     if (const char *e = std::getenv("TDOA_NO_SEGMENT_QUADS")) ctx->segment_quads = !(e[0] == '1');
     if (const char *e = std::getenv("TDOA_NO_DECIMATE")) ctx->decimate = !(e[0] == '1');
     if (const char *e = std::getenv("TDOA_NO_K1_ONCE")) ctx->k1_once = !(e[0] == '1');
+    if (const char *e = std::getenv("TDOA_POW2_ONLY")) ctx->pow2_only = e[0] == '1';
     if (const char *e = std::getenv("TDOA_ZPAD")) {
         const int v = std::atoi(e);
         ctx->zpad = v < 0 ? 0 : v > 4096 ? 4096 : v & ~15;      // rows stay 128-byte aligned (the finish sweep reads 16-byte pairs)
@@ -1587,18 +1625,18 @@ static int process_impl(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host,
     const int S = (int)ctx->caps.size();
     const int P = S * (S - 1) / 2;
     const int W = 3 * wpb;
-    const long long n = std::max<long long>(next_pow2(wlen + ctx->prm.max_lag), 64);
+    // TDOA_LAGS_GO: every window has the same length, so timeDomainCorrelation evaluates lag 0 only (processor.go:668-678)
+    const bool go = ctx->prm.lag_mode == TDOA_LAGS_GO;
+    const int lag_lo = go ? 0 : -(ctx->prm.max_lag - 1), lag_hi = go ? 0 : ctx->prm.max_lag - 1;
     FftPlan pl;
-    if ((rc = make_plan(n, true, &pl, ctx->zpad))) return fail(ctx, rc, "FFT size unsupported");
+    const long long n = choose_fft_size(ctx, wlen + ctx->prm.max_lag, lag_lo, lag_hi, ctx->zpad, &pl, &rc);
+    if (rc) return fail(ctx, rc, "FFT size unsupported");
     ctx->plan = pl;
     ctx->plan_n = n;
-    // TDOA_LAGS_GO: every window has the same length, so timeDomainCorrelation evaluates lag 0 only (processor.go:668-678)
-    // over the first B corr_block samples; with the template cut there the signal's samples beyond do not enter lag 0
-    // either, so every station-window is cut for the transforms (K1 and its statistics see the whole window)
-    const bool go = ctx->prm.lag_mode == TDOA_LAGS_GO;
+    // (TDOA_LAGS_GO) ... over the first B corr_block samples; with the template cut there the signal's samples beyond do not enter
+    // lag 0 either, so every station-window is cut for the transforms (K1 and its statistics see the whole window)
     if (go && fine_host) return fail(ctx, TDOA_ERR_UNSUPPORTED, "sub-sample refinement with TDOA_LAGS_GO");
     const long long corr_len = go ? go_blocks(wlen, ctx->prm.corr_block) * ctx->prm.corr_block : wlen;
-    const int lag_lo = go ? 0 : -(ctx->prm.max_lag - 1), lag_hi = go ? 0 : ctx->prm.max_lag - 1;
 
     // Sharding: window-major -- rank r owns the windows wid = r (mod world), so a station-window
     // is transformed once and reused by all its pairs.  With fewer windows than ranks that would leave ranks idle:
@@ -1621,7 +1659,7 @@ static int process_impl(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host,
     double bytes_per_window = 8.0 * (double)pl.Zs * S + 8.0 * (double)pl.Nc * P;
     if (decimation_applies(ctx, pl, lag_lo, lag_hi))
         bytes_per_window = 8.0 * (double)pl.Zs * S +
-                           8.0 * std::max((double)pl.Nc * P, (double)dec_spectra_offset(pl, P) + (pl.N2 == 4096 ? 0.0 : (double)pl.Nc * S));
+                           8.0 * std::max((double)pl.Nc * P, (double)dec_spectra_offset(pl, P) + (cols_only_plan(pl) ? 0.0 : (double)pl.Nc * S));
     if (!fused_k1_applies(ctx, pl, lag_lo, lag_hi, P, true)) bytes_per_window += 4.0 * (double)(wlen + 16) * S * (ctx->prm.k1_smooth > 1 ? 2 : 1);
     bytes_per_window *= 1.125;
     // the bound: a third of the device (tdoa_create), and not more than is FREE now plus what this context already holds of it
@@ -1725,7 +1763,7 @@ static int process_impl(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host,
                                  (uint64_t)ctx->force_generic | ((uint64_t)ctx->short_lag << 1) |
                                      ((uint64_t)ctx->segment_form << 3) | ((uint64_t)ctx->xcd_rows << 4) |
                                      ((uint64_t)ctx->segment_quads << 6) |
-                                     ((uint64_t)ctx->decimate << 8) | ((uint64_t)ctx->fused_k1 << 9) | ((uint64_t)ctx->k1_once << 11) | ((uint64_t)ctx->seg_pack3 << 12) | ((uint64_t)ctx->dec_cols << 13) | ((uint64_t)ctx->dec_cols_always << 14) |
+                                     ((uint64_t)ctx->decimate << 8) | ((uint64_t)ctx->fused_k1 << 9) | ((uint64_t)ctx->k1_once << 11) | ((uint64_t)ctx->seg_pack3 << 12) | ((uint64_t)ctx->dec_cols << 13) | ((uint64_t)ctx->dec_cols_always << 14) | ((uint64_t)ctx->pow2_only << 15) |
                                      ((uint64_t)ctx->memset_nodes << 10) | ((uint64_t)ctx->seg_chunks_override << 16) | ((uint64_t)ctx->xcd_pair_mb << 40),
                                  ctx->alloc_gen, (uint64_t)(fine_host != nullptr), 0};
     std::memcpy(&key.back(), &gate, sizeof(double));
@@ -2116,6 +2154,7 @@ int tdoa_debug_flags(tdoa_ctx *ctx, unsigned flags)
     ctx->seg_pack3 = !(flags & TDOA_DEBUG_NO_SEG_PACK3);
     ctx->dec_cols = !(flags & TDOA_DEBUG_NO_DEC_COLS);
     ctx->dec_cols_always = (flags & TDOA_DEBUG_DEC_COLS_ALWAYS) != 0;
+    ctx->pow2_only = (flags & TDOA_DEBUG_POW2_ONLY) != 0;
     return TDOA_OK;
 }
 

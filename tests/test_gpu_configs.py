@@ -48,7 +48,7 @@ def test_cfg3_weak_capture_mode_a_bit_exact(oracle):
 
 
 def test_cfg3_weak_capture_mode_b_full_window(oracle, capsys):
-    """one full cfg3 unit: a 10 s window (20 000 000 samples, N = 2^25, three-pass column plan) of the strong target
+    """one full cfg3 unit: a 10 s window (20 000 000 samples, N = 5 x 2^22 = 2 x 4096 x 2560, two-sweep column plan) of the strong target
     block of two weak-simulator stations, against the ob_* oracle (f64 FFT evaluation) and the float64 atan2 pipeline;
     and a reference-block window, whose bytes are constant (amplitude 1.4e-4 -> 127): zero phase, (0, 0.0)"""
     import tdoa_amd
@@ -59,7 +59,7 @@ def test_cfg3_weak_capture_mode_b_full_window(oracle, capsys):
     with tdoa_amd.Context(max_lag=ml, window_len=L) as c:
         lag, corr = c.fm_xcorr(tgt[0], tgt[1], ml)
         n, n1, n2 = c.plan_info()
-        assert (n, n1, n2) == (1 << 25, 4096, 4096)
+        assert (n, n1, n2) == (5 << 22, 4096, 2560)
         assert c.fm_xcorr(ref[0], ref[1], ml) == (0, 0.0)
     pre = [oracle.b_preprocess(x)[0] for x in tgt]
     olag, ocorr, _ = oracle.b_xcorr_peak_fft(pre[0], pre[1], ml)

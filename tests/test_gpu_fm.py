@@ -201,7 +201,8 @@ def test_odd_and_unaligned_windows_use_fallback(oracle):
     (4_000_000, -41, "cfg5 window: 1 s at 4 Msps, N = 2^22 (4096 x 512, radix-2 last column stage)"),
     (8_000_000, 123, "2 s at 4 Msps, N = 2^23 (4096 x 1024, radix-4 last column stage)"),
     (10_000_000, -7, "5 s at 2 Msps, N = 2^24 (4096 x 2048, two-sweep column pass, 8-point finish)"),
-    (20_000_000, 88, "cfg3 window: 10 s at 2 Msps, N = 2^25 (4096 x 4096, two-sweep column pass, 16-point finish)"),
+    (20_000_000, 88, "cfg3 window: 10 s at 2 Msps, N = 5 x 2^22 (4096 x 2560, two-sweep column pass, 10-point finish)"),
+    (21_000_000, -19, "10.5 s at 2 Msps: beyond 5 x 2^22, N = 2^25 (4096 x 4096, two-sweep column pass, 16-point finish)"),
 ])
 def test_long_windows_vs_f64_fft(oracle, n, delay, label):
     """BASELINE configs 3 and 5 window geometries (and the size between them)."""
@@ -268,24 +269,33 @@ def test_decimated_pair_step_column_walk_vs_tiles(oracle, n1, n2, max_lag, delay
 @pytest.mark.parametrize("n1,n2,delay,max_lag", [(20_000_000, 20_000_000, 88, 20000), (20_000_000, 19_876_543, -19999, 20000),
                                                  (18_000_001, 20_000_000, 7, 12000)])
 def test_decimated_inverse_on_the_ten_second_plan(oracle, n1, n2, delay, max_lag):
-    """N = 2^25 (4096 x 4096): consecutive bins run down the columns of the spectrum, and the decimating FIR walks them as a
-    column stencil (k_pair_decimate_cols<12>, dec_stream.hpp) over the unpacked spectra the row pass leaves in place; against
-    the full inverse of the same context (TDOA_DEBUG_NO_DECIMATE), lag by lag, with and without the single-look K1"""
+    """Ten-second windows.  Default (round 5): N = 5 x 2^22 (4096 x 2560) -- ten 256-point sub-transforms and a 10-point finish
+    down the columns, the decimating FIR as a column stencil (k_pair_decimate_cols<2560>, dec_stream.hpp) over the unpacked
+    spectra the row pass leaves in place, a 4096 x 160 small plan.  TDOA_DEBUG_POW2_ONLY: the same in N = 2^25 (4096 x 4096,
+    k_pair_decimate_cols<4096>).  Both against the full inverse (TDOA_DEBUG_NO_DECIMATE: a power-of-two plan by itself), lag by
+    lag, with and without the single-look K1."""
     import tdoa_amd
     a = oracle.simulate_delayed_fm(n1, max(0, -delay), 61, 1)
     b = oracle.simulate_delayed_fm(n2, max(0, delay), 61, 2)
     with tdoa_amd.Context(max_lag=max_lag, window_len=max(n1, n2)) as c:
         dec_lags, dec_peak = c.fm_xcorr_lags(a, b, max_lag), c.fm_xcorr(a, b, max_lag)
-        assert tuple(c.plan_info()) == (1 << 25, 4096, 4096)
+        assert tuple(c.plan_info()) == (5 << 22, 4096, 2560)
         c.debug_flags(no_k1_once=True)
         pre_lags = c.fm_xcorr_lags(a, b, max_lag)
+        assert tuple(c.plan_info()) == (5 << 22, 4096, 2560)
+        c.debug_flags(pow2_only=True)
+        p2_lags, p2_peak = c.fm_xcorr_lags(a, b, max_lag), c.fm_xcorr(a, b, max_lag)
+        assert tuple(c.plan_info()) == (1 << 25, 4096, 4096)
         c.debug_flags(no_decimate=True)
         full_lags, full_peak = c.fm_xcorr_lags(a, b, max_lag), c.fm_xcorr(a, b, max_lag)
-    assert dec_peak[0] == full_peak[0] == delay
+        assert tuple(c.plan_info()) == (1 << 25, 4096, 4096)
+    assert dec_peak[0] == p2_peak[0] == full_peak[0] == delay
     assert abs(dec_peak[1] - full_peak[1]) <= 2e-6 * abs(full_peak[1])
+    assert abs(p2_peak[1] - full_peak[1]) <= 2e-6 * abs(full_peak[1])
     scale = np.abs(full_lags).max()
     assert np.abs(dec_lags - full_lags).max() <= 2e-6 * scale
     assert np.abs(pre_lags - full_lags).max() <= 2e-6 * scale
+    assert np.abs(p2_lags - full_lags).max() <= 2e-6 * scale
 
 
 def test_profiling_inside_the_replayed_graph(oracle):
