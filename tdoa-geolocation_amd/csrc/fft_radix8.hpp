@@ -758,7 +758,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_
             // part of a frame is the positions [P, P + H): whole values r of every thread, except that with P = 256
             // the band starts and ends in the middle of r = 0 and r = 7
             constexpr unsigned kB = SegCodes<PACK3>::kBytes;
-            const unsigned bo = kB * (unsigned)(s0 * H - P) + SegCodes<PACK3>::lane_off(t), sh = SegCodes<PACK3>::lane_sel(t);
+            // (the lane constants are rebuilt per trip from a laundered thread index: kept across the loop next to the roots and
+            //  the mirror offsets they were the 129th register of the packed P = 256 / 512 instances -- 8 bytes of scratch)
+            const int tl = opaque_i(t);
+            const unsigned bo = kB * (unsigned)(s0 * H - P) + SegCodes<PACK3>::lane_off(tl), sh = SegCodes<PACK3>::lane_sel(tl);
 #pragma unroll
             for (int r = 0; r < 8; r++) {
                 const bool tpos = t + 512 * r >= P && t + 512 * r < P + H;
