@@ -286,6 +286,9 @@ enum {
                                         walk (csrc/dec_stream.hpp); 4096 x 4096 plans then take the full inverse             */
     TDOA_DEBUG_DEC_COLS_ALWAYS = 4096, /* (switches a form ON) the column walk wherever the decimated inverse
                                         applies, also where the library would pick the tile form (as many pairs as stations)  */
+    TDOA_DEBUG_NO_DEC_STAGED   = 16384, /* the column walk one pair-window per wave straight from memory (k_pair_decimate_cols)
+                                        instead of one workgroup per window and column block with the stations' rows staged in
+                                        LDS (csrc/dec_staged.hpp; environment: TDOA_NO_DEC_STAGED=1)                            */
     TDOA_DEBUG_POW2_ONLY       = 8192 /* transform lengths are powers of two everywhere (the reference's padding rule,
                                         processor.go:563): ten-second windows then run in N = 2^25 instead of 5 x 2^22
                                         (environment: TDOA_POW2_ONLY=1)                                                      */

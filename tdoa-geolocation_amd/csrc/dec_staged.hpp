@@ -1,0 +1,299 @@
+// dec_staged.hpp -- the column walk of the decimated pair step with the stations' rows STAGED IN LDS (round 5).
+//
+// k_pair_decimate_cols (dec_stream.hpp) gives every pair-window its own walk: each walk loads the rows of its two stations
+// itself, so a window of S stations and P pairs asks for 2 P / S = S - 1 times its spectra and leaves it to the caches to
+// serve the repeats.  They do so poorly: the walks that share a station drift apart by more than the L2 holds, and the
+// memory-side counters showed 2.1 x (8 stations, BASELINE config 4) and 3.2 x (16 stations, config 5) the compulsory bytes
+// coming through the fabric.  Here one workgroup owns 64 columns (and their 64 partner columns) of ONE window
+// for a GROUP of its pairs:
+//   * LOADER waves bring the rows (k2, N2 - k2) of every station the group's pairs touch into LDS by LDS-DMA
+//     (global_load_lds_dwordx4: one wave-instruction = the 512 bytes of a station's row piece + the 512 bytes of its partner
+//     row piece, no VGPR in between), two rows per phase into a ring of three phases -- a phase's bytes are asked for two
+//     phases before they are read;
+//   * every COMPUTE wave walks one pair: the same register stencil as k_pair_decimate_cols (twelve accumulators per walk,
+//     the row's taps from one LDS address per wave, K3 on packed pairs), its four operands per row four ds_read_b64;
+//   * one raw s_barrier per phase; the loaders wait with a counted vmcnt (the next phase stays in flight across the barrier).
+// A station's row piece comes from memory once per GROUP; the groups of one (window, column block) take consecutive slots
+// of one XCD, start together and run in step, so the second and later groups find the rows in that XCD's L2.
+// Outputs: exactly k_pair_decimate_cols's -- G[pw][N2/16][4096] and the neighbour shares X[pw][12][4096].
+//
+// grid: 8 x ceil(windows 32 / 8) x groups workgroups (1-D), 64 (compute waves + loader waves) threads;
+// dynamic LDS nb x R x S KB.
+#pragma once
+
+#include "dec_stream.hpp"
+
+namespace tdoa {
+
+#if TDOA_HAVE_DEC_COLS
+
+constexpr int kStgMaxStations = 16;          // station slots in LDS (1 KB per row and station)
+constexpr int kStgMaxWaves = 16;
+constexpr int kStgLdsBytes = 128 * 1024;     // the ring: phases x rows per phase x stations x 1 KB
+constexpr int kStgMaxInFlight = 60;          // LDS-DMA instructions a loader wave leaves outstanding (the counter holds 63)
+
+// one s_waitcnt vmcnt(n) for a run-time n (the field is an immediate): n = the LDS-DMA instructions of the later phases that
+// may stay in flight, a multiple of 2 (rows per phase) up to kStgMaxInFlight
+__device__ __forceinline__ void stg_wait_vm(int n)
+{
+    switch (n) {
+#define TDOA_VM(n_) case n_: asm volatile("s_waitcnt vmcnt(" #n_ ")" ::: "memory"); break;
+        TDOA_VM(0) TDOA_VM(2) TDOA_VM(4) TDOA_VM(6) TDOA_VM(8) TDOA_VM(10) TDOA_VM(12) TDOA_VM(14) TDOA_VM(16) TDOA_VM(18)
+        TDOA_VM(20) TDOA_VM(22) TDOA_VM(24) TDOA_VM(26) TDOA_VM(28) TDOA_VM(30) TDOA_VM(32) TDOA_VM(34) TDOA_VM(36) TDOA_VM(38)
+        TDOA_VM(40) TDOA_VM(42) TDOA_VM(44) TDOA_VM(46) TDOA_VM(48) TDOA_VM(50) TDOA_VM(52) TDOA_VM(54) TDOA_VM(56) TDOA_VM(58)
+        TDOA_VM(60)
+#undef TDOA_VM
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
+// R_: rows (and partner rows) per phase = per barrier; nb: phases in the ring (nb - 1 of them are in flight or being read:
+// what hides the memory latency is (nb - 2) R S KB per workgroup)
+template <int N2_, int R_>
+__global__ __launch_bounds__(64 * kStgMaxWaves) void k_pair_decimate_staged(const PWDesc *pw, const float2 *U, float2 *G, float2 *X, FftPlan pl,
+                                                                             const float *__restrict__ taps, int n_items, int P, int S,
+                                                                             int n_cw, int n_groups, int nb)
+{
+    constexpr int N2 = N2_, N1 = 4096, C = kDecCentre, SS = kDecSteps, R = R_;
+    constexpr int NG = N2 / 16;
+    constexpr bool POW2 = (N2 & (N2 - 1)) == 0;
+    static_assert(NG >= 2 * C + 2 && 16 % R == 0 && N2 % R == 0 && R % 2 == 0, "ring and loop geometry");
+    extern __shared__ __attribute__((aligned(16))) unsigned char stage_raw[];      // [NB][R][S][2][64] float2
+    __shared__ __attribute__((aligned(16))) float ltaps[17 * SS];
+    __shared__ __attribute__((aligned(16))) float2 lrot[16];
+    const int t = threadIdx.x;
+    for (int e = t; e < 17 * SS; e += blockDim.x) {
+        const int p = e / SS, s = e % SS;
+        ltaps[e] = p < 16 ? taps[16 * p + s] : taps[SS - 1 - s];
+    }
+    if (t < 16) lrot[t] = reinterpret_cast<const float2 *>(taps + 256)[t];
+    // workgroup -> (window, column block, group of pairs): the groups of an item are consecutive slots of one XCD
+    const unsigned int b = blockIdx.x, xcd = b & 7u, slot = b >> 3;
+    const int item = (int)(xcd + 8u * (slot / (unsigned int)n_groups)), grp = (int)(slot % (unsigned int)n_groups);
+    if (item >= n_items) return;                                   // (the whole workgroup: no barrier is left waiting)
+    const int w = item >> 5, cb = item & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
+    const int p_first = grp * n_cw, p_cnt = P - p_first < n_cw ? P - p_first : n_cw;
+    const PWDesc *wpw = pw + (size_t)w * P;
+    const int sw_base = wpw[0].sw_a;                               // the window's stations are sw_base .. sw_base + S - 1
+    unsigned int mask = 0;                                         // stations this group's pairs touch
+    for (int q = 0; q < p_cnt; q++) {
+        const PWDesc d = wpw[p_first + q];
+        mask |= (1u << (d.sw_a - sw_base)) | (1u << (d.sw_b - sw_base));
+    }
+    const int zpad = pl.zpad;
+    auto row_at = [&](const float2 *base, int k2) { return base + (size_t)k2 * N1 + (size_t)(k2 >> 8) * zpad; };
+    constexpr int NP = N2 / R;                                     // phases
+    __syncthreads();                                               // taps in place (the only ordinary barrier)
+
+    if (wave >= n_cw) {
+        // ---- loader: rows (k2, N2 - k2) of the stations in `mask`, phase by phase, nb - 1 phases ahead of the readers -----------
+        // lanes 0..31: 16 bytes each of row k2, columns [64 cb, 64 cb + 64); lanes 32..63: of the partner row, columns
+        // [4032 - 64 cb, 4096 - 64 cb) -- 1 KB per instruction, contiguous in LDS: [row of the phase][station][fwd | partner].
+        // The instruction is spelled out (global_load_lds_dwordx4 v_off, s[base]: the station's base in a scalar pair, ONE lane
+        // offset per row for all stations): built from per-lane 64-bit pointers through the compiler's builtin a loader wave
+        // spent ~20 instructions per LDS-DMA and two of them were slower than the fourteen walks they feed (cfg4 pair step
+        // 4.6-5.1 ms against 4.08 for the per-pair walk).
+        const int lw = wave - n_cw, n_lw = (int)(blockDim.x >> 6) - n_cw;
+        unsigned int mine = 0;                                      // this wave's stations: every n_lw-th of the group's, from the lw-th
+        {
+            unsigned int m = mask;
+            for (int i = 0; m; i++, m &= m - 1)
+                if (i % n_lw == lw) mine |= m & (0u - m);
+        }
+        const int per_phase = R * __builtin_popcount(mine);         // (the counted wait is this wave's own counter)
+        const unsigned int lane_off = 8u * (unsigned int)(lane < 32 ? 64 * cb + 2 * lane : (4032 - 64 * cb) + 2 * (lane - 32));
+        unsigned long long sbase[kStgMaxStations];
+#pragma unroll
+        for (int s_ = 0; s_ < kStgMaxStations; s_++) sbase[s_] = (unsigned long long)(uintptr_t)(U + (size_t)(sw_base + s_) * pl.Zs);
+        typedef __attribute__((address_space(3))) unsigned char *lds_ptr;
+        const unsigned int lds0 = (unsigned int)(uintptr_t)((lds_ptr)stage_raw);      // the ring's LDS byte address
+        auto issue = [&](int ph, int buf) {
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int k2 = ph * R + r, km2 = k2 ? N2 - k2 : 0;
+                const unsigned int of = 8u * ((unsigned int)k2 * N1 + (unsigned int)(k2 >> 8) * (unsigned int)zpad);
+                const unsigned int om = 8u * ((unsigned int)km2 * N1 + (unsigned int)(km2 >> 8) * (unsigned int)zpad);
+                const unsigned int voff = lane_off + (lane < 32 ? of : om);
+                const unsigned int dst_row = lds0 + (unsigned int)((buf * R + r) * S) * 1024u;
+                // (laundered per row: hoisted out of the loops, the sixteen bit tests lived in scalar pairs that were spilled
+                //  into vector lanes and read back with two v_readlane per station)
+                unsigned int mm = mine;
+                asm volatile("" : "+s"(mm));
+#pragma unroll
+                for (int s_ = 0; s_ < kStgMaxStations; s_++) {
+                    if ((mm >> s_) & 1u) {                         // (wave-uniform: s_bitcmp1 + branch)
+                        unsigned int keep;
+                        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                                     : "=&s"(keep)
+                                     : "v"(voff), "s"(sbase[s_]), "s"(dst_row + (unsigned int)s_ * 1024u)
+                                     : "memory");
+                    }
+                }
+            }
+        };
+        // phases 0 .. nb - 2 go out at once; at barrier ph the readers are through with phase ph - 1, whose buffer then takes
+        // phase ph + nb - 1
+        for (int ph = 0; ph < nb - 1 && ph < NP; ph++) issue(ph, ph);
+        int buf_next = (nb - 1) % nb;
+        for (int ph = 0; ph < NP; ph++) {
+            const int later = NP - 1 - ph < nb - 2 ? NP - 1 - ph : nb - 2;      // phases issued after ph that may stay in flight
+            stg_wait_vm(later * per_phase);                        // phase ph has landed
+            __builtin_amdgcn_s_barrier();
+            if (ph + nb - 1 < NP) issue(ph + nb - 1, buf_next);
+            buf_next = buf_next + 1 == nb ? 0 : buf_next + 1;
+        }
+        return;
+    }
+    if (wave >= p_cnt) {                                           // a compute wave without a pair (last group): barriers only
+        for (int ph = 0; ph < NP; ph++) __builtin_amdgcn_s_barrier();
+        return;
+    }
+
+    // ---- compute: the walk of k_pair_decimate_cols for pair-window pwu, operands from LDS -----------------------------------
+    const unsigned int pwu = (unsigned int)(w * P + p_first + wave);
+    const PWDesc d = wpw[p_first + wave];
+    const int sa = d.sw_a - sw_base, sb = d.sw_b - sw_base;
+    const int k1 = cb * 64 + lane, km = N1 - 1 - k1;
+    const float2 *Ua = U + (size_t)d.sw_a * pl.Zs, *Ub = U + (size_t)d.sw_b * pl.Zs;
+    const float invNc = 1.0f / (float)pl.Nc;
+    auto w_n = [&](float num) {
+        if constexpr (POW2) return unit_root(num, invNc, false);
+        else return unit_root_any(num, 0.5f * (float)pl.Nc, 2.0f * invNc, false);
+    };
+    const size_t rc = (size_t)(pl.Nc / kDecD);
+    float2 *g_top = G + (size_t)pwu * rc + k1, *g_bot = G + (size_t)pwu * rc + km;
+    float2 *x_top = X + (size_t)pwu * kDecShareRows * N1 + k1, *x_bot = X + (size_t)pwu * kDecShareRows * N1 + km;
+
+    float2 at[SS], ab[SS];
+#pragma unroll
+    for (int s = 0; s < SS; s++) at[s] = ab[s] = make_float2(0.0f, 0.0f);
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    struct TapRow { v2f h2[SS / 2]; };
+    auto tap_row = [&](int p) {
+        static_assert(SS % 4 == 0, "whole float4 of taps per phase");
+        const float4 *tp = reinterpret_cast<const float4 *>(ltaps + SS * p);
+        TapRow r;
+#pragma unroll
+        for (int s = 0; s < SS / 4; s++) {
+            const float4 v = tp[s];
+            r.h2[2 * s] = v2f{v.x, v.y};
+            r.h2[2 * s + 1] = v2f{v.z, v.w};
+        }
+        return r;
+    };
+    auto mac = [](float2 &acc, const TapRow &tr, auto s_c, float2 q_) {       // acc += tap[s] q
+        constexpr int s = decltype(s_c)::value;
+        v2f a = {acc.x, acc.y};
+        const v2f q = {q_.x, q_.y};
+        if (s & 1) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(a) : "v"(q), "v"(tr.h2[s / 2]));
+        else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "+v"(a) : "v"(q), "v"(tr.h2[s / 2]));
+        acc = make_float2(a.x, a.y);
+    };
+    auto mac_all = [&](float2 (&acc)[SS], const TapRow &tr, float2 q) {
+        mac(acc[0], tr, std::integral_constant<int, 0>{}, q);
+        mac(acc[1], tr, std::integral_constant<int, 1>{}, q);
+        mac(acc[2], tr, std::integral_constant<int, 2>{}, q);
+        mac(acc[3], tr, std::integral_constant<int, 3>{}, q);
+        mac(acc[4], tr, std::integral_constant<int, 4>{}, q);
+        mac(acc[5], tr, std::integral_constant<int, 5>{}, q);
+        mac(acc[6], tr, std::integral_constant<int, 6>{}, q);
+        mac(acc[7], tr, std::integral_constant<int, 7>{}, q);
+        if constexpr (SS > 8) {
+            mac(acc[8], tr, std::integral_constant<int, 8>{}, q);
+            mac(acc[9], tr, std::integral_constant<int, 9>{}, q);
+            mac(acc[10], tr, std::integral_constant<int, 10>{}, q);
+            mac(acc[11], tr, std::integral_constant<int, 11>{}, q);
+        }
+    };
+    // row 0 of column k1 pairs inside row 0 (dec_stream.hpp): straight from memory, once per walk
+    {
+        const float2 *ra = row_at(Ua, 0), *rb = row_at(Ub, 0);
+        const int kp = (N1 - k1) & (N1 - 1);
+        const TapRow tr = tap_row(0);
+        float2 q, qm;
+        pair_u_pk(ra[k1], ra[kp], rb[k1], rb[kp], w_n((float)k1 * (float)N2), k1 == 0, q, qm);
+        mac_all(at, tr, q);
+    }
+    x_top[0] = make_float2(0.0f, 0.0f);
+    x_bot[0] = make_float2(0.0f, 0.0f);
+    auto bottom_leaves = [&](int i) {
+        if (i >= NG) x_bot[(size_t)(kDecEdge + i - NG) * N1] = ab[SS - 1];
+        else if (i >= 0) g_bot[(size_t)i * N1] = ab[SS - 1];
+        else x_bot[(size_t)(kDecEdge + i) * N1] = ab[SS - 1];
+#pragma unroll
+        for (int u = SS - 1; u > 0; u--) ab[u] = ab[u - 1];
+        ab[0] = make_float2(0.0f, 0.0f);
+    };
+    auto top_leaves = [&](int i) {
+        if (i < 0) x_top[(size_t)(kDecEdge + i) * N1] = at[SS - 1];
+        else if (i < NG) g_top[(size_t)i * N1] = at[SS - 1];
+        else x_top[(size_t)(kDecEdge + i - NG) * N1] = at[SS - 1];
+#pragma unroll
+        for (int s = SS - 1; s > 0; s--) at[s] = at[s - 1];
+        at[0] = make_float2(0.0f, 0.0f);
+    };
+    // LDS byte offsets of this lane's four operands inside a (phase, row) block of S KB: column k1 of the forward piece,
+    // column km = 4095 - k1 of the partner piece (its block is stored ascending: lane 63 - l)
+    const unsigned int o_af = (unsigned int)sa * 1024u + 8u * (unsigned int)lane, o_am = (unsigned int)sa * 1024u + 512u + 8u * (unsigned int)(63 - lane);
+    const unsigned int o_bf = (unsigned int)sb * 1024u + 8u * (unsigned int)lane, o_bm = (unsigned int)sb * 1024u + 512u + 8u * (unsigned int)(63 - lane);
+    auto lds_at = [&](unsigned int off) { return *reinterpret_cast<const float2 *>(stage_raw + off); };
+    float2 wg = make_float2(1.0f, 0.0f);
+    auto row = [&](float2 ua, float2 uam, float2 ub, float2 ubm, int k2, auto first_c) {
+        constexpr bool FIRST = decltype(first_c)::value;            // the only row of a phase whose FIR phase can be 0
+        const int p = k2 & 15, g = k2 >> 4;
+        const TapRow tr = tap_row(p);
+        float2 q, qm;
+        pair_u_pk(ua, uam, ub, ubm, cmul(wg, lrot[p]), false, q, qm);
+        if (FIRST && k2 == 0) q = qm = make_float2(0.0f, 0.0f);     // row 0: done above
+        mac_all(at, tr, q);
+        if (!FIRST) {
+            mac_all(ab, tr, qm);
+        } else {
+            const TapRow tb = tap_row(p ? p : 16);                  // (phase 0: the reversed row)
+            mac_all(ab, tb, qm);
+            if (p == 0 && g > 0) bottom_leaves(NG - g + C);
+        }
+    };
+    int buf = 0;
+#pragma unroll 1
+    for (int ph = 0; ph < NP; ph++) {
+        __builtin_amdgcn_s_barrier();                              // phase ph is in LDS
+        const unsigned int base = (unsigned int)(buf * R) * (unsigned int)S * 1024u;
+        buf = buf + 1 == nb ? 0 : buf + 1;
+        const int k2 = ph * R;
+        if ((k2 & 15) == 0) wg = w_n((float)k2 + (float)k1 * (float)N2);
+        // two rows at a time (their eight reads in flight together; four rows' worth of operands did not fit 128 registers)
+#pragma unroll
+        for (int r0 = 0; r0 < R; r0 += 2) {
+            float2 v[2][4];
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                const unsigned int rb = base + (unsigned int)(r0 + r) * (unsigned int)S * 1024u;
+                v[r][0] = lds_at(rb + o_af);
+                v[r][1] = lds_at(rb + o_am);
+                v[r][2] = lds_at(rb + o_bf);
+                v[r][3] = lds_at(rb + o_bm);
+            }
+            if (r0 == 0) row(v[0][0], v[0][1], v[0][2], v[0][3], k2, std::true_type{});
+            else row(v[0][0], v[0][1], v[0][2], v[0][3], k2 + r0, std::false_type{});
+            row(v[1][0], v[1][1], v[1][2], v[1][3], k2 + r0 + 1, std::false_type{});
+        }
+        if (((k2 + R - 1) & 15) == 15) top_leaves((k2 >> 4) - (SS - 1 - C));
+    }
+#pragma unroll
+    for (int n = 0; n < SS - 1; n++) top_leaves(NG - (SS - 1 - C) + n);
+    {
+        const float2 *ra = row_at(Ua, 0), *rb = row_at(Ub, 0);
+        const TapRow tr = tap_row(16);
+        float2 q, qm;
+        pair_u_pk(ra[km], ra[k1 + 1], rb[km], rb[k1 + 1], w_n((float)km * (float)N2), false, q, qm);
+        mac_all(ab, tr, q);
+    }
+#pragma unroll
+    for (int n = 0; n < SS; n++) bottom_leaves(C - n);
+}
+
+#endif  // TDOA_HAVE_DEC_COLS
+
+}  // namespace tdoa

@@ -24,6 +24,7 @@
 #include "fft_radix16.hpp"
 #include "fft_radix8.hpp"
 #include "dec_stream.hpp"
+#include "dec_staged.hpp"
 #include "exact_reference.hpp"
 #include "synth_capture.hpp"
 #include "window_quality.hpp"
@@ -101,6 +102,9 @@ struct tdoa_ctx {
                                             // hipMemsetAsync nodes instead of k_zero_u64 kernel nodes
     bool dec_cols = true;                   // TDOA_NO_DEC_COLS=1: the tile form of the decimated pair step (k_pair_decimate16; none on 4096 x 4096 plans)
     bool dec_cols_always = false;           // TDOA_DEC_COLS_ALWAYS=1: the column walk wherever the decimated inverse applies (measurements)
+    bool dec_staged = true;                 // TDOA_NO_DEC_STAGED=1: the column walk one pair-window per wave from memory (k_pair_decimate_cols), no LDS staging
+    int stg_loaders = 0;                    // TDOA_DEC_STAGED_LOADERS=n: loader waves per workgroup of k_pair_decimate_staged (0: the library's choice)
+    int stg_rows = 0, stg_bufs = 0;         // TDOA_DEC_STAGED_ROWS=2|4, TDOA_DEC_STAGED_BUFS=n: rows per phase, phases in the LDS ring (0: the library's choice)
     bool seg_pack3 = true;                  // TDOA_NO_SEG_PACK3=1: the segment form reads int32 code rows (round 3's layout)
     int seg_chunks_override = 0;            // TDOA_SEG_CHUNKS=n at tdoa_create time: chunk count of the segment form
     int graph_nodes = 0, graph_edges = 0, graph_roots = 0, graph_memsets = 0;      // structure of the captured step (tdoa_debug_graph_info)
@@ -875,7 +879,63 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
             // W_N^DK, DK = N2 / 8 bins between a thread's consecutive elements of a tile (N = 2 Nc)
             const double ang = -2.0 * M_PI * (double)(pl.N2 / 8) / (2.0 * (double)pl.Nc);
             const float2 rot = make_float2((float)std::cos(ang), (float)std::sin(ang));
-            if (dec_walks_columns(ctx, pl, n_sw, n_pw, pairs_per_window)) {
+            // the walk with the stations' rows staged in LDS (dec_staged.hpp): uniform batches -- every window carries all the
+            // P = S (S - 1) / 2 pairs of its S <= 16 stations, station-windows laid out window by window (process_impl's
+            // window-major order) -- so that a workgroup can name a window's stations sw_base .. sw_base + S - 1
+            int stg_s = 0;
+            if (ctx->dec_staged && pairs_per_window > 0 && n_pw % pairs_per_window == 0) {
+                const int n_win = n_pw / pairs_per_window;
+                if (n_sw % n_win == 0) {
+                    const int st = n_sw / n_win;
+                    if (st >= 2 && st <= kStgMaxStations && st * (st - 1) / 2 == pairs_per_window) stg_s = st;
+                }
+            }
+            if (dec_walks_columns(ctx, pl, n_sw, n_pw, pairs_per_window) && stg_s) {
+#if TDOA_HAVE_DEC_COLS
+                // One loader wave (since its instruction is spelled out a second one buys nothing: cfg4 3.56 / 3.56 ms, cfg5 one
+                // group fewer), the other waves of at most sixteen walk one pair each.  What the geometry is chosen for is the
+                // BARRIER: one per phase stops all sixteen waves, and the pair step of BASELINE config 4 took 4.33 / 3.57 / 3.38 ms
+                // with 2 / 4 / 8 rows per phase (the ring's depth made no difference: 3, 6 or 8 phases of two rows all 4.3 ms) --
+                // so the most rows per phase of which TWO phases fit the workgroup's share of the LDS: 8 rows up to eight
+                // stations, 4 up to sixteen; small workgroups (three pairs: four waves) leave room for their neighbours on the CU.
+                const int P = pairs_per_window, n_win = n_pw / P;
+                int n_lw = ctx->stg_loaders ? ctx->stg_loaders : 1;
+                n_lw = std::max(1, std::min(n_lw, std::min(4, stg_s)));
+                const int cw_max = kStgMaxWaves - n_lw;
+                const int groups = (P + cw_max - 1) / cw_max, n_cw = (P + groups - 1) / groups;
+                const int wgs_per_cu = std::max(1, kStgMaxWaves / (n_cw + n_lw));
+                const int budget = kStgLdsBytes / wgs_per_cu;
+                int rows = ctx->stg_rows;
+                if (!rows) rows = 2 * 8 * stg_s * 1024 <= budget ? 8 : 2 * 4 * stg_s * 1024 <= budget ? 4 : 2;
+                const int per_phase = rows * ((stg_s + n_lw - 1) / n_lw);
+                int nb = ctx->stg_bufs ? ctx->stg_bufs : std::max(2, std::min(4, budget / (rows * stg_s * 1024)));
+                if (rows * stg_s * 1024 * 2 > kStgLdsBytes) return fail(ctx, TDOA_ERR_INVALID, "TDOA_DEC_STAGED_ROWS: two phases do not fit the LDS ring");
+                nb = std::min(nb, kStgLdsBytes / (rows * stg_s * 1024));
+                nb = std::max(2, std::min(nb, 2 + kStgMaxInFlight / per_phase));
+                const int n_items = n_win * 32;
+                const unsigned int blocks = (unsigned int)((n_items + 7) / 8 * 8) * (unsigned int)groups;
+                const size_t lds = (size_t)nb * rows * stg_s * 1024;
+                const float *tp = static_cast<const float *>(ctx->dec_taps.p);
+                const dim3 sblock(64 * (n_cw + n_lw));
+#define TDOA_STAGED(N2V)                                                                                              \
+    do {                                                                                                              \
+        if (rows == 8)                                                                                                \
+            hipLaunchKernelGGL((k_pair_decimate_staged<N2V, 8>), dim3(blocks), sblock, lds, st, d_pw, tz, g, edges, pl, tp, n_items, \
+                               P, stg_s, n_cw, groups, nb);                                                           \
+        else if (rows == 4)                                                                                           \
+            hipLaunchKernelGGL((k_pair_decimate_staged<N2V, 4>), dim3(blocks), sblock, lds, st, d_pw, tz, g, edges, pl, tp, n_items, \
+                               P, stg_s, n_cw, groups, nb);                                                           \
+        else                                                                                                          \
+            hipLaunchKernelGGL((k_pair_decimate_staged<N2V, 2>), dim3(blocks), sblock, lds, st, d_pw, tz, g, edges, pl, tp, n_items, \
+                               P, stg_s, n_cw, groups, nb);                                                           \
+    } while (0)
+                if (pl.N2 == 256) TDOA_STAGED(256);
+                else if (pl.N2 == 512) TDOA_STAGED(512);
+                else if (pl.N2 == 2560) TDOA_STAGED(2560);
+                else TDOA_STAGED(4096);
+#undef TDOA_STAGED
+#endif
+            } else if (dec_walks_columns(ctx, pl, n_sw, n_pw, pairs_per_window)) {
 #if TDOA_HAVE_DEC_COLS
                 const dim3 sgrid(32, (unsigned int)((n_pw + kDecWavesPerWg - 1) / kDecWavesPerWg)), sblock(64 * kDecWavesPerWg);
                 const float *tp = static_cast<const float *>(ctx->dec_taps.p);
@@ -1030,6 +1090,20 @@ int allow_big_lds(tdoa_ctx *ctx)
     if ((rc = set_lds(ctx, k_pair_decimate16<8>, all))) return rc;
     if ((rc = set_lds(ctx, k_pair_decimate16<9>, all))) return rc;
     if ((rc = set_lds(ctx, k_inv_rows_plain_r8, all))) return rc;
+#if TDOA_HAVE_DEC_COLS
+    if ((rc = set_lds(ctx, (k_pair_decimate_staged<256, 2>), all))) return rc;
+    if ((rc = set_lds(ctx, (k_pair_decimate_staged<512, 2>), all))) return rc;
+    if ((rc = set_lds(ctx, (k_pair_decimate_staged<2560, 2>), all))) return rc;
+    if ((rc = set_lds(ctx, (k_pair_decimate_staged<4096, 2>), all))) return rc;
+    if ((rc = set_lds(ctx, (k_pair_decimate_staged<256, 8>), all))) return rc;
+    if ((rc = set_lds(ctx, (k_pair_decimate_staged<512, 8>), all))) return rc;
+    if ((rc = set_lds(ctx, (k_pair_decimate_staged<2560, 8>), all))) return rc;
+    if ((rc = set_lds(ctx, (k_pair_decimate_staged<4096, 8>), all))) return rc;
+    if ((rc = set_lds(ctx, (k_pair_decimate_staged<256, 4>), all))) return rc;
+    if ((rc = set_lds(ctx, (k_pair_decimate_staged<512, 4>), all))) return rc;
+    if ((rc = set_lds(ctx, (k_pair_decimate_staged<2560, 4>), all))) return rc;
+    if ((rc = set_lds(ctx, (k_pair_decimate_staged<4096, 4>), all))) return rc;
+#endif
     return TDOA_OK;
 }
 
@@ -1323,6 +1397,10 @@ int tdoa_create(const tdoa_params *p, tdoa_ctx **out)
     if (const char *e = std::getenv("TDOA_NO_FUSED_K1")) ctx->fused_k1 = !(e[0] == '1');
     if (const char *e = std::getenv("TDOA_NO_DEC_COLS")) ctx->dec_cols = !(e[0] == '1');
     if (const char *e = std::getenv("TDOA_DEC_COLS_ALWAYS")) ctx->dec_cols_always = e[0] == '1';
+    if (const char *e = std::getenv("TDOA_NO_DEC_STAGED")) ctx->dec_staged = !(e[0] == '1');
+    if (const char *e = std::getenv("TDOA_DEC_STAGED_LOADERS")) ctx->stg_loaders = std::max(0, std::min(4, std::atoi(e)));
+    if (const char *e = std::getenv("TDOA_DEC_STAGED_ROWS")) ctx->stg_rows = std::atoi(e) == 8 ? 8 : std::atoi(e) == 4 ? 4 : std::atoi(e) == 2 ? 2 : 0;
+    if (const char *e = std::getenv("TDOA_DEC_STAGED_BUFS")) ctx->stg_bufs = std::max(0, std::min(16, std::atoi(e)));
     if (const char *e = std::getenv("TDOA_NO_SEG_PACK3")) ctx->seg_pack3 = !(e[0] == '1');
     if (const char *e = std::getenv("TDOA_SEG_CHUNKS")) ctx->seg_chunks_override = std::max(0, std::atoi(e));
     if (const char *e = std::getenv("TDOA_DEBUG_MEMSET_NODES")) ctx->memset_nodes = e[0] == '1';
@@ -1763,7 +1841,7 @@ static int process_impl(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host,
                                  (uint64_t)ctx->force_generic | ((uint64_t)ctx->short_lag << 1) |
                                      ((uint64_t)ctx->segment_form << 3) | ((uint64_t)ctx->xcd_rows << 4) |
                                      ((uint64_t)ctx->segment_quads << 6) |
-                                     ((uint64_t)ctx->decimate << 8) | ((uint64_t)ctx->fused_k1 << 9) | ((uint64_t)ctx->k1_once << 11) | ((uint64_t)ctx->seg_pack3 << 12) | ((uint64_t)ctx->dec_cols << 13) | ((uint64_t)ctx->dec_cols_always << 14) | ((uint64_t)ctx->pow2_only << 15) |
+                                     ((uint64_t)ctx->decimate << 8) | ((uint64_t)ctx->fused_k1 << 9) | ((uint64_t)ctx->k1_once << 11) | ((uint64_t)ctx->seg_pack3 << 12) | ((uint64_t)ctx->dec_cols << 13) | ((uint64_t)ctx->dec_cols_always << 14) | ((uint64_t)ctx->pow2_only << 15) | ((uint64_t)ctx->dec_staged << 7) | ((uint64_t)ctx->stg_loaders << 36) | ((uint64_t)ctx->stg_rows << 28) | ((uint64_t)ctx->stg_bufs << 31) |
                                      ((uint64_t)ctx->memset_nodes << 10) | ((uint64_t)ctx->seg_chunks_override << 16) | ((uint64_t)ctx->xcd_pair_mb << 40),
                                  ctx->alloc_gen, (uint64_t)(fine_host != nullptr), 0};
     std::memcpy(&key.back(), &gate, sizeof(double));
@@ -2155,6 +2233,7 @@ int tdoa_debug_flags(tdoa_ctx *ctx, unsigned flags)
     ctx->dec_cols = !(flags & TDOA_DEBUG_NO_DEC_COLS);
     ctx->dec_cols_always = (flags & TDOA_DEBUG_DEC_COLS_ALWAYS) != 0;
     ctx->pow2_only = (flags & TDOA_DEBUG_POW2_ONLY) != 0;
+    ctx->dec_staged = !(flags & TDOA_DEBUG_NO_DEC_STAGED);
     return TDOA_OK;
 }
 
