@@ -82,7 +82,7 @@ def station_table(n):
 
 
 HOT_SOURCES = ("device_common.hpp", "k1_discriminator.hpp", "k1_single_look.hpp", "fft_stockham.hpp", "fft_radix16.hpp",
-               "fft_radix8.hpp", "dec_stream.hpp", "tdoa_mi355x.hip")
+               "fft_radix8.hpp", "dec_stream.hpp", "dec_staged.hpp", "tdoa_mi355x.hip")
 
 
 def source_hash():
@@ -705,7 +705,9 @@ def roofline_fields(args, env, cfg_name, scaling, sim, table, prof_timed, domina
         #               the FIR walks the columns of the spectrum (dec_stream.hpp) on the 4096 x 4096 plan and wherever a window
         #               carries more pairs than stations (tdoa_mi355x.hip dec_walks_columns); else 4096-bin tiles in LDS
         cols = os.environ.get("TDOA_NO_DEC_COLS") != "1" and (n2 in (2560, 4096) or n_pairs > S or os.environ.get("TDOA_DEC_COLS_ALWAYS") == "1")
-        hot = dict(hot, k_fwd_row=["k_fwd_row4096_unpack"], k_inv_row_pair=["k_pair_decimate_cols" if cols else "k_pair_decimate16"],
+        staged = cols and os.environ.get("TDOA_NO_DEC_STAGED") != "1" and S <= 16      # (uniform batches: every bench job is one)
+        hot = dict(hot, k_fwd_row=["k_fwd_row4096_unpack"],
+                   k_inv_row_pair=["k_pair_decimate_staged" if staged else "k_pair_decimate_cols" if cols else "k_pair_decimate16"],
                    k_inv_col_peak=["k_inv_rows_plain_r8", "k_small_col_peak"])
     if max_lag <= 1024 and n1 == 4096:
         # segment form; with 3+ pairs per window the station transforms are shared (quads)
@@ -723,7 +725,7 @@ def roofline_fields(args, env, cfg_name, scaling, sim, table, prof_timed, domina
         if name == "k_inv_row_pair" and n_pairs > 0:
             out_per_pair = 8.0 * nc
             if decimated:       # G (Nc/16 points) + the neighbour shares: X[12][4096] behind the column walk, E[N2][12] behind the tiles
-                out_per_pair = 8.0 * nc / 16 + 8.0 * 12 * (4096 if hot["k_inv_row_pair"] == ["k_pair_decimate_cols"] else n2)
+                out_per_pair = 8.0 * nc / 16 + 8.0 * 12 * (4096 if hot["k_inv_row_pair"][0] in ("k_pair_decimate_cols", "k_pair_decimate_staged") else n2)
             compulsory = min(requested, windows_per_launch * (S * 8.0 * nc + n_pairs * out_per_pair))
         standard = args.seconds is None and args.batch == 0 and world == 1 and max_lag == 20000 and sim == "config"
         traffic, src, sq = None, None, None

@@ -34,7 +34,11 @@ FETCH_CORRECTION = {"k_fm_demod": 2.0, "k_fwd_row4096": 2.0, "k_fwd_row4096_unpa
                     # round 5: the finish sweep of the two-sweep column pass reads 16 bytes per lane with non-temporal loads
                     # (fft_radix16.hpp k_fwd_col_finish) and works in place -- it reads exactly what it writes, and its raw
                     # FETCH_SIZE came out at half of its WRITE_SIZE (68.85 GB against 137.8 GB per cfg3 step, round 4) -> x2
-                    "k_fwd_col_finish": 2.0}
+                    "k_fwd_col_finish": 2.0,
+                    # round 5: the staged column walk brings its rows in by LDS-DMA, 16 bytes per lane (global_load_lds_dwordx4,
+                    # 512-byte row pieces); calibrated on cfg3, where a window's three spectra can only come from memory once per
+                    # workgroup group: raw FETCH_SIZE / bytes = 0.50 -> x2 (collect_round's cfg3 file)
+                    "k_pair_decimate_staged": 2.0}
 
 
 def load(d):

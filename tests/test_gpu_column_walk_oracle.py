@@ -1,6 +1,9 @@
-"""GPU: the BATCHED column walk of the decimated pair step -- k_pair_decimate_cols<8> (4096 x 256 plan) and <9> (4096 x 512)
-with four pair-windows per workgroup, the form that dominates BASELINE configs 4 and 5 -- directly against the oracle
-(until round 5 it was only compared with the tile form, the full inverse and the geometry's lags).
+"""GPU: the BATCHED column walk of the decimated pair step -- the form that dominates BASELINE configs 4 and 5 -- directly
+against the oracle (until round 5 it was only compared with the tile form, the full inverse and the
+geometry's lags).  Since round 5 the library runs it with the stations' rows staged in LDS (k_pair_decimate_staged,
+csrc/dec_staged.hpp: one workgroup per window and 64-column block, a loader wave and one walk per compute wave);
+k_pair_decimate_cols<256> / <512> (one pair-window per wave straight from memory, four per workgroup) is what
+TDOA_DEBUG_NO_DEC_STAGED leaves.  BOTH are held against the oracle here.
 
 Every (window, pair) of a tdoa_process batch, in the reference's pair order i < j (processor.go:816-850), is held against
 oracle.b_xcorr_peak_fft (ob_* codes, float64 FFT correlation) on the bytes downloaded from the device: lag identical, corr
@@ -61,10 +64,14 @@ def test_column_walk_batch_4096x256_vs_oracle(oracle, n_stations, capsys):
         # the last bits, not being the same numbers)
         c.debug_flags(no_dec_cols=True)
         tiles = c.process()
+        c.debug_flags(no_dec_staged=True)                            # one pair-window per wave, rows straight from memory
+        walk = c.process()
         c.debug_flags()
         assert np.array_equal(tiles["lag"], peaks["lag"]) and not np.array_equal(tiles["corr"], peaks["corr"])
+        # the staged walk and the per-pair walk run the same arithmetic in the same order: the same bits
+        assert np.array_equal(walk, peaks)
         _check_batch(oracle, c, peaks, n_stations, wl, blk, {(0, 0), (2, len(delays))}, capsys,
-                     "k_pair_decimate_cols<8>, %d stations" % n_stations)
+                     "k_pair_decimate_staged<256>, %d stations" % n_stations)
     want = np.array([delays[j] - delays[i] for i in range(n_stations) for j in range(i + 1, n_stations)])
     assert (peaks["lag"] == want[None, :]).all()
 
@@ -82,6 +89,34 @@ def test_column_walk_batch_4096x512_vs_oracle(oracle, capsys):
         peaks = c.process_u8(caps)
         assert tuple(c.plan_info())[1:] == (4096, 512) and c.last_k1(0)[1]
         assert peaks.size == 18
-        _check_batch(oracle, c, peaks, 4, wl, blk, {(0, 1), (1, 5)}, capsys, "k_pair_decimate_cols<9>, 4 stations")
+        c.debug_flags(no_dec_staged=True)
+        walk = c.process()
+        c.debug_flags()
+        assert np.array_equal(walk, peaks)
+        _check_batch(oracle, c, peaks, 4, wl, blk, {(0, 1), (1, 5)}, capsys, "k_pair_decimate_staged<512>, 4 stations")
     want = np.array([delays[j] - delays[i] for i in range(4) for j in range(i + 1, 4)])
     assert (peaks["lag"] == want[None, :]).all()
+
+
+@pytest.mark.parametrize("n_stations,wl", [(7, 1_100_000), (16, 1_100_000), (16, 2_200_001), (2, 1_100_000)])
+def test_staged_walk_group_geometries_vs_the_per_pair_walk(oracle, n_stations, wl):
+    """the workgroup geometries of the staged walk: 7 stations = 21 pairs in two groups of 11 and 10 (an idle compute wave in the
+    second), 16 stations = 120 pairs in eight groups of 15 with all sixteen station slots of the LDS ring in use (4096 x 256:
+    rows of 8 KB ... 16 KB per phase; 4096 x 512), 2 stations = one pair (a two-wave workgroup).  Reference: the per-pair walk
+    (TDOA_DEBUG_NO_DEC_STAGED), itself held against the oracle above -- the same bits -- and the geometry's lags."""
+    import tdoa_amd
+    blk = wl
+    rng = np.random.default_rng(100 + n_stations)
+    delays = [int(x) for x in rng.integers(0, 300, size=n_stations)]
+    caps = [np.concatenate([oracle.simulate_delayed_fm(blk, d, 700 + k, 100 * (s + 1) + k) for k in range(3)])
+            for s, d in enumerate(delays)]
+    with tdoa_amd.Context(max_lag=ML, window_len=wl) as c:
+        c.debug_flags(dec_cols_always=True)                          # (two stations: the library's own choice is the tile form)
+        peaks = c.process_u8(caps)
+        assert c.last_k1(0)[1]
+        c.debug_flags(dec_cols_always=True, no_dec_staged=True)
+        walk = c.process()
+    assert peaks.shape == (3, n_stations * (n_stations - 1) // 2)
+    assert np.array_equal(walk, peaks)
+    want = np.array([delays[j] - delays[i] for i in range(n_stations) for j in range(i + 1, n_stations)])
+    assert (peaks["lag"] == want[None, :]).all() and (peaks["abs_corr"] > 100.0).all()
