@@ -47,30 +47,13 @@ __device__ __forceinline__ void stg_wait_vm(int n)
     }
 }
 
-// FLAGS_ (the ring without barriers): a phase's hand-over goes through two counters per ring slot in LDS instead of an s_barrier
-// of all sixteen waves -- `ready` (the loader adds 1 when the slot's bytes have landed) and `done` (every walk adds 1 when it
-// has read them); a walk waits for ready >= fills so far, the loader for done >= walks x refills before it overwrites a slot.
-// The walks then drift apart by up to nb - 2 phases instead of meeting every R rows.  Every wait is a bounded spin: a
-// protocol error ends in wrong numbers (the tests see them), never in a hung GPU.
-constexpr int kStgMaxBufs = 16;
-constexpr unsigned int kStgSpinLimit = 1u << 22;
-__device__ __forceinline__ bool stg_spin_until(const unsigned int *counter, unsigned int target)
-{
-    for (unsigned int spins = 0; spins < kStgSpinLimit; spins++) {
-        const unsigned int v = __hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (__builtin_amdgcn_readfirstlane((int)v) >= (int)target) return true;
-        __builtin_amdgcn_s_sleep(1);
-    }
-    return false;
-}
-__device__ __forceinline__ void stg_signal(unsigned int *counter)
-{
-    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-
+// (Round 5 also built the ring WITHOUT barriers -- two LDS counters per slot, `ready` set by the loader and `done` by the walks,
+// bounded spins, the walks free to drift nb - 2 phases apart: bit-identical and slower on every geometry, cfg4 3.98-5.78 ms
+// against 3.45-3.61, cfg5 124-159 against 89.6 (profiles/r05_staged_walk_flag_ring_sweep.txt): an LDS atomic round trip per
+// phase and wave costs more than the barrier it replaces.  Commit 73f2769 holds it.)
 // R_: rows (and partner rows) per phase = per barrier; nb: phases in the ring (nb - 1 of them are in flight or being read:
 // what hides the memory latency is (nb - 2) R S KB per workgroup)
-template <int N2_, int R_, bool FLAGS_ = false>
+template <int N2_, int R_>
 __global__ __launch_bounds__(64 * kStgMaxWaves) void k_pair_decimate_staged(const PWDesc *pw, const float2 *U, float2 *G, float2 *X, FftPlan pl,
                                                                              const float *__restrict__ taps, int n_items, int P, int S,
                                                                              int n_cw, int n_groups, int nb)
@@ -82,9 +65,7 @@ __global__ __launch_bounds__(64 * kStgMaxWaves) void k_pair_decimate_staged(cons
     extern __shared__ __attribute__((aligned(16))) unsigned char stage_raw[];      // [NB][R][S][2][64] float2
     __shared__ __attribute__((aligned(16))) float ltaps[17 * SS];
     __shared__ __attribute__((aligned(16))) float2 lrot[16];
-    __shared__ unsigned int ring_ready[kStgMaxBufs], ring_done[kStgMaxBufs];
     const int t = threadIdx.x;
-    if (FLAGS_ && t < kStgMaxBufs) ring_ready[t] = ring_done[t] = 0u;
     for (int e = t; e < 17 * SS; e += blockDim.x) {
         const int p = e / SS, s = e % SS;
         ltaps[e] = p < 16 ? taps[16 * p + s] : taps[SS - 1 - s];
@@ -97,7 +78,6 @@ __global__ __launch_bounds__(64 * kStgMaxWaves) void k_pair_decimate_staged(cons
     const int w = item >> 5, cb = item & 31;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
     const int p_first = grp * n_cw, p_cnt = P - p_first < n_cw ? P - p_first : n_cw;
-    const int n_lw_all = (int)(blockDim.x >> 6) - n_cw;            // loader waves
     const PWDesc *wpw = pw + (size_t)w * P;
     const int sw_base = wpw[0].sw_a;                               // the window's stations are sw_base .. sw_base + S - 1
     unsigned int mask = 0;                                         // stations this group's pairs touch
@@ -158,27 +138,6 @@ __global__ __launch_bounds__(64 * kStgMaxWaves) void k_pair_decimate_staged(cons
         };
         // phases 0 .. nb - 2 go out at once; at barrier ph the readers are through with phase ph - 1, whose buffer then takes
         // phase ph + nb - 1
-        if (FLAGS_) {
-            // phase ph goes out as soon as every walk has released its slot (refill number ph / nb); `ready` of phase ph - D
-            // follows when the D later phases are all that may still be in flight (D <= nb - 2: a loader waiting for a slot has
-            // then announced every phase a walk can be waiting for)
-            const int D = nb - 2 < 1 ? 1 : (per_phase * (nb - 2) <= kStgMaxInFlight ? nb - 2 : (kStgMaxInFlight / per_phase < 1 ? 1 : kStgMaxInFlight / per_phase));
-            int slot_i = 0, slot_r = 0, fills = 0;
-            for (int ph = 0; ph < NP + D; ph++) {
-                if (ph < NP) {
-                    if (fills > 0 && !stg_spin_until(&ring_done[slot_i], (unsigned int)(p_cnt * fills))) return;
-                    issue(ph, slot_i);
-                    if (++slot_i == nb) { slot_i = 0; fills++; }
-                }
-                if (ph >= D) {
-                    const int last = ph < NP ? ph : NP - 1;            // the newest phase issued so far
-                    stg_wait_vm((last - (ph - D)) * per_phase);       // phase ph - D has landed
-                    stg_signal(&ring_ready[slot_r]);
-                    if (++slot_r == nb) slot_r = 0;
-                }
-            }
-            return;
-        }
         for (int ph = 0; ph < nb - 1 && ph < NP; ph++) issue(ph, ph);
         int buf_next = (nb - 1) % nb;
         for (int ph = 0; ph < NP; ph++) {
@@ -191,8 +150,7 @@ __global__ __launch_bounds__(64 * kStgMaxWaves) void k_pair_decimate_staged(cons
         return;
     }
     if (wave >= p_cnt) {                                           // a compute wave without a pair (last group): barriers only
-        if (!FLAGS_)
-            for (int ph = 0; ph < NP; ph++) __builtin_amdgcn_s_barrier();
+        for (int ph = 0; ph < NP; ph++) __builtin_amdgcn_s_barrier();
         return;
     }
 
@@ -301,17 +259,12 @@ __global__ __launch_bounds__(64 * kStgMaxWaves) void k_pair_decimate_staged(cons
             if (p == 0 && g > 0) bottom_leaves(NG - g + C);
         }
     };
-    int buf = 0, fills = 1;
+    int buf = 0;
 #pragma unroll 1
     for (int ph = 0; ph < NP; ph++) {
-        if (FLAGS_) {
-            if (ph) stg_signal(&ring_done[buf == 0 ? nb - 1 : buf - 1]);                   // the previous phase's slot is free
-            if (!stg_spin_until(&ring_ready[buf], (unsigned int)(n_lw_all * fills))) return; // phase ph is in LDS
-        } else {
-            __builtin_amdgcn_s_barrier();                          // phase ph is in LDS
-        }
+        __builtin_amdgcn_s_barrier();                              // phase ph is in LDS
         const unsigned int base = (unsigned int)(buf * R) * (unsigned int)S * 1024u;
-        if (++buf == nb) { buf = 0; fills++; }
+        if (++buf == nb) buf = 0;
         const int k2 = ph * R;
         if ((k2 & 15) == 0) wg = w_n((float)k2 + (float)k1 * (float)N2);
         // two rows at a time (their eight reads in flight together; four rows' worth of operands did not fit 128 registers)

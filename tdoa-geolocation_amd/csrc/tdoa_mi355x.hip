@@ -105,7 +105,6 @@ struct tdoa_ctx {
     bool dec_staged = true;                 // TDOA_NO_DEC_STAGED=1: the column walk one pair-window per wave from memory (k_pair_decimate_cols), no LDS staging
     int stg_loaders = 0;                    // TDOA_DEC_STAGED_LOADERS=n: loader waves per workgroup of k_pair_decimate_staged (0: the library's choice)
     int stg_rows = 0, stg_bufs = 0;         // TDOA_DEC_STAGED_ROWS=2|4|8, TDOA_DEC_STAGED_BUFS=n: rows per phase, phases in the LDS ring (0: the library's choice)
-    bool stg_flags = false;                 // TDOA_DEC_STAGED_FLAGS=1: the ring handed over through LDS counters instead of a barrier per phase
     bool seg_pack3 = true;                  // TDOA_NO_SEG_PACK3=1: the segment form reads int32 code rows (round 3's layout)
     int seg_chunks_override = 0;            // TDOA_SEG_CHUNKS=n at tdoa_create time: chunk count of the segment form
     int graph_nodes = 0, graph_edges = 0, graph_roots = 0, graph_memsets = 0;      // structure of the captured step (tdoa_debug_graph_info)
@@ -912,22 +911,15 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
                 int nb = ctx->stg_bufs ? ctx->stg_bufs : std::max(2, std::min(4, budget / (rows * stg_s * 1024)));
                 if (rows * stg_s * 1024 * 2 > kStgLdsBytes) return fail(ctx, TDOA_ERR_INVALID, "TDOA_DEC_STAGED_ROWS: two phases do not fit the LDS ring");
                 nb = std::min(nb, kStgLdsBytes / (rows * stg_s * 1024));
-                if (ctx->stg_flags) nb = std::max(2, std::min(nb, kStgMaxBufs));
-                else nb = std::max(2, std::min(nb, 2 + kStgMaxInFlight / per_phase));
+                nb = std::max(2, std::min(nb, 2 + kStgMaxInFlight / per_phase));
                 const int n_items = n_win * 32;
                 const unsigned int blocks = (unsigned int)((n_items + 7) / 8 * 8) * (unsigned int)groups;
                 const size_t lds = (size_t)nb * rows * stg_s * 1024;
                 const float *tp = static_cast<const float *>(ctx->dec_taps.p);
                 const dim3 sblock(64 * (n_cw + n_lw));
 #define TDOA_STAGED_R(N2V, RV)                                                                                       \
-    do {                                                                                                              \
-        if (ctx->stg_flags)                                                                                           \
-            hipLaunchKernelGGL((k_pair_decimate_staged<N2V, RV, true>), dim3(blocks), sblock, lds, st, d_pw, tz, g, edges, pl, tp,  \
-                               n_items, P, stg_s, n_cw, groups, nb);                                                  \
-        else                                                                                                          \
-            hipLaunchKernelGGL((k_pair_decimate_staged<N2V, RV, false>), dim3(blocks), sblock, lds, st, d_pw, tz, g, edges, pl, tp, \
-                               n_items, P, stg_s, n_cw, groups, nb);                                                  \
-    } while (0)
+    hipLaunchKernelGGL((k_pair_decimate_staged<N2V, RV>), dim3(blocks), sblock, lds, st, d_pw, tz, g, edges, pl, tp, n_items, P,  \
+                       stg_s, n_cw, groups, nb)
 #define TDOA_STAGED(N2V)                                                                                              \
     do {                                                                                                              \
         if (rows == 8) TDOA_STAGED_R(N2V, 8);                                                                         \
@@ -1102,8 +1094,7 @@ int allow_big_lds(tdoa_ctx *ctx)
     if ((rc = set_lds(ctx, (k_pair_decimate_staged<2560, 2>), all))) return rc;
     if ((rc = set_lds(ctx, (k_pair_decimate_staged<4096, 2>), all))) return rc;
 #define TDOA_STG_LDS(N2V, RV)                                                                    \
-    if ((rc = set_lds(ctx, (k_pair_decimate_staged<N2V, RV, false>), all))) return rc;           \
-    if ((rc = set_lds(ctx, (k_pair_decimate_staged<N2V, RV, true>), all))) return rc;
+    if ((rc = set_lds(ctx, (k_pair_decimate_staged<N2V, RV>), all))) return rc;
 #define TDOA_STG_LDS_N(N2V) TDOA_STG_LDS(N2V, 2) TDOA_STG_LDS(N2V, 4) TDOA_STG_LDS(N2V, 8)
     TDOA_STG_LDS_N(256) TDOA_STG_LDS_N(512) TDOA_STG_LDS_N(2560) TDOA_STG_LDS_N(4096)
 #undef TDOA_STG_LDS_N
@@ -1406,7 +1397,6 @@ int tdoa_create(const tdoa_params *p, tdoa_ctx **out)
     if (const char *e = std::getenv("TDOA_DEC_STAGED_LOADERS")) ctx->stg_loaders = std::max(0, std::min(4, std::atoi(e)));
     if (const char *e = std::getenv("TDOA_DEC_STAGED_ROWS")) ctx->stg_rows = std::atoi(e) == 8 ? 8 : std::atoi(e) == 4 ? 4 : std::atoi(e) == 2 ? 2 : 0;
     if (const char *e = std::getenv("TDOA_DEC_STAGED_BUFS")) ctx->stg_bufs = std::max(0, std::min(16, std::atoi(e)));
-    if (const char *e = std::getenv("TDOA_DEC_STAGED_FLAGS")) ctx->stg_flags = e[0] == '1';
     if (const char *e = std::getenv("TDOA_NO_SEG_PACK3")) ctx->seg_pack3 = !(e[0] == '1');
     if (const char *e = std::getenv("TDOA_SEG_CHUNKS")) ctx->seg_chunks_override = std::max(0, std::atoi(e));
     if (const char *e = std::getenv("TDOA_DEBUG_MEMSET_NODES")) ctx->memset_nodes = e[0] == '1';
@@ -1847,7 +1837,7 @@ static int process_impl(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host,
                                  (uint64_t)ctx->force_generic | ((uint64_t)ctx->short_lag << 1) |
                                      ((uint64_t)ctx->segment_form << 3) | ((uint64_t)ctx->xcd_rows << 4) |
                                      ((uint64_t)ctx->segment_quads << 6) |
-                                     ((uint64_t)ctx->decimate << 8) | ((uint64_t)ctx->fused_k1 << 9) | ((uint64_t)ctx->k1_once << 11) | ((uint64_t)ctx->seg_pack3 << 12) | ((uint64_t)ctx->dec_cols << 13) | ((uint64_t)ctx->dec_cols_always << 14) | ((uint64_t)ctx->pow2_only << 15) | ((uint64_t)ctx->dec_staged << 7) | ((uint64_t)ctx->stg_loaders << 36) | ((uint64_t)ctx->stg_rows << 28) | ((uint64_t)ctx->stg_flags << 27) | ((uint64_t)ctx->stg_bufs << 32) |
+                                     ((uint64_t)ctx->decimate << 8) | ((uint64_t)ctx->fused_k1 << 9) | ((uint64_t)ctx->k1_once << 11) | ((uint64_t)ctx->seg_pack3 << 12) | ((uint64_t)ctx->dec_cols << 13) | ((uint64_t)ctx->dec_cols_always << 14) | ((uint64_t)ctx->pow2_only << 15) | ((uint64_t)ctx->dec_staged << 7) | ((uint64_t)ctx->stg_loaders << 36) | ((uint64_t)ctx->stg_rows << 28) | ((uint64_t)ctx->stg_bufs << 32) |
                                      ((uint64_t)ctx->memset_nodes << 10) | ((uint64_t)ctx->seg_chunks_override << 16) | ((uint64_t)ctx->xcd_pair_mb << 40),
                                  ctx->alloc_gen, (uint64_t)(fine_host != nullptr), 0};
     std::memcpy(&key.back(), &gate, sizeof(double));
