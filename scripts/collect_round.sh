@@ -48,10 +48,18 @@ cp gpurun_out/${TAG}_default_bench.json profiles/
 say A/B single-look K1 against the pre-pass
 TDOA_NO_K1_ONCE=1 python3 bench.py --no-cpu-baseline --no-h2d > gpurun_out/${TAG}_cfg2_prepass_bench.json 2> gpurun_out/${TAG}_prepass.err
 cp gpurun_out/${TAG}_cfg2_prepass_bench.json profiles/
+say A/B ten-second plan: N = 5 x 2^22 against 2^25
+TDOA_POW2_ONLY=1 python3 bench.py --config cfg3 --steps 2 --warmup 1 --no-cpu-baseline --no-h2d > gpurun_out/${TAG}_cfg3_pow2_bench.json 2> gpurun_out/${TAG}_cfg3_pow2.err
+cp gpurun_out/${TAG}_cfg3_pow2_bench.json profiles/
+say A/B staged column walk against the per-pair walk
+for cfg in cfg4 cfg5 cfg3; do
+  TDOA_NO_DEC_STAGED=1 python3 bench.py --config $cfg --steps 3 --warmup 1 --no-cpu-baseline --no-h2d --no-clocks > gpurun_out/${TAG}_${cfg}_perpair_walk_bench.json 2> gpurun_out/${TAG}_${cfg}_perpair.err
+  cp gpurun_out/${TAG}_${cfg}_perpair_walk_bench.json profiles/
+done
 say multi-rank rehearsals
 python3 bench.py --force-dist --no-cpu-baseline > gpurun_out/${TAG}_forcedist_rccl_world1_bench.json 2> gpurun_out/${TAG}_forcedist.err
-TDOA_BENCH_BACKEND=gloo python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29613 \
-    bench.py --gpus 2 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_bench_2rank_gloo.json 2> gpurun_out/${TAG}_gloo2.err
+# (round 5: bench.py --gpus N starts its own ranks -- the contract verb, no launcher in front)
+TDOA_BENCH_BACKEND=gloo python3 bench.py --gpus 2 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_bench_2rank_gloo.json 2> gpurun_out/${TAG}_gloo2.err
 cp gpurun_out/${TAG}_forcedist_rccl_world1_bench.json gpurun_out/${TAG}_bench_2rank_gloo.json profiles/
 if [ "$QUICK" != quick ]; then
   say K1 on other byte distributions
