@@ -149,6 +149,13 @@ def sq_issue(cfg_name, kernel):
     return None
 
 
+def path_switches():
+    """TDOA_* environment switches that make the library take another path than its default (A/B runs): the committed counter
+    files describe the default path's kernels and are not quoted next to them"""
+    return sorted(k for k, v in os.environ.items() if k.startswith("TDOA_") and k not in ("TDOA_BENCH_BACKEND", "TDOA_LIB_VARIANT",
+                                                                                          "TDOA_UPLOAD_THREADS") and v not in ("", "0"))
+
+
 def decimation_fits(nc, max_lag):
     """the library's rule (tdoa_mi355x.hip decimation_design): a Kaiser filter of at most 95 taps a side must reach 120 dB
     between the pass band |m| <= M = max_lag/2 + 2 and the stop band |m| >= Nc/16 - M"""
@@ -611,7 +618,7 @@ def run_job(args, env, cfg_name, scaling, sim, steps, warmup, full):
             "source_sha16": source_hash(),
             "k1_path": "single look (every capture byte read once; csrc/k1_single_look.hpp)" if ctx.last_k1(0)[1]
                        else "statistics pre-pass + discriminator in the column pass (capture bytes read twice)",
-            "clocks": clocks, "sustained": sustained,
+            "clocks": clocks, "sustained": sustained, "path_switches": path_switches() or None,
         }
         if full:
             out.update(roofline_fields(args, env, cfg_name, scaling, sim, table, prof_timed, dominant, timed_mode, table_steps, steps,
@@ -718,7 +725,8 @@ def roofline_fields(args, env, cfg_name, scaling, sim, table, prof_timed, domina
         requested = rec["bytes"] / rec["launches"]                      # the library's per-kernel byte model: what the launch ASKS for
         avg_s = rec["ms"] / rec["launches"] / 1e3
         kernels = hot.get(name, [name])
-        windows_per_launch = n_windows                                    # (every window of the rank in one launch group)
+        # a step may take several launch groups of windows (cfg3: 4, cfg5: 8): everything here is per LAUNCH
+        windows_per_launch = n_windows * steps / rec["launches"]
         # HBM side of a pair step whose P pairs share S station spectra: each spectrum comes from memory once (its other
         # readers are served by L2 / Infinity Cache), the pair's own output is written -- the compulsory bytes of the launch
         compulsory = requested
@@ -727,7 +735,8 @@ def roofline_fields(args, env, cfg_name, scaling, sim, table, prof_timed, domina
             if decimated:       # G (Nc/16 points) + the neighbour shares: X[12][4096] behind the column walk, E[N2][12] behind the tiles
                 out_per_pair = 8.0 * nc / 16 + 8.0 * 12 * (4096 if hot["k_inv_row_pair"][0] in ("k_pair_decimate_cols", "k_pair_decimate_staged") else n2)
             compulsory = min(requested, windows_per_launch * (S * 8.0 * nc + n_pairs * out_per_pair))
-        standard = args.seconds is None and args.batch == 0 and world == 1 and max_lag == 20000 and sim == "config"
+        standard = (args.seconds is None and args.batch == 0 and world == 1 and max_lag == 20000 and sim == "config"
+                    and not path_switches())
         traffic, src, sq = None, None, None
         if standard and name in hot:
             traffic, src, pmc_total = pmc_traffic(cfg_name, kernels)
@@ -776,7 +785,8 @@ def roofline_fields(args, env, cfg_name, scaling, sim, table, prof_timed, domina
     # within 3 % of each other -- one at the HBM roof, one bound by instruction issue -- and which of them is "dominant"
     # changes from box to box; this table shows both.
     by_kernel = None
-    standard = args.seconds is None and args.batch == 0 and world == 1 and max_lag == 20000 and sim == "config"
+    standard = (args.seconds is None and args.batch == 0 and world == 1 and max_lag == 20000 and sim == "config"
+                and not path_switches())
     if standard and hot:
         by_kernel = []
         for scope, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"]):
