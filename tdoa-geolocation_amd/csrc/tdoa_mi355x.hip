@@ -454,7 +454,8 @@ DecDesign decimation_design(const FftPlan &pl, int reach)
 
 // two-sweep plans with a decimated inverse: a 4096-bin tile of their spectrum is (less than) one column, so only the column
 // walk (dec_stream.hpp) serves them, and the row pass leaves the unpacked spectra in TZ
-bool cols_only_plan(const FftPlan &pl) { return pl.N1 == 4096 && (pl.N2 == 4096 || pl.N2 == 2560); }
+// (N2 = 2048 -- windows of 4 to 8 s at 2 Msps, N = 2^24 -- joined in round 5: until then that plan ran the full inverse)
+bool cols_only_plan(const FftPlan &pl) { return pl.N1 == 4096 && (pl.N2 == 4096 || pl.N2 == 2560 || pl.N2 == 2048); }
 
 bool decimation_applies(const tdoa_ctx *ctx, const FftPlan &pl, int lag_lo, int lag_hi)
 {
@@ -928,6 +929,7 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
     } while (0)
                 if (pl.N2 == 256) TDOA_STAGED(256);
                 else if (pl.N2 == 512) TDOA_STAGED(512);
+                else if (pl.N2 == 2048) TDOA_STAGED(2048);
                 else if (pl.N2 == 2560) TDOA_STAGED(2560);
                 else TDOA_STAGED(4096);
 #undef TDOA_STAGED_R
@@ -939,6 +941,7 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
                 const float *tp = static_cast<const float *>(ctx->dec_taps.p);
                 if (pl.N2 == 256) hipLaunchKernelGGL(k_pair_decimate_cols<256>, sgrid, sblock, 0, st, d_pw, tz, g, edges, pl, tp, n_pw);
                 else if (pl.N2 == 512) hipLaunchKernelGGL(k_pair_decimate_cols<512>, sgrid, sblock, 0, st, d_pw, tz, g, edges, pl, tp, n_pw);
+                else if (pl.N2 == 2048) hipLaunchKernelGGL(k_pair_decimate_cols<2048>, sgrid, sblock, 0, st, d_pw, tz, g, edges, pl, tp, n_pw);
                 else if (pl.N2 == 2560) hipLaunchKernelGGL(k_pair_decimate_cols<2560>, sgrid, sblock, 0, st, d_pw, tz, g, edges, pl, tp, n_pw);
                 else hipLaunchKernelGGL(k_pair_decimate_cols<4096>, sgrid, sblock, 0, st, d_pw, tz, g, edges, pl, tp, n_pw);
 #endif
@@ -1089,14 +1092,10 @@ int allow_big_lds(tdoa_ctx *ctx)
     if ((rc = set_lds(ctx, k_pair_decimate16<9>, all))) return rc;
     if ((rc = set_lds(ctx, k_inv_rows_plain_r8, all))) return rc;
 #if TDOA_HAVE_DEC_COLS
-    if ((rc = set_lds(ctx, (k_pair_decimate_staged<256, 2>), all))) return rc;
-    if ((rc = set_lds(ctx, (k_pair_decimate_staged<512, 2>), all))) return rc;
-    if ((rc = set_lds(ctx, (k_pair_decimate_staged<2560, 2>), all))) return rc;
-    if ((rc = set_lds(ctx, (k_pair_decimate_staged<4096, 2>), all))) return rc;
 #define TDOA_STG_LDS(N2V, RV)                                                                    \
     if ((rc = set_lds(ctx, (k_pair_decimate_staged<N2V, RV>), all))) return rc;
 #define TDOA_STG_LDS_N(N2V) TDOA_STG_LDS(N2V, 2) TDOA_STG_LDS(N2V, 4) TDOA_STG_LDS(N2V, 8)
-    TDOA_STG_LDS_N(256) TDOA_STG_LDS_N(512) TDOA_STG_LDS_N(2560) TDOA_STG_LDS_N(4096)
+    TDOA_STG_LDS_N(256) TDOA_STG_LDS_N(512) TDOA_STG_LDS_N(2048) TDOA_STG_LDS_N(2560) TDOA_STG_LDS_N(4096)
 #undef TDOA_STG_LDS_N
 #undef TDOA_STG_LDS
 #endif

@@ -298,6 +298,31 @@ def test_decimated_inverse_on_the_ten_second_plan(oracle, n1, n2, delay, max_lag
     assert np.abs(p2_lags - full_lags).max() <= 2e-6 * scale
 
 
+@pytest.mark.parametrize("n1,n2,delay", [(9_000_000, 9_000_000, 4321), (8_400_001, 10_000_000, -19999)])
+def test_decimated_inverse_on_the_4096x2048_plan(oracle, n1, n2, delay):
+    """windows of 4 to 8 s at 2 Msps (N = 2^24, 4096 x 2048: two-sweep column pass with the 8-point finish) ran the full inverse
+    until round 5; now the decimating FIR walks their 2048-row columns too (k_pair_decimate_cols<2048> for a pair call,
+    k_pair_decimate_staged<2048> in batches) with a 4096 x 128 small plan.  Against the full inverse of the same context, lag
+    by lag, and the peak against the f64 oracle."""
+    import tdoa_amd
+    a = oracle.simulate_delayed_fm(n1, max(0, -delay), 63, 1)
+    b = oracle.simulate_delayed_fm(n2, max(0, delay), 63, 2)
+    with tdoa_amd.Context(max_lag=20000, window_len=max(n1, n2)) as c:
+        dec_lags, dec_peak = c.fm_xcorr_lags(a, b, 20000), c.fm_xcorr(a, b, 20000)
+        assert tuple(c.plan_info()) == (1 << 24, 4096, 2048) and c.last_k1(0)[1] == (n1 == n2)
+        c.debug_flags(no_decimate=True)
+        full_lags, full_peak = c.fm_xcorr_lags(a, b, 20000), c.fm_xcorr(a, b, 20000)
+    assert dec_peak[0] == full_peak[0] == delay
+    assert not np.array_equal(dec_lags, full_lags)                       # (two different inverses ran)
+    scale = np.abs(full_lags).max()
+    assert np.abs(dec_lags - full_lags).max() <= 2e-6 * scale
+    ta, _ = oracle.b_preprocess(a)
+    tb, _ = oracle.b_preprocess(b)
+    olag, ocorr, want = oracle.b_xcorr_peak_fft(ta, tb, 20000)
+    assert olag == delay and abs(dec_peak[1] - ocorr) <= REL_TOL * abs(ocorr)
+    _assert_lags_close(dec_lags, want)
+
+
 def test_profiling_inside_the_replayed_graph(oracle):
     """tdoa_profile_enable(2): the step keeps replaying as one hipGraph and the selected scope is timed by event-record
     nodes spliced into the captured graph; the results must not change and only the selected scope may report launches"""
