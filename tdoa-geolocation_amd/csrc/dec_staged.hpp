@@ -25,12 +25,12 @@
 
 namespace tdoa {
 
-#if TDOA_HAVE_DEC_COLS
-
 constexpr int kStgMaxStations = 16;          // station slots in LDS (1 KB per row and station)
 constexpr int kStgMaxWaves = 16;
 constexpr int kStgLdsBytes = 128 * 1024;     // the ring: phases x rows per phase x stations x 1 KB
 constexpr int kStgMaxInFlight = 60;          // LDS-DMA instructions a loader wave leaves outstanding (the counter holds 63)
+
+#if TDOA_HAVE_DEC_COLS
 
 // one s_waitcnt vmcnt(n) for a run-time n (the field is an immediate): n = the LDS-DMA instructions of the later phases that
 // may stay in flight, a multiple of 2 (rows per phase) up to kStgMaxInFlight

@@ -256,3 +256,16 @@ def test_segment_quads_cover_every_pair_once(capi, n_stations):
         capi.segment_quads(3, [(0, 3)])
     with pytest.raises(ValueError):
         capi.segment_quads(3, [(1, 1)])
+
+
+def test_the_documented_measurement_variant_still_builds(tmp_path):
+    """fft_radix8.hpp / build.py advertise `build.py --variant dec14 TDOA_DEC_STEPS=14` (the 140 dB decimation filter of rounds
+    2-3) for same-box A/B runs; the column walks are written for 8 or 12 steps per phase and are left out of such a build
+    (TDOA_HAVE_DEC_COLS = 0: the library then runs the tile form and the full inverse) -- ADVICE r04: it no longer compiled"""
+    import os
+    from tdoa_amd import build
+    out = build.build_variant("dec14_test", ["TDOA_DEC_STEPS=14"])
+    try:
+        assert os.path.getsize(out) > 100_000
+    finally:
+        os.remove(out)
