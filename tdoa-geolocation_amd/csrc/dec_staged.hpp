@@ -54,7 +54,14 @@ __device__ __forceinline__ void stg_wait_vm(int n)
 // R_: rows (and partner rows) per phase = per barrier; nb: phases in the ring (nb - 1 of them are in flight or being read:
 // what hides the memory latency is (nb - 2) R S KB per workgroup)
 template <int N2_, int R_>
-__global__ __launch_bounds__(64 * kStgMaxWaves) void k_pair_decimate_staged(const PWDesc *pw, const float2 *U, float2 *G, float2 *X, FftPlan pl,
+// (plain ds_read_b64 with immediate row offsets: left to itself the backend pairs the reads of two rows into ds_read2st64_b64,
+//  which the LDS serves at half the rate of two plain reads -- MI355X_MICROARCH.md, LDS table; -DTDOA_STG_PAIRED_READS for the A/B)
+#ifdef TDOA_STG_PAIRED_READS
+#define TDOA_STG_DS_OPS
+#else
+#define TDOA_STG_DS_OPS TDOA_PLAIN_DS_OPS
+#endif
+__global__ __launch_bounds__(64 * kStgMaxWaves) __attribute__((amdgpu_waves_per_eu(4, 4) TDOA_STG_DS_OPS)) void k_pair_decimate_staged(const PWDesc *pw, const float2 *U, float2 *G, float2 *X, FftPlan pl,
                                                                              const float *__restrict__ taps, int n_items, int P, int S,
                                                                              int n_cw, int n_groups, int nb)
 {
@@ -62,7 +69,9 @@ __global__ __launch_bounds__(64 * kStgMaxWaves) void k_pair_decimate_staged(cons
     constexpr int NG = N2 / 16;
     constexpr bool POW2 = (N2 & (N2 - 1)) == 0;
     static_assert(NG >= 2 * C + 2 && 16 % R == 0 && N2 % R == 0 && R % 2 == 0, "ring and loop geometry");
-    extern __shared__ __attribute__((aligned(16))) unsigned char stage_raw[];      // [NB][R][S][2][64] float2
+    // the ring: [phase slot][station][row of the phase][fwd | partner][64] float2 -- the row index innermost, so that a walk's
+    // four operand addresses change once per PHASE (one v_add each) and the row inside the phase is an immediate offset
+    extern __shared__ __attribute__((aligned(16))) unsigned char stage_raw[];
     __shared__ __attribute__((aligned(16))) float ltaps[17 * SS];
     __shared__ __attribute__((aligned(16))) float2 lrot[16];
     const int t = threadIdx.x;
@@ -119,7 +128,7 @@ __global__ __launch_bounds__(64 * kStgMaxWaves) void k_pair_decimate_staged(cons
                 const unsigned int of = 8u * ((unsigned int)k2 * N1 + (unsigned int)(k2 >> 8) * (unsigned int)zpad);
                 const unsigned int om = 8u * ((unsigned int)km2 * N1 + (unsigned int)(km2 >> 8) * (unsigned int)zpad);
                 const unsigned int voff = lane_off + (lane < 32 ? of : om);
-                const unsigned int dst_row = lds0 + (unsigned int)((buf * R + r) * S) * 1024u;
+                const unsigned int dst_row = lds0 + (unsigned int)(buf * S * R + r) * 1024u;      // + station R KB
                 // (laundered per row: hoisted out of the loops, the sixteen bit tests lived in scalar pairs that were spilled
                 //  into vector lanes and read back with two v_readlane per station)
                 unsigned int mm = mine;
@@ -130,7 +139,7 @@ __global__ __launch_bounds__(64 * kStgMaxWaves) void k_pair_decimate_staged(cons
                         unsigned int keep;
                         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                                      : "=&s"(keep)
-                                     : "v"(voff), "s"(sbase[s_]), "s"(dst_row + (unsigned int)s_ * 1024u)
+                                     : "v"(voff), "s"(sbase[s_]), "s"(dst_row + (unsigned int)(s_ * R) * 1024u)
                                      : "memory");
                     }
                 }
@@ -239,8 +248,8 @@ __global__ __launch_bounds__(64 * kStgMaxWaves) void k_pair_decimate_staged(cons
     };
     // LDS byte offsets of this lane's four operands inside a (phase, row) block of S KB: column k1 of the forward piece,
     // column km = 4095 - k1 of the partner piece (its block is stored ascending: lane 63 - l)
-    const unsigned int o_af = (unsigned int)sa * 1024u + 8u * (unsigned int)lane, o_am = (unsigned int)sa * 1024u + 512u + 8u * (unsigned int)(63 - lane);
-    const unsigned int o_bf = (unsigned int)sb * 1024u + 8u * (unsigned int)lane, o_bm = (unsigned int)sb * 1024u + 512u + 8u * (unsigned int)(63 - lane);
+    const unsigned int o_af = (unsigned int)(sa * R) * 1024u + 8u * (unsigned int)lane, o_am = (unsigned int)(sa * R) * 1024u + 512u + 8u * (unsigned int)(63 - lane);
+    const unsigned int o_bf = (unsigned int)(sb * R) * 1024u + 8u * (unsigned int)lane, o_bm = (unsigned int)(sb * R) * 1024u + 512u + 8u * (unsigned int)(63 - lane);
     auto lds_at = [&](unsigned int off) { return *reinterpret_cast<const float2 *>(stage_raw + off); };
     float2 wg = make_float2(1.0f, 0.0f);
     auto row = [&](float2 ua, float2 uam, float2 ub, float2 ubm, int k2, auto first_c) {
@@ -264,6 +273,7 @@ __global__ __launch_bounds__(64 * kStgMaxWaves) void k_pair_decimate_staged(cons
     for (int ph = 0; ph < NP; ph++) {
         __builtin_amdgcn_s_barrier();                              // phase ph is in LDS
         const unsigned int base = (unsigned int)(buf * R) * (unsigned int)S * 1024u;
+        const unsigned int a_af = base + o_af, a_am = base + o_am, a_bf = base + o_bf, a_bm = base + o_bm;      // this phase's operands
         if (++buf == nb) buf = 0;
         const int k2 = ph * R;
         if ((k2 & 15) == 0) wg = w_n((float)k2 + (float)k1 * (float)N2);
@@ -273,11 +283,10 @@ __global__ __launch_bounds__(64 * kStgMaxWaves) void k_pair_decimate_staged(cons
             float2 v[2][4];
 #pragma unroll
             for (int r = 0; r < 2; r++) {
-                const unsigned int rb = base + (unsigned int)(r0 + r) * (unsigned int)S * 1024u;
-                v[r][0] = lds_at(rb + o_af);
-                v[r][1] = lds_at(rb + o_am);
-                v[r][2] = lds_at(rb + o_bf);
-                v[r][3] = lds_at(rb + o_bm);
+                v[r][0] = lds_at(a_af + 1024u * (unsigned int)(r0 + r));
+                v[r][1] = lds_at(a_am + 1024u * (unsigned int)(r0 + r));
+                v[r][2] = lds_at(a_bf + 1024u * (unsigned int)(r0 + r));
+                v[r][3] = lds_at(a_bm + 1024u * (unsigned int)(r0 + r));
             }
             if (r0 == 0) row(v[0][0], v[0][1], v[0][2], v[0][3], k2, std::true_type{});
             else row(v[0][0], v[0][1], v[0][2], v[0][3], k2 + r0, std::false_type{});
