@@ -2,7 +2,7 @@
 # A/B of the LDS-staged column walk (dec_staged.hpp) against the per-pair walk, and of its ring geometry, on one box:
 #   bash scripts/sweep_staged.sh <tag> <cfg> [steps]
 # prints one line per variant: pair-step ms (the scope k_inv_row_pair) and the step
-# STG_VARIANTS="rows bufs loaders;..." : geometries of the staged walk to run (0 = the library's choice)
+# STG_VARIANTS="rows bufs loaders [walks per workgroup];..." : geometries of the staged walk to run (0 = the library's choice)
 TAG=${1:-r05}; CFG=${2:-cfg4}; STEPS=${3:-5}
 mkdir -p gpurun_out/$TAG
 run() {   # name, env...
@@ -23,5 +23,5 @@ VARIANTS=${STG_VARIANTS:-"2 4 0;4 2 0;4 4 0;8 2 0;4 4 1"}
 IFS=';' read -ra VS <<< "$VARIANTS"
 for v in "${VS[@]}"; do
   set -- $v
-  run staged_r$1_b$2_l$3 TDOA_DEC_STAGED_ROWS=$1 TDOA_DEC_STAGED_BUFS=$2 TDOA_DEC_STAGED_LOADERS=$3 $STG_ENV || exit 1
+  run staged_r$1_b$2_l$3_c${4:-0} TDOA_DEC_STAGED_ROWS=$1 TDOA_DEC_STAGED_BUFS=$2 TDOA_DEC_STAGED_LOADERS=$3 TDOA_DEC_STAGED_CW=${4:-0} $STG_ENV || exit 1
 done

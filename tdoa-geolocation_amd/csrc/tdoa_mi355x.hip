@@ -104,6 +104,7 @@ struct tdoa_ctx {
     bool dec_cols_always = false;           // TDOA_DEC_COLS_ALWAYS=1: the column walk wherever the decimated inverse applies (measurements)
     bool dec_staged = true;                 // TDOA_NO_DEC_STAGED=1: the column walk one pair-window per wave from memory (k_pair_decimate_cols), no LDS staging
     int stg_loaders = 0;                    // TDOA_DEC_STAGED_LOADERS=n: loader waves per workgroup of k_pair_decimate_staged (0: the library's choice)
+    int stg_cw = 0;                         // TDOA_DEC_STAGED_CW=n: at most n walks (compute waves) per workgroup (0: sixteen waves less the loaders)
     int stg_rows = 0, stg_bufs = 0;         // TDOA_DEC_STAGED_ROWS=2|4|8, TDOA_DEC_STAGED_BUFS=n: rows per phase, phases in the LDS ring (0: the library's choice)
     bool seg_pack3 = true;                  // TDOA_NO_SEG_PACK3=1: the segment form reads int32 code rows (round 3's layout)
     int seg_chunks_override = 0;            // TDOA_SEG_CHUNKS=n at tdoa_create time: chunk count of the segment form
@@ -902,7 +903,7 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
                 const int P = pairs_per_window, n_win = n_pw / P;
                 int n_lw = ctx->stg_loaders ? ctx->stg_loaders : 1;
                 n_lw = std::max(1, std::min(n_lw, std::min(4, stg_s)));
-                const int cw_max = kStgMaxWaves - n_lw;
+                const int cw_max = ctx->stg_cw > 0 ? std::min(ctx->stg_cw, kStgMaxWaves - n_lw) : kStgMaxWaves - n_lw;
                 const int groups = (P + cw_max - 1) / cw_max, n_cw = (P + groups - 1) / groups;
                 const int wgs_per_cu = std::max(1, kStgMaxWaves / (n_cw + n_lw));
                 const int budget = kStgLdsBytes / wgs_per_cu;
@@ -1395,6 +1396,7 @@ int tdoa_create(const tdoa_params *p, tdoa_ctx **out)
     if (const char *e = std::getenv("TDOA_NO_DEC_STAGED")) ctx->dec_staged = !(e[0] == '1');
     if (const char *e = std::getenv("TDOA_DEC_STAGED_LOADERS")) ctx->stg_loaders = std::max(0, std::min(4, std::atoi(e)));
     if (const char *e = std::getenv("TDOA_DEC_STAGED_ROWS")) ctx->stg_rows = std::atoi(e) == 8 ? 8 : std::atoi(e) == 4 ? 4 : std::atoi(e) == 2 ? 2 : 0;
+    if (const char *e = std::getenv("TDOA_DEC_STAGED_CW")) ctx->stg_cw = std::max(0, std::min(15, std::atoi(e)));
     if (const char *e = std::getenv("TDOA_DEC_STAGED_BUFS")) ctx->stg_bufs = std::max(0, std::min(16, std::atoi(e)));
     if (const char *e = std::getenv("TDOA_NO_SEG_PACK3")) ctx->seg_pack3 = !(e[0] == '1');
     if (const char *e = std::getenv("TDOA_SEG_CHUNKS")) ctx->seg_chunks_override = std::max(0, std::atoi(e));
