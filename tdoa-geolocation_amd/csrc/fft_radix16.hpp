@@ -443,7 +443,7 @@ __device__ __forceinline__ void batch_general(F &f, int g, std::integer_sequence
 }
 
 // ONCE (k1_single_look.hpp): `stats` holds the estimates (m0, s0) of k_once_estimate, and every wave leaves the exact sums
-// of its stored codes of a tile in once_tiles[16 tile + wave].
+// of its stored codes of a tile, one record per row of 16 lanes, in once_tiles[(16 tile + wave) 4 + row].
 // (Round 4 also built this kernel with the whole 128 KB half-plane table in LDS -- 5.5 instructions per look-up instead of
 // 13 -- next to an exchange plane of half the tile: bit-identical results, 2 % SLOWER on cfg2 / cfg4 / cfg3, because the
 // half plane doubles the exchange's barriers (8 per tile) and LDS instructions.  Commit f53a7d8)
@@ -570,7 +570,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
                     batch_general(row_general, g, std::make_integer_sequence<int, kColBatch>{});      // the batch's rows, one by one
                 }
             }
-            if (ONCE) col_once_wave_record(t1, t2, once_tiles + (size_t)tile * kOnceWavesPerTile + (tid >> 6));
+            if (ONCE) col_once_wave_record(t1, t2, once_tiles + (size_t)tile * kOnceWavesPerTile + (size_t)(tid >> 6) * kOnceRecordsPerWave);
         }
         // the capture bytes of the next tile: asked for now, used a whole transform later
         __builtin_amdgcn_sched_barrier(0);
@@ -949,7 +949,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
                     batch_general(row_general, g, std::make_integer_sequence<int, kColBatch>{});      // the batch's rows, one by one
                 }
             }
-            if (ONCE) col_once_wave_record(t1, t2, once_tiles + (size_t)tile * kOnceWavesPerTile + (tid >> 6));
+            if (ONCE) col_once_wave_record(t1, t2, once_tiles + (size_t)tile * kOnceWavesPerTile + (size_t)(tid >> 6) * kOnceRecordsPerWave);
         }
         // the capture bytes of the next tile: asked for now, used a whole transform later
         __builtin_amdgcn_sched_barrier(0);

@@ -136,27 +136,28 @@ __device__ __forceinline__ double dpp_add_f64(double x)
     return x + __hiloint2double(hi2, lo2);
 }
 
-// sum over the 64 lanes of a wave, valid in lane 63: four steps inside the rows of 16, then row_bcast:15 into rows 1 and
-// 3 and row_bcast:31 into rows 2 and 3.  Exact as long as the wave's sum is (every caller splits its values so that it is).
-__device__ __forceinline__ double wave_sum_f64_lane63(double x)
+// sum over each ROW of 16 lanes of a wave, valid in the row's last lane (15, 31, 47, 63): four steps inside the rows.  Exact as
+// long as every row's sum is (every caller splits its values so that it is).
+__device__ __forceinline__ double row_sum_f64_lane15(double x)
 {
     x = dpp_add_f64<0xB1>(x);                // quad_perm [1,0,3,2]
     x = dpp_add_f64<0x4E>(x);                // quad_perm [2,3,0,1]
     x = dpp_add_f64<0x141>(x);               // row_half_mirror
     x = dpp_add_f64<0x140>(x);               // row_mirror
-    x = dpp_add_f64<0x142, 0xa>(x);          // row_bcast:15 -> rows 1, 3
-    x = dpp_add_f64<0x143, 0xc>(x);          // row_bcast:31 -> rows 2, 3
     return x;
 }
 
-// A WAVE's record for one tile: three float64 that hold exact integers.  A lane's t2 = 2^16 q with q < 2^51 an integer, and
-// 64 such lanes would exceed 2^53, so q is split first: hi = floor(q / 2^26) < 2^25, lo = q - 2^26 hi < 2^26; over a wave's 64
-// lanes the parts stay below 2^31 and 2^32.  t1 = -256 x (a lane's sum of codes), |sum over the wave| <= 64 x 2^36.
-// Lane 63 writes the record straight to memory (16 records per tile, 32 bytes each: 10 MB per cfg2 step) -- no LDS, no
-// barrier, nothing for another wave to wait for; k_once_final adds a window's records up.
-constexpr int kOnceWavesPerTile = 16;
+// A wave's records for one tile: ONE PER ROW OF 16 LANES, three float64 that hold exact integers.  A lane's t2 = 2^16 q with
+// q < 2^51 an integer, and the lanes of a row would exceed 2^53, so q is split first: hi = floor(q / 2^26) < 2^25, lo = q - 2^26 hi
+// < 2^26; over 16 lanes the parts stay below 2^29 and 2^30.  t1 = -256 x (a lane's sum of codes), |sum over a row| <= 16 x 2^36.
+// The rows' last lanes write the four records straight to memory in one store instruction -- no LDS, no barrier, nothing for
+// another wave to wait for; k_once_final adds a window's records up.  (Rounds 4-5 reduced over the whole wave first -- two more
+// DPP steps, row_bcast:15 and :31, on each of the three values: 18 vector instructions per tile and wave in a kernel that is
+// short of exactly those -- and wrote one record per wave; four records per wave are 40 MB per cfg2 step instead of 10.)
+constexpr int kOnceRecordsPerWave = 4;
+constexpr int kOnceWavesPerTile = 16 * kOnceRecordsPerWave;      // records per tile (sixteen waves)
 struct OnceTile {
-    double s1;             // sum st over the wave's part of the tile           (= -256 x sum code)
+    double s1;             // sum st over a 16-lane row's part of the tile     (= -256 x sum code)
     double q_hi, q_lo;     // sum of floor(q / 2^26) and of q mod 2^26, q = sum code^2 of a lane
     double pad;
 };
@@ -168,16 +169,17 @@ __device__ __forceinline__ void col_once_split(double t2, double &q_hi, double &
     q_lo = __builtin_fma(q_hi, -0x1p26, q);              // exact
 }
 
+// rec: the wave's first record (kOnceRecordsPerWave consecutive ones)
 __device__ __forceinline__ void col_once_wave_record(double t1, double t2, OnceTile *rec)
 {
     double hi, lo;
     col_once_split(t2, hi, lo);
-    t1 = wave_sum_f64_lane63(t1);
-    hi = wave_sum_f64_lane63(hi);
-    lo = wave_sum_f64_lane63(lo);
-    if ((threadIdx.x & 63) == 63) {
+    t1 = row_sum_f64_lane15(t1);
+    hi = row_sum_f64_lane15(hi);
+    lo = row_sum_f64_lane15(lo);
+    if ((threadIdx.x & 15) == 15) {
         typedef double d2 __attribute__((ext_vector_type(2)));
-        d2 *o = reinterpret_cast<d2 *>(rec);
+        d2 *o = reinterpret_cast<d2 *>(rec + ((threadIdx.x & 63) >> 4));
         o[0] = d2{t1, hi};
         o[1] = d2{lo, 0.0};
     }
@@ -351,7 +353,7 @@ __global__ __launch_bounds__(kDemodThreads) void k_once_edges(const SWDesc *sw, 
 // ---- k_once_final ---------------------------------------------------------------------------------------------------
 // One 256-thread workgroup per station-window adds its tiles' records (integers; any order gives the same bits) and evaluates the
 // statistics with the expressions of k_fm_stats_final, then eps and g against the (m0, s0) the column kernel used.
-// tiles: the records of tile (w, a, bx) at index ((w G + a) nbx + bx) 16 + wave, i.e. 16 tiles_per_sw consecutive records
+// tiles: the records of tile (w, a, bx) at index (((w G + a) nbx + bx) 16 + wave) 4 + row of 16 lanes, i.e. 64 x tiles consecutive records
 // per window (tiles_per_sw counts records here).
 __global__ __launch_bounds__(256) void k_once_final(const SWDesc *sw, const OnceTile *tiles, int tiles_per_sw, FmStats *stats,
                                                     OnceFin *fin, int n_sw)
