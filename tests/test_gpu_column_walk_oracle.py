@@ -120,3 +120,24 @@ def test_staged_walk_group_geometries_vs_the_per_pair_walk(oracle, n_stations, w
     assert np.array_equal(walk, peaks)
     want = np.array([delays[j] - delays[i] for i in range(n_stations) for j in range(i + 1, n_stations)])
     assert (peaks["lag"] == want[None, :]).all() and (peaks["abs_corr"] > 100.0).all()
+
+
+def test_staged_walk_in_launch_groups_and_shards(oracle):
+    """the staged walk behind tdoa_process's batching and sharding: two windows per launch group (three windows: a group of two
+    and a group of one), and the windows dealt to two ranks (wid % 2: rank 0 two windows, rank 1 one) -- every variant must
+    return the bytes of the one-group, one-rank run (each pair-window's arithmetic does not depend on its neighbours)"""
+    import tdoa_amd
+    from tdoa_amd import sharding
+    wl = blk = 1_100_000
+    delays = [0, 41, -17, 203, -350]
+    caps = [np.concatenate([oracle.simulate_delayed_fm(blk, 400 + d, 900 + k, 100 * (s + 1) + k) for k in range(3)])
+            for s, d in enumerate(delays)]
+    with tdoa_amd.Context(max_lag=ML, window_len=wl) as c:
+        full = c.process_u8(caps)
+        parts = [c.process(rank=r, world=2) for r in range(2)]
+    with tdoa_amd.Context(max_lag=ML, window_len=wl, windows_per_batch=2) as c:
+        grouped = c.process_u8(caps)
+    assert np.array_equal(grouped, full)
+    merged = sharding.merge_sharded(np.stack([sharding.peaks_as_bytes(p) for p in parts]), 3, 10)
+    assert np.array_equal(merged, full)
+    assert not parts[0][1]["lag"].any() and not parts[1][[0, 2]]["lag"].any()      # a rank leaves the windows it does not own at zero
