@@ -49,7 +49,8 @@ def _check_batch(oracle, c, peaks, n_stations, wl, blk, float_units, capsys, tag
 
 @pytest.mark.parametrize("n_stations", [8, 5])
 def test_column_walk_batch_4096x256_vs_oracle(oracle, n_stations, capsys):
-    """8 stations: 28 pairs x 3 windows = 84 pair-windows, 21 full workgroups of the walk; 5 stations: 10 x 3 = 30, the
+    """8 stations: 28 pairs x 3 windows = 84 pair-windows -- staged: two groups of 14 walks per window and column block;
+    per-pair walk: 21 full workgroups of four --; 5 stations: 10 x 3 = 30 -- staged: one group of ten walks; per-pair walk: the
     eighth workgroup half empty.  Delayed FM content per block, every station its own delay and noise."""
     import tdoa_amd
     wl = blk = 1_100_000
@@ -78,8 +79,8 @@ def test_column_walk_batch_4096x256_vs_oracle(oracle, n_stations, capsys):
 
 def test_column_walk_batch_4096x512_vs_oracle(oracle, capsys):
     """4 stations x 3 windows of 2 200 001 samples (odd: the last element of a window holds one sample):
-    2 200 001 + 20 000 -> N = 2^22 = 2 x 4096 x 512, k_pair_decimate_cols<9>; 6 pairs x 3 windows = 18 pair-windows, the
-    fifth workgroup of the walk half empty"""
+    2 200 001 + 20 000 -> N = 2^22 = 2 x 4096 x 512, k_pair_decimate_staged<512, 8>; 6 pairs x 3 windows = 18 pair-windows (one
+    group of six walks; the per-pair walk's fifth workgroup half empty)"""
     import tdoa_amd
     wl = blk = 2_200_001
     delays = [0, -123, 64, 1999]
