@@ -695,7 +695,7 @@ def roofline_fields(args, env, cfg_name, scaling, sim, table, prof_timed, domina
     hot = {}
     once = os.environ.get("TDOA_NO_K1_ONCE") != "1"
     if n1 == 4096:          # the radix-16 register kernels (fft_radix16.hpp); the column pass depends on N2
-        fused_k1 = n2 in (256, 512, 2048, 2560, 4096) and os.environ.get("TDOA_NO_FUSED_K1") != "1" and max_lag > 1024
+        fused_k1 = n2 in (256, 512, 2048, 2560, 3072, 4096) and os.environ.get("TDOA_NO_FUSED_K1") != "1" and max_lag > 1024
         if fused_k1:
             col = ["k_fwd_col512_k1"] if n2 == 512 else ["k_fwd_col256_k1"] + (["k_fwd_col_finish"] if n2 > 256 else [])
         else:
@@ -705,13 +705,13 @@ def roofline_fields(args, env, cfg_name, scaling, sim, table, prof_timed, domina
                "k_fwd_col": col, "k_fwd_row": ["k_fwd_row4096"],
                "k_inv_row_pair": ["k_inv_row_pair4096"], "k_inv_col_peak": ["k_inv_col_pruned"]}
     reach = max_lag                     # lags -(max_lag - 1) .. max_lag - 1 plus the refinement neighbours
-    decimated = (n1 == 4096 and n2 in (256, 512, 2048, 2560, 4096) and reach > 4095 and os.environ.get("TDOA_NO_DECIMATE") != "1"
+    decimated = (n1 == 4096 and n2 in (256, 512, 2048, 2560, 3072, 4096) and reach > 4095 and os.environ.get("TDOA_NO_DECIMATE") != "1"
                  and decimation_fits(n1 * n2, max_lag))
     if decimated:     # K3 + 16:1 FIR decimation of the pair spectrum, then an Nc/16-point inverse;
         #               on the 4096 x 4096 plan the FIR walks the columns of the spectrum (dec_stream.hpp)
         #               the FIR walks the columns of the spectrum (dec_stream.hpp) on the 4096 x 4096 plan and wherever a window
         #               carries more pairs than stations (tdoa_mi355x.hip dec_walks_columns); else 4096-bin tiles in LDS
-        cols = os.environ.get("TDOA_NO_DEC_COLS") != "1" and (n2 in (2048, 2560, 4096) or n_pairs > S or os.environ.get("TDOA_DEC_COLS_ALWAYS") == "1")
+        cols = os.environ.get("TDOA_NO_DEC_COLS") != "1" and (n2 in (2048, 2560, 3072, 4096) or n_pairs > S or os.environ.get("TDOA_DEC_COLS_ALWAYS") == "1")
         staged = cols and os.environ.get("TDOA_NO_DEC_STAGED") != "1" and S <= 16      # (uniform batches: every bench job is one)
         hot = dict(hot, k_fwd_row=["k_fwd_row4096_unpack"],
                    k_inv_row_pair=["k_pair_decimate_staged" if staged else "k_pair_decimate_cols" if cols else "k_pair_decimate16"],

@@ -648,7 +648,36 @@ __device__ __forceinline__ void dft10(float2 (&v)[10])
     for (int k = 0; k < 10; k++) v[k] = x[k];
 }
 
-// second half, G = 16 (N2 = 4096), 8 (N2 = 2048) or 10 (N2 = 2560, round 5): X[kb + 256 ka] = sum_a W_G^(a ka) Y_a[kb] in
+// 12-point DFT, forward, natural order in and out: n = 3 a + b, k = c + 4 d -- four-point transforms over a for each b,
+// twiddle W_12^(b c), three-point transforms over b for each c
+__device__ __forceinline__ void dft12(float2 (&v)[12])
+{
+    float2 y[3][4];
+#pragma unroll
+    for (int b = 0; b < 3; b++) {
+        y[b][0] = v[b]; y[b][1] = v[3 + b]; y[b][2] = v[6 + b]; y[b][3] = v[9 + b];
+        bfly4<false>(y[b][0], y[b][1], y[b][2], y[b][3]);            // Y_b[c], c = 0..3
+    }
+    // W_12^m = exp(-2 pi i m / 12): m = 1: (sqrt3/2, -1/2)  2: (1/2, -sqrt3/2)  3: (0, -1)  4: (-1/2, -sqrt3/2)  6: (-1, 0)
+    constexpr float h = 0.5f, r = 0.86602540378443865f;
+    y[1][1] = cmul(y[1][1], make_float2(r, -h));                     // b c = 1
+    y[1][2] = cmul(y[1][2], make_float2(h, -r));                     // 2
+    y[1][3] = make_float2(y[1][3].y, -y[1][3].x);                    // 3: times -i
+    y[2][1] = cmul(y[2][1], make_float2(h, -r));                     // 2
+    y[2][2] = cmul(y[2][2], make_float2(-h, -r));                    // 4
+    y[2][3] = make_float2(-y[2][3].x, -y[2][3].y);                   // 6: times -1
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        // three-point DFT over b: X[c + 4 d], d = 0, 1, 2;  w = exp(-2 pi i / 3) = (-1/2, -sqrt3/2)
+        const float2 x0 = y[0][c], t = cadd(y[1][c], y[2][c]), u = csub(y[1][c], y[2][c]);
+        const float2 m = make_float2(x0.x - h * t.x, x0.y - h * t.y), su = make_float2(r * u.x, r * u.y);
+        v[c] = cadd(x0, t);
+        v[c + 4] = make_float2(m.x + su.y, m.y - su.x);              // m - i s u
+        v[c + 8] = make_float2(m.x - su.y, m.y + su.x);              // m + i s u
+    }
+}
+
+// second half, G = 16 (N2 = 4096), 8 (N2 = 2048), 10 (N2 = 2560) or 12 (N2 = 3072; both round 5): X[kb + 256 ka] = sum_a W_G^(a ka) Y_a[kb] in
 // registers (G = 8 runs the 16-point butterfly on inputs spread to the even slots: W_16^(2a k) = W_8^(a k); G = 10 a
 // 10-point DFT as 2 x 5), then the four-step twiddle W_Nc^(n1 k2) = W^(n1 kb) * (W^(256 n1))^ka; in place (a thread rewrites
 // the rows it read).
@@ -656,26 +685,31 @@ __device__ __forceinline__ void dft10(float2 (&v)[10])
 template <int G>
 __global__ __launch_bounds__(256) void k_fwd_col_finish(float2 *T, FftPlan pl)
 {
-    static_assert(G == 8 || G == 16 || G == 10, "two-sweep column pass: N2 = 2048, 2560 or 4096");
+    static_assert(G == 8 || G == 16 || G == 10 || G == 12, "two-sweep column pass: N2 = 2048, 2560, 3072 or 4096");
     // a thread takes TWO adjacent columns (one 16-byte access per row): a workgroup moves 4 KB runs of each of its 16 rows
     const int n1 = ((blockIdx.x << 8) + threadIdx.x) * 2, kb = blockIdx.y;
     float2 *base = T + (size_t)blockIdx.z * pl.Zs + (size_t)kb * pl.N1 + n1;
     const size_t stride = (size_t)256 * pl.N1 + pl.zpad;      // (zpad = 0: 27 % slower -- every row of the sum on one channel)
     typedef float f4v __attribute__((ext_vector_type(4)));
-    if constexpr (G == 10) {
-        float2 v[10], u[10];
+    if constexpr (G == 10 || G == 12) {
+        float2 v[G], u[G];
 #pragma unroll
-        for (int a = 0; a < 10; a++) {
+        for (int a = 0; a < G; a++) {
             const f4v x = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(base + a * stride));      // read once
             v[a] = make_float2(x.x, x.y);
             u[a] = make_float2(x.z, x.w);
         }
-        dft10(v);
-        dft10(u);
-        // W_Nc^(n1 (kb + 256 ka)), Nc = 4096 x 2560: n1 kb, 256 n1 < 2^20 -- no wrap; the denominator is 5 x 2^21
+        if constexpr (G == 10) {
+            dft10(v);
+            dft10(u);
+        } else {
+            dft12(v);
+            dft12(u);
+        }
+        // W_Nc^(n1 (kb + 256 ka)), Nc = 4096 x 2560 or x 3072: n1 kb, 256 n1 < 2^20 -- no wrap; the denominator is 5 x 2^21 / 3 x 2^22
         const float qd = 0.25f * (float)pl.Nc, iq = 4.0f / (float)pl.Nc;
-        // base * step^ka, ka = 0..9, by products of depth <= 5 (like mul_base_step16): step^2, ^4, ^8 by squaring
-        auto twiddle10 = [&](float2 (&x)[10], int col) {
+        // base * step^ka, ka = 0..G-1, by products of depth <= 5 (like mul_base_step16): step^2, ^4, ^8 by squaring
+        auto twiddle10 = [&](float2 (&x)[G], int col) {
             const float2 g = unit_root_any((float)(col * kb), qd, iq, false), s1 = unit_root_any((float)(col * 256), qd, iq, false);
             const float2 s2 = cmul(s1, s1), s4 = cmul(s2, s2), s8 = cmul(s4, s4), g4 = cmul(g, s4), g8 = cmul(g, s8);
             const float2 s3 = cmul(s2, s1);
@@ -689,11 +723,15 @@ __global__ __launch_bounds__(256) void k_fwd_col_finish(float2 *T, FftPlan pl)
             x[7] = cmul(x[7], cmul(g4, s3));
             x[8] = cmul(x[8], g8);
             x[9] = cmul(x[9], cmul(g8, s1));
+            if constexpr (G == 12) {
+                x[10] = cmul(x[10], cmul(g8, s2));
+                x[11] = cmul(x[11], cmul(g8, s3));
+            }
         };
         twiddle10(v, n1);
         twiddle10(u, n1 + 1);
 #pragma unroll
-        for (int ka = 0; ka < 10; ka++) {
+        for (int ka = 0; ka < G; ka++) {
             f4v y;
             y.x = v[ka].x; y.y = v[ka].y; y.z = u[ka].x; y.w = u[ka].y;
             __builtin_nontemporal_store(y, reinterpret_cast<f4v *>(base + ka * stride));

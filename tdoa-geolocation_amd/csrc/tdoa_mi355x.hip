@@ -213,7 +213,8 @@ int make_plan(long long n_real, bool packed, FftPlan *pl, int zpad = 0)
     // 5 x 2^k (round 5): only the two shapes that have kernels -- 4096 x 2560 (N = 5 x 2^22, the column pass as ten 256-point
     // sub-transforms + k_fwd_col_finish<10>, the pair step as a column walk) and the small plan of its decimated inverse,
     // 4096 x 160
-    const int odd = (nc == 4096ll * 2560 || nc == 4096ll * 160) ? 5 : 1;
+    // 3 x 2^k likewise: 4096 x 3072 (N = 3 x 2^23: twelve sub-transforms + k_fwd_col_finish<12>) and its small plan 4096 x 192
+    const int odd = (nc == 4096ll * 2560 || nc == 4096ll * 160) ? 5 : (nc == 4096ll * 3072 || nc == 4096ll * 192) ? 3 : 1;
     if (nc < 32 || nc > (1ll << 24) || (odd == 1 && (nc & (nc - 1)))) return TDOA_ERR_UNSUPPORTED;
     long long n1, n2;
     pl->odd = odd;
@@ -236,7 +237,7 @@ int make_plan(long long n_real, bool packed, FftPlan *pl, int zpad = 0)
     pl->C = (int)c;
     pl->logC = ilog2(c);
     pl->Nc = nc;
-    pl->zpad = n1 == 4096 && (n2 == 4096 || n2 == 2048 || n2 == 2560) ? zpad : 0;      // two-sweep column pass (fft_stockham.hpp, FftPlan)
+    pl->zpad = n1 == 4096 && (n2 == 4096 || n2 == 2048 || n2 == 2560 || n2 == 3072) ? zpad : 0;      // two-sweep column pass (fft_stockham.hpp, FftPlan)
     pl->Zs = nc + (long long)(n2 / 256) * pl->zpad;
     return TDOA_OK;
 }
@@ -456,7 +457,7 @@ DecDesign decimation_design(const FftPlan &pl, int reach)
 // two-sweep plans with a decimated inverse: a 4096-bin tile of their spectrum is (less than) one column, so only the column
 // walk (dec_stream.hpp) serves them, and the row pass leaves the unpacked spectra in TZ
 // (N2 = 2048 -- windows of 4 to 8 s at 2 Msps, N = 2^24 -- joined in round 5: until then that plan ran the full inverse)
-bool cols_only_plan(const FftPlan &pl) { return pl.N1 == 4096 && (pl.N2 == 4096 || pl.N2 == 2560 || pl.N2 == 2048); }
+bool cols_only_plan(const FftPlan &pl) { return pl.N1 == 4096 && (pl.N2 == 4096 || pl.N2 == 3072 || pl.N2 == 2560 || pl.N2 == 2048); }
 
 bool decimation_applies(const tdoa_ctx *ctx, const FftPlan &pl, int lag_lo, int lag_hi)
 {
@@ -563,7 +564,7 @@ int segment_pq(const tdoa_ctx *ctx, const FftPlan &pl, int lag_lo, int lag_hi, i
 bool fused_k1_applies(const tdoa_ctx *ctx, const FftPlan &pl, int lag_lo, int lag_hi, int n_pw, bool allow)
 {
     if (!allow || !ctx->fused_k1 || ctx->force_generic || ctx->prm.k1_smooth > 1 || ctx->prm.k1_gate) return false;
-    if (pl.N1 != 4096 || !(pl.N2 == 256 || pl.N2 == 512 || pl.N2 == 2048 || pl.N2 == 2560 || pl.N2 == 4096)) return false;
+    if (pl.N1 != 4096 || !(pl.N2 == 256 || pl.N2 == 512 || pl.N2 == 2048 || pl.N2 == 2560 || pl.N2 == 3072 || pl.N2 == 4096)) return false;
     return segment_pq(ctx, pl, lag_lo, lag_hi, n_pw) == 0;
 }
 
@@ -608,6 +609,7 @@ void launch_col_finish(hipStream_t st, float2 *tz, const FftPlan &pl, int n_sw)
     const dim3 grid(pl.N1 / 512, 256, n_sw), blk(256);
     if (pl.N2 == 4096) hipLaunchKernelGGL(k_fwd_col_finish<16>, grid, blk, 0, st, tz, pl);
     else if (pl.N2 == 2560) hipLaunchKernelGGL(k_fwd_col_finish<10>, grid, blk, 0, st, tz, pl);
+    else if (pl.N2 == 3072) hipLaunchKernelGGL(k_fwd_col_finish<12>, grid, blk, 0, st, tz, pl);
     else hipLaunchKernelGGL(k_fwd_col_finish<8>, grid, blk, 0, st, tz, pl);
 }
 
@@ -639,7 +641,7 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
     // fft_stockham.hpp
     const bool row16 = pl.N1 == 4096 && !ctx->force_generic;
     const bool col16 = row16 && pl.N2 == 256;
-    const bool col2pass = row16 && (pl.N2 == 4096 || pl.N2 == 2048 || pl.N2 == 2560);   // 256-point sub-transforms + G-point finish (two sweeps)
+    const bool col2pass = row16 && (pl.N2 == 4096 || pl.N2 == 2048 || pl.N2 == 2560 || pl.N2 == 3072);   // 256-point sub-transforms + G-point finish (two sweeps)
     const int col16x = row16 && pl.N2 >= 16 && pl.N2 <= 128 ? pl.N2 / 16 : 0;   // short columns: k_fwd_col16x_c16<F>
     const int colx = row16 && (pl.N2 == 512 || pl.N2 == 1024) ? pl.N2 / 256 : 0;   // last radix of k_fwd_colx_c16
     int np = 0, nn = 0;
@@ -932,6 +934,7 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
                 else if (pl.N2 == 512) TDOA_STAGED(512);
                 else if (pl.N2 == 2048) TDOA_STAGED(2048);
                 else if (pl.N2 == 2560) TDOA_STAGED(2560);
+                else if (pl.N2 == 3072) TDOA_STAGED(3072);
                 else TDOA_STAGED(4096);
 #undef TDOA_STAGED_R
 #undef TDOA_STAGED
@@ -944,6 +947,7 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
                 else if (pl.N2 == 512) hipLaunchKernelGGL(k_pair_decimate_cols<512>, sgrid, sblock, 0, st, d_pw, tz, g, edges, pl, tp, n_pw);
                 else if (pl.N2 == 2048) hipLaunchKernelGGL(k_pair_decimate_cols<2048>, sgrid, sblock, 0, st, d_pw, tz, g, edges, pl, tp, n_pw);
                 else if (pl.N2 == 2560) hipLaunchKernelGGL(k_pair_decimate_cols<2560>, sgrid, sblock, 0, st, d_pw, tz, g, edges, pl, tp, n_pw);
+                else if (pl.N2 == 3072) hipLaunchKernelGGL(k_pair_decimate_cols<3072>, sgrid, sblock, 0, st, d_pw, tz, g, edges, pl, tp, n_pw);
                 else hipLaunchKernelGGL(k_pair_decimate_cols<4096>, sgrid, sblock, 0, st, d_pw, tz, g, edges, pl, tp, n_pw);
 #endif
             } else if (pl.N2 == 256)
@@ -1096,7 +1100,7 @@ int allow_big_lds(tdoa_ctx *ctx)
 #define TDOA_STG_LDS(N2V, RV)                                                                    \
     if ((rc = set_lds(ctx, (k_pair_decimate_staged<N2V, RV>), all))) return rc;
 #define TDOA_STG_LDS_N(N2V) TDOA_STG_LDS(N2V, 2) TDOA_STG_LDS(N2V, 4) TDOA_STG_LDS(N2V, 8)
-    TDOA_STG_LDS_N(256) TDOA_STG_LDS_N(512) TDOA_STG_LDS_N(2048) TDOA_STG_LDS_N(2560) TDOA_STG_LDS_N(4096)
+    TDOA_STG_LDS_N(256) TDOA_STG_LDS_N(512) TDOA_STG_LDS_N(2048) TDOA_STG_LDS_N(2560) TDOA_STG_LDS_N(3072) TDOA_STG_LDS_N(4096)
 #undef TDOA_STG_LDS_N
 #undef TDOA_STG_LDS
 #endif
@@ -1121,13 +1125,15 @@ int check_ctx(tdoa_ctx *ctx)
 long long choose_fft_size(const tdoa_ctx *ctx, long long need, int lag_lo, int lag_hi, int zpad, FftPlan *pl, int *rc)
 {
     const long long p = std::max<long long>(next_pow2(need), 64);
-    const long long five = 5ll << 22;
-    if (!ctx->pow2_only && p == (1ll << 25) && need <= five) {
-        FftPlan q;
-        if (make_plan(five, true, &q, zpad) == TDOA_OK && decimation_applies(ctx, q, lag_lo, lag_hi)) {
-            *pl = q;
-            *rc = TDOA_OK;
-            return five;
+    if (!ctx->pow2_only && p == (1ll << 25)) {
+        // 5 x 2^22 = 20 971 520 (4096 x 2560), then 3 x 2^23 = 25 165 824 (4096 x 3072: windows of 10.5 to 12.6 s at 2 Msps)
+        for (const long long cand : {5ll << 22, 3ll << 23}) {
+            FftPlan q;
+            if (need <= cand && make_plan(cand, true, &q, zpad) == TDOA_OK && decimation_applies(ctx, q, lag_lo, lag_hi)) {
+                *pl = q;
+                *rc = TDOA_OK;
+                return cand;
+            }
         }
     }
     *rc = make_plan(p, true, pl, zpad);

@@ -202,7 +202,8 @@ def test_odd_and_unaligned_windows_use_fallback(oracle):
     (8_000_000, 123, "2 s at 4 Msps, N = 2^23 (4096 x 1024, radix-4 last column stage)"),
     (10_000_000, -7, "5 s at 2 Msps, N = 2^24 (4096 x 2048, two-sweep column pass, 8-point finish)"),
     (20_000_000, 88, "cfg3 window: 10 s at 2 Msps, N = 5 x 2^22 (4096 x 2560, two-sweep column pass, 10-point finish)"),
-    (21_000_000, -19, "10.5 s at 2 Msps: beyond 5 x 2^22, N = 2^25 (4096 x 4096, two-sweep column pass, 16-point finish)"),
+    (21_000_000, -19, "10.5 s at 2 Msps: beyond 5 x 2^22, N = 3 x 2^23 (4096 x 3072, two-sweep column pass, 12-point finish)"),
+    (25_200_000, 5, "12.6 s at 2 Msps: beyond 3 x 2^23, N = 2^25 (4096 x 4096, two-sweep column pass, 16-point finish)"),
 ])
 def test_long_windows_vs_f64_fft(oracle, n, delay, label):
     """BASELINE configs 3 and 5 window geometries (and the size between them)."""

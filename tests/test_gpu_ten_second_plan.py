@@ -10,7 +10,8 @@ rows, a 4096 x 160 small plan (column roots W_160).  Checked here:
     its fullest window, BASELINE's 20 000 000, an odd length, the shortest one (2^24 + 1 points needed), unequal lengths --
     through the single-look path, the pre-pass path and materialised codes (k_fwd_col256_c16<true> writes the sub-transforms);
   * the same windows in N = 2^25 (TDOA_DEBUG_POW2_ONLY): lag arrays equal to rounding;
-  * the window lengths either side of the plan's range keep their powers of two;
+  * the window lengths either side of the plans' ranges take the next plan up (2^24 below, 3 x 2^23 above 5 x 2^22, 2^25 above that);
+  * N = 3 x 2^23 (4096 x 3072, a 12-point finish) for windows of 10.5 to 12.6 s, the same way;
   * the sub-sample refinement on the small plan 4096 x 160 (k_refine_peaks with W_160);
   * a batch through tdoa_process (device-generated weak-simulator captures, three windows x three pairs) on both plans and
     against the oracle and the float64 atan2 pipeline."""
@@ -23,7 +24,9 @@ pytestmark = pytest.mark.gpu
 
 ML = 20000
 N5 = 5 << 22                                    # 20 971 520
+N3 = 3 << 23                                    # 25 165 824: windows between 10.5 and 12.6 s at 2 Msps
 PLAN5 = (N5, 4096, 2560)
+PLAN3 = (N3, 4096, 3072)
 PLAN25 = (1 << 25, 4096, 4096)
 
 
@@ -80,7 +83,38 @@ def test_every_lag_vs_f64_oracle_on_the_5x2p22_plan(oracle, n1, n2, delay, f64, 
               "2^25 plan %.2e" % (n1, n2, 2 * ML - 1, "f64 oracle" if f64 else "the 2^25 plan", e0, e1, e2, e3))
 
 
-@pytest.mark.parametrize("n,plan", [((1 << 24) - ML, (1 << 24, 4096, 2048)), (N5 - ML + 1, PLAN25)])
+@pytest.mark.parametrize("n1,n2,delay,f64", [(23_000_000, 23_000_000, -4097, True), (N3 - ML, N3 - ML, 19999, False),
+                                             (N5 - ML + 1, 22_222_221, 77, False)])
+def test_every_lag_on_the_3x2p23_plan(oracle, n1, n2, delay, f64, capsys):
+    """N = 3 x 2^23 (4096 x 3072: twelve 256-point sub-transforms, a 12-point finish as 3 x 4, denominators 3 x 2^k, a
+    4096 x 192 small plan) for windows that need between 5 x 2^22 + 1 and 25 165 824 points: every lag against the f64 oracle
+    (once: half a minute of host time) or against the same window in N = 2^25"""
+    import tdoa_amd
+    a = oracle.simulate_delayed_fm(n1, max(0, -delay), 67, 1)
+    b = oracle.simulate_delayed_fm(n2, max(0, delay), 67, 2)
+    with tdoa_amd.Context(max_lag=ML, window_len=max(n1, n2)) as c:
+        lags, peak = c.fm_xcorr_lags(a, b, ML), c.fm_xcorr(a, b, ML)
+        assert tuple(c.plan_info()) == PLAN3 and c.last_k1(0)[1] == (n1 == n2)
+        c.debug_flags(no_fused_k1=True)
+        codes = c.fm_xcorr_lags(a, b, ML)
+        assert tuple(c.plan_info()) == PLAN3
+        c.debug_flags(pow2_only=True)
+        p2, p2_peak = c.fm_xcorr_lags(a, b, ML), c.fm_xcorr(a, b, ML)
+        assert tuple(c.plan_info()) == PLAN25
+    assert peak[0] == p2_peak[0] == delay
+    e_p2 = _lags_close(lags, p2, 2e-6)
+    _lags_close(codes, p2, 2e-6)
+    if f64:
+        ta, _ = oracle.b_preprocess(a)
+        tb, _ = oracle.b_preprocess(b)
+        olag, ocorr, want = oracle.b_xcorr_peak_fft(ta, tb, ML)
+        assert olag == delay and abs(peak[1] - ocorr) <= 1e-5 * abs(ocorr)
+        e = _lags_close(lags, want, 1e-5)
+        with capsys.disabled():
+            print("\n  L = %d on 4096 x 3072: all %d lags vs f64 oracle %.2e, vs the 2^25 plan %.2e" % (n1, 2 * ML - 1, e, e_p2))
+
+
+@pytest.mark.parametrize("n,plan", [((1 << 24) - ML, (1 << 24, 4096, 2048)), (N5 - ML + 1, PLAN3), (N3 - ML + 1, PLAN25)])
 def test_window_lengths_either_side_keep_their_power_of_two(oracle, n, plan):
     import tdoa_amd
     a = oracle.simulate_delayed_fm(n, 0, 13, 1)
