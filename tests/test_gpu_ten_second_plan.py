@@ -183,11 +183,16 @@ def test_cfg3_batch_on_both_plans(oracle, capsys):
         peaks = c.process()
         assert tuple(c.plan_info()) == PLAN5 and c.last_k1(0)[1]
         again = c.process()                                          # the replayed graph
+        fpk, fine = c.process_fine(25000.0)                          # + the refinement on the 4096 x 160 small plan, batched
         c.debug_flags(pow2_only=True)
         p2 = c.process()
         assert tuple(c.plan_info()) == PLAN25
+        fpk2, fine2 = c.process_fine(25000.0)
         tgt = [c.capture_download(s, L, L) for s in range(3)]
     assert peaks.shape == (3, 3) and np.array_equal(peaks, again)
+    assert np.array_equal(fpk, peaks) and np.array_equal(fpk2, p2)     # the integer peaks are untouched by the refinement
+    assert np.abs(fine["delay"][1] - fine2["delay"][1]).max() < 1e-4 and fine["plausible"][1].all()
+    assert np.abs(fine["y"][1] - fine2["y"][1]).max() <= 2e-6 * np.abs(p2["corr"][1]).max()
     assert np.array_equal(peaks["lag"], p2["lag"])
     assert (np.abs(peaks["corr"] - p2["corr"]) <= 2e-6 * np.abs(p2["corr"])).all()
     assert not peaks[[0, 2]]["lag"].any() and not peaks[[0, 2]]["corr"].any()          # constant reference blocks: (0, 0.0)
