@@ -463,6 +463,14 @@ bool decimation_applies(const tdoa_ctx *ctx, const FftPlan &pl, int lag_lo, int 
 {
     if (!ctx->decimate || ctx->force_generic || pl.N1 != 4096 || (pl.N2 != 256 && pl.N2 != 512 && !cols_only_plan(pl))) return false;
     if (cols_only_plan(pl) && !(ctx->dec_cols && TDOA_HAVE_DEC_COLS)) return false;
+    {   // the small plan's K5 kernel evaluates the column outputs that can hold a searched lag as direct sums: at most kPruneMax
+        // of them (run_fm_batch's `pruned`; 4096 packed lags per output: search ranges up to ~32 000 lags).  choose_fft_size
+        // relies on this function alone -- a 5 x 2^k plan has no other inverse to fall back to.
+        const long long n_real = 2 * pl.Nc;
+        const int np = lag_hi >= 0 ? (int)((lag_hi / 2) / pl.N1) + 1 : 0;
+        const int nn = lag_lo < 0 ? pl.N2 - (int)(((n_real + lag_lo) / 2) / pl.N1) : 0;
+        if (np + nn > kPruneMax || lag_hi >= pl.Nc || lag_lo <= -pl.Nc) return false;
+    }
     const int reach = std::max(lag_hi + 1, -(lag_lo - 1));
     if (reach <= 4095) return false;                       // the short-lag forms take those
     return decimation_design(pl, reach).ok;

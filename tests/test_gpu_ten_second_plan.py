@@ -145,6 +145,32 @@ def test_where_the_5x2p22_plan_does_not_apply(oracle):
         assert c.fm_xcorr(a, b, ML)[0] == 0 and tuple(c.plan_info()) == PLAN25
 
 
+def test_go_lag_set_and_wide_ranges_on_ten_second_windows(oracle):
+    """TDOA_LAGS_GO with unequal lengths searches [0, min(maxLag, Ls - Lt)): 20 000 non-negative lags -- the decimated path on
+    the 5 x 2^22 plan with a one-sided output set (k_small_col_peak's run-time form, W_160 by index); a search range too wide
+    for the pruned column outputs (40 000 lags: ten of them) has no 5 x 2^k form and keeps N = 2^25.  Both against the same
+    call in N = 2^25."""
+    import tdoa_amd
+    nt, ns, delay = 18_000_000, 20_000_000, 12345
+    a = oracle.simulate_delayed_fm(nt, 0, 19, 1)
+    b = oracle.simulate_delayed_fm(ns, delay, 19, 2)
+    with tdoa_amd.Context(max_lag=ML, window_len=ns, lag_mode=tdoa_amd.capi.LAGS_GO) as c:
+        lag, corr = c.fm_xcorr(a, b, ML)
+        lags = c.fm_xcorr_lags(a, b, ML)
+        assert tuple(c.plan_info()) == PLAN5
+        c.debug_flags(pow2_only=True)
+        lag2, corr2 = c.fm_xcorr(a, b, ML)
+        lags2 = c.fm_xcorr_lags(a, b, ML)
+        assert tuple(c.plan_info()) == PLAN25
+    assert lag == lag2 == delay and abs(corr - corr2) <= 2e-6 * abs(corr2)
+    assert not lags[:ML - 1].any() and np.abs(lags - lags2).max() <= 2e-6 * np.abs(lags2).max()      # no negative lag is reported
+    wide = 40000
+    with tdoa_amd.Context(max_lag=wide, window_len=ns) as c:
+        lagw, corrw = c.fm_xcorr(a[:2 * 17_000_000], b[:2 * 17_000_000], wide)
+        assert tuple(c.plan_info()) == PLAN25
+    assert lagw == delay
+
+
 def test_refinement_on_the_small_plan_4096x160(oracle):
     """tdoa_fm_xcorr_fine_u8 on a ten-second window: the three neighbours come from the 4096 x 160 small plan's row-pass output
     (k_refine_peaks: 160 values per column, W_160); against ob_refine_peak's parabola on values from the f64 FFT and against
