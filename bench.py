@@ -1007,6 +1007,13 @@ def main():
                 "note": "BASELINE config 4 as written, timed right after the contract line's job in the same process group: ONE "
                         "8-station capture set, windows dealt wid % N, one all-gather of the peak records, owner merge and "
                         "N-station solve on rank 0, all inside the timed region"}
+    if rank == 0 and os.environ.get("TDOA_STG_PROF"):
+        # measurement build of the staged column walk (-DTDOA_STG_TIMING, TDOA_LIB_VARIANT): its wave-cycle counters, to stderr
+        import ctypes
+        import tdoa_amd
+        buf = (ctypes.c_ulonglong * 8)()
+        tdoa_amd.capi.load().tdoa_debug_stg_prof(buf)
+        print("stg_prof " + " ".join(str(v) for v in buf), file=sys.stderr)
     if rank == 0:
         if world > 1:
             out["same_config_one_gpu"] = same_config_one_gpu(cfg_name)

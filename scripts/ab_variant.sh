@@ -1,16 +1,17 @@
 #!/bin/bash
-# same-box A/B of a compile-time variant (tdoa_amd/build.py --variant NAME -D...) against the default build
-# usage: scripts/ab_variant.sh NAME "cfg2 cfg4" [steps]   -> gpurun_out/r04/abv_<NAME>_<cfg>_<default|variant>_<n>.json
-cd "$(dirname "$0")/.." || exit 1
-name=$1
-mkdir -p gpurun_out/r04
-for cfg in ${2:-cfg2 cfg4}; do
-  for n in 1 2; do
-    for mode in default variant; do
-      if [ $mode = variant ]; then export TDOA_LIB_VARIANT=$name; else unset TDOA_LIB_VARIANT; fi
-      f=gpurun_out/r04/abv_${name}_${cfg}_${mode}_$n
-      python3 bench.py --no-cpu-baseline --no-graph-leg --config $cfg ${3:+--steps $3} > $f.json 2> $f.err || exit 1
-      python3 -c "import json; d=json.load(open('$f.json')); print('$cfg $mode $n', d['ms_per_step'], d['roofline']['kernels_ms_per_step'])"
-    done
+# A/B of library variants (TDOA_LIB_VARIANT): bash scripts/ab_variant.sh "<variants>" "<configs>"
+mkdir -p gpurun_out/r05s
+VARS=${1:-"stap"}; CFGS=${2:-"cfg4 cfg5"}
+for cfg in $CFGS; do
+  for v in base $VARS; do
+    if [ $v = base ]; then unset TDOA_LIB_VARIANT; else export TDOA_LIB_VARIANT=$v; fi
+    timeout -k 10 300 python3 bench.py --config $cfg --steps 4 --warmup 2 --no-cpu-baseline --no-h2d --no-clocks --no-graph-leg > gpurun_out/r05s/${cfg}_$v.json 2> gpurun_out/r05s/${cfg}_$v.err || { echo "$cfg $v FAILED"; tail -3 gpurun_out/r05s/${cfg}_$v.err; continue; }
+    python3 - $cfg $v <<'PY'
+import json, sys
+d = json.loads(open("gpurun_out/r05s/%s_%s.json" % (sys.argv[1], sys.argv[2])).read().strip().splitlines()[-1])
+k = d["roofline"]["kernels_ms_per_step"]
+print("%s %-8s pair step %8.4f ms   step %8.4f ms" % (sys.argv[1], sys.argv[2], k["k_inv_row_pair"], d["ms_per_step"]))
+PY
   done
+  unset TDOA_LIB_VARIANT
 done

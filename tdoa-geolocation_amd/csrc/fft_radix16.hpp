@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void k_fwd_row4096(float2 *TZ, FftPlan pl, boo
 #define TDOA_ROW_STORE(p, val) (*(p) = (val))
 #endif
 template <bool ROWMAJOR = false>
-__global__ __launch_bounds__(512) void k_fwd_row4096_unpack(const float2 *TZ, FftPlan pl, float2 *tiled, bool pre_tw)
+__global__ __launch_bounds__(512) void k_fwd_row4096_unpack(const float2 *TZ, FftPlan pl, float2 *tiled, bool pre_tw, int tile_cols)
 {
     extern __shared__ float2 lds2[];                             // [2][kRowLds]
     const int a = blockIdx.x, g = threadIdx.x >> 8, j = threadIdx.x & 255;
@@ -247,11 +247,13 @@ __global__ __launch_bounds__(512) void k_fwd_row4096_unpack(const float2 *TZ, Ff
 #pragma unroll
         for (int k = 0; k < 16; k++) TDOA_ROW_STORE(out + 256 * k, v[oreg(k)]);
     } else {
-        // tiles of COLS = 4096 / N2 columns x N2 rows = 4096 elements: column k1 = j + 256 k -> tile k1 / COLS
-        const int cols = 4096 / pl.N2;
-        float2 *out = tiled + (size_t)blockIdx.y * pl.Nc + (size_t)(j / cols) * 4096 + (size_t)k2 * cols + (j % cols);
+        // tiles of COLS columns x N2 rows: column k1 = j + 256 k -> tile k1 / COLS.  COLS = 4096 / N2 (4096 elements per tile:
+        // k_pair_decimate16) or tile_cols = 64 (the staged column walk's blocks, dec_staged.hpp) -- a divisor of 256 either way,
+        // so the sixteen elements of a thread are 256 / COLS tiles = 256 N2 elements apart
+        const int cols = tile_cols ? tile_cols : 4096 / pl.N2;
+        float2 *out = tiled + (size_t)blockIdx.y * pl.Nc + (size_t)(j / cols) * ((size_t)pl.N2 * cols) + (size_t)k2 * cols + (j % cols);
 #pragma unroll
-        for (int k = 0; k < 16; k++) TDOA_ROW_STORE(out + (size_t)(256 / cols) * k * 4096, v[oreg(k)]);
+        for (int k = 0; k < 16; k++) TDOA_ROW_STORE(out + (size_t)256 * pl.N2 * k, v[oreg(k)]);
     }
 }
 

@@ -104,7 +104,12 @@ struct tdoa_ctx {
     bool dec_cols_always = false;           // TDOA_DEC_COLS_ALWAYS=1: the column walk wherever the decimated inverse applies (measurements)
     bool dec_staged = true;                 // TDOA_NO_DEC_STAGED=1: the column walk one pair-window per wave from memory (k_pair_decimate_cols), no LDS staging
     int stg_loaders = 0;                    // TDOA_DEC_STAGED_LOADERS=n: loader waves per workgroup of k_pair_decimate_staged (0: the library's choice)
-    int stg_cw = 0;                         // TDOA_DEC_STAGED_CW=n: at most n walks (compute waves) per workgroup (0: sixteen waves less the loaders)
+    // the staged walk's share-out of a window's pairs to workgroups, for every station count 2 .. 16 (build_stg_groups)
+    struct StgTable { int off = 0, count = 0, slots = 0, max_n = 0; } stg_tab[kStgMaxStations + 1];
+    DevBuf stg_groups;
+    bool stg_ready = false;
+    bool stg_blocks = true;                 // TDOA_NO_STG_BLOCKS=1: the staged walk reads row-major spectra on every plan
+    int stg_cw = 0;                         // TDOA_DEC_STAGED_CW=n: at most n walks (compute waves) per workgroup (0: fifteen -- sixteen waves less the loader)
     int stg_rows = 0, stg_bufs = 0;         // TDOA_DEC_STAGED_ROWS=2|4|8, TDOA_DEC_STAGED_BUFS=n: rows per phase, phases in the LDS ring (0: the library's choice)
     bool seg_pack3 = true;                  // TDOA_NO_SEG_PACK3=1: the segment form reads int32 code rows (round 3's layout)
     int seg_chunks_override = 0;            // TDOA_SEG_CHUNKS=n at tdoa_create time: chunk count of the segment form
@@ -509,6 +514,26 @@ bool dec_walks_columns(const tdoa_ctx *ctx, const FftPlan &pl, int n_sw, int n_p
     return pairs_per_window > n_sw / (n_pw / pairs_per_window);
 }
 
+// stations per window when the decimated pair step runs as the LDS-staged column walk (dec_staged.hpp), else 0: uniform batches
+// -- every window carries all the P = S (S - 1) / 2 pairs of its S <= 16 stations, station-windows laid out window by window
+// (process_impl's window-major order) -- so that a workgroup can name a window's stations sw_base .. sw_base + S - 1
+int staged_walk_stations(const tdoa_ctx *ctx, const FftPlan &pl, int n_sw, int n_pw, int pairs_per_window)
+{
+    if (!TDOA_HAVE_DEC_COLS || !ctx->dec_staged || pairs_per_window <= 0 || n_pw % pairs_per_window != 0) return 0;
+    if (!dec_walks_columns(ctx, pl, n_sw, n_pw, pairs_per_window)) return 0;
+    const int n_win = n_pw / pairs_per_window;
+    if (n_sw % n_win != 0) return 0;
+    const int st = n_sw / n_win;
+    return st >= 2 && st <= kStgMaxStations && st * (st - 1) / 2 == pairs_per_window ? st : 0;
+}
+// ... and whether its spectra are laid out in blocks of 64 columns (out of place, where the tile form keeps its tiles: the
+// plans that have that room; the 4096 x 2048 and larger plans keep their rows in place).  A loader's piece of a row is then
+// followed in memory by its piece of the next row -- 4 KB runs per station and phase instead of 512-byte pieces 32 KB apart.
+bool staged_walk_blocks(const tdoa_ctx *ctx, const FftPlan &pl, int n_sw, int n_pw, int pairs_per_window)
+{
+    return ctx->stg_blocks && !cols_only_plan(pl) && staged_walk_stations(ctx, pl, n_sw, n_pw, pairs_per_window) > 0;
+}
+
 // taps h[t] = sinc(t/16) * kaiser(t), |t| <= T, rounded to f32; gain[m] = 1 / w[m], w[m] = sum_t h[t] cos(2 pi t m / Nc) / 16
 // evaluated from the ROUNDED taps, so the correction is exact for the filter that runs.  No-op when already built.
 int ensure_decimation(tdoa_ctx *ctx, const FftPlan &pl, int lag_lo, int lag_hi)
@@ -533,11 +558,13 @@ int ensure_decimation(tdoa_ctx *ctx, const FftPlan &pl, int lag_lo, int lag_hi)
     }
     // the kernel's layout: phase p x step s, the tap t = 16 (s - kDecCentre) + p (zero where |t| > T)
     // (then W_N^p, p = 0..15, N = 2 Nc, as float2: the row rotations of k_pair_decimate_cols)
-    std::vector<float> tab(256 + 32, 0.0f);
+    // (then, at 288: phase 0 with its steps reversed -- the upward walks' row of phase 0)
+    std::vector<float> tab(256 + 32 + 16, 0.0f);
     for (int t = -T; t <= T; t++) {
         const int p = ((t % 16) + 16) % 16, sidx = (t - p) / 16 + kDecCentre;
         tab[16 * p + sidx] = taps[t + T];
     }
+    for (int s = 0; s < kDecSteps; s++) tab[288 + s] = tab[kDecSteps - 1 - s];
     for (int p = 0; p < 16; p++) {
         const double ang = -M_PI * (double)p / (double)pl.Nc;
         tab[256 + 2 * p] = (float)std::cos(ang);
@@ -585,6 +612,110 @@ int once_tiles_per_sw(const FftPlan &pl)      // records per station-window: one
     return kOnceWavesPerTile * (pl.N2 == 512 ? pl.N1 / 32 : (pl.N1 / 64) * std::max(1, pl.N2 / 256));
 }
 
+// The staged column walk (dec_staged.hpp) gives a workgroup up to `cap` of a window's pairs and stages the rows of every
+// station those pairs touch.  Pairs are numbered as process_impl lays them out: (0,1), (0,2), ..., (S-2,S-1).
+//  * Up to eight stations: consecutive runs of equal length (28 pairs: 14 + 14) -- every group touches every station anyway.
+//  * More: what the loader can bring in is the bound there (the CU's memory pipeline takes ~1 KB of LDS-DMA per 50 - 65 cycles),
+//    and sixteen stations per group leave room for four rows per phase only.  Groups are grown greedily around the first pair
+//    not yet placed -- the station that adds the most unplaced pairs joins until `cap` pairs or eight stations are reached
+//    (the first groups are the 15 pairs of six stations) --, then small leftovers are merged: 16 stations become 9 groups that
+//    stage 59 station-rows per row of the window instead of 8 x 16 = 128, each within eight stations: eight rows per phase.
+std::vector<StgGroup> build_stg_groups(int S, int cap)
+{
+    const int P = S * (S - 1) / 2, M = 8;
+    std::vector<std::pair<int, int>> pairs;
+    for (int i = 0; i < S; i++)
+        for (int j = i + 1; j < S; j++) pairs.emplace_back(i, j);
+    auto pidx = [&](int a, int b) { if (a > b) std::swap(a, b); return a * S - a * (a + 1) / 2 + (b - a - 1); };
+    std::vector<StgGroup> out;
+    if (S <= M) {
+        const int groups = (P + cap - 1) / cap, n = (P + groups - 1) / groups;
+        for (int g = 0; g < groups; g++) {
+            StgGroup sg{};
+            for (int p = g * n; p < std::min(P, (g + 1) * n); p++) {
+                sg.pair[sg.n++] = (uint8_t)p;
+                sg.mask |= (1u << pairs[p].first) | (1u << pairs[p].second);
+            }
+            out.push_back(sg);
+        }
+        return out;
+    }
+    std::vector<char> open(P, 1);
+    int left = P;
+    while (left) {
+        int seed = 0;
+        while (!open[seed]) seed++;
+        std::vector<int> T = {pairs[seed].first, pairs[seed].second};
+        auto inside = [&] {
+            int c = 0;
+            for (size_t x = 0; x < T.size(); x++)
+                for (size_t y = x + 1; y < T.size(); y++) c += open[pidx(T[x], T[y])];
+            return c;
+        };
+        while ((int)T.size() < M && inside() < cap) {
+            int best = -1, gain = 0;
+            for (int v = 0; v < S; v++) {
+                if (std::find(T.begin(), T.end(), v) != T.end()) continue;
+                int g = 0;
+                for (int t : T) g += open[pidx(t, v)];
+                if (g > gain) { gain = g; best = v; }
+            }
+            if (best < 0) break;
+            T.push_back(best);
+        }
+        std::sort(T.begin(), T.end());
+        StgGroup sg{};
+        for (size_t x = 0; x < T.size(); x++)
+            for (size_t y = x + 1; y < T.size(); y++) {
+                const int p = pidx(T[x], T[y]);
+                if (!open[p] || sg.n >= cap) continue;
+                open[p] = 0;
+                left--;
+                sg.pair[sg.n++] = (uint8_t)p;
+                sg.mask |= (1u << T[x]) | (1u << T[y]);
+            }
+        out.push_back(sg);
+    }
+    for (bool merged = true; merged;) {          // leftovers: two groups that fit one workgroup and eight stations together
+        merged = false;
+        for (size_t a = 0; a < out.size() && !merged; a++)
+            for (size_t b = a + 1; b < out.size() && !merged; b++)
+                if (out[a].n + out[b].n <= cap && __builtin_popcount(out[a].mask | out[b].mask) <= M) {
+                    for (int q = 0; q < out[b].n; q++) out[a].pair[out[a].n++] = out[b].pair[q];
+                    out[a].mask |= out[b].mask;
+                    out.erase(out.begin() + (long)b);
+                    merged = true;
+                }
+    }
+    return out;
+}
+
+int ensure_stg_groups(tdoa_ctx *ctx)
+{
+    if (ctx->stg_ready) return TDOA_OK;
+    const int n_lw = std::max(1, std::min(ctx->stg_loaders ? ctx->stg_loaders : 1, 4));
+    const int cap = ctx->stg_cw > 0 ? std::min(ctx->stg_cw, kStgMaxWaves - n_lw) : kStgMaxWaves - n_lw;
+    std::vector<StgGroup> all;
+    for (int S = 2; S <= kStgMaxStations; S++) {
+        const std::vector<StgGroup> g = build_stg_groups(S, cap);
+        auto &t = ctx->stg_tab[S];
+        t.off = (int)all.size();
+        t.count = (int)g.size();
+        t.slots = t.max_n = 0;
+        for (const StgGroup &x : g) {
+            t.slots = std::max(t.slots, __builtin_popcount(x.mask));
+            t.max_n = std::max(t.max_n, (int)x.n);
+        }
+        all.insert(all.end(), g.begin(), g.end());
+    }
+    int rc;
+    if ((rc = ensure(ctx, ctx->stg_groups, sizeof(StgGroup) * all.size()))) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->stg_groups.p, all.data(), sizeof(StgGroup) * all.size(), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stg_ready = true;
+    return TDOA_OK;
+}
+
 int reserve_fm_batch(tdoa_ctx *ctx, int n_sw, int maxlen, int n_pw, const FftPlan &pl, int lag_lo, int lag_hi,
                      bool allow_fused_k1)
 {
@@ -604,6 +735,7 @@ int reserve_fm_batch(tdoa_ctx *ctx, int n_sw, int maxlen, int n_pw, const FftPla
     }
     if ((rc = ensure(ctx, ctx->tz, sizeof(float2) * (size_t)pl.Zs * n_sw))) return rc;
     if (n_pw && decimation_applies(ctx, pl, lag_lo, lag_hi) && (rc = ensure_decimation(ctx, pl, lag_lo, lag_hi))) return rc;
+    if (n_pw && decimation_applies(ctx, pl, lag_lo, lag_hi) && (rc = ensure_stg_groups(ctx))) return rc;
     size_t v_elems = (size_t)pl.Nc * n_pw;
     if (n_pw && decimation_applies(ctx, pl, lag_lo, lag_hi))      // G + V' of the pairs, then the tiled spectra of the stations
         v_elems = std::max(v_elems, dec_spectra_offset(pl, n_pw) + (cols_only_plan(pl) ? 0 : (size_t)pl.Nc * n_sw));
@@ -813,12 +945,15 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
     }
     if (!seg_chunks) {
         ProfScope ps(ctx, TDOA_K_FWD_ROW, 2.0 * nc8 * n_sw);
-        if (row16 && decim && dec_walks_columns(ctx, pl, n_sw, n_pw, pairs_per_window))     // unpacked spectra back into their rows (k_pair_decimate_cols walks the columns)
+        if (row16 && decim && staged_walk_blocks(ctx, pl, n_sw, n_pw, pairs_per_window))     // unpacked spectra in blocks of 64 columns (k_pair_decimate_staged)
+            hipLaunchKernelGGL(k_fwd_row4096_unpack<false>, dim3(pl.N2 / 2, n_sw), dim3(512), sizeof(float2) * 2 * kRowLds, st, tz, pl,
+                               v + dec_spectra_offset(pl, n_pw), fused_k1 && (col16 || colx == 2), kStgBlockCols);
+        else if (row16 && decim && dec_walks_columns(ctx, pl, n_sw, n_pw, pairs_per_window))     // unpacked spectra back into their rows (k_pair_decimate_cols walks the columns)
             hipLaunchKernelGGL(k_fwd_row4096_unpack<true>, dim3(pl.N2 / 2, n_sw), dim3(512), sizeof(float2) * 2 * kRowLds, st, tz, pl,
-                               tz, fused_k1 && (col16 || colx == 2));
+                               tz, fused_k1 && (col16 || colx == 2), 0);
         else if (row16 && decim)     // unpacked spectra in COLS-column tiles behind G and V' in the V workspace (k_pair_decimate16 streams them)
             hipLaunchKernelGGL(k_fwd_row4096_unpack<false>, dim3(pl.N2 / 2, n_sw), dim3(512), sizeof(float2) * 2 * kRowLds, st, tz, pl,
-                               v + dec_spectra_offset(pl, n_pw), fused_k1 && (col16 || colx == 2));
+                               v + dec_spectra_offset(pl, n_pw), fused_k1 && (col16 || colx == 2), 0);
         else if (row16)
             hipLaunchKernelGGL(k_fwd_row4096, dim3(pl.N2, n_sw), dim3(256), 0, st, tz, pl, fused_k1 && (col16 || colx == 2));
         else
@@ -891,47 +1026,38 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
             // W_N^DK, DK = N2 / 8 bins between a thread's consecutive elements of a tile (N = 2 Nc)
             const double ang = -2.0 * M_PI * (double)(pl.N2 / 8) / (2.0 * (double)pl.Nc);
             const float2 rot = make_float2((float)std::cos(ang), (float)std::sin(ang));
-            // the walk with the stations' rows staged in LDS (dec_staged.hpp): uniform batches -- every window carries all the
-            // P = S (S - 1) / 2 pairs of its S <= 16 stations, station-windows laid out window by window (process_impl's
-            // window-major order) -- so that a workgroup can name a window's stations sw_base .. sw_base + S - 1
-            int stg_s = 0;
-            if (ctx->dec_staged && pairs_per_window > 0 && n_pw % pairs_per_window == 0) {
-                const int n_win = n_pw / pairs_per_window;
-                if (n_sw % n_win == 0) {
-                    const int st = n_sw / n_win;
-                    if (st >= 2 && st <= kStgMaxStations && st * (st - 1) / 2 == pairs_per_window) stg_s = st;
-                }
-            }
+            const int stg_s = staged_walk_stations(ctx, pl, n_sw, n_pw, pairs_per_window);
+            const bool stg_blk = staged_walk_blocks(ctx, pl, n_sw, n_pw, pairs_per_window);
             if (dec_walks_columns(ctx, pl, n_sw, n_pw, pairs_per_window) && stg_s) {
 #if TDOA_HAVE_DEC_COLS
-                // One loader wave (since its instruction is spelled out a second one buys nothing: cfg4 3.56 / 3.56 ms, cfg5 one
-                // group fewer), the other waves of at most sixteen walk one pair each.  What the geometry is chosen for is the
-                // BARRIER: one per phase stops all sixteen waves, and the pair step of BASELINE config 4 took 4.33 / 3.57 / 3.38 ms
-                // with 2 / 4 / 8 rows per phase (the ring's depth made no difference: 3, 6 or 8 phases of two rows all 4.3 ms) --
-                // so the most rows per phase of which TWO phases fit the workgroup's share of the LDS: 8 rows up to eight
-                // stations, 4 up to sixteen; small workgroups (three pairs: four waves) leave room for their neighbours on the CU.
+                // One loader wave, the other waves of at most sixteen walk one pair each; the share-out of the window's pairs comes
+                // from build_stg_groups.  What the geometry is chosen for is the BARRIER: one per phase stops all sixteen waves, and
+                // the pair step of BASELINE config 4 took 4.33 / 3.57 / 3.38 ms with 2 / 4 / 8 rows per phase (the ring's depth
+                // made no difference: 3, 6 or 8 phases of two rows all 4.3 ms) -- so the most rows per phase of which TWO phases
+                // fit the workgroup's share of the LDS: 8 rows up to eight station slots; small workgroups (three pairs: four
+                // waves) leave room for their neighbours on the CU.
                 const int P = pairs_per_window, n_win = n_pw / P;
-                int n_lw = ctx->stg_loaders ? ctx->stg_loaders : 1;
-                n_lw = std::max(1, std::min(n_lw, std::min(4, stg_s)));
-                const int cw_max = ctx->stg_cw > 0 ? std::min(ctx->stg_cw, kStgMaxWaves - n_lw) : kStgMaxWaves - n_lw;
-                const int groups = (P + cw_max - 1) / cw_max, n_cw = (P + groups - 1) / groups;
+                const auto &tab = ctx->stg_tab[stg_s];
+                const int groups = tab.count, n_cw = tab.max_n, slots = tab.slots;
+                const int n_lw = std::max(1, std::min(ctx->stg_loaders ? ctx->stg_loaders : 1, std::min(4, slots)));
                 const int wgs_per_cu = std::max(1, kStgMaxWaves / (n_cw + n_lw));
                 const int budget = kStgLdsBytes / wgs_per_cu;
                 int rows = ctx->stg_rows;
-                if (!rows) rows = 2 * 8 * stg_s * 1024 <= budget ? 8 : 2 * 4 * stg_s * 1024 <= budget ? 4 : 2;
-                const int per_phase = rows * ((stg_s + n_lw - 1) / n_lw);
-                int nb = ctx->stg_bufs ? ctx->stg_bufs : std::max(2, std::min(4, budget / (rows * stg_s * 1024)));
-                if (rows * stg_s * 1024 * 2 > kStgLdsBytes) return fail(ctx, TDOA_ERR_INVALID, "TDOA_DEC_STAGED_ROWS: two phases do not fit the LDS ring");
-                nb = std::min(nb, kStgLdsBytes / (rows * stg_s * 1024));
+                if (!rows) rows = 2 * 8 * slots * 1024 <= budget ? 8 : 2 * 4 * slots * 1024 <= budget ? 4 : 2;
+                const int per_phase = rows * ((slots + n_lw - 1) / n_lw);
+                int nb = ctx->stg_bufs ? ctx->stg_bufs : std::max(2, std::min(4, budget / (rows * slots * 1024)));
+                if (rows * slots * 1024 * 2 > kStgLdsBytes) return fail(ctx, TDOA_ERR_INVALID, "TDOA_DEC_STAGED_ROWS: two phases do not fit the LDS ring");
+                nb = std::min(nb, kStgLdsBytes / (rows * slots * 1024));
                 nb = std::max(2, std::min(nb, 2 + kStgMaxInFlight / per_phase));
                 const int n_items = n_win * 32;
                 const unsigned int blocks = (unsigned int)((n_items + 7) / 8 * 8) * (unsigned int)groups;
-                const size_t lds = (size_t)nb * rows * stg_s * 1024;
+                const size_t lds = (size_t)nb * rows * slots * 1024;
                 const float *tp = static_cast<const float *>(ctx->dec_taps.p);
+                const StgGroup *gt = static_cast<const StgGroup *>(ctx->stg_groups.p) + tab.off;
                 const dim3 sblock(64 * (n_cw + n_lw));
 #define TDOA_STAGED_R(N2V, RV)                                                                                       \
-    hipLaunchKernelGGL((k_pair_decimate_staged<N2V, RV>), dim3(blocks), sblock, lds, st, d_pw, tz, g, edges, pl, tp, n_items, P,  \
-                       stg_s, n_cw, groups, nb)
+    hipLaunchKernelGGL((k_pair_decimate_staged<N2V, RV>), dim3(blocks), sblock, lds, st, d_pw, stg_blk ? spectra : tz, g, edges, pl, tp, gt, \
+                       n_items, P, slots, n_cw, groups, nb, stg_blk ? (long long)pl.Nc : (long long)pl.Zs, (int)stg_blk)
 #define TDOA_STAGED(N2V)                                                                                              \
     do {                                                                                                              \
         if (rows == 8) TDOA_STAGED_R(N2V, 8);                                                                         \
@@ -1408,6 +1534,7 @@ int tdoa_create(const tdoa_params *p, tdoa_ctx **out)
     if (const char *e = std::getenv("TDOA_NO_DEC_COLS")) ctx->dec_cols = !(e[0] == '1');
     if (const char *e = std::getenv("TDOA_DEC_COLS_ALWAYS")) ctx->dec_cols_always = e[0] == '1';
     if (const char *e = std::getenv("TDOA_NO_DEC_STAGED")) ctx->dec_staged = !(e[0] == '1');
+    if (const char *e = std::getenv("TDOA_NO_STG_BLOCKS")) ctx->stg_blocks = !(e[0] == '1');
     if (const char *e = std::getenv("TDOA_DEC_STAGED_LOADERS")) ctx->stg_loaders = std::max(0, std::min(4, std::atoi(e)));
     if (const char *e = std::getenv("TDOA_DEC_STAGED_ROWS")) ctx->stg_rows = std::atoi(e) == 8 ? 8 : std::atoi(e) == 4 ? 4 : std::atoi(e) == 2 ? 2 : 0;
     if (const char *e = std::getenv("TDOA_DEC_STAGED_CW")) ctx->stg_cw = std::max(0, std::min(15, std::atoi(e)));
@@ -1432,7 +1559,7 @@ void tdoa_destroy(tdoa_ctx *ctx)
     clear_graph_marks(ctx);
     if (ctx->graph) (void)hipGraphDestroy(ctx->graph);
     tdoa_capture_clear(ctx);
-    DevBuf *bufs[] = {&ctx->k1_direct, &ctx->k1_quad, &ctx->sw_desc, &ctx->pw_desc, &ctx->partials, &ctx->stats, &ctx->codes, &ctx->codes_lp, &ctx->k1_power, &ctx->dec_taps, &ctx->dec_gain, &ctx->tz, &ctx->v, &ctx->keys,
+    DevBuf *bufs[] = {&ctx->k1_direct, &ctx->k1_quad, &ctx->sw_desc, &ctx->pw_desc, &ctx->partials, &ctx->stats, &ctx->codes, &ctx->codes_lp, &ctx->k1_power, &ctx->dec_taps, &ctx->dec_gain, &ctx->stg_groups, &ctx->tz, &ctx->v, &ctx->keys,
                       &ctx->scales, &ctx->peaks, &ctx->scratch_a, &ctx->scratch_b, &ctx->lagdump,
                       &ctx->ex_a, &ctx->ex_b, &ctx->ex_c, &ctx->ex_d, &ctx->ex_part,
                       &ctx->g_sw_desc, &ctx->g_pw_desc, &ctx->g_quad_desc, &ctx->g_scales, &ctx->g_keys, &ctx->fine_raw, &ctx->fine, &ctx->qual,
@@ -1852,7 +1979,7 @@ static int process_impl(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host,
                                  (uint64_t)ctx->force_generic | ((uint64_t)ctx->short_lag << 1) |
                                      ((uint64_t)ctx->segment_form << 3) | ((uint64_t)ctx->xcd_rows << 4) |
                                      ((uint64_t)ctx->segment_quads << 6) |
-                                     ((uint64_t)ctx->decimate << 8) | ((uint64_t)ctx->fused_k1 << 9) | ((uint64_t)ctx->k1_once << 11) | ((uint64_t)ctx->seg_pack3 << 12) | ((uint64_t)ctx->dec_cols << 13) | ((uint64_t)ctx->dec_cols_always << 14) | ((uint64_t)ctx->pow2_only << 15) | ((uint64_t)ctx->dec_staged << 7) | ((uint64_t)ctx->stg_loaders << 36) | ((uint64_t)ctx->stg_rows << 28) | ((uint64_t)ctx->stg_bufs << 32) |
+                                     ((uint64_t)ctx->decimate << 8) | ((uint64_t)ctx->fused_k1 << 9) | ((uint64_t)ctx->k1_once << 11) | ((uint64_t)ctx->seg_pack3 << 12) | ((uint64_t)ctx->dec_cols << 13) | ((uint64_t)ctx->dec_cols_always << 14) | ((uint64_t)ctx->pow2_only << 15) | ((uint64_t)ctx->dec_staged << 7) | ((uint64_t)ctx->stg_cw << 58) | ((uint64_t)ctx->stg_loaders << 54) | ((uint64_t)ctx->stg_blocks << 53) | ((uint64_t)ctx->stg_rows << 28) | ((uint64_t)ctx->stg_bufs << 32) |
                                      ((uint64_t)ctx->memset_nodes << 10) | ((uint64_t)ctx->seg_chunks_override << 16) | ((uint64_t)ctx->xcd_pair_mb << 40),
                                  ctx->alloc_gen, (uint64_t)(fine_host != nullptr), 0};
     std::memcpy(&key.back(), &gate, sizeof(double));
@@ -2322,6 +2449,15 @@ int tdoa_solve_surface(const double *stations_lle, int n_stations, const double 
     return rc == 0 ? TDOA_OK : (rc == -2 ? TDOA_ERR_UNSUPPORTED : rc == -3 ? TDOA_ERR_INVALID : TDOA_ERR_SINGULAR);
 }
 
+#ifdef TDOA_STG_TIMING
+// measurement build only: read and clear the staged walk's wave-cycle counters (dec_staged.hpp)
+int tdoa_debug_stg_prof(unsigned long long *out8)
+{
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(tdoa::g_stg_prof), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    unsigned long long z[8] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(tdoa::g_stg_prof), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+#endif
 }  // extern "C"
 
 #include "exact_reference_api.inc"

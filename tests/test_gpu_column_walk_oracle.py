@@ -99,12 +99,15 @@ def test_column_walk_batch_4096x512_vs_oracle(oracle, capsys):
     assert (peaks["lag"] == want[None, :]).all()
 
 
-@pytest.mark.parametrize("n_stations,wl", [(7, 1_100_000), (16, 1_100_000), (16, 2_200_001), (2, 1_100_000)])
+@pytest.mark.parametrize("n_stations,wl", [(7, 1_100_000), (16, 1_100_000), (16, 2_200_001), (2, 1_100_000), (11, 1_100_000),
+                                           (13, 1_100_000), (9, 2_200_001)])
 def test_staged_walk_group_geometries_vs_the_per_pair_walk(oracle, n_stations, wl):
     """the workgroup geometries of the staged walk: 7 stations = 21 pairs in two groups of 11 and 10 (an idle compute wave in the
-    second), 16 stations = 120 pairs in eight groups of 15 with all sixteen station slots of the LDS ring in use (4096 x 256:
-    rows of 8 KB ... 16 KB per phase; 4096 x 512), 2 stations = one pair (a two-wave workgroup).  Reference: the per-pair walk
-    (TDOA_DEBUG_NO_DEC_STAGED), itself held against the oracle above -- the same bits -- and the geometry's lags."""
+    second), 2 stations = one pair (a two-wave workgroup); more than eight stations: the greedy share-out of build_stg_groups --
+    groups of at most 15 pairs that touch at most eight stations, each station at its rank among the group's stations in the LDS
+    ring (16 stations: nine groups, the first three the 15 pairs of six stations; 9, 11, 13: with merged leftovers), on the
+    4096 x 256 and the 4096 x 512 plan.  Reference: the per-pair walk (TDOA_DEBUG_NO_DEC_STAGED), itself held against the oracle
+    above -- the same bits -- and the geometry's lags."""
     import tdoa_amd
     blk = wl
     rng = np.random.default_rng(100 + n_stations)
