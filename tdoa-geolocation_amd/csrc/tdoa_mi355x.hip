@@ -501,30 +501,36 @@ size_t dec_spectra_offset(const FftPlan &pl, int n_pw)
 {
     return dec_edge_offset(pl, n_pw) + (size_t)n_pw * (size_t)std::max(pl.N2, 4096) * (2 * kDecEdge);
 }
-// Which form the decimated pair step takes.  The column walk (dec_stream.hpp; unpacked spectra in TZ, row-major) is the only
-// one on the 4096 x 4096 plan and the faster one where the pair step is bound by instruction issue: batches whose windows
-// carry more pairs than stations (cfg4: 4.2 ms against 5.05 per step, cfg5: 108 against 118).  With as many pairs as stations
-// the step waits for the spectra's first trip from memory and the tile form, which asks for a tile's 32 KB at once, is
-// ahead (cfg2: 0.66 ms against 0.73).
+// stations per window of a UNIFORM batch -- every window carries all the P = S (S - 1) / 2 pairs of its S <= 16 stations,
+// station-windows laid out window by window (process_impl's window-major order), so that a workgroup can name a window's
+// stations sw_base .. sw_base + S - 1 -- else 0
+int uniform_batch_stations(int n_sw, int n_pw, int pairs_per_window)
+{
+    if (pairs_per_window <= 0 || n_pw % pairs_per_window != 0) return 0;
+    const int n_win = n_pw / pairs_per_window;
+    if (n_sw % n_win != 0) return 0;
+    const int st = n_sw / n_win;
+    return st >= 2 && st <= kStgMaxStations && st * (st - 1) / 2 == pairs_per_window ? st : 0;
+}
+// Which form the decimated pair step takes.  The column walk (dec_stream.hpp, dec_staged.hpp) is the only one on the 4096 x 2048
+// and larger plans.  On the others: with the stations' rows staged in LDS it is ahead from three stations on (cfg2, 3 pairs:
+// 0.57 ms against 0.60 for the tile form; cfg4: 3.0 against 5.05; cfg5: 72 against 118); one pair-window per wave from memory
+// (batches the staged walk does not take) where windows carry more pairs than stations; the tile form otherwise -- it asks
+// for a tile's 32 KB at once and a lone pair waits for nothing else.
 bool dec_walks_columns(const tdoa_ctx *ctx, const FftPlan &pl, int n_sw, int n_pw, int pairs_per_window)
 {
     if (!ctx->dec_cols || !TDOA_HAVE_DEC_COLS) return false;      // (TDOA_DEC_STEPS other than 8 / 12: the walk is not built)
     if (cols_only_plan(pl) || ctx->dec_cols_always) return true;
     if (pairs_per_window <= 0 || n_pw % pairs_per_window != 0 || n_sw <= 0) return false;
+    if (ctx->dec_staged && uniform_batch_stations(n_sw, n_pw, pairs_per_window) >= 3) return true;
     return pairs_per_window > n_sw / (n_pw / pairs_per_window);
 }
 
-// stations per window when the decimated pair step runs as the LDS-staged column walk (dec_staged.hpp), else 0: uniform batches
-// -- every window carries all the P = S (S - 1) / 2 pairs of its S <= 16 stations, station-windows laid out window by window
-// (process_impl's window-major order) -- so that a workgroup can name a window's stations sw_base .. sw_base + S - 1
+// stations per window when the decimated pair step runs as the LDS-staged column walk (dec_staged.hpp), else 0
 int staged_walk_stations(const tdoa_ctx *ctx, const FftPlan &pl, int n_sw, int n_pw, int pairs_per_window)
 {
-    if (!TDOA_HAVE_DEC_COLS || !ctx->dec_staged || pairs_per_window <= 0 || n_pw % pairs_per_window != 0) return 0;
-    if (!dec_walks_columns(ctx, pl, n_sw, n_pw, pairs_per_window)) return 0;
-    const int n_win = n_pw / pairs_per_window;
-    if (n_sw % n_win != 0) return 0;
-    const int st = n_sw / n_win;
-    return st >= 2 && st <= kStgMaxStations && st * (st - 1) / 2 == pairs_per_window ? st : 0;
+    if (!TDOA_HAVE_DEC_COLS || !ctx->dec_staged || !dec_walks_columns(ctx, pl, n_sw, n_pw, pairs_per_window)) return 0;
+    return uniform_batch_stations(n_sw, n_pw, pairs_per_window);
 }
 // ... and whether its spectra are laid out in blocks of 64 columns (out of place, where the tile form keeps its tiles: the
 // plans that have that room; the 4096 x 2048 and larger plans keep their rows in place).  A loader's piece of a row is then
@@ -1040,12 +1046,15 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
                 const auto &tab = ctx->stg_tab[stg_s];
                 const int groups = tab.count, n_cw = tab.max_n, slots = tab.slots;
                 const int n_lw = std::max(1, std::min(ctx->stg_loaders ? ctx->stg_loaders : 1, std::min(4, slots)));
-                const int wgs_per_cu = std::max(1, kStgMaxWaves / (n_cw + n_lw));
-                const int budget = kStgLdsBytes / wgs_per_cu;
+                // (few-station batches wait for memory rather than for the barrier: eight rows per phase there as well, and on the
+                //  blocked plans a third phase in the ring where two workgroups still share a CU's LDS -- cfg2: 0.594 -> 0.571 ms;
+                //  a fourth, or a third on the in-place plans, lost: cfg2 0.63, cfg3 17.8 against 16.3)
+                const int wgs_by_waves = std::max(1, kStgMaxWaves / (n_cw + n_lw));
+                const int budget = wgs_by_waves >= 2 ? 80 * 1024 : kStgLdsBytes;
                 int rows = ctx->stg_rows;
-                if (!rows) rows = 2 * 8 * slots * 1024 <= budget ? 8 : 2 * 4 * slots * 1024 <= budget ? 4 : 2;
+                if (!rows) rows = 2 * 8 * slots * 1024 <= kStgLdsBytes ? 8 : 2 * 4 * slots * 1024 <= kStgLdsBytes ? 4 : 2;
                 const int per_phase = rows * ((slots + n_lw - 1) / n_lw);
-                int nb = ctx->stg_bufs ? ctx->stg_bufs : std::max(2, std::min(4, budget / (rows * slots * 1024)));
+                int nb = ctx->stg_bufs ? ctx->stg_bufs : stg_blk ? std::max(2, std::min(3, budget / (rows * slots * 1024))) : 2;
                 if (rows * slots * 1024 * 2 > kStgLdsBytes) return fail(ctx, TDOA_ERR_INVALID, "TDOA_DEC_STAGED_ROWS: two phases do not fit the LDS ring");
                 nb = std::min(nb, kStgLdsBytes / (rows * slots * 1024));
                 nb = std::max(2, std::min(nb, 2 + kStgMaxInFlight / per_phase));
