@@ -289,9 +289,14 @@ enum {
     TDOA_DEBUG_NO_DEC_STAGED   = 16384, /* the column walk one pair-window per wave straight from memory (k_pair_decimate_cols)
                                         instead of one workgroup per window and column block with the stations' rows staged in
                                         LDS (csrc/dec_staged.hpp; environment: TDOA_NO_DEC_STAGED=1)                            */
-    TDOA_DEBUG_POW2_ONLY       = 8192 /* transform lengths are powers of two everywhere (the reference's padding rule,
+    TDOA_DEBUG_POW2_ONLY       = 8192, /* transform lengths are powers of two everywhere (the reference's padding rule,
                                         processor.go:563): ten-second windows then run in N = 2^25 instead of 5 x 2^22
                                         (environment: TDOA_POW2_ONLY=1)                                                      */
+    TDOA_DEBUG_NO_SMALL_FUSED  = 32768, /* the decimated inverse's small plan as two kernels (row pass -> V' -> column sums + K5)
+                                        instead of one workgroup per pair-window that keeps the column sums in registers
+                                        (k_small_rows_col_peak; environment: TDOA_NO_SMALL_FUSED=1)                            */
+    TDOA_DEBUG_SMALL_FUSED_ALWAYS = 65536 /* (switches a form ON) ... for any number of pair-windows; the library takes it from
+                                        1024 pair-windows per launch on (environment: TDOA_SMALL_FUSED_ALWAYS=1)              */
 };
 int tdoa_debug_flags(tdoa_ctx *ctx, unsigned flags);
 /* inspection: the K1 statistics of station-window `sw_index` of the last batch (the order of the batch's descriptors:

@@ -710,6 +710,156 @@ __global__ __launch_bounds__(256) void k_small_col_peak(const float2 *V, unsigne
     }
 }
 
+// k_inv_rows_plain_r8 + k_small_col_peak<3, 3> in ONE pass (round 5): V' -- 8 Nc/16 bytes written and read back per
+// pair-window, a seventh of BASELINE config 5's step -- never exists.  One workgroup takes a pair-window and runs its N2' / 2 row
+// pairs one after the other; the six column outputs that can hold a searched lag (n2 = 0, 1, 2 and N2' - 3 .. N2' - 1: direct
+// sums, as in k_small_col_peak) are accumulated in registers across the rows -- thread t keeps them for its eight columns
+// n1 = t + 512 k: 6 x 8 complex numbers --, in the rows' order and with the same factors (powers of w_k = e^{2 pi i k / N2'} by
+// multiplication), so the candidates are bit for bit those of the two kernels.  The next row pair is asked for before the
+// current one is transformed.  Same lag bookkeeping, window gain, residual-mean terms and key as k_small_col_peak.
+// Power-of-two small plans (4096 x 16 / x 32) with the 3 + 3 output set; everything else keeps the two kernels.
+// grid (n_pw), 512 threads at two waves per SIMD (~200 VGPRs), dynamic LDS 64 KB.
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2) TDOA_PLAIN_DS_OPS)) void k_small_rows_col_peak(
+    const float2 *G, const float2 *E, unsigned long long *keys, const PWDesc *pw, FftPlan pl, int big_n2, int by_column, int lag_lo,
+    int lag_hi, float *lag_dump, float dump_scale, const float *gain, OnceCorr oc)
+{
+    constexpr int NO = 6;                                           // outputs n2 = 0, 1, 2, N2 - 3, N2 - 2, N2 - 1
+    extern __shared__ float2 lds[];   // 2 * kRow8Lds
+    __shared__ unsigned long long red[8];
+    float2 *la = lds, *lb = lds + kRow8Lds;
+    const int t = threadIdx.x, N2 = pl.N2, N1 = pl.N1;
+    const float2 *g = G + (size_t)blockIdx.x * pl.Nc;
+    const float2 *e = E + (size_t)blockIdx.x * big_n2 * (2 * kDecEdge);
+    const PWDesc pwd = pw[blockIdx.x];
+    if (oc.fin && t == 0) once_publish_gain(oc, pwd);
+    float2 acc[NO][8];
+#pragma unroll
+    for (int o = 0; o < NO; o++)
+#pragma unroll
+        for (int k = 0; k < 8; k++) acc[o][k] = make_float2(0.0f, 0.0f);
+    // the neighbours' shares of a row near the ends of the big plan's columns (k_inv_rows_plain_r8's merge)
+    auto merge = [&](int row, float2 (&v)[8]) {
+        if (by_column) {
+            const bool left = row < kDecEdge;
+            if ((!left && row < N2 - kDecEdge) || row == N2 - kDecEdge) return;
+            const float2 *x = E + ((size_t)blockIdx.x * (2 * kDecEdge) + (size_t)(left ? kDecEdge + row : row - (N2 - kDecEdge))) * 4096;
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const float2 s_ = x[(t + 512 * r + (left ? 4095 : 1)) & 4095];
+                v[r].x += s_.x;
+                v[r].y += s_.y;
+            }
+            return;
+        }
+        const int i = (row + N2 * t) & 255;
+        if (i >= kDecEdge && i < 256 - kDecEdge) return;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int tn = (row + N2 * (t + 512 * r)) >> 8;
+            const float2 x = i < kDecEdge ? e[(size_t)((tn + big_n2 - 1) & (big_n2 - 1)) * (2 * kDecEdge) + kDecEdge + i]
+                                          : e[(size_t)((tn + 1) & (big_n2 - 1)) * (2 * kDecEdge) + (i - (256 - kDecEdge))];
+            v[r].x += x.x;
+            v[r].y += x.y;
+        }
+    };
+    // acc[o] += x w^n2(o): the factors of row `row` are powers of w = e^{2 pi i row / N2'}, conjugates on the negative side
+    auto gather = [&](int row, const float2 (&v)[8]) {
+        float2 wp[4];
+        wp[1] = unit_root((float)row, 2.0f / (float)N2, true);
+        wp[2] = cmul(wp[1], wp[1]);
+        wp[3] = cmul(wp[2], wp[1]);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const float2 x = v[oreg8(k)];
+            acc[0][k] = cadd(acc[0][k], x);
+            acc[1][k] = cadd(acc[1][k], cmul(x, wp[1]));
+            acc[2][k] = cadd(acc[2][k], cmul(x, wp[2]));
+            acc[3][k] = cadd(acc[3][k], cmul(x, cconj(wp[3])));
+            acc[4][k] = cadd(acc[4][k], cmul(x, cconj(wp[2])));
+            acc[5][k] = cadd(acc[5][k], cmul(x, cconj(wp[1])));
+        }
+    };
+    float2 va[8], vb[8], na[8], nb[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        va[r] = g[t + 512 * r];
+        vb[r] = g[(size_t)4096 + t + 512 * r];
+    }
+    const float inv2 = 2.0f / (float)pl.Nc;
+#pragma unroll 1
+    for (int a = 0; a < N2; a += 2) {
+        const int b = a + 1;
+        if (a + 2 < N2) {
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                na[r] = g[(size_t)(a + 2) * 4096 + t + 512 * r];
+                nb[r] = g[(size_t)(a + 3) * 4096 + t + 512 * r];
+            }
+        }
+        merge(a, va);
+        merge(b, vb);
+        fft8<true>(va);
+        fft8<true>(vb);
+        rows2_r8_finish<true>(va, vb, la, lb, t, t, t);
+        // V'[k2][n1] = y[n1] W_Nc^(-n1 k2), n1 = t + 512 k (inv_rows_twiddle_store, kept in registers)
+        const long long e0 = ((long long)t * a) & (pl.Nc - 1), e1 = ((long long)512 * a) & (pl.Nc - 1);
+        mul_base_step8(va, unit_root((float)e0, inv2, true), unit_root((float)e1, inv2, true));
+        const long long f0 = ((long long)t * b) & (pl.Nc - 1), f1 = ((long long)512 * b) & (pl.Nc - 1);
+        mul_base_step8(vb, unit_root((float)f0, inv2, true), unit_root((float)f1, inv2, true));
+        gather(a, va);
+        gather(b, vb);
+        __syncthreads();                                            // the images are free for the next pair
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            va[r] = na[r];
+            vb[r] = nb[r];
+        }
+    }
+    // K5 over this thread's 6 x 8 candidates (two lags each)
+    OncePair op{};
+    if (oc.fin) op = once_pair(oc, pwd);
+    unsigned long long best = 0;
+#pragma unroll
+    for (int o = 0; o < NO; o++) {
+        const int n2 = o < 3 ? o : N2 - 3 + (o - 3);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int n1 = t + 512 * k;
+            long long d = 2 * ((long long)n2 * N1 + n1);           // lags d (real part) and d + 1 (imaginary part)
+            if (d >= pl.Nc) d -= 2 * pl.Nc;
+            float term0 = 0.0f, term1 = 0.0f;
+            if (oc.fin) {
+                const int di = (int)(d < -oc.k_max ? -oc.k_max : d > oc.k_max ? oc.k_max - 1 : d);      // (d + 1 stays on d's side)
+                const OnceSide &sd = o < 3 ? op.pos : op.neg;
+                term0 = once_term(oc.edges, sd, op.a, di, oc.k_max);
+                term1 = once_term(oc.edges, sd, op.a, di + 1, oc.k_max);
+            }
+            if (d + 1 >= lag_lo && d <= lag_hi) {
+                const long long m = d >> 1;
+                const float gg = gain[m < 0 ? -m : m];
+                const float vals[2] = {acc[o][k].x * gg + term0, acc[o][k].y * gg + term1};
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const long long dq = d + q;
+                    if (dq >= lag_lo && dq <= lag_hi && vals[q] == vals[q]) {
+                        const unsigned long long key = peak_key(vals[q], (int)dq);
+                        best = key > best ? key : best;
+                        if (lag_dump) lag_dump[dq - lag_lo] = vals[q] * dump_scale;
+                    }
+                }
+            }
+        }
+    }
+    best = wave_max_u64(best);
+    if ((t & 63) == 0) red[t >> 6] = best;
+    __syncthreads();
+    if (t == 0) {
+        unsigned long long bb = red[0];
+        for (int w = 1; w < 8; w++) bb = red[w] > bb ? red[w] : bb;
+        if (bb) atomicMax(&keys[pwd.out_index], bb);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Segment form (search ranges up to 1024 lags): the whole correlation stays in LDS and registers.
 // The deployed geometry bounds |TDOA| by 114 samples (PROJECT_NOTES.md:29-32); a caller who searches a few hundred

@@ -108,6 +108,8 @@ struct tdoa_ctx {
     struct StgTable { int off = 0, count = 0, slots = 0, max_n = 0; } stg_tab[kStgMaxStations + 1];
     DevBuf stg_groups;
     bool stg_ready = false;
+    bool small_fused_always = false;        // TDOA_SMALL_FUSED_ALWAYS=1 / tdoa_debug_flags: ... for any number of pair-windows (tests)
+    bool small_fused = true;                // TDOA_NO_SMALL_FUSED=1: the small plan of the decimated inverse as two kernels with V' in memory between them
     bool stg_blocks = true;                 // TDOA_NO_STG_BLOCKS=1: the staged walk reads row-major spectra on every plan
     int stg_cw = 0;                         // TDOA_DEC_STAGED_CW=n: at most n walks (compute waves) per workgroup (0: fifteen -- sixteen waves less the loader)
     int stg_rows = 0, stg_bufs = 0;         // TDOA_DEC_STAGED_ROWS=2|4|8, TDOA_DEC_STAGED_BUFS=n: rows per phase, phases in the LDS ring (0: the library's choice)
@@ -1102,14 +1104,25 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
         }
         {
             ProfScope ps(ctx, TDOA_K_INV_COL, 3.0 * 8.0 * (double)rc_pts * n_pw);
+            const int by_col = dec_walks_columns(ctx, pl, n_sw, n_pw, pairs_per_window) ? 1 : 0;
+            if (ctx->small_fused && np2 == 3 && nn2 == 3 && ps2.odd == 1 && ps2.N1 == 4096 && ps2.N2 >= 8 && (n_pw >= 1024 || ctx->small_fused_always)) {
+                // rows, column sums and K5 in one pass, V' never written (the reference's 20 000 lags on the 4096 x 16 / x 32 small
+                // plans).  One workgroup per pair-window and CU at a time: for batches of a thousand pair-windows and more -- cfg5
+                // (4500 per launch, 32 rows each) 25.2 -> 21.7 ms per step, cfg4 (2772, 16 rows) 1.26 -> 1.24; cfg2's 297 pair-windows
+                // are one round and a tail of such workgroups (0.165 -> 0.253 ms) and keep the two kernels.
+                hipLaunchKernelGGL(k_small_rows_col_peak, dim3(n_pw), dim3(512), sizeof(float2) * 2 * kRow8Lds, st, g,
+                                   v + dec_edge_offset(pl, n_pw), d_keys, d_pw, ps2, pl.N2, by_col, lag_lo, lag_hi, lag_dump, dump_scale,
+                                   static_cast<const float *>(ctx->dec_gain.p), oc);
+            } else {
             hipLaunchKernelGGL(k_inv_rows_plain_r8, dim3(ps2.N2 / 2, n_pw), dim3(512), sizeof(float2) * 2 * kRow8Lds, st, g,
-                               v + dec_edge_offset(pl, n_pw), vs, ps2, pl.N2, dec_walks_columns(ctx, pl, n_sw, n_pw, pairs_per_window) ? 1 : 0);
+                               v + dec_edge_offset(pl, n_pw), vs, ps2, pl.N2, by_col);
             if (np2 == 3 && nn2 == 3)          // the reference's 20 000 lags on either small plan
                 hipLaunchKernelGGL((k_small_col_peak<3, 3>), dim3(ps2.N1 / 256, n_pw), dim3(256), 0, st, vs, d_keys, d_pw, ps2, lag_lo,
                                    lag_hi, np2, nn2, lag_dump, dump_scale, static_cast<const float *>(ctx->dec_gain.p), oc);
             else
                 hipLaunchKernelGGL((k_small_col_peak<0, 0>), dim3(ps2.N1 / 256, n_pw), dim3(256), 0, st, vs, d_keys, d_pw, ps2, lag_lo,
                                    lag_hi, np2, nn2, lag_dump, dump_scale, static_cast<const float *>(ctx->dec_gain.p), oc);
+            }
         }
     } else if (n_pw) {
         {
@@ -1239,6 +1252,7 @@ int allow_big_lds(tdoa_ctx *ctx)
     if ((rc = set_lds(ctx, k_pair_decimate16<8>, all))) return rc;
     if ((rc = set_lds(ctx, k_pair_decimate16<9>, all))) return rc;
     if ((rc = set_lds(ctx, k_inv_rows_plain_r8, all))) return rc;
+    if ((rc = set_lds(ctx, k_small_rows_col_peak, all))) return rc;
 #if TDOA_HAVE_DEC_COLS
 #define TDOA_STG_LDS(N2V, RV)                                                                    \
     if ((rc = set_lds(ctx, (k_pair_decimate_staged<N2V, RV>), all))) return rc;
@@ -1543,6 +1557,8 @@ int tdoa_create(const tdoa_params *p, tdoa_ctx **out)
     if (const char *e = std::getenv("TDOA_NO_DEC_COLS")) ctx->dec_cols = !(e[0] == '1');
     if (const char *e = std::getenv("TDOA_DEC_COLS_ALWAYS")) ctx->dec_cols_always = e[0] == '1';
     if (const char *e = std::getenv("TDOA_NO_DEC_STAGED")) ctx->dec_staged = !(e[0] == '1');
+    if (const char *e = std::getenv("TDOA_NO_SMALL_FUSED")) ctx->small_fused = !(e[0] == '1');
+    if (const char *e = std::getenv("TDOA_SMALL_FUSED_ALWAYS")) ctx->small_fused_always = e[0] == '1';
     if (const char *e = std::getenv("TDOA_NO_STG_BLOCKS")) ctx->stg_blocks = !(e[0] == '1');
     if (const char *e = std::getenv("TDOA_DEC_STAGED_LOADERS")) ctx->stg_loaders = std::max(0, std::min(4, std::atoi(e)));
     if (const char *e = std::getenv("TDOA_DEC_STAGED_ROWS")) ctx->stg_rows = std::atoi(e) == 8 ? 8 : std::atoi(e) == 4 ? 4 : std::atoi(e) == 2 ? 2 : 0;
@@ -1988,7 +2004,7 @@ static int process_impl(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host,
                                  (uint64_t)ctx->force_generic | ((uint64_t)ctx->short_lag << 1) |
                                      ((uint64_t)ctx->segment_form << 3) | ((uint64_t)ctx->xcd_rows << 4) |
                                      ((uint64_t)ctx->segment_quads << 6) |
-                                     ((uint64_t)ctx->decimate << 8) | ((uint64_t)ctx->fused_k1 << 9) | ((uint64_t)ctx->k1_once << 11) | ((uint64_t)ctx->seg_pack3 << 12) | ((uint64_t)ctx->dec_cols << 13) | ((uint64_t)ctx->dec_cols_always << 14) | ((uint64_t)ctx->pow2_only << 15) | ((uint64_t)ctx->dec_staged << 7) | ((uint64_t)ctx->stg_cw << 58) | ((uint64_t)ctx->stg_loaders << 54) | ((uint64_t)ctx->stg_blocks << 53) | ((uint64_t)ctx->stg_rows << 28) | ((uint64_t)ctx->stg_bufs << 32) |
+                                     ((uint64_t)ctx->decimate << 8) | ((uint64_t)ctx->fused_k1 << 9) | ((uint64_t)ctx->k1_once << 11) | ((uint64_t)ctx->seg_pack3 << 12) | ((uint64_t)ctx->dec_cols << 13) | ((uint64_t)ctx->dec_cols_always << 14) | ((uint64_t)ctx->pow2_only << 15) | ((uint64_t)ctx->dec_staged << 7) | ((uint64_t)ctx->stg_cw << 58) | ((uint64_t)ctx->stg_loaders << 54) | ((uint64_t)ctx->stg_blocks << 53) | ((uint64_t)ctx->small_fused << 52) | ((uint64_t)ctx->small_fused_always << 51) | ((uint64_t)ctx->stg_rows << 28) | ((uint64_t)ctx->stg_bufs << 32) |
                                      ((uint64_t)ctx->memset_nodes << 10) | ((uint64_t)ctx->seg_chunks_override << 16) | ((uint64_t)ctx->xcd_pair_mb << 40),
                                  ctx->alloc_gen, (uint64_t)(fine_host != nullptr), 0};
     std::memcpy(&key.back(), &gate, sizeof(double));
@@ -2381,6 +2397,8 @@ int tdoa_debug_flags(tdoa_ctx *ctx, unsigned flags)
     ctx->dec_cols_always = (flags & TDOA_DEBUG_DEC_COLS_ALWAYS) != 0;
     ctx->pow2_only = (flags & TDOA_DEBUG_POW2_ONLY) != 0;
     ctx->dec_staged = !(flags & TDOA_DEBUG_NO_DEC_STAGED);
+    ctx->small_fused = !(flags & TDOA_DEBUG_NO_SMALL_FUSED);
+    ctx->small_fused_always = (flags & TDOA_DEBUG_SMALL_FUSED_ALWAYS) != 0;
     return TDOA_OK;
 }
 

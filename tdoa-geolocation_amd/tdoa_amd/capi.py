@@ -446,7 +446,7 @@ class Context:
         self._chk(self._L.tdoa_debug_force_generic(self._h, 1 if on else 0))
 
     def debug_flags(self, generic=False, no_short_lag=False, no_fused_k1=False, no_segment_form=False, no_xcd_rows=False,
-                    no_segment_quads=False, no_decimate=False, no_k1_once=False, no_seg_pack3=False, no_dec_cols=False, dec_cols_always=False, pow2_only=False, no_dec_staged=False):
+                    no_segment_quads=False, no_decimate=False, no_k1_once=False, no_seg_pack3=False, no_dec_cols=False, dec_cols_always=False, pow2_only=False, no_dec_staged=False, no_small_fused=False, small_fused_always=False):
         """pick kernel variants by hand (tests / measurements): include/tdoa_mi355x.h TDOA_DEBUG_*; no argument = the
         library's default path, every argument switches one specialised form off"""
         self._chk(self._L.tdoa_debug_flags(self._h, (1 if generic else 0) | (2 if no_short_lag else 0) |
@@ -454,7 +454,7 @@ class Context:
                                            (16 if no_xcd_rows else 0) | (64 if no_segment_quads else 0) |
                                            (256 if no_decimate else 0) | (512 if no_k1_once else 0) |
                                            (1024 if no_seg_pack3 else 0) | (2048 if no_dec_cols else 0) |
-                                           (4096 if dec_cols_always else 0) | (8192 if pow2_only else 0) | (16384 if no_dec_staged else 0)))
+                                           (4096 if dec_cols_always else 0) | (8192 if pow2_only else 0) | (16384 if no_dec_staged else 0) | (32768 if no_small_fused else 0) | (65536 if small_fused_always else 0)))
 
     def last_k1(self, sw_index=0):
         """(statistics of station-window `sw_index` of the last batch, True if that batch read every capture byte once:
