@@ -734,11 +734,14 @@ def roofline_fields(args, env, cfg_name, scaling, sim, table, prof_timed, domina
         #               on the 4096 x 4096 plan the FIR walks the columns of the spectrum (dec_stream.hpp)
         #               the FIR walks the columns of the spectrum (dec_stream.hpp) on the 4096 x 4096 plan and wherever a window
         #               carries more pairs than stations (tdoa_mi355x.hip dec_walks_columns); else 4096-bin tiles in LDS
-        cols = os.environ.get("TDOA_NO_DEC_COLS") != "1" and (n2 in (2048, 2560, 3072, 4096) or n_pairs > S or os.environ.get("TDOA_DEC_COLS_ALWAYS") == "1")
-        staged = cols and os.environ.get("TDOA_NO_DEC_STAGED") != "1" and S <= 16      # (uniform batches: every bench job is one)
+        #               ... and, with the stations' rows staged in LDS, from three stations on (every bench job is a uniform batch)
+        can_stage = os.environ.get("TDOA_NO_DEC_STAGED") != "1" and 3 <= S <= 16
+        cols = os.environ.get("TDOA_NO_DEC_COLS") != "1" and (n2 in (2048, 2560, 3072, 4096) or n_pairs > S or can_stage
+                                                              or os.environ.get("TDOA_DEC_COLS_ALWAYS") == "1")
+        staged = cols and os.environ.get("TDOA_NO_DEC_STAGED") != "1" and S <= 16
         hot = dict(hot, k_fwd_row=["k_fwd_row4096_unpack"],
                    k_inv_row_pair=["k_pair_decimate_staged" if staged else "k_pair_decimate_cols" if cols else "k_pair_decimate16"],
-                   k_inv_col_peak=["k_inv_rows_plain_r8", "k_small_col_peak"])
+                   k_inv_col_peak=["k_inv_rows_plain_r8", "k_small_col_peak", "k_small_rows_col_peak"])
     if max_lag <= 1024 and n1 == 4096:
         # segment form; with 3+ pairs per window the station transforms are shared (quads)
         hot = dict(hot, k_inv_row_pair=["k_xcorr_segments_quad" if n_pairs >= 3 and os.environ.get("TDOA_NO_SEGMENT_QUADS") != "1"

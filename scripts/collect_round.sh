@@ -56,6 +56,29 @@ for cfg in cfg4 cfg5 cfg3; do
   TDOA_NO_DEC_STAGED=1 python3 bench.py --config $cfg --steps 3 --warmup 1 --no-cpu-baseline --no-h2d --no-clocks > gpurun_out/${TAG}_${cfg}_perpair_walk_bench.json 2> gpurun_out/${TAG}_${cfg}_perpair.err
   cp gpurun_out/${TAG}_${cfg}_perpair_walk_bench.json profiles/
 done
+say A/B cfg2: tile form of the pair step, two-kernel small plan on cfg5
+TDOA_NO_DEC_COLS=1 python3 bench.py --no-cpu-baseline --no-h2d --no-clocks > gpurun_out/${TAG}_cfg2_tile_form_bench.json 2> gpurun_out/${TAG}_cfg2_tile.err
+TDOA_NO_SMALL_FUSED=1 python3 bench.py --config cfg5 --steps 3 --warmup 1 --no-cpu-baseline --no-h2d --no-clocks > gpurun_out/${TAG}_cfg5_two_kernel_small_plan_bench.json 2> gpurun_out/${TAG}_cfg5_two_kernel.err
+cp gpurun_out/${TAG}_cfg2_tile_form_bench.json gpurun_out/${TAG}_cfg5_two_kernel_small_plan_bench.json profiles/
+if [ -x scripts/microbench/lds_dma_probe ]; then
+  say LDS-DMA probe
+  timeout -k 10 300 scripts/microbench/lds_dma_probe > gpurun_out/${TAG}_lds_dma_probe.txt 2>&1 || true
+  cp gpurun_out/${TAG}_lds_dma_probe.txt profiles/
+fi
+if [ -f tdoa-geolocation_amd/libtdoa_mi355x_stgt.so ]; then      # tdoa_amd.build.build_variant("stgt", ["TDOA_STG_TIMING"])
+  say wave-cycle counters of the staged walk
+  : > gpurun_out/${TAG}_staged_walk_wave_cycles.txt
+  for cfg in cfg2 cfg4 cfg5 cfg3; do
+    TDOA_STG_PROF=1 TDOA_LIB_VARIANT=stgt python3 bench.py --config $cfg --steps 3 --warmup 1 --no-cpu-baseline --no-h2d --no-clocks --no-graph-leg > /dev/null 2> gpurun_out/${TAG}_stgt_$cfg.err || true
+    python3 - $cfg "$(grep stg_prof gpurun_out/${TAG}_stgt_$cfg.err)" >> gpurun_out/${TAG}_staged_walk_wave_cycles.txt <<'PY'
+import sys
+v = [int(x) for x in sys.argv[2].split()[1:]]
+print("%s: walks %.0fk ticks each, at the barrier %.1f %%; %d loaders: %.0fk ticks each, inside issue() %.1f %%, waiting for their data %.1f %%, at the barrier %.1f %%  (raw: %s)"
+      % (sys.argv[1], v[0] / v[5] / 1e3, 100 * v[1] / v[0], v[6], v[2] / v[6] / 1e3, 100 * v[7] / v[2], 100 * v[3] / v[2], 100 * v[4] / v[2], " ".join(map(str, v))))
+PY
+  done
+  cp gpurun_out/${TAG}_staged_walk_wave_cycles.txt profiles/
+fi
 say multi-rank rehearsals
 python3 bench.py --force-dist --no-cpu-baseline > gpurun_out/${TAG}_forcedist_rccl_world1_bench.json 2> gpurun_out/${TAG}_forcedist.err
 # (round 5: bench.py --gpus N starts its own ranks -- the contract verb, no launcher in front)

@@ -19,7 +19,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import source_hash  # noqa: E402  (hash of the kernel sources the counters were taken on)
 
 FETCH_CORRECTION = {"k_fm_demod": 2.0, "k_fwd_row4096": 2.0, "k_fwd_row4096_unpack": 2.0, "k_inv_row_pair4096": 2.0, "k_inv_col_pruned": 2.0,
-                    "k_fwd_col256_c16": 1.0, "k_pair_decimate16": 2.0, "k_inv_rows_plain_r8": 2.0, "k_inv_col_pruned_any": 2.0,
+                    "k_fwd_col256_c16": 1.0, "k_pair_decimate16": 2.0, "k_inv_rows_plain_r8": 2.0, "k_small_rows_col_peak": 2.0,      # (the same loads as k_inv_rows_plain_r8)
+                    "k_inv_col_pruned_any": 2.0,
                     # round 3: k_fwd_col256_k1 reads the capture bytes (2 bytes per sample: 1.19 GB per cfg2 step) as 4 B/lane.
                     # Its first form (512 threads, 128-byte runs per half-wave, like k_fwd_col256_c16's codes) counted x1
                     # (FETCH_SIZE*1024 / bytes = 1.00); the 1024-thread form reads 256-byte runs per wave and counts like
