@@ -22,12 +22,15 @@
 // a loader's pieces of consecutive rows are then consecutive in memory and a station's R rows go out back to back.
 // Outputs: exactly k_pair_decimate_cols's -- G[pw][N2/16][4096] and the neighbour shares X[pw][12][4096].
 //
-// What bounds it (round 5, measurement build -DTDOA_STG_TIMING + scripts/microbench/lds_dma_probe.hip, profiles/r05_*): the walks
-// spend 35 - 42 % of their cycles at the barrier waiting for the loader, and the loader 76 - 86 % of its cycles getting its
-// LDS-DMA ACCEPTED -- one KB per 76 (8 stations) to 111 ticks (16), next to the 88 - 104 a lone wave per CU sustains in the
-// probe.  A second loader wave doubles the rate in the probe and changes nothing here, and neither do the loader's instruction
-// count (a branch-free block for eight stations), the cache-policy bits of the load, the spectra's layout or dropping the
-// walks' stores: the limit is not in the loader.  Recorded as found; DESIGN.md section 9.
+// What bounds it (round 5, measurement build -DTDOA_STG_TIMING + scripts/microbench/lds_dma_probe.hip, profiles/r05_staged_walk_*):
+// the walks' vector issue.  The counters first read otherwise -- the walks 28 - 37 % of their cycles at the barrier, the loader
+// 73 - 82 % of its cycles inside its issue loop -- but (a) with the loader's priority raised (s_setprio 3) its issue share falls
+// to 35 - 38 %, it waits 38 - 46 % at the barrier, and the kernel takes the same time: the loader was only being served last, in
+// slots the walks left; (b) with the walks idle the loaders alone need half the kernel's time (cfg4 1.55 of 3.0 ms, cfg5 32 of
+// 72); (c) a walk's time "at the barrier" is mostly spent while the other walks of its SIMD issue -- the oldest wave runs
+// ahead and waits for its neighbours.  What is left: 42 vector instructions per row and pair (24 of them the filter), issue
+// share 0.70, fourteen or fifteen walks on four SIMDs.  Nothing on the loader's side changes the time: a second loader wave,
+// a branch-free block, the cache-policy bits, the layout of the spectra.
 //
 // grid: 8 x ceil(windows 32 / 8) x groups workgroups (1-D), 64 (compute waves + 1) threads; dynamic LDS nb x R x slots KB.
 #pragma once
