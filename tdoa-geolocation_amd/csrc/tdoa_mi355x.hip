@@ -627,7 +627,7 @@ int once_tiles_per_sw(const FftPlan &pl)      // records per station-window: one
 //    and sixteen stations per group leave room for four rows per phase only.  Groups are grown greedily around the first pair
 //    not yet placed -- the station that adds the most unplaced pairs joins until `cap` pairs or eight stations are reached
 //    (the first groups are the 15 pairs of six stations) --, then small leftovers are merged: 16 stations become 9 groups that
-//    stage 59 station-rows per row of the window instead of 8 x 16 = 128, each within eight stations: eight rows per phase.
+//    stage 62 station-rows per row of the window instead of 8 x 16 = 128, each within eight stations: eight rows per phase.
 std::vector<StgGroup> build_stg_groups(int S, int cap)
 {
     const int P = S * (S - 1) / 2, M = 8;
@@ -2348,6 +2348,21 @@ int tdoa_debug_segment_quads(int n_stations, const int32_t *pairs, int n_pairs, 
         for (int k = 0; k < 4; k++) o[4 + k] = q[i].pair[k];
     }
     return (int)q.size();
+}
+
+int tdoa_debug_staged_groups(int n_stations, int max_pairs, uint32_t *masks_out, int32_t *counts_out, uint8_t *pairs_out, int max_groups)
+{
+    if (n_stations < 2 || n_stations > kStgMaxStations || max_pairs < 1 || max_pairs > kStgMaxWaves - 1 || max_groups < 0 ||
+        (max_groups && (!masks_out || !counts_out || !pairs_out)))
+        return -TDOA_ERR_INVALID;
+    const std::vector<StgGroup> g = build_stg_groups(n_stations, max_pairs);
+    if ((int)g.size() > max_groups) return -TDOA_ERR_INVALID;
+    for (size_t i = 0; i < g.size(); i++) {
+        masks_out[i] = g[i].mask;
+        counts_out[i] = g[i].n;
+        std::memcpy(pairs_out + 16 * i, g[i].pair, 16);
+    }
+    return (int)g.size();
 }
 
 int tdoa_debug_graph_info(tdoa_ctx *ctx, int32_t info[4], const char *dot_path)

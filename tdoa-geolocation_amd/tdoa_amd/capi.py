@@ -72,7 +72,7 @@ SYMBOLS = [
     "tdoa_num_windows", "tdoa_num_pairs", "tdoa_process", "tdoa_process_u8",
     "tdoa_process_fine", "tdoa_fm_xcorr_fine_u8", "tdoa_window_quality_all", "tdoa_window_quality_u8",
     "tdoa_fm_xcorr_u8", "tdoa_fm_preprocess_u8", "tdoa_fm_xcorr_lags_u8", "tdoa_debug_force_generic",
-    "tdoa_debug_flags", "tdoa_debug_last_k1", "tdoa_debug_graph_info", "tdoa_debug_segment_quads", "tdoa_cross_correlate_batch_c64",
+    "tdoa_debug_flags", "tdoa_debug_last_k1", "tdoa_debug_graph_info", "tdoa_debug_segment_quads", "tdoa_debug_staged_groups", "tdoa_cross_correlate_batch_c64",
     "tdoa_latlon_to_ecef", "tdoa_ecef_to_latlon", "tdoa_solve_3station", "tdoa_solve_nstation", "tdoa_solve_surface",
     "tdoa_profile_enable", "tdoa_profile_select", "tdoa_profile_reset", "tdoa_profile_get", "tdoa_kernel_name",
     "tdoa_plan_info",
@@ -145,6 +145,7 @@ def load(build_if_missing=True):
     L.tdoa_debug_last_k1.argtypes = [vp, C.c_int, C.POINTER(FmStats), C.POINTER(C.c_int32)]
     L.tdoa_debug_graph_info.argtypes = [vp, C.POINTER(C.c_int32), C.c_char_p]
     L.tdoa_debug_segment_quads.argtypes = [C.c_int, C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_int32), C.c_int]
+    L.tdoa_debug_staged_groups.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_int32), C.POINTER(C.c_uint8), C.c_int]
     L.tdoa_latlon_to_ecef.argtypes = [C.c_double, C.c_double, C.c_double, dp]
     L.tdoa_latlon_to_ecef.restype = None
     L.tdoa_ecef_to_latlon.argtypes = [C.c_double, C.c_double, C.c_double, dp]
@@ -528,6 +529,18 @@ def segment_quads(n_stations, pairs):
     if n < 0:
         raise ValueError("tdoa_debug_segment_quads: error %d" % -n)
     return out[:n]
+
+
+def staged_groups(n_stations, max_pairs=15):
+    """host only: the staged column walk's share-out of a window's pairs to workgroups: a list of (station mask, [pair numbers])"""
+    masks = np.zeros(128, dtype=np.uint32)
+    counts = np.zeros(128, dtype=np.int32)
+    pairs = np.zeros((128, 16), dtype=np.uint8)
+    n = load().tdoa_debug_staged_groups(int(n_stations), int(max_pairs), masks.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                        counts.ctypes.data_as(C.POINTER(C.c_int32)), pairs.ctypes.data_as(C.POINTER(C.c_uint8)), 128)
+    if n < 0:
+        raise ValueError("tdoa_debug_staged_groups: error %d" % -n)
+    return [(int(masks[g]), [int(x) for x in pairs[g, :counts[g]]]) for g in range(n)]
 
 
 def solve_nstation(stations_lle, range_diff, weights=None, solve_z=False):

@@ -269,3 +269,38 @@ def test_the_documented_measurement_variant_still_builds(tmp_path):
         assert os.path.getsize(out) > 100_000
     finally:
         os.remove(out)
+
+
+@pytest.mark.parametrize("max_pairs", [15, 14, 12, 5])
+def test_staged_walk_groups_place_every_pair_once(capi, max_pairs):
+    """the LDS-staged column walk's share-out of a window's pairs to workgroups (build_stg_groups, tdoa_mi355x.hip): for every
+    station count 2..16 every pair is in exactly one group, no group carries more pairs than a workgroup has walks, a group's
+    mask is exactly the stations its pairs touch, and above eight stations every group stays within eight -- the LDS ring then
+    holds eight rows per phase for any number of stations"""
+    for S in range(2, 17):
+        pairs = [(i, j) for i in range(S) for j in range(i + 1, S)]
+        groups = capi.staged_groups(S, max_pairs)
+        seen = []
+        for mask, members in groups:
+            assert 1 <= len(members) <= max_pairs
+            touched = 0
+            for p in members:
+                i, j = pairs[p]
+                touched |= (1 << i) | (1 << j)
+            assert touched == mask
+            if S > 8:
+                assert bin(mask).count("1") <= 8
+            seen += members
+        assert sorted(seen) == list(range(len(pairs)))
+        need = -(-len(pairs) // max_pairs)
+        assert need <= len(groups) <= need + 2 + (S > 8) * (len(pairs) // 40)
+    # the timed geometries: 8 stations two equal runs of 14, 16 stations nine groups whose first three are the 15 pairs of six stations
+    g8 = capi.staged_groups(8, 15)
+    assert [len(m) for _, m in g8] == [14, 14] and g8[0][1] == list(range(14)) and [mask for mask, _ in g8] == [0xFF, 0xFC]
+    g16 = capi.staged_groups(16, 15)
+    assert len(g16) == 9 and [len(m) for _, m in g16[:3]] == [15, 15, 15] and all(bin(mask).count("1") == 6 for mask, _ in g16[:3])
+    assert sum(bin(mask).count("1") for mask, _ in g16) <= 64                 # station-rows staged per row of the window (one group of all: 8 x 16 = 128)
+    with pytest.raises(ValueError):
+        capi.staged_groups(17)
+    with pytest.raises(ValueError):
+        capi.staged_groups(8, 16)
