@@ -317,9 +317,10 @@ int tdoa_debug_segment_quads(int n_stations, const int32_t *pairs, int n_pairs, 
 
 /* tests only (host, no GPU): how the LDS-staged column walk of the decimated pair step (csrc/dec_staged.hpp) deals the
  * n_stations (n_stations - 1) / 2 pairs of a window -- numbered (0,1), (0,2), ..., as tdoa_process lays them out -- to
- * workgroups of at most max_pairs (1..15) walks: group g takes counts_out[g] pairs, pairs_out[16 g ..] their numbers, and stages
- * the stations of masks_out[g] (bit s = station s).  More than eight stations: every group stays within eight.  Returns the
- * number of groups, or a negative TDOA_ERR_* value (stations outside 2..16, max_pairs outside 1..15, more than max_groups). */
+ * workgroups of at most max_pairs walks (1..15 next to a loader wave; 16: the form without one, full workgroups first): group g
+ * takes counts_out[g] pairs, pairs_out[16 g ..] their numbers, and stages the stations of masks_out[g] (bit s = station s).
+ * More than eight stations: every group stays within eight.  Returns the number of groups, or a negative TDOA_ERR_* value
+ * (stations outside 2..16, max_pairs outside 1..16, more than max_groups). */
 int tdoa_debug_staged_groups(int n_stations, int max_pairs, uint32_t *masks_out, int32_t *counts_out, uint8_t *pairs_out, int max_groups);
 
 /* ---- downstream (processor.go:125-163, 932-1045), host side ---------------- */

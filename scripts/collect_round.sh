@@ -73,8 +73,12 @@ if [ -f tdoa-geolocation_amd/libtdoa_mi355x_stgt.so ]; then      # tdoa_amd.buil
     python3 - $cfg "$(grep stg_prof gpurun_out/${TAG}_stgt_$cfg.err)" >> gpurun_out/${TAG}_staged_walk_wave_cycles.txt <<'PY'
 import sys
 v = [int(x) for x in sys.argv[2].split()[1:]]
-print("%s: walks %.0fk ticks each, at the barrier %.1f %%; %d loaders: %.0fk ticks each, inside issue() %.1f %%, waiting for their data %.1f %%, at the barrier %.1f %%  (raw: %s)"
-      % (sys.argv[1], v[0] / v[5] / 1e3, 100 * v[1] / v[0], v[6], v[2] / v[6] / 1e3, 100 * v[7] / v[2], 100 * v[3] / v[2], 100 * v[4] / v[2], " ".join(map(str, v))))
+walks = "%s: walks %.0fk ticks each, at the barrier %.1f %%" % (sys.argv[1], v[0] / v[5] / 1e3, 100 * v[1] / v[0])
+if v[6]:
+    print("%s; %d loaders: %.0fk ticks each, inside issue() %.1f %%, waiting for their data %.1f %%, at the barrier %.1f %%  (raw: %s)"
+          % (walks, v[6], v[2] / v[6] / 1e3, 100 * v[7] / v[2], 100 * v[3] / v[2], 100 * v[4] / v[2], " ".join(map(str, v))))
+else:
+    print("%s; no loader wave (the walks bring the rows themselves)  (raw: %s)" % (walks, " ".join(map(str, v))))
 PY
   done
   cp gpurun_out/${TAG}_staged_walk_wave_cycles.txt profiles/

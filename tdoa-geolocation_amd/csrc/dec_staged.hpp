@@ -13,6 +13,8 @@
 //   * every COMPUTE wave walks one pair: the same register stencil as k_pair_decimate_cols (twelve accumulators per walk, K3 on
 //     packed pairs), its four operands per row four ds_read_b64, the row's taps through the scalar cache into SGPR pairs;
 //   * one raw s_barrier per phase; the loader waits with a counted vmcnt (later phases stay in flight across the barrier).
+// (Or no loader wave at all -- the FOLDED form below: sixteen walks, the last waves each bring one station -- where that makes
+// fewer workgroups: 13 - 16 stations.)
 // Which pairs a workgroup takes comes from a table the host builds once (StgGroup, build_stg_groups in tdoa_mi355x.hip): up to
 // eight stations consecutive runs of the window's pair list, more than eight a greedy share-out that keeps every group within
 // eight stations -- a station sits in the ring at its RANK among the group's stations, so eight rows per phase fit for any S.
@@ -122,6 +124,50 @@ __global__ __launch_bounds__(64 * kStgMaxWaves) __attribute__((amdgpu_waves_per_
     // or blocks of 64 columns, [c / 64][k2][c % 64] (kStgBlockCols; see the loader)
     auto row0_at = [&](const float2 *base, int c) { return blocked ? base + (size_t)(c >> 6) * ((size_t)N2 * 64) + (c & 63) : base + c; };
     constexpr int NP = N2 / R;                                     // phases
+
+    // FOLDED form (no loader wave: blockDim = 64 n_cw; blocked layout, two phases in the ring): the LAST popcount(mask) waves of the
+    // workgroup -- idle ones first -- each bring ONE station's rows, at the top of a phase for the next one: 3 instructions per
+    // LDS-DMA next to the 336 of a walk's phase.  All sixteen waves can then walk: 28 pairs are 16 + 12 walks (four and three per
+    // SIMD) instead of 14 + 14 (two SIMDs a wave short in both).
+    const int n_waves = (int)(blockDim.x >> 6);
+    const bool folded = n_waves == n_cw;
+    const int duty = folded ? n_waves - 1 - wave : -1;                 // this wave's station: the duty-th of the group's (by rank)
+    const bool has_duty = folded && duty < __builtin_popcount(mask);
+    unsigned long long duty_base = 0;
+    if (has_duty) {
+        unsigned int m = mask;
+        for (int i = 0; i < duty; i++) m &= m - 1;
+        duty_base = (unsigned long long)(uintptr_t)(U + (size_t)(sw_base + __builtin_ctz(m)) * (size_t)u_stride);
+    }
+    typedef __attribute__((address_space(3))) unsigned char *lds_ptr_f;
+    const unsigned int lds0_f = (unsigned int)(uintptr_t)((lds_ptr_f)stage_raw);
+    auto issue_one = [&](int ph, int buf_) {                           // rows ph R .. ph R + R - 1 of the duty station -> ring slot buf_
+        unsigned int keep;
+        const unsigned int dst = lds0_f + (unsigned int)(buf_ * S * R + duty * R) * 1024u;
+        asm volatile("s_mov_b32 %[keep], m0\n\ts_mov_b32 m0, %[dst]" : [keep] "=&s"(keep) : [dst] "s"(dst) : "memory");
+        if (ph > 0) {                                                  // a station's pieces of consecutive rows: 512 bytes apart
+            const int k2 = ph * R, km2 = N2 - k2;
+            const unsigned int of = 8u * ((unsigned int)cb * (N2 * 64u) + (unsigned int)k2 * 64u);
+            const unsigned int om = 8u * ((unsigned int)(63 - cb) * (N2 * 64u) + (unsigned int)km2 * 64u);
+            unsigned int v = 16u * (unsigned int)(lane & 31) + (lane < 32 ? of : om);
+            const int dv = lane < 32 ? 512 : -512;
+#pragma unroll
+            for (int r = 0; r < R; r++)
+                asm volatile("global_load_lds_dwordx4 %[v], %[b]\n\tv_add_u32 %[v], %[v], %[dv]\n\ts_add_u32 m0, m0, 0x400"
+                             : [v] "+v"(v) : [b] "s"(duty_base), [dv] "v"(dv) : "memory", "scc");
+        } else {                                                       // (row 0 pairs with row 0, not with row N2)
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int k2 = r, km2 = k2 ? N2 - k2 : 0;
+                const unsigned int of = 8u * ((unsigned int)cb * (N2 * 64u) + (unsigned int)k2 * 64u);
+                const unsigned int om = 8u * ((unsigned int)(63 - cb) * (N2 * 64u) + (unsigned int)km2 * 64u);
+                const unsigned int v = 16u * (unsigned int)(lane & 31) + (lane < 32 ? of : om);
+                asm volatile("s_nop 0\n\tglobal_load_lds_dwordx4 %[v], %[b]\n\ts_add_u32 m0, m0, 0x400" : : [v] "v"(v), [b] "s"(duty_base) : "memory", "scc");
+            }
+        }
+        asm volatile("s_mov_b32 m0, %[keep]" : : [keep] "s"(keep) : "memory");
+    };
+    if (has_duty) issue_one(0, 0);                                     // phase 0; phase ph + 1 goes out at the top of phase ph
 
     if (wave >= n_cw) {
         // ---- loader: rows (k2, N2 - k2) of the stations in `mask`, phase by phase, nb - 1 phases ahead of the readers -----------
@@ -241,7 +287,11 @@ __global__ __launch_bounds__(64 * kStgMaxWaves) __attribute__((amdgpu_waves_per_
         return;
     }
     if (wave >= p_cnt) {                                           // a compute wave without a pair (last group): barriers only
-        for (int ph = 0; ph < NP; ph++) __builtin_amdgcn_s_barrier();
+        for (int ph = 0; ph < NP; ph++) {
+            if (has_duty) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (has_duty && ph + 1 < NP) issue_one(ph + 1, (ph + 1) & 1);
+        }
         return;
     }
 
@@ -361,8 +411,10 @@ __global__ __launch_bounds__(64 * kStgMaxWaves) __attribute__((amdgpu_waves_per_
 #pragma unroll 1
     for (int ph = 0; ph < NP; ph++) {
         TDOA_STG_T(const unsigned long long t0 = __builtin_readcyclecounter();)
+        if (has_duty) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's share of phase ph has landed
         __builtin_amdgcn_s_barrier();                              // phase ph is in LDS
         TDOA_STG_T(t_bar += __builtin_readcyclecounter() - t0;)
+        if (has_duty && ph + 1 < NP) issue_one(ph + 1, (ph + 1) & 1);      // (folded form: nb = 2)
         const unsigned int base = (unsigned int)(buf * R) * (unsigned int)S * 1024u;
         const unsigned int a_af = base + o_af, a_am = base + o_am, a_bf = base + o_bf, a_bm = base + o_bm;      // this phase's operands
         if (++buf == nb) buf = 0;

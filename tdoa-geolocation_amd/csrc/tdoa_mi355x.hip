@@ -105,7 +105,9 @@ struct tdoa_ctx {
     bool dec_staged = true;                 // TDOA_NO_DEC_STAGED=1: the column walk one pair-window per wave from memory (k_pair_decimate_cols), no LDS staging
     int stg_loaders = 0;                    // TDOA_DEC_STAGED_LOADERS=n: loader waves per workgroup of k_pair_decimate_staged (0: the library's choice)
     // the staged walk's share-out of a window's pairs to workgroups, for every station count 2 .. 16 (build_stg_groups)
-    struct StgTable { int off = 0, count = 0, slots = 0, max_n = 0; } stg_tab[kStgMaxStations + 1];
+    struct StgTable { int off = 0, count = 0, slots = 0, max_n = 0; } stg_tab[kStgMaxStations + 1], stg_tab16[kStgMaxStations + 1];      // (..16: the folded form's, sixteen walks per workgroup)
+    bool stg_folded_always = false;         // TDOA_STG_FOLDED_ALWAYS=1: ... wherever the blocked layout applies (tests)
+    bool stg_folded = true;                 // TDOA_NO_STG_FOLDED=1: always a loader wave next to at most fifteen walks
     DevBuf stg_groups;
     bool stg_ready = false;
     bool small_fused_always = false;        // TDOA_SMALL_FUSED_ALWAYS=1 / tdoa_debug_flags: ... for any number of pair-windows (tests)
@@ -628,7 +630,7 @@ int once_tiles_per_sw(const FftPlan &pl)      // records per station-window: one
 //    not yet placed -- the station that adds the most unplaced pairs joins until `cap` pairs or eight stations are reached
 //    (the first groups are the 15 pairs of six stations) --, then small leftovers are merged: 16 stations become 9 groups that
 //    stage 62 station-rows per row of the window instead of 8 x 16 = 128, each within eight stations: eight rows per phase.
-std::vector<StgGroup> build_stg_groups(int S, int cap)
+std::vector<StgGroup> build_stg_groups(int S, int cap, bool fill = false)
 {
     const int P = S * (S - 1) / 2, M = 8;
     std::vector<std::pair<int, int>> pairs;
@@ -637,7 +639,8 @@ std::vector<StgGroup> build_stg_groups(int S, int cap)
     auto pidx = [&](int a, int b) { if (a > b) std::swap(a, b); return a * S - a * (a + 1) / 2 + (b - a - 1); };
     std::vector<StgGroup> out;
     if (S <= M) {
-        const int groups = (P + cap - 1) / cap, n = (P + groups - 1) / groups;
+        // (fill: full groups first -- sixteen walks are four per SIMD, the remainder of 28 pairs three -- instead of equal runs)
+        const int groups = (P + cap - 1) / cap, n = fill ? cap : (P + groups - 1) / groups;
         for (int g = 0; g < groups; g++) {
             StgGroup sg{};
             for (int p = g * n; p < std::min(P, (g + 1) * n); p++) {
@@ -704,9 +707,11 @@ int ensure_stg_groups(tdoa_ctx *ctx)
     const int n_lw = std::max(1, std::min(ctx->stg_loaders ? ctx->stg_loaders : 1, 4));
     const int cap = ctx->stg_cw > 0 ? std::min(ctx->stg_cw, kStgMaxWaves - n_lw) : kStgMaxWaves - n_lw;
     std::vector<StgGroup> all;
+    for (int pass = 0; pass < 2; pass++)
     for (int S = 2; S <= kStgMaxStations; S++) {
-        const std::vector<StgGroup> g = build_stg_groups(S, cap);
-        auto &t = ctx->stg_tab[S];
+        const std::vector<StgGroup> g = pass ? build_stg_groups(S, ctx->stg_cw > 0 ? std::min(ctx->stg_cw + 1, kStgMaxWaves) : kStgMaxWaves, true)
+                                             : build_stg_groups(S, cap);
+        auto &t = pass ? ctx->stg_tab16[S] : ctx->stg_tab[S];
         t.off = (int)all.size();
         t.count = (int)g.size();
         t.slots = t.max_n = 0;
@@ -1045,9 +1050,15 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
                 // fit the workgroup's share of the LDS: 8 rows up to eight station slots; small workgroups (three pairs: four
                 // waves) leave room for their neighbours on the CU.
                 const int P = pairs_per_window, n_win = n_pw / P;
-                const auto &tab = ctx->stg_tab[stg_s];
+                // the FOLDED form (dec_staged.hpp: no loader wave, up to sixteen walks, the last waves bring one station each): blocked
+                // spectra, a two-phase ring -- where sixteen walks per workgroup make FEWER workgroups (16 stations: eight groups
+                // instead of nine, cfg5 pair step 73.5 -> 70.2 ms; 8 stations: 16 + 12 walks measured 3.21 ms against 3.12 for
+                // 14 + 14 next to a loader wave, and keep the loader)
+                const bool folded = stg_blk && ctx->stg_folded && !ctx->stg_loaders && ctx->stg_bufs <= 2 && ctx->stg_tab16[stg_s].slots <= 8 &&
+                                    (ctx->stg_tab16[stg_s].count < ctx->stg_tab[stg_s].count || ctx->stg_folded_always);
+                const auto &tab = folded ? ctx->stg_tab16[stg_s] : ctx->stg_tab[stg_s];
                 const int groups = tab.count, n_cw = tab.max_n, slots = tab.slots;
-                const int n_lw = std::max(1, std::min(ctx->stg_loaders ? ctx->stg_loaders : 1, std::min(4, slots)));
+                const int n_lw = folded ? 0 : std::max(1, std::min(ctx->stg_loaders ? ctx->stg_loaders : 1, std::min(4, slots)));
                 // (few-station batches wait for memory rather than for the barrier: eight rows per phase there as well, and on the
                 //  blocked plans a third phase in the ring where two workgroups still share a CU's LDS -- cfg2: 0.594 -> 0.571 ms;
                 //  a fourth, or a third on the in-place plans, lost: cfg2 0.63, cfg3 17.8 against 16.3)
@@ -1055,8 +1066,8 @@ int run_fm_batch(tdoa_ctx *ctx, const SWDesc *d_sw, int n_sw, int maxlen, const 
                 const int budget = wgs_by_waves >= 2 ? 80 * 1024 : kStgLdsBytes;
                 int rows = ctx->stg_rows;
                 if (!rows) rows = 2 * 8 * slots * 1024 <= kStgLdsBytes ? 8 : 2 * 4 * slots * 1024 <= kStgLdsBytes ? 4 : 2;
-                const int per_phase = rows * ((slots + n_lw - 1) / n_lw);
-                int nb = ctx->stg_bufs ? ctx->stg_bufs : stg_blk ? std::max(2, std::min(3, budget / (rows * slots * 1024))) : 2;
+                const int per_phase = n_lw ? rows * ((slots + n_lw - 1) / n_lw) : rows;
+                int nb = folded ? 2 : ctx->stg_bufs ? ctx->stg_bufs : stg_blk ? std::max(2, std::min(3, budget / (rows * slots * 1024))) : 2;
                 if (rows * slots * 1024 * 2 > kStgLdsBytes) return fail(ctx, TDOA_ERR_INVALID, "TDOA_DEC_STAGED_ROWS: two phases do not fit the LDS ring");
                 nb = std::min(nb, kStgLdsBytes / (rows * slots * 1024));
                 nb = std::max(2, std::min(nb, 2 + kStgMaxInFlight / per_phase));
@@ -1559,6 +1570,8 @@ int tdoa_create(const tdoa_params *p, tdoa_ctx **out)
     if (const char *e = std::getenv("TDOA_NO_DEC_STAGED")) ctx->dec_staged = !(e[0] == '1');
     if (const char *e = std::getenv("TDOA_NO_SMALL_FUSED")) ctx->small_fused = !(e[0] == '1');
     if (const char *e = std::getenv("TDOA_SMALL_FUSED_ALWAYS")) ctx->small_fused_always = e[0] == '1';
+    if (const char *e = std::getenv("TDOA_NO_STG_FOLDED")) ctx->stg_folded = !(e[0] == '1');
+    if (const char *e = std::getenv("TDOA_STG_FOLDED_ALWAYS")) ctx->stg_folded_always = e[0] == '1';
     if (const char *e = std::getenv("TDOA_NO_STG_BLOCKS")) ctx->stg_blocks = !(e[0] == '1');
     if (const char *e = std::getenv("TDOA_DEC_STAGED_LOADERS")) ctx->stg_loaders = std::max(0, std::min(4, std::atoi(e)));
     if (const char *e = std::getenv("TDOA_DEC_STAGED_ROWS")) ctx->stg_rows = std::atoi(e) == 8 ? 8 : std::atoi(e) == 4 ? 4 : std::atoi(e) == 2 ? 2 : 0;
@@ -2004,7 +2017,7 @@ static int process_impl(tdoa_ctx *ctx, int rank, int world, tdoa_peak *out_host,
                                  (uint64_t)ctx->force_generic | ((uint64_t)ctx->short_lag << 1) |
                                      ((uint64_t)ctx->segment_form << 3) | ((uint64_t)ctx->xcd_rows << 4) |
                                      ((uint64_t)ctx->segment_quads << 6) |
-                                     ((uint64_t)ctx->decimate << 8) | ((uint64_t)ctx->fused_k1 << 9) | ((uint64_t)ctx->k1_once << 11) | ((uint64_t)ctx->seg_pack3 << 12) | ((uint64_t)ctx->dec_cols << 13) | ((uint64_t)ctx->dec_cols_always << 14) | ((uint64_t)ctx->pow2_only << 15) | ((uint64_t)ctx->dec_staged << 7) | ((uint64_t)ctx->stg_cw << 58) | ((uint64_t)ctx->stg_loaders << 54) | ((uint64_t)ctx->stg_blocks << 53) | ((uint64_t)ctx->small_fused << 52) | ((uint64_t)ctx->small_fused_always << 51) | ((uint64_t)ctx->stg_rows << 28) | ((uint64_t)ctx->stg_bufs << 32) |
+                                     ((uint64_t)ctx->decimate << 8) | ((uint64_t)ctx->fused_k1 << 9) | ((uint64_t)ctx->k1_once << 11) | ((uint64_t)ctx->seg_pack3 << 12) | ((uint64_t)ctx->dec_cols << 13) | ((uint64_t)ctx->dec_cols_always << 14) | ((uint64_t)ctx->pow2_only << 15) | ((uint64_t)ctx->dec_staged << 7) | ((uint64_t)ctx->stg_cw << 58) | ((uint64_t)ctx->stg_loaders << 54) | ((uint64_t)ctx->stg_blocks << 53) | ((uint64_t)ctx->stg_folded << 50) | ((uint64_t)ctx->stg_folded_always << 49) | ((uint64_t)ctx->small_fused << 52) | ((uint64_t)ctx->small_fused_always << 51) | ((uint64_t)ctx->stg_rows << 28) | ((uint64_t)ctx->stg_bufs << 32) |
                                      ((uint64_t)ctx->memset_nodes << 10) | ((uint64_t)ctx->seg_chunks_override << 16) | ((uint64_t)ctx->xcd_pair_mb << 40),
                                  ctx->alloc_gen, (uint64_t)(fine_host != nullptr), 0};
     std::memcpy(&key.back(), &gate, sizeof(double));
@@ -2352,10 +2365,10 @@ int tdoa_debug_segment_quads(int n_stations, const int32_t *pairs, int n_pairs, 
 
 int tdoa_debug_staged_groups(int n_stations, int max_pairs, uint32_t *masks_out, int32_t *counts_out, uint8_t *pairs_out, int max_groups)
 {
-    if (n_stations < 2 || n_stations > kStgMaxStations || max_pairs < 1 || max_pairs > kStgMaxWaves - 1 || max_groups < 0 ||
+    if (n_stations < 2 || n_stations > kStgMaxStations || max_pairs < 1 || max_pairs > kStgMaxWaves || max_groups < 0 ||
         (max_groups && (!masks_out || !counts_out || !pairs_out)))
         return -TDOA_ERR_INVALID;
-    const std::vector<StgGroup> g = build_stg_groups(n_stations, max_pairs);
+    const std::vector<StgGroup> g = build_stg_groups(n_stations, max_pairs, max_pairs == kStgMaxWaves);      // (16: the folded form's table)
     if ((int)g.size() > max_groups) return -TDOA_ERR_INVALID;
     for (size_t i = 0; i < g.size(); i++) {
         masks_out[i] = g[i].mask;

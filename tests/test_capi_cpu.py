@@ -271,7 +271,7 @@ def test_the_documented_measurement_variant_still_builds(tmp_path):
         os.remove(out)
 
 
-@pytest.mark.parametrize("max_pairs", [15, 14, 12, 5])
+@pytest.mark.parametrize("max_pairs", [16, 15, 14, 12, 5])
 def test_staged_walk_groups_place_every_pair_once(capi, max_pairs):
     """the LDS-staged column walk's share-out of a window's pairs to workgroups (build_stg_groups, tdoa_mi355x.hip): for every
     station count 2..16 every pair is in exactly one group, no group carries more pairs than a workgroup has walks, a group's
@@ -300,7 +300,11 @@ def test_staged_walk_groups_place_every_pair_once(capi, max_pairs):
     g16 = capi.staged_groups(16, 15)
     assert len(g16) == 9 and [len(m) for _, m in g16[:3]] == [15, 15, 15] and all(bin(mask).count("1") == 6 for mask, _ in g16[:3])
     assert sum(bin(mask).count("1") for mask, _ in g16) <= 64                 # station-rows staged per row of the window (one group of all: 8 x 16 = 128)
+    # the form without a loader wave: sixteen walks (four per SIMD) first, the remainder after them
+    assert [len(m) for _, m in capi.staged_groups(8, 16)] == [16, 12]
+    g16f = capi.staged_groups(16, 16)
+    assert len(g16f) <= 9 and max(len(m) for _, m in g16f) == 16
     with pytest.raises(ValueError):
         capi.staged_groups(17)
     with pytest.raises(ValueError):
-        capi.staged_groups(8, 16)
+        capi.staged_groups(8, 17)

@@ -126,6 +126,28 @@ def test_staged_walk_group_geometries_vs_the_per_pair_walk(oracle, n_stations, w
     assert (peaks["lag"] == want[None, :]).all() and (peaks["abs_corr"] > 100.0).all()
 
 
+@pytest.mark.parametrize("n_stations,folded", [(5, True), (8, True), (12, True), (16, False)])
+def test_staged_walk_with_and_without_a_loader_wave(oracle, n_stations, folded, monkeypatch):
+    """the two forms of the staged walk's workgroup: a loader wave next to at most fifteen walks, or up to sixteen walks whose
+    last waves each bring one station's rows (the library takes the second where it makes fewer workgroups: 13 to 16 stations).
+    Each forced on geometries the library would give the other (TDOA_STG_FOLDED_ALWAYS / TDOA_NO_STG_FOLDED, read when the
+    context is made): the same bits as the per-pair walk"""
+    import tdoa_amd
+    monkeypatch.setenv("TDOA_STG_FOLDED_ALWAYS" if folded else "TDOA_NO_STG_FOLDED", "1")
+    wl = 1_100_000
+    rng = np.random.default_rng(300 + n_stations)
+    delays = [int(x) for x in rng.integers(0, 300, size=n_stations)]
+    caps = [np.concatenate([oracle.simulate_delayed_fm(wl, d, 800 + k, 100 * (s + 1) + k) for k in range(3)])
+            for s, d in enumerate(delays)]
+    with tdoa_amd.Context(max_lag=ML, window_len=wl) as c:
+        peaks = c.process_u8(caps)
+        c.debug_flags(dec_cols_always=True, no_dec_staged=True)
+        walk = c.process()
+    assert np.array_equal(walk, peaks)
+    want = np.array([delays[j] - delays[i] for i in range(n_stations) for j in range(i + 1, n_stations)])
+    assert (peaks["lag"] == want[None, :]).all() and (peaks["abs_corr"] > 100.0).all()
+
+
 def test_staged_walk_in_launch_groups_and_shards(oracle):
     """the staged walk behind tdoa_process's batching and sharding: two windows per launch group (three windows: a group of two
     and a group of one), and the windows dealt to two ranks (wid % 2: rank 0 two windows, rank 1 one) -- every variant must
