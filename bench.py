@@ -1014,9 +1014,13 @@ def main():
         # measurement build of the staged column walk (-DTDOA_STG_TIMING, TDOA_LIB_VARIANT): its wave-cycle counters, to stderr
         import ctypes
         import tdoa_amd
-        buf = (ctypes.c_ulonglong * 8)()
-        tdoa_amd.capi.load().tdoa_debug_stg_prof(buf)
-        print("stg_prof " + " ".join(str(v) for v in buf), file=sys.stderr)
+        lib = tdoa_amd.capi.load()
+        if hasattr(lib, "tdoa_debug_stg_prof"):
+            buf = (ctypes.c_ulonglong * 8)()
+            lib.tdoa_debug_stg_prof(buf)
+            print("stg_prof " + " ".join(str(v) for v in buf), file=sys.stderr)
+        else:
+            print("TDOA_STG_PROF: the loaded library is not a -DTDOA_STG_TIMING build (TDOA_LIB_VARIANT)", file=sys.stderr)
     if rank == 0:
         if world > 1:
             out["same_config_one_gpu"] = same_config_one_gpu(cfg_name)

@@ -1,7 +1,8 @@
 #!/bin/bash
-# A/B of library variants (TDOA_LIB_VARIANT): bash scripts/ab_variant.sh "<variants>" "<configs>"
+# A/B of library variants (measurement builds, tdoa_amd.build.build_variant + TDOA_LIB_VARIANT) against the shipped library, per
+# kernel scope:  bash scripts/ab_variant.sh "<variant names, or a blank for none>" "<configs>"
 mkdir -p gpurun_out/r05s
-VARS=${1:-"stap"}; CFGS=${2:-"cfg4 cfg5"}
+VARS=${1:-" "}; CFGS=${2:-"cfg4 cfg5"}
 for cfg in $CFGS; do
   for v in base $VARS; do
     if [ $v = base ]; then unset TDOA_LIB_VARIANT; else export TDOA_LIB_VARIANT=$v; fi
